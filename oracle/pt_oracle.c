@@ -1,0 +1,1411 @@
+/*
+ * pt_oracle.c — CPU restatement of the reference's unidirectional path tracer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, load or call it, and only as the checker.
+ *
+ * What it restates (reference = brickray/gpu-pathtracer, paths relative to
+ * /root/reference/src):
+ *   RNG            pathtracer.cu:40-49,888-889 + thrust minstd_rand /
+ *                  uniform_real_distribution<float> (thrust is a CUDA-toolkit
+ *                  dependency, not vendored; rocThrust 7.2 ships the same
+ *                  linear_congruential_engine.inl / uniform_real_distribution.inl,
+ *                  against which tests/golden/rng_table.json was generated)
+ *   camera         camera.h:31-46,48-84,123-128
+ *   AABB slab      bbox.h:77-96
+ *   triangle       mesh.h:28-43,45-98,100-109   (Moeller-Trumbore, pbrt-v2 form)
+ *   traversal      pathtracer.cu:214-296        (closest hit / any hit, 64-int stack)
+ *   samplers       wrap.h:6-24,26-36,51-62,78-85,110-115
+ *   BSDFs          pathtracer.cu:51-169,491-826 (all six material types)
+ *   textures       pathtracer.cu:324-359
+ *   lights         area.h:14-41, infinite.h:17-94, pathtracer.cu:172-185
+ *   integrator     pathtracer.cu:880-1021       (Path)
+ *   film           pathtracer.cu:187-204,2516-2531 (Output: accumulate + tonemap)
+ *   BVH build      bvh.cpp:38-173               (binned SAH, preorder flatten)
+ *   scene init     scene.h:50-83                (light power CDF, env bounding sphere)
+ *
+ * Pinned compiler-dependent behaviour:
+ *   - draws inside an argument list are taken LEFT TO RIGHT (source order);
+ *   - flatten() numbers nodes in preorder: left child = cur+1, right child =
+ *     cur+1+size(left subtree), second_child_offset = that index;
+ *   - no FMA contraction (-ffp-contract=off), IEEE divide and sqrt,
+ *     normalize(v) = v * (1.0f / sqrtf(dot(v,v)))  (cutil_math.h:55-58,1187-1191).
+ *
+ * Parity pin: the reference has no tests and cannot be compiled in this image
+ * (CUDA runtime, thrust device headers, assimp and MSVC-only constructs; a
+ * build would need stand-in headers, which this project does not write).  The
+ * restatement is pinned against the golden values the survey obtained from the
+ * reference's own code (RNG table, Cornell BVH listing,
+ * rendered radiance at fixed pixels / means), committed under tests/golden/.
+ *
+ * Two builds of this one file (oracle/Makefile):
+ *   liboracle_libm.so  transcendental functions from glibc libm, as in the
+ *                      build that produced the Appendix B values;
+ *   liboracle_soft.so  -DORACLE_SOFTMATH: include/gpt_softmath.h, the same
+ *                      operation sequences the HIP kernel executes, so the
+ *                      GPU comparison can be bit-exact.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "../include/gpt_types.h"
+#include "../include/gpt_softmath.h"
+
+#ifdef ORACLE_SOFTMATH
+#define M_SIN(x)   gpt_sinf(x)
+#define M_COS(x)   gpt_cosf(x)
+#define M_TAN(x)   gpt_tanf(x)
+#define M_ATAN(x)  gpt_atanf(x)
+#define M_ACOS(x)  gpt_acosf(x)
+#define M_POW(x,y) gpt_powf(x, y)
+#else
+#define M_SIN(x)   sinf(x)
+#define M_COS(x)   cosf(x)
+#define M_TAN(x)   tanf(x)
+#define M_ATAN(x)  atanf(x)
+#define M_ACOS(x)  acosf(x)
+#define M_POW(x,y) powf(x, y)
+#endif
+
+#define API __attribute__((visibility("default")))
+
+/* common.h:22-27 — truncated float literals, used verbatim */
+#define PI               3.14159265358f
+#define TWOPI            6.28318530716f
+#define FOURPI           12.56637061432f
+#define ONE_OVER_PI      0.3183098861847f
+#define ONE_OVER_TWO_PI  0.1591549430923f
+#define ONE_OVER_FOUR_PI 0.0795774715461f
+
+typedef gpt_float3 f3;
+typedef gpt_float2 f2;
+
+/* ---- cutil_math.h semantics (rewritten, not copied) -------------------- */
+static inline f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+static inline f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 div3(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline f3 scl3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }     /* a*s and s*a */
+static inline f3 dvs3(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+static inline f3 adds3(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+static inline f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float rsqrt_host(float x) { return 1.0f / sqrtf(x); }                  /* cutil_math.h:55-58 */
+static inline f3 normalize3(f3 v) { float il = rsqrt_host(dot3(v, v)); return scl3(v, il); }
+static inline float length3(f3 v) { return sqrtf(dot3(v, v)); }
+static inline float clampf(float f, float a, float b) { return gpt_fmaxf(a, gpt_fminf(f, b)); }
+static inline f2 add2(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+static inline f2 sub2(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
+static inline f2 scl2(f2 a, float s) { return mk2(a.x * s, a.y * s); }
+static inline int is_black(f3 c) { return c.x == 0 && c.y == 0 && c.z == 0; }         /* common.h:71-73 */
+static inline int is_nan3(f3 c) { return isnan(c.x) || isnan(c.y) || isnan(c.z); }
+static inline int is_inf3(f3 c) { return isinf(c.x) || isinf(c.y) || isinf(c.z); }
+
+/* ---- work counters (B_alg terms) ------------------------- */
+typedef struct {
+    uint64_t node_visits, prim_tests, bounce_iters, shadow_rays, closest_rays, samples;
+} counters_t;
+static counters_t g_cnt;
+static _Thread_local counters_t t_cnt;
+
+/* ---- RNG: WangHash + minstd_rand + uniform_real_distribution<float> ------ */
+static inline uint32_t wang_hash(uint32_t seed)                 /* pathtracer.cu:40-49 */
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed = seed + (seed << 3);
+    seed = seed ^ (seed >> 4);
+    seed = seed * 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+typedef struct { uint32_t x; } rng_t;
+static inline void rng_seed(rng_t *r, uint32_t s)
+{
+    /* thrust::linear_congruential_engine<uint32,48271,0,2147483647>::seed */
+    uint32_t x = s % 2147483647u;
+    r->x = x == 0 ? 1u : x;
+}
+static inline float rng_uniform(rng_t *r)
+{
+    r->x = (uint32_t)(((uint64_t)r->x * 48271ull) % 2147483647ull);
+    /* uniform_real_distribution<float>(0,1): float(x - min) / (1 + float(max - min)) */
+    return (float)(r->x - 1u) / 2147483648.0f;
+}
+
+/* ---- Ray / Intersection ------------------------------------------------- */
+typedef struct { f3 o, d; float tmin, tmax; } ray_t;                  /* ray.h:7-12 (medium unused in PT) */
+typedef struct { f3 pos, nor; f2 uv; f3 dpdu; int matIdx, lightIdx; } isect_t; /* intersection.h:6-19 */
+
+static inline ray_t mk_ray(f3 o, f3 d, float tmin, float tmax) { ray_t r; r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax; return r; }
+static inline f3 ray_at(const ray_t *r, float t) { return add3(r->o, scl3(r->d, t)); }
+
+/* ---- samplers and frames: wrap.h ----------------------------------------- */
+static inline void make_coordinate(f3 n, f3 *u, f3 *w)              /* wrap.h:6-16 */
+{
+    if (fabsf(n.x) > fabsf(n.y)) {
+        float invLen = 1.0f / sqrtf(n.x * n.x + n.z * n.z);
+        *w = mk3(n.z * invLen, 0.0f, -n.x * invLen);
+    } else {
+        float invLen = 1.0f / sqrtf(n.y * n.y + n.z * n.z);
+        *w = mk3(0.0f, n.z * invLen, -n.y * invLen);
+    }
+    *u = cross3(*w, n);
+}
+static inline f3 to_world(f3 dir, f3 u, f3 v, f3 w)                 /* wrap.h:18-20 */
+{
+    return add3(add3(scl3(u, dir.x), scl3(v, dir.y)), scl3(w, dir.z));
+}
+static inline f3 uniform_sphere(float u1, float u2, float *pdf)      /* wrap.h:26-36 */
+{
+    float costheta = 1.f - 2.f * u1;
+    float sintheta = sqrtf(1.f - costheta * costheta);
+    float phi = TWOPI * u2;
+    float cosphi = M_COS(phi);
+    float sinphi = M_SIN(phi);
+    *pdf = ONE_OVER_FOUR_PI;
+    return mk3(sintheta * cosphi, costheta, sintheta * sinphi);
+}
+static inline f3 cosine_hemisphere(float u1, float u2, float *pdf)   /* wrap.h:51-62 */
+{
+    float sintheta = sqrtf(u1);
+    float costheta = sqrtf(1.f - u1);
+    float phi = TWOPI * u2;
+    float cosphi = M_COS(phi);
+    float sinphi = M_SIN(phi);
+    *pdf = costheta * ONE_OVER_PI;
+    return mk3(sintheta * cosphi, costheta, sintheta * sinphi);
+}
+static inline f2 uniform_disk(float u1, float u2)                    /* wrap.h:78-85 */
+{
+    float r = sqrtf(u1);
+    float phi = TWOPI * u2;
+    return mk2(r * M_COS(phi), r * M_SIN(phi));
+}
+static inline f2 uniform_triangle(float u1, float u2)                /* wrap.h:110-115 */
+{
+    float su1 = sqrtf(u1);
+    float u = 1.f - su1;
+    float v = u2 * su1;
+    return mk2(u, v);
+}
+
+/* ---- camera: camera.h ---------------------------------------------------- */
+API void oracle_camera_init(gpt_camera *c, const float pos[3], const float lookat[3], const float up[3],
+                            float res_x, float res_y, float distance, float fov, float aperture_radius,
+                            float focal_distance, int filmic, int environment)
+{
+    memset(c, 0, sizeof(*c));
+    f3 eye = mk3(pos[0], pos[1], pos[2]);
+    f3 dest = mk3(lookat[0], lookat[1], lookat[2]);
+    f3 upv = mk3(up[0], up[1], up[2]);
+    /* Lookat, camera.h:123-128 */
+    c->position = eye;
+    c->w = normalize3(sub3(eye, dest));
+    c->u = normalize3(cross3(upv, c->w));
+    c->v = normalize3(cross3(c->w, c->u));
+    /* constructor, camera.h:31-46 (called as in main.cpp:268-270) */
+    c->resolution = mk2(res_x, res_y);
+    c->distance = distance;
+    c->fov = fov;
+    c->apertureRadius = aperture_radius;
+    c->focalDistance = focal_distance;
+    c->filmic = (uint8_t)(filmic != 0);
+    c->environment = (uint8_t)(environment != 0);
+    c->medium = -1;
+    float half_fov = fov * .5f;
+    float radians = (float)((double)half_fov / 180.0 * (double)PI);   /* common.h:46-49 */
+    c->height = tanf(radians) * distance;                              /* host-side only: libm on both sides */
+    c->width = c->height * res_x / res_y;
+    c->area = 4.f * c->width * c->height;
+    c->pixel2screen.x = 2.f * c->width / res_x;
+    c->pixel2screen.y = 2.f * c->height / res_y;
+    c->ratio = focal_distance / distance;
+}
+
+static ray_t generate_primary_ray(const gpt_camera *c, float x, float y, f2 xy)     /* camera.h:48-84 */
+{
+    if (c->environment) {
+        float theta = PI * (1.f - y / c->resolution.y);
+        float phi = TWOPI * (1.f - x / c->resolution.x);
+        f3 dir = mk3(M_SIN(theta) * M_COS(phi), M_COS(theta), M_SIN(theta) * M_SIN(phi));
+        dir = sub3(add3(scl3(c->u, dir.x), scl3(c->v, dir.y)), scl3(c->w, dir.z));
+        return mk_ray(c->position, dir, 0.001f, INFINITY);
+    }
+    float xx = x * c->pixel2screen.x - c->width;
+    float yy = y * c->pixel2screen.y - c->height;
+    f3 dir, orig = c->position;
+    if (c->apertureRadius > 0.00001f) {
+        f2 aperture_xy = scl2(xy, c->apertureRadius);
+        float focal_x = c->ratio * xx;
+        float focal_y = c->ratio * yy;
+        f3 aperture = mk3(aperture_xy.x, aperture_xy.y, 0);
+        f3 focal = mk3(focal_x, focal_y, -c->focalDistance);
+        dir = sub3(focal, aperture);
+        dir = add3(add3(scl3(c->u, dir.x), scl3(c->v, dir.y)), scl3(c->w, dir.z));
+        orig = add3(orig, add3(scl3(c->u, aperture.x), scl3(c->v, aperture.y)));
+    } else {
+        dir = add3(add3(scl3(c->u, xx), scl3(c->v, yy)), scl3(c->w, -c->distance));
+    }
+    dir = normalize3(dir);
+    return mk_ray(orig, dir, 0.001f, INFINITY);
+}
+
+/* ---- scene view ----------------------------------------------------------- */
+typedef struct {
+    const gpt_scene_desc *d;
+    gpt_infinite inf;     /* copy; isvalid = 0 when desc->infinite is NULL */
+    float eps;
+} scene_t;
+
+/* ---- AABB slab test: bbox.h:77-96 ------------------------------------------ */
+static inline int bbox_intersect(const gpt_bvh_node *n, const ray_t *r)
+{
+    f3 inv_dir = mk3(1.f / r->d.x, 1.f / r->d.y, 1.f / r->d.z);
+    float t1 = (n->fmin.x - r->o.x) * inv_dir.x;
+    float t2 = (n->fmax.x - r->o.x) * inv_dir.x;
+    float t3 = (n->fmin.y - r->o.y) * inv_dir.y;
+    float t4 = (n->fmax.y - r->o.y) * inv_dir.y;
+    float t5 = (n->fmin.z - r->o.z) * inv_dir.z;
+    float t6 = (n->fmax.z - r->o.z) * inv_dir.z;
+    float tmin = gpt_fmaxf(gpt_fmaxf(gpt_fminf(t1, t2), gpt_fminf(t3, t4)), gpt_fminf(t5, t6));
+    float tmax = gpt_fminf(gpt_fminf(gpt_fmaxf(t1, t2), gpt_fmaxf(t3, t4)), gpt_fmaxf(t5, t6));
+    if (tmax <= 0.00001f) return 0;
+    if (tmin > tmax) return 0;
+    if (tmin > r->tmax) return 0;
+    return 1;
+}
+
+/* ---- triangle: mesh.h:45-98 -------------------------------------------------- */
+static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isect)
+{
+    f3 e1 = sub3(t->v2.v, t->v1.v);
+    f3 e2 = sub3(t->v3.v, t->v1.v);
+    f3 s1 = cross3(ray->d, e2);
+    float divisor = dot3(s1, e1);
+    if (fabsf(divisor) < 1e-8f)
+        return 0;
+    float invDivisor = (float)(1.0 / (double)divisor);
+    f3 s = sub3(ray->o, t->v1.v);
+    float b1 = dot3(s, s1) * invDivisor;
+    if (b1 < 0.0 || b1 > 1.0)
+        return 0;
+    f3 s2 = cross3(s, e1);
+    float b2 = dot3(ray->d, s2) * invDivisor;
+    if (b2 < 0.0 || b1 + b2 > 1.0)
+        return 0;
+    float tt = dot3(e2, s2) * invDivisor;
+    if (tt < ray->tmin || tt > ray->tmax)
+        return 0;
+
+    ray->tmax = tt;
+    if (isect) {
+        f3 dpdu, dpdv;
+        f2 duv1 = sub2(t->v2.uv, t->v1.uv);
+        f2 duv2 = sub2(t->v3.uv, t->v1.uv);
+        float det = duv1.x * duv2.y - duv1.y * duv2.x;
+        if ((double)fabsf(det) < 1e-8) {
+            f3 nn = normalize3(cross3(e1, e2));
+            make_coordinate(nn, &dpdu, &dpdv);
+        } else {
+            float invDet = 1 / det;
+            dpdu = scl3(sub3(scl3(e1, duv2.y), scl3(e2, duv1.y)), invDet);
+            dpdv = scl3(add3(scl3(e1, -duv2.x), scl3(e2, duv1.x)), invDet);
+        }
+        (void)dpdu;
+        isect->pos = ray_at(ray, tt);
+        float b0 = 1.f - b1 - b2;
+        isect->nor = normalize3(add3(add3(scl3(t->v1.n, b0), scl3(t->v2.n, b1)), scl3(t->v3.n, b2)));
+        isect->uv = add2(add2(scl2(t->v1.uv, b0), scl2(t->v2.uv, b1)), scl2(t->v3.uv, b2));
+        isect->matIdx = t->matIdx;
+        isect->lightIdx = t->lightIdx;
+        isect->dpdu = normalize3(cross3(isect->nor, normalize3(dpdv)));
+    }
+    return 1;
+}
+
+/* ---- traversal: pathtracer.cu:214-296 ------------------------------------------ */
+static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
+{
+    int stack[64];
+    int top = 0;
+    int ret = 0;
+    int node_idx = 0;
+    t_cnt.closest_rays++;
+    if (sc->d->n_nodes <= 0) return 0;
+    for (;;) {
+        const gpt_bvh_node *node = &sc->d->nodes[node_idx];
+        t_cnt.node_visits++;
+        if (bbox_intersect(node, ray)) {
+            if (!node->is_leaf) {
+                stack[top++] = node->second_child_offset;
+                stack[top++] = node_idx + 1;
+            } else {
+                for (int i = node->start; i <= node->end; ++i) {
+                    const gpt_primitive *prim = &sc->d->prims[i];
+                    t_cnt.prim_tests++;
+                    if (prim->type == GPT_GT_TRIANGLE) {
+                        if (tri_intersect(&prim->triangle, ray, isect))
+                            ret = 1;
+                    }
+                    /* GT_LINES / GT_SPHERE: out of scope */
+                }
+            }
+        }
+        if (top == 0) break;
+        node_idx = stack[--top];
+    }
+    return ret;
+}
+
+static int intersect_any(const scene_t *sc, ray_t *ray)
+{
+    int stack[64];
+    int top = 0;
+    int node_idx = 0;
+    t_cnt.shadow_rays++;
+    if (sc->d->n_nodes <= 0) return 0;
+    for (;;) {
+        const gpt_bvh_node *node = &sc->d->nodes[node_idx];
+        t_cnt.node_visits++;
+        if (bbox_intersect(node, ray)) {
+            if (!node->is_leaf) {
+                stack[top++] = node->second_child_offset;
+                stack[top++] = node_idx + 1;
+            } else {
+                for (int i = node->start; i <= node->end; ++i) {
+                    const gpt_primitive *prim = &sc->d->prims[i];
+                    t_cnt.prim_tests++;
+                    if (prim->type == GPT_GT_TRIANGLE) {
+                        if (tri_intersect(&prim->triangle, ray, NULL))
+                            return 1;
+                    }
+                }
+            }
+        }
+        if (top == 0) break;
+        node_idx = stack[--top];
+    }
+    return 0;
+}
+
+/* ---- texture lookup: pathtracer.cu:324-359 ---------------------------------------- */
+typedef struct { float x, y, z, w; } f4;
+static inline f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+static inline f4 scl4(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline f4 add4(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+static inline f4 get_texel_int(const gpt_texture *tex, int w, int h, int x, int y)
+{
+    float inv = 1.f / 255.f;
+    float rx = (float)(x - (x / w) * w);
+    float ry = (float)(y - (y / h) * h);
+    x = (int)((rx < 0) ? rx + w : rx);
+    y = (int)((ry < 0) ? ry + h : ry);
+    if (x < 0) x = 0;
+    if (x > w - 1) x = w - 1;
+    if (y < 0) y = 0;
+    if (y > h - 1) y = h - 1;
+    gpt_uchar4 c = tex->data[y * w + x];
+    return mk4(c.x * inv, c.y * inv, c.z * inv, c.w * inv);
+}
+
+static inline f3 get_texel(const scene_t *sc, const gpt_material *m, f2 uv)
+{
+    if (m->textureIdx == -1)
+        return m->diffuse;
+    const gpt_texture *tex = &sc->d->textures[m->textureIdx];
+    int w = tex->width, h = tex->height;
+    float xx = w * uv.x;
+    float yy = h * uv.y;
+    int x = (int)floorf(xx);
+    int y = (int)floorf(yy);
+    float dx = fabsf(xx - x);
+    float dy = fabsf(yy - y);
+    f4 c00 = get_texel_int(tex, w, h, x, y);
+    f4 c10 = get_texel_int(tex, w, h, x + 1, y);
+    f4 c01 = get_texel_int(tex, w, h, x, y + 1);
+    f4 c11 = get_texel_int(tex, w, h, x + 1, y + 1);
+    f4 r = add4(scl4(add4(scl4(c00, 1 - dx), scl4(c10, dx)), 1 - dy),
+                scl4(add4(scl4(c01, 1 - dx), scl4(c11, dx)), dy));
+    return mk3(r.x, r.y, r.z);
+}
+
+/* ---- BSDF helpers: pathtracer.cu:51-169, 206-212 -------------------------------------- */
+static inline float dielectric_fresnel(float cosi, float cost, float etai, float etat)
+{
+    float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
+    float Rperp = (etai * cosi - etat * cost) / (etai * cosi + etat * cost);
+    return (Rparl * Rparl + Rperp * Rperp) * 0.5f;
+}
+static inline f3 conduct_fresnel(float cosi, f3 eta, f3 k)
+{
+    f3 tmp = scl3(scl3(add3(mul3(eta, eta), mul3(k, k)), cosi), cosi);
+    f3 ec2 = scl3(scl3(eta, cosi), 2.f);
+    f3 Rparl2 = div3(adds3(sub3(tmp, ec2), 1.f), adds3(add3(tmp, ec2), 1.f));
+    f3 tmp_f = add3(mul3(eta, eta), mul3(k, k));
+    float c2 = cosi * cosi;
+    f3 Rperp2 = div3(adds3(sub3(tmp_f, ec2), c2), adds3(add3(tmp_f, ec2), c2));
+    return scl3(add3(Rparl2, Rperp2), 0.5f);
+}
+static inline float ggx_d(f3 wh, f3 normal, f3 dpdu, float alphaU, float alphaV)
+{
+    float costheta = dot3(wh, normal);
+    if (costheta <= 0.f) return 0.f;
+    costheta = clampf(costheta, 0.f, 1.f);
+    float costheta2 = costheta * costheta;
+    float sintheta2 = 1.f - costheta2;
+    float costheta4 = costheta2 * costheta2;
+    float tantheta2 = sintheta2 / costheta2;
+    f3 dir = normalize3(sub3(wh, scl3(normal, costheta)));
+    float cosphi = dot3(dir, dpdu);
+    float cosphi2 = cosphi * cosphi;
+    float sinphi2 = 1.f - cosphi2;
+    float sqrD = 1.f + tantheta2 * (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
+    return 1.f / (PI * alphaU * alphaV * costheta4 * sqrD * sqrD);
+}
+static inline float smith_g(f3 w, f3 normal, f3 wh, f3 dpdu, float alphaU, float alphaV)
+{
+    float wdn = dot3(w, normal);
+    if (wdn * dot3(w, wh) < 0.f) return 0.f;
+    float sintheta = sqrtf(clampf(1.f - wdn * wdn, 0.f, 1.f));
+    float tantheta = sintheta / wdn;
+    if (isinf(tantheta)) return 0.f;
+    f3 dir = normalize3(sub3(w, scl3(normal, wdn)));
+    float cosphi = dot3(dir, dpdu);
+    float cosphi2 = cosphi * cosphi;
+    float sinphi2 = 1.f - cosphi2;
+    float alpha2 = cosphi2 * (alphaU * alphaU) + sinphi2 * (alphaV * alphaV);
+    float sqrD = alpha2 * tantheta * tantheta;
+    return 2.f / (1.f + sqrtf(1 + sqrD));
+}
+static inline float ggx_g(f3 wo, f3 wi, f3 normal, f3 wh, f3 dpdu, float aU, float aV)
+{
+    return smith_g(wo, normal, wh, dpdu, aU, aV) * smith_g(wi, normal, wh, dpdu, aU, aV);
+}
+static inline f3 sample_ggx(float alphaU, float alphaV, float u1, float u2)
+{
+    if (alphaU == alphaV) {
+        float costheta = sqrtf((1.f - u1) / (u1 * (alphaU * alphaV - 1.f) + 1.f));
+        float sintheta = sqrtf(1.f - costheta * costheta);
+        float phi = 2 * PI * u2;
+        float cosphi = M_COS(phi);
+        float sinphi = M_SIN(phi);
+        return mk3(sintheta * cosphi, costheta, sintheta * sinphi);
+    } else {
+        float phi;
+        if (u2 <= 0.25) phi = M_ATAN(alphaV / alphaU * M_TAN(TWOPI * u2));
+        else if (u2 >= 0.75f) phi = M_ATAN(alphaV / alphaU * M_TAN(TWOPI * u2)) + TWOPI;
+        else phi = M_ATAN(alphaV / alphaU * M_TAN(TWOPI * u2)) + PI;
+        float sinphi = M_SIN(phi), cosphi = M_COS(phi);
+        float sinphi2 = sinphi * sinphi;
+        float cosphi2 = 1.0f - sinphi2;
+        float inverseA = 1.0f / (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
+        float theta = M_ATAN(sqrtf(inverseA * u1 / (1.0f - u1)));
+        float sintheta = M_SIN(theta), costheta = M_COS(theta);
+        return mk3(sintheta * cosphi, costheta, sintheta * sinphi);
+    }
+}
+static inline f3 reflect3(f3 in, f3 nor) { return sub3(scl3(nor, 2.f * dot3(in, nor)), in); }
+static inline f3 refract3(f3 in, f3 nor, float etai, float etat)
+{
+    float cosi = dot3(in, nor);
+    int enter = cosi > 0;
+    if (!enter) { float t = etai; etai = etat; etat = t; }
+    float eta = etai / etat;
+    float sini2 = 1.f - cosi * cosi;
+    float sint2 = sini2 * eta * eta;
+    float cost = sqrtf(1.f - sint2);
+    return normalize3(add3(scl3(sub3(scl3(nor, cosi), in), eta), scl3(nor, enter ? -cost : cost)));
+}
+static inline f3 schlick_fresnel(f3 rs, float costheta)
+{
+    float c = 1.f - costheta;
+    return add3(rs, scl3(sub3(mk3(1.f, 1.f, 1.f), rs), c * c * c * c * c));
+}
+static inline float power_heuristic(int nf, float fPdf, int ng, float gPdf)
+{
+    float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+static inline float luminance(f3 c) { return dot3(c, mk3(0.212671f, 0.715160f, 0.072169f)); }
+static inline int same_hemisphere(f3 in, f3 out, f3 nor) { return dot3(in, nor) * dot3(out, nor) > 0 ? 1 : 0; }
+static inline int is_delta(int type) { return type == GPT_MT_MIRROR || type == GPT_MT_DIELECTRIC; }
+
+/* ---- SampleBSDF: pathtracer.cu:491-695 (TransportMode::Radiance) --------------------------- */
+static void sample_bsdf(const scene_t *sc, const gpt_material *m, f3 in, f3 nor, f2 uv, f3 dpdu, f3 u,
+                        f3 *out, f3 *fr, float *pdf)
+{
+    switch (m->type) {
+    case GPT_MT_LAMBERTIAN: {
+        f3 n = nor;
+        if (dot3(nor, in) < 0) n = neg3(n);
+        *out = cosine_hemisphere(u.x, u.y, pdf);
+        f3 uu = dpdu, ww;
+        ww = cross3(uu, n);
+        *out = to_world(*out, uu, n, ww);
+        *fr = scl3(get_texel(sc, m, uv), ONE_OVER_PI);
+        break;
+    }
+    case GPT_MT_MIRROR:
+        *out = reflect3(in, nor);
+        *fr = dvs3(m->specular, fabsf(dot3(*out, nor)));
+        *pdf = 1.f;
+        break;
+    case GPT_MT_DIELECTRIC: {
+        f3 wi = neg3(in);
+        f3 normal = nor;
+        float ei = m->outsideIOR, et = m->insideIOR;
+        float cosi = dot3(wi, normal);
+        int enter = cosi < 0;
+        if (!enter) { float t = ei; ei = et; et = t; }
+        float eta = ei / et, cost;
+        float sint2 = eta * eta * (1.f - cosi * cosi);
+        cost = sqrtf(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+        f3 rdir = reflect3(neg3(wi), normal);
+        f3 tdir = refract3(in, nor, m->outsideIOR, m->insideIOR);
+        if (sint2 > 1.f) {
+            *out = rdir;
+            *fr = dvs3(m->specular, fabsf(dot3(*out, normal)));
+            *pdf = 1.f;
+            return;
+        }
+        float fresnel = dielectric_fresnel(fabsf(cost), fabsf(cosi), et, ei);
+        if (u.x > fresnel) {
+            *out = tdir;
+            *fr = scl3(dvs3(m->specular, fabsf(dot3(*out, normal))), 1.f - fresnel);
+            *fr = scl3(*fr, eta * eta);
+            *pdf = 1.f - fresnel;
+        } else {
+            *out = rdir;
+            *fr = scl3(dvs3(m->specular, fabsf(dot3(*out, normal))), fresnel);
+            *pdf = fresnel;
+        }
+        break;
+    }
+    case GPT_MT_ROUGHCONDUCTOR: {
+        f3 n = nor;
+        if (dot3(nor, in) < 0) n = neg3(n);
+        f3 wh = sample_ggx(m->alphaU, m->alphaV, u.x, u.y);
+        f3 uu = dpdu, ww;
+        ww = cross3(uu, n);
+        wh = to_world(wh, uu, n, ww);
+        *out = reflect3(in, wh);
+        if (!same_hemisphere(in, *out, nor)) {
+            *fr = mk3(0, 0, 0);
+            *pdf = 0.f;
+            return;
+        }
+        float cosi = dot3(*out, wh);
+        f3 F = conduct_fresnel(fabsf(cosi), m->eta, m->k);
+        float D = ggx_d(wh, n, dpdu, m->alphaU, m->alphaV);
+        float G = ggx_g(in, *out, n, wh, dpdu, m->alphaU, m->alphaV);
+        *fr = dvs3(scl3(scl3(mul3(m->specular, F), D), G), 4.f * fabsf(dot3(in, n)) * fabsf(dot3(*out, n)));
+        *pdf = D * fabsf(dot3(wh, n)) / (4.f * fabsf(dot3(in, wh)));
+        break;
+    }
+    case GPT_MT_SUBSTRATE: {
+        f3 n = nor;
+        if (dot3(nor, in) < 0) n = neg3(n);
+        if (u.x < 0.5) {
+            float ux = u.x * 2.f;
+            *out = cosine_hemisphere(ux, u.y, pdf);
+            f3 uu = dpdu, ww;
+            ww = cross3(uu, n);
+            *out = to_world(*out, uu, n, ww);
+        } else {
+            float ux = (u.x - 0.5f) * 2.f;
+            f3 wh = sample_ggx(m->alphaU, m->alphaV, ux, u.y);
+            f3 uu = dpdu, ww;
+            ww = cross3(uu, n);
+            wh = to_world(wh, uu, n, ww);
+            *out = reflect3(in, wh);
+        }
+        if (!same_hemisphere(in, *out, n)) {
+            *fr = mk3(0.f, 0.f, 0.f);
+            *pdf = 0.f;
+            return;
+        }
+        float c0 = fabsf(dot3(in, n));
+        float c1 = fabsf(dot3(*out, n));
+        f3 Rd = get_texel(sc, m, uv);
+        f3 Rs = m->specular;
+        float cons0 = 1 - 0.5f * c0;
+        float cons1 = 1 - 0.5f * c1;
+        f3 diffuse = scl3(scl3(mul3(scl3(Rd, 28.f / (23.f * PI)), sub3(mk3(1.f, 1.f, 1.f), Rs)),
+                               1 - cons0 * cons0 * cons0 * cons0 * cons0),
+                          1 - cons1 * cons1 * cons1 * cons1 * cons1);
+        f3 wh = normalize3(add3(in, *out));
+        float D = ggx_d(wh, n, dpdu, m->alphaU, m->alphaV);
+        f3 specular = scl3(schlick_fresnel(Rs, dot3(*out, wh)),
+                           D / (4.f * fabsf(dot3(*out, wh)) * (c0 > c1 ? c0 : c1)));
+        *fr = add3(diffuse, specular);
+        *pdf = 0.5f * (fabsf(dot3(*out, n)) * ONE_OVER_PI + D * fabsf(dot3(wh, n)) / (4.f * dot3(in, wh)));
+        break;
+    }
+    case GPT_MT_ROUGHDIELECTRIC: {
+        f3 wi = neg3(in);
+        f3 n = nor;
+        f3 wh = sample_ggx(m->alphaU, m->alphaV, u.x, u.y);
+        f3 uu = dpdu, ww;
+        ww = cross3(uu, n);
+        wh = to_world(wh, uu, n, ww);
+        float ei = m->outsideIOR, et = m->insideIOR;
+        float cosi = dot3(wi, n);
+        int enter = cosi < 0;
+        if (!enter) { float t = ei; ei = et; et = t; }
+        float D = ggx_d(wh, n, dpdu, m->alphaU, m->alphaV);
+        float eta = ei / et, cost;
+        cosi = dot3(wi, wh);
+        float sint2 = eta * eta * (1.f - cosi * cosi);
+        cost = sqrtf(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+        f3 rdir = reflect3(neg3(wi), wh);
+        f3 tdir = normalize3(add3(scl3(sub3(wi, scl3(wh, cosi)), eta), scl3(wh, enter ? -cost : cost)));
+        if (sint2 > 1.f) {
+            *out = rdir;
+            float G = ggx_g(in, *out, n, wh, dpdu, m->alphaU, m->alphaV);
+            *fr = dvs3(scl3(scl3(m->specular, D), G), 4.f * fabsf(dot3(in, n)) * fabsf(dot3(*out, n)));
+            *pdf = D * fabsf(dot3(wh, n)) / (4.f * fabsf(dot3(wh, in)));
+            return;
+        }
+        float fresnel = dielectric_fresnel(fabsf(cost), fabsf(cosi), et, ei);
+        if (u.z > fresnel) {
+            *out = tdir;
+            float G = ggx_g(in, *out, n, wh, dpdu, m->alphaU, m->alphaV);
+            float c = et * dot3(*out, wh) + ei * dot3(in, wh);
+            *fr = dvs3(scl3(scl3(scl3(scl3(scl3(scl3(scl3(m->specular, ei), ei), D), G), 1.f - fresnel),
+                                 fabsf(dot3(in, wh))), fabsf(dot3(*out, wh))),
+                       fabsf(dot3(*out, n)) * fabsf(dot3(in, n)) * c * c);
+            *fr = scl3(*fr, 1.f / (eta * eta));
+            *pdf = (1.f - fresnel) * D * fabsf(dot3(wh, n)) * et * et * fabsf(dot3(*out, wh)) / (c * c);
+        } else {
+            *out = rdir;
+            float G = ggx_g(in, *out, n, wh, dpdu, m->alphaU, m->alphaV);
+            *fr = dvs3(scl3(scl3(scl3(m->specular, fresnel), D), G), 4.f * fabsf(dot3(in, n)) * fabsf(dot3(*out, n)));
+            *pdf = D * fabsf(dot3(wh, n)) / (4.f * fabsf(dot3(wh, in))) * fresnel;
+        }
+        break;
+    }
+    default:
+        *fr = mk3(0, 0, 0);
+        *pdf = 0.f;
+        *out = mk3(0, 0, 0);
+        break;
+    }
+}
+
+/* ---- Fr: pathtracer.cu:698-826 --------------------------------------------------------------- */
+static void eval_bsdf(const scene_t *sc, const gpt_material *m, f3 in, f3 out, f3 nor, f2 uv, f3 dpdu,
+                      f3 *fr, float *pdf)
+{
+    switch (m->type) {
+    case GPT_MT_LAMBERTIAN:
+        if (!same_hemisphere(in, out, nor)) {
+            *fr = mk3(0.f, 0.f, 0.f);
+            *pdf = 0.f;
+            return;
+        }
+        *fr = scl3(get_texel(sc, m, uv), ONE_OVER_PI);
+        *pdf = fabsf(dot3(out, nor)) * ONE_OVER_PI;
+        break;
+    case GPT_MT_MIRROR:
+    case GPT_MT_DIELECTRIC:
+        *fr = mk3(0.f, 0.f, 0.f);
+        *pdf = 0.f;
+        break;
+    case GPT_MT_ROUGHCONDUCTOR: {
+        if (!same_hemisphere(in, out, nor)) {
+            *fr = mk3(0, 0, 0);
+            *pdf = 0;
+            return;
+        }
+        f3 n = nor;
+        if (dot3(nor, in) < 0) n = neg3(n);
+        f3 wh = normalize3(add3(in, out));
+        float cosi = dot3(out, wh);
+        float D = ggx_d(wh, n, dpdu, m->alphaU, m->alphaV);
+        float G = ggx_g(in, out, n, wh, dpdu, m->alphaU, m->alphaV);
+        f3 F = conduct_fresnel(fabsf(cosi), m->eta, m->k);
+        *fr = dvs3(scl3(scl3(mul3(m->specular, F), D), G), 4.f * fabsf(dot3(in, n)) * fabsf(dot3(out, n)));
+        *pdf = D * fabsf(dot3(wh, n)) / (4.f * fabsf(dot3(in, wh)));
+        break;
+    }
+    case GPT_MT_SUBSTRATE: {
+        if (!same_hemisphere(in, out, nor)) {
+            *fr = mk3(0, 0, 0);
+            *pdf = 0;
+            return;
+        }
+        f3 n = nor;
+        if (dot3(nor, in) < 0) n = neg3(n);
+        float c0 = fabsf(dot3(in, n));
+        float c1 = fabsf(dot3(out, n));
+        f3 Rd = get_texel(sc, m, uv);
+        f3 Rs = m->specular;
+        float cons0 = 1 - 0.5f * c0;
+        float cons1 = 1 - 0.5f * c1;
+        f3 wh = normalize3(add3(in, out));
+        float D = ggx_d(wh, n, dpdu, m->alphaU, m->alphaV);
+        f3 diffuse = scl3(scl3(mul3(scl3(Rd, 28.f / (23.f * PI)), sub3(mk3(1.f, 1.f, 1.f), Rs)),
+                               1 - cons0 * cons0 * cons0 * cons0 * cons0),
+                          1 - cons1 * cons1 * cons1 * cons1 * cons1);
+        f3 specular = scl3(schlick_fresnel(Rs, dot3(out, wh)),
+                           D / (4.f * fabsf(dot3(out, wh)) * (c0 > c1 ? c0 : c1)));
+        *fr = add3(diffuse, specular);
+        *pdf = 0.5f * (fabsf(dot3(out, n)) * ONE_OVER_PI + D * fabsf(dot3(wh, n)) / (4.f * dot3(in, wh)));
+        break;
+    }
+    case GPT_MT_ROUGHDIELECTRIC: {
+        f3 wi = neg3(in);
+        f3 n = nor;
+        int reflect = dot3(in, n) * dot3(out, n) > 0;
+        float ei = m->outsideIOR, et = m->insideIOR;
+        float cosi = dot3(wi, n);
+        int enter = cosi < 0;
+        if (!enter) { float t = ei; ei = et; et = t; }
+        f3 wh = normalize3(neg3(add3(scl3(in, ei), scl3(out, et))));
+        float eta = ei / et, cost;
+        cosi = dot3(wi, wh);
+        float sint2 = eta * eta * (1.f - cosi * cosi);
+        cost = sqrtf(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+        float fresnel = dielectric_fresnel(fabsf(cost), fabsf(cosi), et, ei);
+        float D = ggx_d(wh, n, dpdu, m->alphaU, m->alphaV);
+        if (!reflect) {
+            float G = ggx_g(in, out, n, wh, dpdu, m->alphaU, m->alphaV);
+            float c = et * dot3(out, wh) + ei * dot3(in, wh);
+            *fr = dvs3(scl3(scl3(scl3(scl3(scl3(scl3(scl3(m->specular, ei), ei), D), G), 1.f - fresnel),
+                                 fabsf(dot3(in, wh))), fabsf(dot3(out, wh))),
+                       fabsf(dot3(out, n)) * fabsf(dot3(in, n)) * c * c);
+            *fr = scl3(*fr, 1.f / (eta * eta));
+            *pdf = (1.f - fresnel) * D * fabsf(dot3(wh, n)) * et * et * fabsf(dot3(out, wh)) / (c * c);
+        } else {
+            float G = ggx_g(in, out, n, wh, dpdu, m->alphaU, m->alphaV);
+            *fr = dvs3(scl3(scl3(scl3(m->specular, fresnel), D), G), 4.f * fabsf(dot3(in, n)) * fabsf(dot3(out, n)));
+            *pdf = fresnel * D * fabsf(dot3(wh, n)) / (4.f * fabsf(dot3(wh, in)));
+        }
+        break;
+    }
+    default:
+        *fr = mk3(0, 0, 0);
+        *pdf = 0.f;
+        break;
+    }
+}
+
+/* ---- lights ------------------------------------------------------------------------------------ */
+static inline float tri_surface_area(const gpt_triangle *t)          /* mesh.h:39-43 */
+{
+    f3 e1 = sub3(t->v2.v, t->v1.v);
+    f3 e2 = sub3(t->v3.v, t->v1.v);
+    return length3(cross3(e1, e2)) * 0.5f;
+}
+
+/* Area::SampleLight (area.h:14-19) + Triangle::SampleShape (mesh.h:100-109) */
+static void area_sample_light(const gpt_area *a, f3 pos, f2 u, f3 *rad, ray_t *ray, f3 *nor, float *pdf, float eps)
+{
+    const gpt_triangle *t = &a->triangle;
+    f2 uv = uniform_triangle(u.x, u.y);
+    float w3 = 1 - uv.x - uv.y;
+    f3 p = add3(add3(scl3(t->v1.v, uv.x), scl3(t->v2.v, uv.y)), scl3(t->v3.v, w3));
+    f3 normal = normalize3(add3(add3(scl3(t->v1.n, uv.x), scl3(t->v2.n, uv.y)), scl3(t->v3.n, w3)));
+    f3 dir = sub3(p, pos);
+    *nor = normal;
+    *pdf = 1.f / (tri_surface_area(t) * fabsf(dot3(normal, normalize3(dir)))) * dot3(dir, dir);
+    if (dot3(normal, dir) >= 0.f)
+        *pdf = 0.f;
+    *rad = *pdf != 0.f ? a->radiance : mk3(0.f, 0.f, 0.f);
+    *ray = mk_ray(pos, normalize3(dir), eps, sqrtf(dot3(dir, dir) - eps));
+}
+static inline f3 area_le(const gpt_area *a, f3 nor, f3 dir)           /* area.h:38-41 */
+{
+    if (dot3(nor, dir) > 0.f) return a->radiance;
+    return mk3(0.f, 0.f, 0.f);
+}
+
+/* infinite.h:79-94 */
+static inline f3 inf_get_texel(const gpt_infinite *inf, int x, int y)
+{
+    int width = inf->width, height = inf->height;
+    float rx = (float)(x - (x / width) * width);
+    float ry = (float)(y - (y / height) * height);
+    x = (int)((rx < 0) ? rx + width : rx);
+    y = (int)((ry < 0) ? ry + height : ry);
+    if (x < 0) x = 0;
+    if (x > width - 1) x = width - 1;
+    if (y < 0) y = 0;
+    if (y > height - 1) y = height - 1;
+    return inf->data[y * width + x];
+}
+/* infinite.h:66-77 */
+static inline f3 inf_texel_bilinear(const gpt_infinite *inf, f2 uv)
+{
+    float xx = inf->width * uv.x;
+    float yy = inf->height * uv.y;
+    int x = (int)floorf(xx);
+    int y = (int)floorf(yy);
+    float dx = fabsf(xx - x);
+    float dy = fabsf(yy - y);
+    f3 c00 = inf_get_texel(inf, x, y);
+    f3 c10 = inf_get_texel(inf, x + 1, y);
+    f3 c01 = inf_get_texel(inf, x, y + 1);
+    f3 c11 = inf_get_texel(inf, x + 1, y + 1);
+    return add3(scl3(add3(scl3(c00, 1 - dx), scl3(c10, dx)), 1 - dy),
+                scl3(add3(scl3(c01, 1 - dx), scl3(c11, dx)), dy));
+}
+/* direction -> lat-long lookup, shared by Le and SampleLight (infinite.h:22-36, 47-59) */
+static inline f3 inf_lookup(const gpt_infinite *inf, f3 dir)
+{
+    float costheta = dot3(dir, inf->v);
+    float theta = M_ACOS(costheta);
+    f3 d = normalize3(sub3(dir, scl3(inf->v, costheta)));
+    float cosphi = dot3(d, inf->u);
+    float phi = M_ACOS(cosphi);
+    float c = dot3(d, inf->w);
+    phi = c > 0 ? TWOPI - phi : phi;
+    float uu = phi / TWOPI;
+    float vv = theta / PI;
+    return inf_texel_bilinear(inf, mk2(1.f - uu, vv));
+}
+static void inf_sample_light(const gpt_infinite *inf, f3 pos, f2 uniform, f3 *rad, ray_t *ray, f3 *nor,
+                             float *pdf, float eps)                     /* infinite.h:17-36 */
+{
+    float pdfW;
+    f3 dir = uniform_sphere(uniform.x, uniform.y, &pdfW);
+    *nor = neg3(dir);
+    *ray = mk_ray(pos, dir, eps, 2.f * inf->radius - eps);
+    *pdf = pdfW;
+    *rad = inf_lookup(inf, dir);
+}
+
+/* pathtracer.cu:172-181.  Falls off the end without a return value in the
+ * reference when no interval matches (only possible for NaN u); -1 here. */
+static inline int lookup_light_distribution(const scene_t *sc, float u, float *pdf)
+{
+    const float *cdf = sc->d->light_distribution;
+    int n = sc->d->n_light_distribution;
+    for (int i = 0; i + 1 < n; ++i) {
+        float s = cdf[i];
+        float e = cdf[i + 1];
+        if (u >= s && u <= e) {
+            *pdf = e - s;
+            return i;
+        }
+    }
+    *pdf = 0.f;
+    return -1;
+}
+static inline float pdf_from_light_distribution(const scene_t *sc, int idx)
+{
+    return sc->d->light_distribution[idx + 1] - sc->d->light_distribution[idx];
+}
+
+/* ---- Path: pathtracer.cu:880-1021 ---------------------------------------------------------------- */
+/* returns 1 and writes *Li_out when the sample is finite (the reference then
+ * stores it in kernel_color[pixel]); 0 when the reference skips the store. */
+static int path_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint32_t y, uint32_t pixel,
+                       uint32_t iter, int maxDepth, f3 *Li_out)
+{
+    rng_t rng;
+    rng_seed(&rng, wang_hash(pixel) + wang_hash(iter));
+
+    float offsetx = rng_uniform(&rng) - 0.5f;
+    float offsety = rng_uniform(&rng) - 0.5f;
+    float du1 = rng_uniform(&rng);          /* argument list drawn left to right */
+    float du2 = rng_uniform(&rng);
+    f2 aperture = uniform_disk(du1, du2);
+    ray_t ray = generate_primary_ray(cam, x + offsetx, y + offsety, aperture);
+    ray.tmin = sc->eps;
+
+    f3 Li = mk3(0.f, 0.f, 0.f);
+    f3 beta = mk3(1.f, 1.f, 1.f);
+    ray_t r = ray;
+    isect_t isect;
+    isect.lightIdx = -1;
+    int specular = 0;
+    t_cnt.samples++;
+    for (int bounces = 0; bounces < maxDepth; ++bounces) {
+        t_cnt.bounce_iters++;
+        if (!intersect_closest(sc, &r, &isect)) {
+            if ((bounces == 0 || specular) && sc->inf.isvalid)
+                Li = add3(Li, mul3(beta, inf_lookup(&sc->inf, r.d)));
+            break;
+        }
+
+        f3 pos = isect.pos;
+        f3 nor = isect.nor;
+        f2 uv = isect.uv;
+        f3 dpdu = isect.dpdu;
+        gpt_material material = sc->d->materials[isect.matIdx];
+
+        if (bounces == 0 || specular) {
+            if (isect.lightIdx != -1) {
+                Li = add3(Li, mul3(beta, area_le(&sc->d->lights[isect.lightIdx], nor, neg3(r.d))));
+                break;
+            }
+        }
+
+        if (!is_delta(material.type)) {
+            f3 Ld = mk3(0.f, 0.f, 0.f);
+            int inf = 0;
+            float u = rng_uniform(&rng);
+            float choicePdf;
+            int idx = lookup_light_distribution(sc, u, &choicePdf);
+            if (idx == sc->d->n_lights) inf = 1;
+            float u1x = rng_uniform(&rng);
+            float u1y = rng_uniform(&rng);
+            f2 u1 = mk2(u1x, u1y);
+            f3 radiance = mk3(0, 0, 0), lightNor;
+            ray_t shadowRay = mk_ray(pos, mk3(0, 0, 0), sc->eps, 0.f);
+            float lightPdf = 0.f;
+            if (idx >= 0) {
+                if (!inf)
+                    area_sample_light(&sc->d->lights[idx], pos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
+                else
+                    inf_sample_light(&sc->inf, pos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
+            }
+
+            if (!is_black(radiance) && !intersect_any(sc, &shadowRay)) {
+                f3 fr;
+                float samplePdf;
+                eval_bsdf(sc, &material, neg3(r.d), shadowRay.d, nor, uv, dpdu, &fr, &samplePdf);
+                float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                Ld = add3(Ld, dvs3(scl3(mul3(scl3(fr, weight), radiance), fabsf(dot3(nor, shadowRay.d))),
+                                   lightPdf * choicePdf));
+            }
+
+            float usx = rng_uniform(&rng);
+            float usy = rng_uniform(&rng);
+            float usz = rng_uniform(&rng);
+            f3 us = mk3(usx, usy, usz);
+            f3 out, fr;
+            float pdf;
+            sample_bsdf(sc, &material, neg3(r.d), nor, uv, dpdu, us, &out, &fr, &pdf);
+            if (!(is_black(fr) || pdf == 0)) {
+                isect_t lightIsect;
+                lightIsect.lightIdx = -1;
+                ray_t lightRay = mk_ray(pos, out, sc->eps, INFINITY);
+                if (intersect_closest(sc, &lightRay, &lightIsect)) {
+                    f3 p = lightIsect.pos;
+                    f3 n = lightIsect.nor;
+                    f3 radiance2 = mk3(0.f, 0.f, 0.f);
+                    if (lightIsect.lightIdx != -1)
+                        radiance2 = area_le(&sc->d->lights[lightIsect.lightIdx], n, neg3(lightRay.d));
+                    if (!is_black(radiance2)) {
+                        float pdfA = 1.f / tri_surface_area(&sc->d->lights[lightIsect.lightIdx].triangle); /* area.h:28-32 */
+                        float choicePdf2 = pdf_from_light_distribution(sc, lightIsect.lightIdx);
+                        f3 pp = sub3(p, pos);
+                        float lenSquare = dot3(pp, pp);
+                        float costheta = fabsf(dot3(n, lightRay.d));
+                        float lPdf = pdfA * lenSquare / (costheta);
+                        float weight = power_heuristic(1, pdf, 1, lPdf * choicePdf2);
+                        Ld = add3(Ld, dvs3(scl3(mul3(scl3(fr, weight), radiance2), fabsf(dot3(out, nor))), pdf));
+                    }
+                } else {
+                    if (sc->inf.isvalid) {
+                        f3 radiance2 = inf_lookup(&sc->inf, lightRay.d);
+                        float choicePdf2 = pdf_from_light_distribution(sc, sc->d->n_lights);
+                        float lightPdf2 = ONE_OVER_FOUR_PI;                       /* infinite.h:38-41 */
+                        float weight = power_heuristic(1, pdf, 1, lightPdf2 * choicePdf2);
+                        Ld = add3(Ld, dvs3(scl3(mul3(scl3(fr, weight), radiance2), fabsf(dot3(out, nor))), pdf));
+                    }
+                }
+            }
+            Li = add3(Li, mul3(beta, Ld));
+        }
+
+        float ux = rng_uniform(&rng);
+        float uy = rng_uniform(&rng);
+        float uz = rng_uniform(&rng);
+        f3 u = mk3(ux, uy, uz);
+        f3 out, fr;
+        float pdf;
+        sample_bsdf(sc, &material, neg3(r.d), nor, uv, dpdu, u, &out, &fr, &pdf);
+        if (is_black(fr))
+            break;
+
+        beta = mul3(beta, dvs3(scl3(fr, fabsf(dot3(nor, out))), pdf));
+        specular = is_delta(material.type);
+
+        r = mk_ray(pos, out, sc->eps, INFINITY);
+
+        if (bounces > 3) {
+            float illumate = clampf(1.f - luminance(beta), 0.f, 1.f);
+            if (rng_uniform(&rng) < illumate)
+                break;
+            beta = dvs3(beta, 1 - illumate);
+        }
+    }
+
+    if (!is_inf3(Li) && !is_nan3(Li)) {
+        *Li_out = Li;
+        return 1;
+    }
+    return 0;
+}
+
+/* ---- Output: pathtracer.cu:187-204, 2516-2531 ---------------------------------------------------------- */
+static inline f3 tonemap(f3 color, int filmic)
+{
+    if (filmic) {
+        f3 c = adds3(color, -0.004f);
+        c = mk3(gpt_fmaxf(0, c.x), gpt_fmaxf(0, c.y), gpt_fmaxf(0, c.z));
+        f3 num = mul3(c, adds3(scl3(c, 6.2f), 0.5f));
+        f3 den = adds3(mul3(c, adds3(scl3(c, 6.2f), 1.7f)), 0.06f);
+        return div3(num, den);
+    } else {
+        float one_over_gamma = 1.f / 2.2f;
+        float exposure = 1.41421356f;
+        f3 in = mk3(gpt_fmaxf(color.x, 1e-5f), gpt_fmaxf(color.y, 1e-5f), gpt_fmaxf(color.z, 1e-5f));
+        in.x = M_POW(in.x * exposure, one_over_gamma);
+        in.y = M_POW(in.y * exposure, one_over_gamma);
+        in.z = M_POW(in.z * exposure, one_over_gamma);
+        return in;
+    }
+}
+
+/*
+ * One or more Render() calls (pathtracer.cu:2705-2750) for iter = iter_first ..
+ * iter_first+iter_count-1.  `acc` (kernel_acc_image) and `color` (kernel_color)
+ * are W*H*3 floats of persistent state owned by the caller; `out` (nullable)
+ * receives tonemap(acc/iter) of the last iteration.  `reset` zeroes acc before
+ * the first iteration of this call.  Pixel addressing follows the reference's
+ * launch geometry: stride = 32*(W/32), rows = 4*(H/4) (pathtracer.cu:881-883,2709).
+ * Only rows with (y/4) % n_ranks == rank are rendered (multi-GPU tile ownership;
+ * rank=0,n_ranks=1 renders everything).
+ */
+API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_t width, uint32_t height,
+                      float eps, uint32_t iter_first, uint32_t iter_count, int reset,
+                      float *acc, float *color, float *out, int rank, int n_ranks, int n_threads)
+{
+    if (desc->integrator_type != GPT_IT_PT) return -1;
+    scene_t sc;
+    sc.d = desc;
+    sc.eps = eps;
+    if (desc->infinite) sc.inf = *desc->infinite; else { memset(&sc.inf, 0, sizeof(sc.inf)); }
+    uint32_t stride = 32u * (width / 32u);
+    uint32_t rows = 4u * (height / 4u);
+    int maxDepth = desc->max_depth;
+    int filmic = cam->filmic;
+    if (n_threads < 1) n_threads = 1;
+    memset(&g_cnt, 0, sizeof(g_cnt));
+
+#pragma omp parallel num_threads(n_threads)
+    {
+        memset(&t_cnt, 0, sizeof(t_cnt));
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t y = 0; y < rows; ++y) {
+            if ((int)((y / 4u) % (uint32_t)n_ranks) != rank) continue;
+            for (uint32_t x = 0; x < stride; ++x) {
+                uint32_t pixel = x + y * stride;
+                f3 a = mk3(acc[3 * pixel], acc[3 * pixel + 1], acc[3 * pixel + 2]);
+                f3 c = mk3(color[3 * pixel], color[3 * pixel + 1], color[3 * pixel + 2]);
+                if (reset) a = mk3(0, 0, 0);
+                for (uint32_t it = iter_first; it < iter_first + iter_count; ++it) {
+                    f3 Li;
+                    if (path_sample(&sc, cam, x, y, pixel, it, maxDepth, &Li))
+                        c = Li;
+                    a = add3(a, c);
+                }
+                acc[3 * pixel] = a.x; acc[3 * pixel + 1] = a.y; acc[3 * pixel + 2] = a.z;
+                color[3 * pixel] = c.x; color[3 * pixel + 1] = c.y; color[3 * pixel + 2] = c.z;
+                if (out && iter_count > 0) {
+                    uint32_t last = iter_first + iter_count - 1;
+                    f3 o = tonemap(dvs3(a, (float)last), filmic);
+                    out[3 * pixel] = o.x; out[3 * pixel + 1] = o.y; out[3 * pixel + 2] = o.z;
+                }
+            }
+        }
+#pragma omp critical
+        {
+            g_cnt.node_visits += t_cnt.node_visits;
+            g_cnt.prim_tests += t_cnt.prim_tests;
+            g_cnt.bounce_iters += t_cnt.bounce_iters;
+            g_cnt.shadow_rays += t_cnt.shadow_rays;
+            g_cnt.closest_rays += t_cnt.closest_rays;
+            g_cnt.samples += t_cnt.samples;
+        }
+    }
+    return 0;
+}
+
+/* counters of the last oracle_render call: node visits, primitive tests, bounce
+ * iterations, shadow rays, closest-hit rays, samples */
+API void oracle_get_counters(uint64_t out6[6])
+{
+    out6[0] = g_cnt.node_visits; out6[1] = g_cnt.prim_tests; out6[2] = g_cnt.bounce_iters;
+    out6[3] = g_cnt.shadow_rays; out6[4] = g_cnt.closest_rays; out6[5] = g_cnt.samples;
+}
+
+/* ---- BVH build: bvh.cpp:38-173 ------------------------------------------------------------------------------ */
+typedef struct { f3 fmin, fmax; } bbox_t;
+static inline bbox_t bbox_empty(void) { bbox_t b; b.fmin = mk3(INFINITY, INFINITY, INFINITY); b.fmax = mk3(-INFINITY, -INFINITY, -INFINITY); return b; }
+static inline void bbox_expand_pt(bbox_t *b, f3 v)                    /* bbox.h:40-48 */
+{
+    b->fmin.x = gpt_fminf(b->fmin.x, v.x); b->fmin.y = gpt_fminf(b->fmin.y, v.y); b->fmin.z = gpt_fminf(b->fmin.z, v.z);
+    b->fmax.x = gpt_fmaxf(b->fmax.x, v.x); b->fmax.y = gpt_fmaxf(b->fmax.y, v.y); b->fmax.z = gpt_fmaxf(b->fmax.z, v.z);
+}
+static inline void bbox_expand_box(bbox_t *b, const bbox_t *o)        /* bbox.h:30-38 */
+{
+    b->fmin.x = gpt_fminf(o->fmin.x, b->fmin.x); b->fmin.y = gpt_fminf(o->fmin.y, b->fmin.y); b->fmin.z = gpt_fminf(o->fmin.z, b->fmin.z);
+    b->fmax.x = gpt_fmaxf(o->fmax.x, b->fmax.x); b->fmax.y = gpt_fmaxf(o->fmax.y, b->fmax.y); b->fmax.z = gpt_fmaxf(o->fmax.z, b->fmax.z);
+}
+static inline float bbox_surface_area(const bbox_t *b)               /* bbox.h:62-65 */
+{
+    f3 d = sub3(b->fmax, b->fmin);
+    return 2.f * (d.x * d.y + d.y * d.z + d.z * d.x);
+}
+static inline bbox_t tri_bbox(const gpt_triangle *t)                 /* mesh.h:29-37 */
+{
+    bbox_t b = bbox_empty();
+    bbox_expand_pt(&b, t->v1.v);
+    bbox_expand_pt(&b, t->v2.v);
+    bbox_expand_pt(&b, t->v3.v);
+    return b;
+}
+static inline float axis3(f3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+typedef struct build_node {
+    struct build_node *left, *right;
+    bbox_t bbox;
+    int is_leaf;
+    int *prims; int n_prims;
+} build_node;
+
+typedef struct {
+    const gpt_primitive *in;
+    int total_nodes;
+} build_ctx;
+
+static build_node *make_leaf(const int *idx, int n, const bbox_t *bbox)
+{
+    build_node *leaf = (build_node *)calloc(1, sizeof(build_node));
+    leaf->bbox = *bbox;
+    leaf->is_leaf = 1;
+    leaf->n_prims = n;
+    leaf->prims = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    memcpy(leaf->prims, idx, sizeof(int) * (size_t)n);
+    return leaf;
+}
+
+static build_node *bvh_split(build_ctx *ctx, const int *idx, int n, const bbox_t *bbox)
+{
+    ++ctx->total_nodes;
+    f3 diagonal = sub3(bbox->fmax, bbox->fmin);
+    if (n <= 4 || diagonal.x < 0.0001f || diagonal.y < 0.0001f || diagonal.z < 0.0001f)
+        return make_leaf(idx, n, bbox);
+
+    int best_axis = -1;
+    int best_bucket = 0;
+    float best_cost = (float)(size_t)n * bbox_surface_area(bbox);
+    enum { bucket_num = 12 };
+    for (int i = 0; i < 3; ++i) {
+        bbox_t bb[bucket_num];
+        int cnt[bucket_num];
+        for (int k = 0; k < bucket_num; ++k) { bb[k] = bbox_empty(); cnt[k] = 0; }
+        float value_start = axis3(bbox->fmin, i);
+        float value_end = axis3(bbox->fmax, i);
+        for (int j = 0; j < n; ++j) {
+            bbox_t bounds = tri_bbox(&ctx->in[idx[j]].triangle);
+            f3 center = scl3(add3(bounds.fmin, bounds.fmax), 0.5f);
+            float value = axis3(center, i);
+            int no = (int)((value - value_start) / (value_end - value_start) * bucket_num);
+            no = (no == 12) ? no - 1 : no;
+            cnt[no]++;
+            bbox_expand_box(&bb[no], &bounds);
+        }
+        for (int j = 1; j < bucket_num; ++j) {
+            bbox_t b0 = bbox_empty(), b1 = bbox_empty();
+            int count0 = 0, count1 = 0;
+            for (int k = 0; k < j; ++k) { bbox_expand_box(&b0, &bb[k]); count0 += cnt[k]; }
+            for (int k = j; k < bucket_num; ++k) { bbox_expand_box(&b1, &bb[k]); count1 += cnt[k]; }
+            float surface_a = (count0 == 0) ? 0 : bbox_surface_area(&b0) * count0;
+            float surface_b = (count1 == 0) ? 0 : bbox_surface_area(&b1) * count1;
+            float cost = surface_a + surface_b;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = i;
+                best_bucket = j;
+            }
+        }
+    }
+    if (best_axis == -1)
+        return make_leaf(idx, n, bbox);
+
+    int *left = (int *)malloc(sizeof(int) * (size_t)n);
+    int *right = (int *)malloc(sizeof(int) * (size_t)n);
+    int nl = 0, nr = 0;
+    bbox_t best_left = bbox_empty(), best_right = bbox_empty();
+    float value_start = axis3(bbox->fmin, best_axis);
+    float value_end = axis3(bbox->fmax, best_axis);
+    for (int i = 0; i < n; ++i) {
+        bbox_t bounds = tri_bbox(&ctx->in[idx[i]].triangle);
+        f3 center = scl3(add3(bounds.fmin, bounds.fmax), 0.5f);
+        float value = axis3(center, best_axis);
+        int no = (int)((value - value_start) / (value_end - value_start) * bucket_num);
+        no = (no == bucket_num) ? no - 1 : no;
+        if (no < best_bucket) { left[nl++] = idx[i]; bbox_expand_box(&best_left, &bounds); }
+        else { right[nr++] = idx[i]; bbox_expand_box(&best_right, &bounds); }
+    }
+    build_node *inner = (build_node *)calloc(1, sizeof(build_node));
+    inner->bbox = *bbox;
+    inner->is_leaf = 0;
+    inner->left = bvh_split(ctx, left, nl, &best_left);
+    inner->right = bvh_split(ctx, right, nr, &best_right);
+    free(left);
+    free(right);
+    return inner;
+}
+
+typedef struct {
+    const gpt_primitive *in;
+    gpt_primitive *prims_out; int n_prims_out;
+    gpt_bvh_node *nodes;
+} flat_ctx;
+
+/* bvh.cpp:153-173 with the intended (right-to-left) evaluation: preorder numbering */
+static void bvh_flatten(flat_ctx *f, build_node *node, int cur, int *next)
+{
+    gpt_bvh_node *ln = &f->nodes[cur];
+    memset(ln, 0, sizeof(*ln));
+    ln->fmin = node->bbox.fmin;
+    ln->fmax = node->bbox.fmax;
+    ln->is_leaf = (uint8_t)node->is_leaf;
+    ln->start = ln->end = -1;
+    if (node->n_prims) {
+        ln->start = f->n_prims_out;
+        for (int i = 0; i < node->n_prims; ++i)
+            f->prims_out[f->n_prims_out++] = f->in[node->prims[i]];
+        ln->end = f->n_prims_out - 1;
+    }
+    if (node->left) {
+        ++*next;
+        bvh_flatten(f, node->left, cur + 1, next);
+    }
+    if (node->right) {
+        ln->second_child_offset = *next + 1;
+        int c = ++*next;
+        bvh_flatten(f, node->right, c, next);
+    } else {
+        ln->second_child_offset = -1;
+    }
+}
+static void bvh_free(build_node *n)
+{
+    if (!n) return;
+    bvh_free(n->left);
+    bvh_free(n->right);
+    free(n->prims);
+    free(n);
+}
+
+/*
+ * BVH::build (bvh.cpp:18-36).  prims_out must hold n primitives, nodes_out
+ * 2*n (upper bound).  Returns the node count; root_box6 = fmin.xyz, fmax.xyz.
+ */
+API int oracle_bvh_build(const gpt_primitive *prims_in, int n, gpt_primitive *prims_out,
+                         gpt_bvh_node *nodes_out, float root_box6[6])
+{
+    if (n == 0) return 0;
+    bbox_t root_box = bbox_empty();
+    for (int i = 0; i < n; ++i) {
+        bbox_t b = tri_bbox(&prims_in[i].triangle);
+        bbox_expand_box(&root_box, &b);
+    }
+    int *idx = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    build_ctx ctx; ctx.in = prims_in; ctx.total_nodes = 0;
+    build_node *root = bvh_split(&ctx, idx, n, &root_box);
+    root->bbox = root_box;
+    free(idx);
+    flat_ctx f; f.in = prims_in; f.prims_out = prims_out; f.n_prims_out = 0; f.nodes = nodes_out;
+    int next = 0;
+    bvh_flatten(&f, root, 0, &next);
+    bvh_free(root);
+    root_box6[0] = root_box.fmin.x; root_box6[1] = root_box.fmin.y; root_box6[2] = root_box.fmin.z;
+    root_box6[3] = root_box.fmax.x; root_box6[4] = root_box.fmax.y; root_box6[5] = root_box.fmax.z;
+    return ctx.total_nodes;
+}
+
+/* ---- Scene::Init: scene.h:50-83 ------------------------------------------------------------------------------- */
+/* cdf_out must hold n_lights + 2 floats; returns the number written. */
+API int oracle_light_distribution(const gpt_area *lights, int n_lights, const gpt_infinite *inf, float *cdf_out)
+{
+    f3 luma = mk3(0.212671f, 0.715160f, 0.072169f);
+    float sum = 0.f;
+    int n = 0;
+    cdf_out[n++] = 0.f;
+    for (int i = 0; i < n_lights; ++i) {
+        f3 power = scl3(scl3(lights[i].radiance, tri_surface_area(&lights[i].triangle)), PI);   /* area.h:34-36 */
+        float p = dot3(luma, power);
+        sum += p;
+        cdf_out[n++] = sum;
+    }
+    if (inf && inf->isvalid) {
+        f3 power = scl3(inf->data[0], FOURPI * inf->radius * inf->radius);                    /* infinite.h:43-45 */
+        sum += dot3(luma, power);
+        cdf_out[n++] = sum;
+    }
+    for (int i = 0; i < n; ++i)
+        cdf_out[i] /= sum;
+    return n;
+}
+
+/* Infinite::Init -> BBox::boundingSphere (infinite.h:61-63, bbox.h:98-101) */
+API void oracle_infinite_init(gpt_infinite *inf, const float root_box6[6])
+{
+    f3 fmin = mk3(root_box6[0], root_box6[1], root_box6[2]);
+    f3 fmax = mk3(root_box6[3], root_box6[4], root_box6[5]);
+    inf->center = scl3(add3(fmin, fmax), 0.5f);
+    f3 d = sub3(fmax, inf->center);
+    inf->radius = sqrtf(dot3(d, d));
+}
+
+/* ---- per-function entry points for unit vectors --------------------------------------------------------------- */
+API void oracle_rng_table(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n)
+{
+    rng_t r;
+    uint32_t s = wang_hash(pixel) + wang_hash(iter);
+    *seed_out = s;
+    rng_seed(&r, s);
+    for (int i = 0; i < n; ++i) u_out[i] = rng_uniform(&r);
+}
+API float oracle_sinf(float x) { return M_SIN(x); }
+API float oracle_cosf(float x) { return M_COS(x); }
+API float oracle_tanf(float x) { return M_TAN(x); }
+API float oracle_atanf(float x) { return M_ATAN(x); }
+API float oracle_acosf(float x) { return M_ACOS(x); }
+API float oracle_powf(float x, float y) { return M_POW(x, y); }
+API void oracle_math_batch(int fn, const float *x, const float *y, float *out, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        switch (fn) {
+        case 0: out[i] = M_SIN(x[i]); break;
+        case 1: out[i] = M_COS(x[i]); break;
+        case 2: out[i] = M_TAN(x[i]); break;
+        case 3: out[i] = M_ATAN(x[i]); break;
+        case 4: out[i] = M_ACOS(x[i]); break;
+        case 5: out[i] = M_POW(x[i], y[i]); break;
+        case 6: out[i] = x[i] / y[i]; break;
+        case 7: out[i] = sqrtf(x[i]); break;
+        case 8: out[i] = 1.0f / sqrtf(x[i]); break;
+        default: out[i] = 0.f; break;
+        }
+    }
+}
+API int oracle_uses_softmath(void)
+{
+#ifdef ORACLE_SOFTMATH
+    return 1;
+#else
+    return 0;
+#endif
+}
