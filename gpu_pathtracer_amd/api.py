@@ -1,0 +1,202 @@
+"""ctypes binding of libgpt.so (include/gpt.h) — the C ABI behind the reference's
+BeginRender / Render / EndRender (reference src/pathtracer.h:10-12).
+
+Plumbing only.  There is no Python or CPU implementation behind these calls:
+if the HIP library is missing or no GPU is visible, they raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scene_types as st
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpt.so")
+
+_lib = None
+
+
+class GptError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgpt.so (built in-tree by `make -C gpu_pathtracer_amd/csrc` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GptError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
+    lib.gpt_last_error.restype = C.c_char_p
+    lib.gpt_version.restype = C.c_char_p
+    sig = {
+        "gpt_begin": [vp, u32, u32, f32, C.c_int, C.POINTER(vp)],
+        "gpt_set_tile_owner": [vp, C.c_int, C.c_int],
+        "gpt_render": [vp, vp, u32, u32, C.c_int, vp],
+        "gpt_tonemap": [vp, u32, C.c_int, vp],
+        "gpt_synchronize": [vp],
+        "gpt_read_accum": [vp, vp],
+        "gpt_read_color": [vp, vp],
+        "gpt_write_state": [vp, vp, vp],
+        "gpt_copy_to_host": [vp, vp, vp, C.c_size_t],
+        "gpt_end": [vp],
+        "gpt_kernel_time": [vp, C.POINTER(u32), C.POINTER(C.c_double)],
+        "gpt_kernel_time_reset": [vp],
+        "gpt_enable_counters": [vp, C.c_int],
+        "gpt_read_counters": [vp, vp],
+        "gpt_debug_math": [C.c_int, C.c_int, vp, vp, vp, C.c_int],
+        "gpt_debug_rng": [C.c_int, u32, u32, vp, vp, C.c_int],
+        "gpt_bvh_build": [vp, i32, vp, vp, C.POINTER(i32), vp],
+        "gpt_light_distribution": [vp, i32, vp, vp, C.POINTER(i32)],
+        "gpt_infinite_init": [vp, vp],
+        "gpt_camera_init": [vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, C.c_int, C.c_int],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name in ("gpt_accum_device_ptr", "gpt_color_device_ptr"):
+        fn = getattr(lib, name)
+        fn.argtypes = [vp]
+        fn.restype = vp
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GptError(f"gpt error {rc}: {load().gpt_last_error().decode()}")
+
+
+# ---- host-side preparation (CPU) ----------------------------------------------
+
+def bvh_build(prims):
+    lib = load()
+    prims = np.ascontiguousarray(prims)
+    n = len(prims)
+    out = np.zeros(n, dtype=st.PRIMITIVE)
+    nodes = np.zeros(max(1, 2 * n), dtype=st.BVH_NODE)
+    box = np.zeros(6, dtype=np.float32)
+    nn = C.c_int32(0)
+    check(lib.gpt_bvh_build(st.ptr(prims), n, st.ptr(out), st.ptr(nodes), C.byref(nn), st.ptr(box)))
+    return out, nodes[: nn.value].copy(), box
+
+
+def light_distribution(lights, infinite=None):
+    lib = load()
+    cdf = np.zeros(len(lights) + 2, dtype=np.float32)
+    n = C.c_int32(0)
+    check(lib.gpt_light_distribution(st.ptr(lights), len(lights), C.byref(infinite) if infinite is not None else None,
+                                     st.ptr(cdf), C.byref(n)))
+    return cdf[: n.value].copy()
+
+
+def camera_init(position, lookat, up=(0, 1, 0), res=(512, 512), fov=60.0, aperture=0.0, focal=0.0, distance=0.1,
+                filmic=True, environment=False):
+    cam = st.Camera()
+    p, la, u = (C.c_float * 3)(*position), (C.c_float * 3)(*lookat), (C.c_float * 3)(*up)
+    check(load().gpt_camera_init(C.byref(cam), p, la, u, float(res[0]), float(res[1]), float(distance), float(fov),
+                                 float(aperture), float(focal), int(filmic), int(environment)))
+    return cam
+
+
+# ---- renderer --------------------------------------------------------------------
+
+class Renderer:
+    """gpt_begin .. gpt_end around one scene; mirrors BeginRender/Render/EndRender."""
+
+    def __init__(self, desc, width, height, epsilon, device=0):
+        self.lib = load()
+        self.width, self.height = int(width), int(height)
+        self.ctx = C.c_void_p()
+        check(self.lib.gpt_begin(C.byref(desc), self.width, self.height, float(epsilon), int(device), C.byref(self.ctx)))
+
+    def set_tile_owner(self, rank, n_ranks):
+        check(self.lib.gpt_set_tile_owner(self.ctx, rank, n_ranks))
+
+    def render(self, camera, iter_first, iter_count, reset=False, out_dev=None):
+        check(self.lib.gpt_render(self.ctx, C.byref(camera), int(iter_first), int(iter_count), int(bool(reset)), out_dev))
+
+    def tonemap(self, iteration, filmic, out_dev):
+        check(self.lib.gpt_tonemap(self.ctx, int(iteration), int(bool(filmic)), out_dev))
+
+    def synchronize(self):
+        check(self.lib.gpt_synchronize(self.ctx))
+
+    def accum_ptr(self):
+        return self.lib.gpt_accum_device_ptr(self.ctx)
+
+    def color_ptr(self):
+        return self.lib.gpt_color_device_ptr(self.ctx)
+
+    def read_accum(self):
+        a = np.empty(self.width * self.height * 3, dtype=np.float32)
+        check(self.lib.gpt_read_accum(self.ctx, st.ptr(a)))
+        return a
+
+    def read_color(self):
+        a = np.empty(self.width * self.height * 3, dtype=np.float32)
+        check(self.lib.gpt_read_color(self.ctx, st.ptr(a)))
+        return a
+
+    def read_device(self, dev_ptr, n_floats):
+        a = np.empty(n_floats, dtype=np.float32)
+        check(self.lib.gpt_copy_to_host(self.ctx, dev_ptr, st.ptr(a), n_floats))
+        return a
+
+    def write_state(self, acc, color):
+        acc = np.ascontiguousarray(acc, dtype=np.float32)
+        color = np.ascontiguousarray(color, dtype=np.float32)
+        check(self.lib.gpt_write_state(self.ctx, st.ptr(acc), st.ptr(color)))
+
+    def kernel_time(self):
+        n, ms = C.c_uint32(0), C.c_double(0)
+        check(self.lib.gpt_kernel_time(self.ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def kernel_time_reset(self):
+        check(self.lib.gpt_kernel_time_reset(self.ctx))
+
+    def enable_counters(self, on=True):
+        check(self.lib.gpt_enable_counters(self.ctx, int(on)))
+
+    def read_counters(self):
+        c = np.zeros(6, dtype=np.uint64)
+        check(self.lib.gpt_read_counters(self.ctx, st.ptr(c)))
+        names = ["node_visits", "prim_tests", "bounce_iters", "shadow_rays", "closest_rays", "samples"]
+        return dict(zip(names, map(int, c)))
+
+    def close(self):
+        if self.ctx:
+            self.lib.gpt_end(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def debug_math(fn, x, y=None, device=0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else x, dtype=np.float32)
+    out = np.empty_like(x)
+    check(load().gpt_debug_math(device, fn, st.ptr(x), st.ptr(y), st.ptr(out), len(x)))
+    return out
+
+
+def debug_rng(pixel, iteration, n, device=0):
+    seed = C.c_uint32(0)
+    u = np.zeros(n, dtype=np.float32)
+    check(load().gpt_debug_rng(device, pixel, iteration, C.byref(seed), st.ptr(u), n))
+    return seed.value, u

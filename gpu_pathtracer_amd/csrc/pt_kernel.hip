@@ -1,0 +1,1116 @@
+// pt_kernel.hip — the per-pixel-sample path-tracing kernel for gfx950 (MI355X).
+//
+// Replaces the reference's `Path` + `Output` kernels (reference
+// src/pathtracer.cu:880-1021, 2516-2531) and everything they call:
+//   camera ray            src/camera.h:48-84
+//   BVH traversal         src/pathtracer.cu:214-296, src/bbox.h:77-96
+//   ray/triangle          src/mesh.h:45-98
+//   BSDF sample / eval    src/pathtracer.cu:491-826 (+ helpers :51-169)
+//   textures              src/pathtracer.cu:324-359
+//   area / env lights     src/area.h:14-41, src/infinite.h:17-94, src/pathtracer.cu:172-185
+//   RNG                   src/pathtracer.cu:40-49,888-889 (WangHash + thrust minstd_rand)
+//
+// Design (not a translation of the CUDA kernel, which is one thread per
+// pixel-sample, one launch per spp, a 64-int private stack and 176-byte AoS
+// primitive fetches):
+//   * ONE launch renders a whole batch of iterations.  Waves are persistent:
+//     each 64-lane wavefront pulls 8x8-pixel tiles from a global atomic queue
+//     and one lane owns one pixel for all iterations of the batch, so the
+//     accumulator (acc += sample, in iteration order, exactly the reference's
+//     fp32 summation order) lives in registers; the film is read and written
+//     once per launch instead of 48 B/pixel/spp.
+//   * Path regeneration: a lane whose path ends starts its next sample in the
+//     same loop trip, so every lane carries a live path into every
+//     closest-hit traversal.
+//   * Traversal is threaded ("escape index") preorder: identical visit order
+//     to the reference's push-right/push-left stack, but stackless — no
+//     scratch, no LDS traffic, and the per-ray 1/d is hoisted.
+//   * Nodes are 32 B, triangles 48 B (pt_layout.h): aligned 16-byte gathers.
+//   * The hit record is built once per ray from (prim, b1, b2, t), not on every
+//     accepted candidate.
+//   * Float contract: no FMA contraction, IEEE divide/sqrt, soft-math
+//     transcendentals (include/gpt_softmath.h) — the same operation sequence as
+//     oracle/pt_oracle.c, so parity is checked bit for bit.
+//
+// Draw order inside argument lists is left to right.
+
+#include <hip/hip_runtime.h>
+#include "pt_layout.h"
+
+namespace pt {
+
+// ---------------------------------------------------------------- RNG --------
+struct Rng {
+    uint32_t x;
+};
+__device__ __forceinline__ uint32_t wang_hash(uint32_t seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed = seed + (seed << 3);
+    seed = seed ^ (seed >> 4);
+    seed = seed * 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+__device__ __forceinline__ void rng_seed(Rng &r, uint32_t s)
+{
+    uint32_t x = s % 2147483647u;     // minstd_rand::seed
+    r.x = x == 0 ? 1u : x;
+}
+// x <- x * 48271 mod (2^31 - 1) without a 64-bit division: for p < 2^47,
+// p mod (2^31-1) = (p & m) + (p >> 31), minus m once if that reaches m.
+__device__ __forceinline__ float rng_uniform(Rng &r)
+{
+    uint64_t p = (uint64_t)r.x * 48271ull;
+    uint32_t s = (uint32_t)(p & 0x7fffffffu) + (uint32_t)(p >> 31);
+    if (s >= 2147483647u) s -= 2147483647u;
+    r.x = s;
+    // uniform_real_distribution<float>(0,1): float(x - 1) / 2^31 (exact scaling)
+    return (float)(s - 1u) * 4.656612873077392578125e-10f;
+}
+
+// -------------------------------------------------------------- records ------
+struct Ray {
+    V3 o, d;
+    float tmin, tmax;
+};
+struct Hit {
+    V3 pos, nor;
+    V2 uv;
+    V3 dpdu;
+    int matIdx, lightIdx;
+};
+struct Counters {
+    uint32_t node_visits, prim_tests, bounce_iters, shadow_rays, closest_rays, samples;
+};
+
+__device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+
+// ------------------------------------------------------------ traversal ------
+// Closest hit (ANY=false): shrinks tmax, records (prim, b1, b2).  Any hit
+// (ANY=true): returns at the first accepted triangle.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool traverse(const DevParams &P, const Ray &ray, float &tmax_io, int &hit_prim,
+                                         float &hit_b1, float &hit_b2, Counters &cnt)
+{
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(P.tris);
+    const V3 o = ray.o, d = ray.d;
+    // bbox.h:79 computes 1/d per node visit; the quotient is the same every time
+    const V3 inv = V3{1.f / d.x, 1.f / d.y, 1.f / d.z};
+    const float tmin_ray = ray.tmin;
+    float tmax = tmax_io;
+    bool hit = false;
+    int idx = 0;
+    const int end = P.n_nodes;
+    while (idx < end) {
+        // ---- node phase: walk until a leaf whose box is hit --------------------
+        int leaf_first = 0, leaf_last = -1;
+        while (idx < end) {
+            const float4 a = nodes[2 * idx];
+            const float4 b = nodes[2 * idx + 1];
+            if (COUNT) cnt.node_visits++;
+            const float t1 = (a.x - o.x) * inv.x;
+            const float t2 = (a.w - o.x) * inv.x;
+            const float t3 = (a.y - o.y) * inv.y;
+            const float t4 = (b.x - o.y) * inv.y;
+            const float t5 = (a.z - o.z) * inv.z;
+            const float t6 = (b.y - o.z) * inv.z;
+            const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
+            const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
+            // bbox.h:91-95, with the reference's comparison senses (NaN passes)
+            const bool box = !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
+            const int link = __float_as_int(b.z);
+            const int last = __float_as_int(b.w);
+            const bool leaf = last >= 0;
+            const int next = (box || leaf) ? idx + 1 : link;
+            idx = next;
+            if (box && leaf) {
+                leaf_first = link;
+                leaf_last = last;
+                break;
+            }
+        }
+        // ---- leaf phase: Moeller-Trumbore, mesh.h:45-67 ------------------------
+        for (int i = leaf_first; i <= leaf_last; ++i) {
+            const float4 q0 = tris[3 * i];
+            const float4 q1 = tris[3 * i + 1];
+            const float e2z = reinterpret_cast<const float *>(tris + 3 * i + 2)[0];
+            if (COUNT) cnt.prim_tests++;
+            const V3 v1 = V3{q0.x, q0.y, q0.z};
+            const V3 e1 = V3{q0.w, q1.x, q1.y};
+            const V3 e2 = V3{q1.z, q1.w, e2z};
+            const V3 s1 = cross(d, e2);
+            const float divisor = dot(s1, e1);
+            if (fabs_(divisor) < 1e-8f) continue;
+            // reference: float invDivisor = 1.0 / divisor (double divide, rounded to
+            // float) == the correctly rounded float quotient (53 >= 2*24+2 bits)
+            const float invDivisor = 1.0f / divisor;
+            const V3 s = o - v1;
+            const float b1 = dot(s, s1) * invDivisor;
+            if (b1 < 0.0f || b1 > 1.0f) continue;
+            const V3 s2 = cross(s, e1);
+            const float b2 = dot(d, s2) * invDivisor;
+            if (b2 < 0.0f || b1 + b2 > 1.0f) continue;
+            const float tt = dot(e2, s2) * invDivisor;
+            if (tt < tmin_ray || tt > tmax) continue;
+            tmax = tt;
+            hit = true;
+            if (ANY) {
+                tmax_io = tmax;
+                return true;
+            }
+            hit_prim = i;
+            hit_b1 = b1;
+            hit_b2 = b2;
+        }
+    }
+    tmax_io = tmax;
+    return hit;
+}
+
+// mesh.h:68-95 evaluated once for the final hit
+__device__ __forceinline__ Hit make_hit(const DevParams &P, const Ray &ray, float tt, int prim, float b1, float b2)
+{
+    const float4 *__restrict__ sp = reinterpret_cast<const float4 *>(P.shade) + 5 * prim;
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+    const V3 n1 = V3{s0.x, s0.y, s0.z}, n2 = V3{s0.w, s1.x, s1.y}, n3 = V3{s1.z, s1.w, s2.x};
+    const V2 uv1 = V2{s2.y, s2.z}, uv2 = V2{s2.w, s3.x}, uv3 = V2{s3.y, s3.z};
+    const V3 ndpdv = V3{s3.w, s4.x, s4.y};
+    Hit h;
+    h.pos = ray.o + tt * ray.d;
+    h.nor = normalize(n1 * (1.f - b1 - b2) + n2 * b1 + n3 * b2);
+    h.uv = uv1 * (1.f - b1 - b2) + uv2 * b1 + uv3 * b2;
+    h.matIdx = __float_as_int(s4.z);
+    h.lightIdx = __float_as_int(s4.w);
+    h.dpdu = normalize(cross(h.nor, ndpdv));
+    return h;
+}
+
+// ------------------------------------------------------------- samplers ------
+__device__ __forceinline__ V3 to_world(V3 dir, V3 u, V3 v, V3 w) { return dir.x * u + dir.y * v + dir.z * w; }
+
+__device__ __forceinline__ V3 cosine_hemisphere(float u1, float u2, float &pdf)   // wrap.h:51-62
+{
+    float sintheta = sqrt_rn(u1);
+    float costheta = sqrt_rn(1.f - u1);
+    float phi = TWOPI * u2;
+    float cosphi = gpt_cosf(phi);
+    float sinphi = gpt_sinf(phi);
+    pdf = costheta * ONE_OVER_PI;
+    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+}
+__device__ __forceinline__ V3 uniform_sphere(float u1, float u2, float &pdf)      // wrap.h:26-36
+{
+    float costheta = 1.f - 2.f * u1;
+    float sintheta = sqrt_rn(1.f - costheta * costheta);
+    float phi = TWOPI * u2;
+    float cosphi = gpt_cosf(phi);
+    float sinphi = gpt_sinf(phi);
+    pdf = ONE_OVER_FOUR_PI;
+    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+}
+
+// --------------------------------------------------------------- camera ------
+__device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y, V2 xy)   // camera.h:48-84
+{
+    const V3 cu = V3{c.u.x, c.u.y, c.u.z}, cv = V3{c.v.x, c.v.y, c.v.z}, cw = V3{c.w.x, c.w.y, c.w.z};
+    Ray ray;
+    ray.tmin = 0.001f;
+    ray.tmax = __builtin_inff();
+    V3 orig = V3{c.position.x, c.position.y, c.position.z};
+    if (c.environment) {
+        float theta = PI * (1.f - y / c.resolution.y);
+        float phi = TWOPI * (1.f - x / c.resolution.x);
+        V3 dir = v3(gpt_sinf(theta) * gpt_cosf(phi), gpt_cosf(theta), gpt_sinf(theta) * gpt_sinf(phi));
+        dir = dir.x * cu + dir.y * cv - dir.z * cw;
+        ray.o = orig;
+        ray.d = dir;
+        return ray;
+    }
+    float xx = x * c.pixel2screen.x - c.width;
+    float yy = y * c.pixel2screen.y - c.height;
+    V3 dir;
+    if (c.apertureRadius > 0.00001f) {
+        V2 aperture_xy = xy * c.apertureRadius;
+        float focal_x = c.ratio * xx;
+        float focal_y = c.ratio * yy;
+        V3 aperture = v3(aperture_xy.x, aperture_xy.y, 0);
+        V3 focal = v3(focal_x, focal_y, -c.focalDistance);
+        dir = focal - aperture;
+        dir = dir.x * cu + dir.y * cv + dir.z * cw;
+        orig += (aperture.x * cu + aperture.y * cv);
+    } else {
+        dir = xx * cu + yy * cv + -c.distance * cw;
+    }
+    dir = normalize(dir);
+    ray.o = orig;
+    ray.d = dir;
+    return ray;
+}
+
+// ------------------------------------------------------------- textures ------
+__device__ __forceinline__ V4 texel_int(const DevTexture &t, int w, int h, int x, int y)   // pathtracer.cu:324-339
+{
+    float inv = 1.f / 255.f;
+    float rx = x - (x / w) * w;
+    float ry = y - (y / h) * h;
+    x = (rx < 0) ? rx + w : rx;
+    y = (ry < 0) ? ry + h : ry;
+    if (x < 0) x = 0;
+    if (x > w - 1) x = w - 1;
+    if (y < 0) y = 0;
+    if (y > h - 1) y = h - 1;
+    gpt_uchar4 c = t.data[y * w + x];
+    return v4(c.x * inv, c.y * inv, c.z * inv, c.w * inv);
+}
+__device__ __forceinline__ V3 get_texel(const DevParams &P, const gpt_material &m, V2 uv)   // pathtracer.cu:341-359
+{
+    if (m.textureIdx == -1)
+        return V3{m.diffuse.x, m.diffuse.y, m.diffuse.z};
+    const DevTexture t = P.textures[m.textureIdx];
+    int w = t.width, h = t.height;
+    float xx = w * uv.x;
+    float yy = h * uv.y;
+    int x = (int)__builtin_floorf(xx);
+    int y = (int)__builtin_floorf(yy);
+    float dx = fabs_(xx - x);
+    float dy = fabs_(yy - y);
+    V4 c00 = texel_int(t, w, h, x, y);
+    V4 c10 = texel_int(t, w, h, x + 1, y);
+    V4 c01 = texel_int(t, w, h, x, y + 1);
+    V4 c11 = texel_int(t, w, h, x + 1, y + 1);
+    V4 r = (1 - dy) * ((1 - dx) * c00 + dx * c10) + dy * ((1 - dx) * c01 + dx * c11);
+    return V3{r.x, r.y, r.z};
+}
+
+// --------------------------------------------------------- BSDF helpers ------
+__device__ __forceinline__ float dielectric_fresnel(float cosi, float cost, float etai, float etat)   // :51-56
+{
+    float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
+    float Rperp = (etai * cosi - etat * cost) / (etai * cosi + etat * cost);
+    return (Rparl * Rparl + Rperp * Rperp) * 0.5f;
+}
+__device__ __forceinline__ V3 conduct_fresnel(float cosi, V3 eta, V3 k)                              // :58-66
+{
+    V3 tmp = (eta * eta + k * k) * cosi * cosi;
+    V3 Rparl2 = (tmp - eta * cosi * 2.f + 1.f) / (tmp + eta * cosi * 2.f + 1.f);
+    V3 tmp_f = (eta * eta + k * k);
+    V3 Rperp2 = (tmp_f - eta * cosi * 2.f + cosi * cosi) / (tmp_f + eta * cosi * 2.f + cosi * cosi);
+    return (Rparl2 + Rperp2) * 0.5f;
+}
+__device__ __forceinline__ float ggx_d(V3 wh, V3 normal, V3 dpdu, float alphaU, float alphaV)        // :68-84
+{
+    float costheta = dot(wh, normal);
+    if (costheta <= 0.f) return 0.f;
+    costheta = clamp(costheta, 0.f, 1.f);
+    float costheta2 = costheta * costheta;
+    float sintheta2 = 1.f - costheta2;
+    float costheta4 = costheta2 * costheta2;
+    float tantheta2 = sintheta2 / costheta2;
+    V3 uu = dpdu;
+    V3 dir = normalize(wh - costheta * normal);
+    float cosphi = dot(dir, uu);
+    float cosphi2 = cosphi * cosphi;
+    float sinphi2 = 1.f - cosphi2;
+    float sqrD = 1.f + tantheta2 * (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
+    return 1.f / (PI * alphaU * alphaV * costheta4 * sqrD * sqrD);
+}
+__device__ __forceinline__ float smith_g(V3 w, V3 normal, V3 wh, V3 dpdu, float alphaU, float alphaV)  // :86-101
+{
+    float wdn = dot(w, normal);
+    if (wdn * dot(w, wh) < 0.f) return 0.f;
+    float sintheta = sqrt_rn(clamp(1.f - wdn * wdn, 0.f, 1.f));
+    float tantheta = sintheta / wdn;
+    if (gpt_isinff(tantheta)) return 0.f;
+    V3 uu = dpdu;
+    V3 dir = normalize(w - wdn * normal);
+    float cosphi = dot(dir, uu);
+    float cosphi2 = cosphi * cosphi;
+    float sinphi2 = 1.f - cosphi2;
+    float alpha2 = cosphi2 * (alphaU * alphaU) + sinphi2 * (alphaV * alphaV);
+    float sqrD = alpha2 * tantheta * tantheta;
+    return 2.f / (1.f + sqrt_rn(1 + sqrD));
+}
+__device__ __forceinline__ float ggx_g(V3 wo, V3 wi, V3 normal, V3 wh, V3 dpdu, float aU, float aV)    // :103-105
+{
+    return smith_g(wo, normal, wh, dpdu, aU, aV) * smith_g(wi, normal, wh, dpdu, aU, aV);
+}
+__device__ __forceinline__ V3 sample_ggx(float alphaU, float alphaV, float u1, float u2)              // :107-138
+{
+    if (alphaU == alphaV) {
+        float costheta = sqrt_rn((1.f - u1) / (u1 * (alphaU * alphaV - 1.f) + 1.f));
+        float sintheta = sqrt_rn(1.f - costheta * costheta);
+        float phi = 2 * PI * u2;
+        float cosphi = gpt_cosf(phi);
+        float sinphi = gpt_sinf(phi);
+        return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+    } else {
+        float phi;
+        if (u2 <= 0.25f) phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2));
+        else if (u2 >= 0.75f) phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2)) + TWOPI;
+        else phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2)) + PI;
+        float sinphi = gpt_sinf(phi), cosphi = gpt_cosf(phi);
+        float sinphi2 = sinphi * sinphi;
+        float cosphi2 = 1.0f - sinphi2;
+        float inverseA = 1.0f / (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
+        float theta = gpt_atanf(sqrt_rn(inverseA * u1 / (1.0f - u1)));
+        float sintheta = gpt_sinf(theta), costheta = gpt_cosf(theta);
+        return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+    }
+}
+__device__ __forceinline__ V3 reflect(V3 in, V3 nor) { return 2.f * dot(in, nor) * nor - in; }       // :140-142
+__device__ __forceinline__ V3 refract(V3 in, V3 nor, float etai, float etat)                          // :144-158
+{
+    float cosi = dot(in, nor);
+    bool enter = cosi > 0;
+    if (!enter) {
+        float t = etai;
+        etai = etat;
+        etat = t;
+    }
+    float eta = etai / etat;
+    float sini2 = 1.f - cosi * cosi;
+    float sint2 = sini2 * eta * eta;
+    float cost = sqrt_rn(1.f - sint2);
+    return normalize((nor * cosi - in) * eta + (enter ? -cost : cost) * nor);
+}
+__device__ __forceinline__ V3 schlick_fresnel(V3 specular, float costheta)                            // :160-164
+{
+    V3 rs = specular;
+    float c = 1.f - costheta;
+    return rs + c * c * c * c * c * (v3(1.f, 1.f, 1.f) - rs);
+}
+__device__ __forceinline__ float power_heuristic(int nf, float fPdf, int ng, float gPdf)              // :166-169
+{
+    float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+__device__ __forceinline__ float luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)); }
+__device__ __forceinline__ bool same_hemisphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }
+__device__ __forceinline__ bool is_delta(int type) { return type == GPT_MT_MIRROR || type == GPT_MT_DIELECTRIC; }
+__device__ __forceinline__ float max_(float a, float b) { return a > b ? a : b; }                     // common.h:98-101
+
+// ------------------------------------------------- SampleBSDF, :491-695 ------
+__device__ __forceinline__ void sample_bsdf(const DevParams &P, const gpt_material &material, V3 in, V3 nor, V2 uv,
+                                            V3 dpdu, V3 u, V3 &out, V3 &fr, float &pdf)
+{
+    const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
+    switch (material.type) {
+    case GPT_MT_LAMBERTIAN: {
+        V3 n = nor;
+        if (dot(nor, in) < 0)
+            n = -n;
+        out = cosine_hemisphere(u.x, u.y, pdf);
+        V3 uu = dpdu, ww;
+        ww = cross(uu, n);
+        out = to_world(out, uu, n, ww);
+        fr = get_texel(P, material, uv) * ONE_OVER_PI;
+        break;
+    }
+    case GPT_MT_MIRROR:
+        out = reflect(in, nor);
+        fr = m_spec / fabs_(dot(out, nor));
+        pdf = 1.f;
+        break;
+    case GPT_MT_DIELECTRIC: {
+        V3 wi = -in;
+        V3 normal = nor;
+        float ei = material.outsideIOR, et = material.insideIOR;
+        float cosi = dot(wi, normal);
+        bool enter = cosi < 0;
+        if (!enter) {
+            float t = ei;
+            ei = et;
+            et = t;
+        }
+        float eta = ei / et, cost;
+        float sint2 = eta * eta * (1.f - cosi * cosi);
+        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+        V3 rdir = reflect(-wi, normal);
+        V3 tdir = refract(in, nor, material.outsideIOR, material.insideIOR);
+        if (sint2 > 1.f) {   // total reflection
+            out = rdir;
+            fr = m_spec / fabs_(dot(out, normal));
+            pdf = 1.f;
+            return;
+        }
+        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
+        if (u.x > fresnel) {   // refract
+            out = tdir;
+            fr = m_spec / fabs_(dot(out, normal)) * (1.f - fresnel);
+            fr *= eta * eta;   // TransportMode::Radiance
+            pdf = 1.f - fresnel;
+        } else {               // reflect
+            out = rdir;
+            fr = m_spec / fabs_(dot(out, normal)) * fresnel;
+            pdf = fresnel;
+        }
+        break;
+    }
+    case GPT_MT_ROUGHCONDUCTOR: {
+        V3 n = nor;
+        if (dot(nor, in) < 0)
+            n = -n;
+        V3 wh = sample_ggx(material.alphaU, material.alphaV, u.x, u.y);
+        V3 uu = dpdu, ww;
+        ww = cross(uu, n);
+        wh = to_world(wh, uu, n, ww);
+        out = reflect(in, wh);
+        if (!same_hemisphere(in, out, nor)) {
+            fr = v3(0, 0, 0);
+            pdf = 0.f;
+            return;
+        }
+        float cosi = dot(out, wh);
+        V3 F = conduct_fresnel(fabs_(cosi), V3{material.eta.x, material.eta.y, material.eta.z},
+                               V3{material.k.x, material.k.y, material.k.z});
+        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
+        float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+        fr = m_spec * F * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
+        pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(in, wh)));
+        break;
+    }
+    case GPT_MT_SUBSTRATE: {
+        V3 n = nor;
+        if (dot(nor, in) < 0)
+            n = -n;
+        if (u.x < 0.5f) {
+            float ux = u.x * 2.f;
+            out = cosine_hemisphere(ux, u.y, pdf);
+            V3 uu = dpdu, ww;
+            ww = cross(uu, n);
+            out = to_world(out, uu, n, ww);
+        } else {
+            float ux = (u.x - 0.5f) * 2.f;
+            V3 wh = sample_ggx(material.alphaU, material.alphaV, ux, u.y);
+            V3 uu = dpdu, ww;
+            ww = cross(uu, n);
+            wh = to_world(wh, uu, n, ww);
+            out = reflect(in, wh);
+        }
+        if (!same_hemisphere(in, out, n)) {
+            fr = v3(0.f, 0.f, 0.f);
+            pdf = 0.f;
+            return;
+        }
+        float c0 = fabs_(dot(in, n));
+        float c1 = fabs_(dot(out, n));
+        V3 Rd = get_texel(P, material, uv);
+        V3 Rs = m_spec;
+        float cons0 = 1 - 0.5f * c0;
+        float cons1 = 1 - 0.5f * c1;
+        V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) *
+                     (1 - cons0 * cons0 * cons0 * cons0 * cons0) *
+                     (1 - cons1 * cons1 * cons1 * cons1 * cons1);
+        V3 wh = normalize(in + out);
+        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
+        V3 specular = D / (4.f * fabs_(dot(out, wh)) * max_(c0, c1)) * schlick_fresnel(Rs, dot(out, wh));
+        fr = diffuse + specular;
+        pdf = 0.5f * (fabs_(dot(out, n)) * ONE_OVER_PI + D * fabs_(dot(wh, n)) / (4.f * dot(in, wh)));
+        break;
+    }
+    case GPT_MT_ROUGHDIELECTRIC: {
+        V3 wi = -in;
+        V3 n = nor;
+        V3 wh = sample_ggx(material.alphaU, material.alphaV, u.x, u.y);
+        V3 uu = dpdu, ww;
+        ww = cross(uu, n);
+        wh = to_world(wh, uu, n, ww);
+        float ei = material.outsideIOR, et = material.insideIOR;
+        float cosi = dot(wi, n);
+        bool enter = cosi < 0;
+        if (!enter) {
+            float t = ei;
+            ei = et;
+            et = t;
+        }
+        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
+        float eta = ei / et, cost;
+        cosi = dot(wi, wh);
+        float sint2 = eta * eta * (1.f - cosi * cosi);
+        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+        V3 rdir = reflect(-wi, wh);
+        V3 tdir = normalize((wi - wh * cosi) * eta + (enter ? -cost : cost) * wh);
+        if (sint2 > 1.f) {   // total reflection
+            out = rdir;
+            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+            fr = m_spec * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
+            pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in)));
+            return;
+        }
+        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
+        if (u.z > fresnel) {   // refract
+            out = tdir;
+            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+            float c = et * dot(out, wh) + ei * dot(in, wh);
+            fr = m_spec * ei * ei * D * G * (1.f - fresnel) * fabs_(dot(in, wh)) * fabs_(dot(out, wh)) /
+                 (fabs_(dot(out, n)) * fabs_(dot(in, n)) * c * c);
+            fr *= (1.f / (eta * eta));
+            pdf = (1.f - fresnel) * D * fabs_(dot(wh, n)) * et * et * fabs_(dot(out, wh)) / (c * c);
+        } else {               // reflect
+            out = rdir;
+            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+            fr = m_spec * fresnel * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
+            pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in))) * fresnel;
+        }
+        break;
+    }
+    default:
+        out = v3(0, 0, 0);
+        fr = v3(0, 0, 0);
+        pdf = 0.f;
+        break;
+    }
+}
+
+// ----------------------------------------------------------- Fr, :698-826 ----
+__device__ __forceinline__ void eval_bsdf(const DevParams &P, const gpt_material &material, V3 in, V3 out, V3 nor,
+                                          V2 uv, V3 dpdu, V3 &fr, float &pdf)
+{
+    const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
+    switch (material.type) {
+    case GPT_MT_LAMBERTIAN:
+        if (!same_hemisphere(in, out, nor)) {
+            fr = v3(0.f, 0.f, 0.f);
+            pdf = 0.f;
+            return;
+        }
+        fr = get_texel(P, material, uv) * ONE_OVER_PI;
+        pdf = fabs_(dot(out, nor)) * ONE_OVER_PI;
+        break;
+    case GPT_MT_MIRROR:
+    case GPT_MT_DIELECTRIC:
+        fr = v3(0.f, 0.f, 0.f);
+        pdf = 0.f;
+        break;
+    case GPT_MT_ROUGHCONDUCTOR: {
+        if (!same_hemisphere(in, out, nor)) {
+            fr = v3(0, 0, 0);
+            pdf = 0;
+            return;
+        }
+        V3 n = nor;
+        if (dot(nor, in) < 0)
+            n = -n;
+        V3 wh = normalize(in + out);
+        float cosi = dot(out, wh);
+        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
+        float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+        V3 F = conduct_fresnel(fabs_(cosi), V3{material.eta.x, material.eta.y, material.eta.z},
+                               V3{material.k.x, material.k.y, material.k.z});
+        fr = m_spec * F * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
+        pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(in, wh)));
+        break;
+    }
+    case GPT_MT_SUBSTRATE: {
+        if (!same_hemisphere(in, out, nor)) {
+            fr = v3(0, 0, 0);
+            pdf = 0;
+            return;
+        }
+        V3 n = nor;
+        if (dot(nor, in) < 0)
+            n = -n;
+        float c0 = fabs_(dot(in, n));
+        float c1 = fabs_(dot(out, n));
+        V3 Rd = get_texel(P, material, uv);
+        V3 Rs = m_spec;
+        float cons0 = 1 - 0.5f * c0;
+        float cons1 = 1 - 0.5f * c1;
+        V3 wh = normalize(in + out);
+        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
+        V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) *
+                     (1 - cons0 * cons0 * cons0 * cons0 * cons0) *
+                     (1 - cons1 * cons1 * cons1 * cons1 * cons1);
+        V3 specular = D / (4.f * fabs_(dot(out, wh)) * max_(c0, c1)) * schlick_fresnel(Rs, dot(out, wh));
+        fr = diffuse + specular;
+        pdf = 0.5f * (fabs_(dot(out, n)) * ONE_OVER_PI + D * fabs_(dot(wh, n)) / (4.f * dot(in, wh)));
+        break;
+    }
+    case GPT_MT_ROUGHDIELECTRIC: {
+        V3 wi = -in;
+        V3 n = nor;
+        bool refl = dot(in, n) * dot(out, n) > 0;
+        float ei = material.outsideIOR, et = material.insideIOR;
+        float cosi = dot(wi, n);
+        bool enter = cosi < 0;
+        if (!enter) {
+            float t = ei;
+            ei = et;
+            et = t;
+        }
+        V3 wh = normalize(-(ei * in + et * out));
+        float eta = ei / et, cost;
+        cosi = dot(wi, wh);
+        float sint2 = eta * eta * (1.f - cosi * cosi);
+        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
+        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
+        if (!refl) {   // refract
+            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+            float c = et * dot(out, wh) + ei * dot(in, wh);
+            fr = m_spec * ei * ei * D * G * (1.f - fresnel) * fabs_(dot(in, wh)) * fabs_(dot(out, wh)) /
+                 (fabs_(dot(out, n)) * fabs_(dot(in, n)) * c * c);
+            fr *= (1.f / (eta * eta));
+            pdf = (1.f - fresnel) * D * fabs_(dot(wh, n)) * et * et * fabs_(dot(out, wh)) / (c * c);
+        } else {
+            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
+            fr = m_spec * fresnel * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
+            pdf = fresnel * D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in)));
+        }
+        break;
+    }
+    default:
+        fr = v3(0, 0, 0);
+        pdf = 0.f;
+        break;
+    }
+}
+
+// --------------------------------------------------------------- lights ------
+// Area::SampleLight (area.h:14-19) -> Triangle::SampleShape (mesh.h:100-109)
+__device__ __forceinline__ void area_sample_light(const DevLight &L, V3 pos, V2 u, V3 &rad, Ray &ray, V3 &nor,
+                                                  float &pdf, float eps)
+{
+    float su1 = sqrt_rn(u.x);                         // UniformTriangle, wrap.h:110-115
+    V2 uv = v2(1.f - su1, u.y * su1);
+    V3 p = uv.x * ld3(L.v1) + uv.y * ld3(L.v2) + (1 - uv.x - uv.y) * ld3(L.v3);
+    V3 normal = normalize(uv.x * ld3(L.n1) + uv.y * ld3(L.n2) + (1 - uv.x - uv.y) * ld3(L.n3));
+    V3 dir = p - pos;
+    nor = normal;
+    pdf = 1.f / (L.area * fabs_(dot(normal, normalize(dir)))) * dot(dir, dir);
+    if (dot(normal, dir) >= 0.f)
+        pdf = 0.f;
+    rad = pdf != 0.f ? ld3(L.radiance) : v3(0.f, 0.f, 0.f);
+    ray.o = pos;
+    ray.d = normalize(dir);
+    ray.tmin = eps;
+    ray.tmax = sqrt_rn(dot(dir, dir) - eps);
+}
+__device__ __forceinline__ V3 area_le(const DevLight &L, V3 nor, V3 dir)   // area.h:38-41
+{
+    if (dot(nor, dir) > 0.f) return ld3(L.radiance);
+    return v3(0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ V3 inf_texel(const DevInfinite &I, int x, int y)   // infinite.h:79-94
+{
+    int width = I.width, height = I.height;
+    float rx = x - (x / width) * width;
+    float ry = y - (y / height) * height;
+    x = (rx < 0) ? rx + width : rx;
+    y = (ry < 0) ? ry + height : ry;
+    if (x < 0) x = 0;
+    if (x > width - 1) x = width - 1;
+    if (y < 0) y = 0;
+    if (y > height - 1) y = height - 1;
+    const float *c = I.data + 3 * (size_t)(y * width + x);
+    return V3{c[0], c[1], c[2]};
+}
+__device__ __forceinline__ V3 inf_texel_bilinear(const DevInfinite &I, V2 uv)   // infinite.h:66-77
+{
+    float xx = I.width * uv.x;
+    float yy = I.height * uv.y;
+    int x = (int)__builtin_floorf(xx);
+    int y = (int)__builtin_floorf(yy);
+    float dx = fabs_(xx - x);
+    float dy = fabs_(yy - y);
+    V3 c00 = inf_texel(I, x, y);
+    V3 c10 = inf_texel(I, x + 1, y);
+    V3 c01 = inf_texel(I, x, y + 1);
+    V3 c11 = inf_texel(I, x + 1, y + 1);
+    return (1 - dy) * ((1 - dx) * c00 + dx * c10) + dy * ((1 - dx) * c01 + dx * c11);
+}
+// Infinite::Le (infinite.h:47-59); SampleLight's lookup (:22-36) is the same arithmetic
+__device__ __forceinline__ V3 inf_le(const DevInfinite &I, V3 dir)
+{
+    const V3 iu = ld3(I.u), iv = ld3(I.v), iw = ld3(I.w);
+    float costheta = dot(dir, iv);
+    float theta = gpt_acosf(costheta);
+    V3 d = normalize(dir - costheta * iv);
+    float cosphi = dot(d, iu);
+    float phi = gpt_acosf(cosphi);
+    float c = dot(d, iw);
+    phi = c > 0 ? TWOPI - phi : phi;
+    float uu = phi / TWOPI;
+    float vv = theta / PI;
+    return inf_texel_bilinear(I, v2(1.f - uu, vv));
+}
+__device__ __forceinline__ void inf_sample_light(const DevInfinite &I, V3 pos, V2 uniform, V3 &rad, Ray &ray, V3 &nor,
+                                                 float &pdf, float eps)   // infinite.h:17-36
+{
+    float pdfW;
+    V3 dir = uniform_sphere(uniform.x, uniform.y, pdfW);
+    nor = -dir;
+    ray.o = pos;
+    ray.d = dir;
+    ray.tmin = eps;
+    ray.tmax = 2.f * I.radius - eps;
+    pdf = pdfW;
+    rad = inf_le(I, dir);
+}
+
+// pathtracer.cu:172-181 (no match — only for NaN u — returns -1 here; the
+// reference falls off the end of a non-void function)
+__device__ __forceinline__ int lookup_light_distribution(const DevParams &P, float u, float &pdf)
+{
+    for (int i = 0; i + 1 < P.n_cdf; ++i) {
+        float s = P.light_cdf[i];
+        float e = P.light_cdf[i + 1];
+        if (u >= s && u <= e) {
+            pdf = e - s;
+            return i;
+        }
+    }
+    pdf = 0.f;
+    return -1;
+}
+__device__ __forceinline__ float pdf_from_light_distribution(const DevParams &P, int idx)
+{
+    return P.light_cdf[idx + 1] - P.light_cdf[idx];
+}
+
+// ----------------------------------------------------------------- film ------
+__device__ __forceinline__ V3 tonemap(V3 in, bool filmic)   // pathtracer.cu:187-204
+{
+    if (filmic) {
+        V3 c = in - v3(0.004f, 0.004f, 0.004f);
+        c = V3{fmax_(0.f, c.x), fmax_(0.f, c.y), fmax_(0.f, c.z)};
+        c = (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
+        return c;
+    }
+    float one_over_gamma = 1.f / 2.2f;
+    float exposure = 1.41421356f;
+    in = V3{fmax_(in.x, 1e-5f), fmax_(in.y, 1e-5f), fmax_(in.z, 1e-5f)};
+    in.x = gpt_powf(in.x * exposure, one_over_gamma);
+    in.y = gpt_powf(in.y * exposure, one_over_gamma);
+    in.z = gpt_powf(in.z * exposure, one_over_gamma);
+    return in;
+}
+
+// ----------------------------------------------------- the render kernel -----
+template <bool COUNT>
+__global__ void __launch_bounds__(256) pt_render_kernel(const DevParams P)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
+    Counters cnt = {0, 0, 0, 0, 0, 0};
+
+    for (;;) {
+        // ---- persistent scheduler: one atomic per wave per tile -----------------
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_owned) break;
+        const uint32_t tile = P.rank + t * P.n_ranks;
+        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        const uint32_t x = tx * 8u + (lane & 7u);
+        const uint32_t y = ty * 8u + (lane >> 3);
+        const bool valid = x < P.stride && y < P.rows;
+        const uint32_t pixel = x + y * P.stride;       // pathtracer.cu:881-883
+
+        V3 acc = v3(0.f), col = v3(0.f);
+        if (valid) {
+            col = V3{P.color[3 * pixel], P.color[3 * pixel + 1], P.color[3 * pixel + 2]};
+            if (!P.reset) acc = V3{P.acc[3 * pixel], P.acc[3 * pixel + 1], P.acc[3 * pixel + 2]};
+        }
+        const uint32_t hash_pixel = wang_hash(pixel);
+
+        uint32_t iter = P.iter_first;
+        uint32_t left = valid ? P.iter_count : 0u;
+        bool alive = false;
+
+        // per-path state
+        Rng rng;
+        rng.x = 1;
+        Ray r;
+        r.o = r.d = v3(0.f);
+        r.tmin = P.eps;
+        r.tmax = 0.f;
+        V3 Li = v3(0.f), beta = v3(1.f);
+        bool specular = false;
+        int bounces = 0;
+
+        while (__any(alive || left > 0)) {
+            // ---- regenerate: pathtracer.cu:888-903 -------------------------------
+            if (!alive && left > 0) {
+                rng_seed(rng, hash_pixel + wang_hash(iter));
+                float offsetx = rng_uniform(rng) - 0.5f;
+                float offsety = rng_uniform(rng) - 0.5f;
+                float du1 = rng_uniform(rng);
+                float du2 = rng_uniform(rng);
+                float rr = sqrt_rn(du1);                  // UniformDisk, wrap.h:78-85
+                float phi = TWOPI * du2;
+                V2 aperture = v2(rr * gpt_cosf(phi), rr * gpt_sinf(phi));
+                r = primary_ray(P.cam, x + offsetx, y + offsety, aperture);
+                r.tmin = P.eps;
+                Li = v3(0.f, 0.f, 0.f);
+                beta = v3(1.f, 1.f, 1.f);
+                specular = false;
+                bounces = 0;
+                alive = true;
+                left--;
+                if (COUNT) cnt.samples++;
+            }
+            if (!alive) continue;
+
+            // ---- one bounce: pathtracer.cu:904-1017 -------------------------------
+            bool finish = false;
+            if (COUNT) { cnt.bounce_iters++; cnt.closest_rays++; }
+            int hp = 0;
+            float hb1 = 0.f, hb2 = 0.f;
+            float tmax = r.tmax;
+            if (!traverse<false, COUNT>(P, r, tmax, hp, hb1, hb2, cnt)) {
+                if ((bounces == 0 || specular) && P.inf.isvalid)
+                    Li += beta * inf_le(P.inf, r.d);
+                finish = true;
+            } else {
+                const Hit isect = make_hit(P, r, tmax, hp, hb1, hb2);
+                const V3 pos = isect.pos;
+                const V3 nor = isect.nor;
+                const V2 uv = isect.uv;
+                const V3 dpdu = isect.dpdu;
+                const gpt_material material = P.materials[isect.matIdx];
+
+                if ((bounces == 0 || specular) && isect.lightIdx != -1) {
+                    Li += beta * area_le(P.lights[isect.lightIdx], nor, -r.d);
+                    finish = true;
+                } else {
+                    // direct light with multiple importance sampling
+                    if (!is_delta(material.type)) {
+                        V3 Ld = v3(0.f, 0.f, 0.f);
+                        float u = rng_uniform(rng);
+                        float choicePdf;
+                        int idx = lookup_light_distribution(P, u, choicePdf);
+                        bool inf = idx == P.n_lights;
+                        float u1x = rng_uniform(rng);
+                        float u1y = rng_uniform(rng);
+                        V2 u1 = v2(u1x, u1y);
+                        V3 radiance = v3(0.f), lightNor;
+                        Ray shadowRay;
+                        shadowRay.o = pos;
+                        shadowRay.d = v3(0.f);
+                        shadowRay.tmin = P.eps;
+                        shadowRay.tmax = 0.f;
+                        float lightPdf = 0.f;
+                        if (idx >= 0) {
+                            if (!inf)
+                                area_sample_light(P.lights[idx], pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
+                            else
+                                inf_sample_light(P.inf, pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
+                        }
+                        if (!is_black(radiance)) {
+                            if (COUNT) cnt.shadow_rays++;
+                            int d0;
+                            float d1, d2;
+                            float stmax = shadowRay.tmax;
+                            if (!traverse<true, COUNT>(P, shadowRay, stmax, d0, d1, d2, cnt)) {
+                                V3 fr;
+                                float samplePdf;
+                                eval_bsdf(P, material, -r.d, shadowRay.d, nor, uv, dpdu, fr, samplePdf);
+                                float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                                Ld += weight * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
+                            }
+                        }
+
+                        float usx = rng_uniform(rng);
+                        float usy = rng_uniform(rng);
+                        float usz = rng_uniform(rng);
+                        V3 us = v3(usx, usy, usz);
+                        V3 out, fr;
+                        float pdf;
+                        sample_bsdf(P, material, -r.d, nor, uv, dpdu, us, out, fr, pdf);
+                        if (!(is_black(fr) || pdf == 0)) {
+                            Ray lightRay;
+                            lightRay.o = pos;
+                            lightRay.d = out;
+                            lightRay.tmin = P.eps;
+                            lightRay.tmax = __builtin_inff();
+                            int lp = 0;
+                            float lb1 = 0.f, lb2 = 0.f;
+                            float ltmax = lightRay.tmax;
+                            if (COUNT) cnt.closest_rays++;
+                            if (traverse<false, COUNT>(P, lightRay, ltmax, lp, lb1, lb2, cnt)) {
+                                const Hit lightIsect = make_hit(P, lightRay, ltmax, lp, lb1, lb2);
+                                V3 p = lightIsect.pos;
+                                V3 n = lightIsect.nor;
+                                V3 radiance2 = v3(0.f, 0.f, 0.f);
+                                if (lightIsect.lightIdx != -1)
+                                    radiance2 = area_le(P.lights[lightIsect.lightIdx], n, -lightRay.d);
+                                if (!is_black(radiance2)) {
+                                    float pdfA = 1.f / P.lights[lightIsect.lightIdx].area;   // area.h:28-32
+                                    float choicePdf2 = pdf_from_light_distribution(P, lightIsect.lightIdx);
+                                    float lenSquare = dot(p - pos, p - pos);
+                                    float costheta = fabs_(dot(n, lightRay.d));
+                                    float lPdf = pdfA * lenSquare / (costheta);
+                                    float weight = power_heuristic(1, pdf, 1, lPdf * choicePdf2);
+                                    Ld += weight * fr * radiance2 * fabs_(dot(out, nor)) / pdf;
+                                }
+                            } else if (P.inf.isvalid) {
+                                V3 radiance2 = inf_le(P.inf, lightRay.d);
+                                float choicePdf2 = pdf_from_light_distribution(P, P.n_lights);
+                                float lightPdf2 = ONE_OVER_FOUR_PI;                           // infinite.h:38-41
+                                float weight = power_heuristic(1, pdf, 1, lightPdf2 * choicePdf2);
+                                Ld += weight * fr * radiance2 * fabs_(dot(out, nor)) / pdf;
+                            }
+                        }
+                        Li += beta * Ld;
+                    }
+
+                    float ux = rng_uniform(rng);
+                    float uy = rng_uniform(rng);
+                    float uz = rng_uniform(rng);
+                    V3 u = v3(ux, uy, uz);
+                    V3 out, fr;
+                    float pdf;
+                    sample_bsdf(P, material, -r.d, nor, uv, dpdu, u, out, fr, pdf);
+                    if (is_black(fr)) {
+                        finish = true;
+                    } else {
+                        beta *= fr * fabs_(dot(nor, out)) / pdf;
+                        specular = is_delta(material.type);
+                        r.o = pos;
+                        r.d = out;
+                        r.tmin = P.eps;
+                        r.tmax = __builtin_inff();
+                        if (bounces > 3) {
+                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                            if (rng_uniform(rng) < illumate) {
+                                finish = true;
+                            } else {
+                                beta /= (1 - illumate);
+                            }
+                        }
+                        bounces++;
+                        if (bounces >= P.max_depth) finish = true;
+                    }
+                }
+            }
+
+            if (finish) {
+                // pathtracer.cu:1019-1020 (a non-finite sample leaves the previous
+                // value in kernel_color) + Output's accumulate (:2523-2525)
+                if (!is_inf(Li) && !is_nan(Li)) col = Li;
+                acc += col;
+                alive = false;
+                iter++;
+            }
+        }
+
+        if (valid) {
+            P.acc[3 * pixel] = acc.x;
+            P.acc[3 * pixel + 1] = acc.y;
+            P.acc[3 * pixel + 2] = acc.z;
+            P.color[3 * pixel] = col.x;
+            P.color[3 * pixel + 1] = col.y;
+            P.color[3 * pixel + 2] = col.z;
+            if (P.out != nullptr && P.iter_count > 0) {
+                const uint32_t last = P.iter_first + P.iter_count - 1u;
+                V3 o = tonemap(acc / (float)(int)last, P.cam.filmic != 0);   // Output: acc / iter, iter is int
+                P.out[3 * pixel] = o.x;
+                P.out[3 * pixel + 1] = o.y;
+                P.out[3 * pixel + 2] = o.z;
+            }
+        }
+    }
+
+    if (COUNT) {
+        atomicAdd(&P.counters[0], (unsigned long long)cnt.node_visits);
+        atomicAdd(&P.counters[1], (unsigned long long)cnt.prim_tests);
+        atomicAdd(&P.counters[2], (unsigned long long)cnt.bounce_iters);
+        atomicAdd(&P.counters[3], (unsigned long long)cnt.shadow_rays);
+        atomicAdd(&P.counters[4], (unsigned long long)cnt.closest_rays);
+        atomicAdd(&P.counters[5], (unsigned long long)cnt.samples);
+    }
+}
+
+// Output without the accumulate: out = tonemap(acc / iter)
+__global__ void __launch_bounds__(256) pt_tonemap_kernel(const float *acc, float *out, uint32_t stride, uint32_t rows,
+                                                         uint32_t iter, int filmic)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= stride * rows) return;
+    V3 a = V3{acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]};
+    V3 o = tonemap(a / (float)(int)iter, filmic != 0);
+    out[3 * i] = o.x;
+    out[3 * i + 1] = o.y;
+    out[3 * i + 2] = o.z;
+}
+
+// elementary-operation probes for the parity tests (gpt_debug_math / gpt_debug_rng)
+__global__ void pt_debug_math_kernel(int fn, const float *x, const float *y, float *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.f;
+    switch (fn) {
+    case 0: r = gpt_sinf(x[i]); break;
+    case 1: r = gpt_cosf(x[i]); break;
+    case 2: r = gpt_tanf(x[i]); break;
+    case 3: r = gpt_atanf(x[i]); break;
+    case 4: r = gpt_acosf(x[i]); break;
+    case 5: r = gpt_powf(x[i], y[i]); break;
+    case 6: r = x[i] / y[i]; break;
+    case 7: r = sqrt_rn(x[i]); break;
+    case 8: r = rsqrt_rn(x[i]); break;
+    default: break;
+    }
+    out[i] = r;
+}
+__global__ void pt_debug_rng_kernel(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng r;
+    uint32_t s = wang_hash(pixel) + wang_hash(iter);
+    *seed_out = s;
+    rng_seed(r, s);
+    for (int i = 0; i < n; ++i) u_out[i] = rng_uniform(r);
+}
+
+}  // namespace pt
+
+// ------------------------------------------------------------ launchers -------
+namespace pt {
+
+// resident 256-thread workgroups per CU for the persistent grid
+int render_kernel_blocks_per_cu(bool count)
+{
+    int n = 0;
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true>, 256, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false>, 256, 0);
+    if (e != hipSuccess || n < 1) n = 2;
+    if (n > 8) n = 8;
+    return n;
+}
+
+hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream)
+{
+    if (count)
+        hipLaunchKernelGGL(pt_render_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, P);
+    else
+        hipLaunchKernelGGL(pt_render_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_t rows, uint32_t iter, int filmic,
+                          hipStream_t stream)
+{
+    const uint32_t n = stride * rows;
+    hipLaunchKernelGGL(pt_tonemap_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, acc, out, stride, rows, iter, filmic);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, x, y, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_debug_rng_kernel, dim3(1), dim3(64), 0, stream, pixel, iter, seed_out, u_out, n);
+    return hipGetLastError();
+}
+
+}  // namespace pt

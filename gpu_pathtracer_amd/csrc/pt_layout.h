@@ -1,0 +1,112 @@
+// pt_layout.h — how the scene sits in HBM for the gfx950 kernel.
+//
+// The reference uploads its host structs verbatim (AoS: 40-B LinearBVHNode,
+// 176-B Primitive fetched by value per triangle test, reference
+// src/pathtracer.cu:222,231).  Here the same information is re-laid-out once in
+// gpt_begin() so that every per-lane gather is a small number of aligned
+// 16-byte loads:
+//
+//   DevNode   32 B  two dwordx4: AABB + threaded-traversal links
+//   DevTri    48 B  three dwordx4: v1, e1 = v2-v1, e2 = v3-v1 (all the
+//                   Moeller-Trumbore test reads; 36 B used)
+//   DevShade  80 B  five dwordx4: what is needed once per ACCEPTED FINAL hit
+//                   (normals, uvs, normalised dp/dv, material and light index)
+//   DevLight  96 B  six dwordx4: one emissive triangle for sampling / Le / pdf
+//
+// Everything precomputed here (e1, e2, normalize(dpdv), triangle area) is a
+// pure function of one triangle evaluated with the same IEEE operations, in the
+// same order, as the per-hit code of the reference (src/mesh.h:45-98,39-43), so
+// the values are bit-identical to computing them per hit.
+#pragma once
+
+#include <stdint.h>
+#include "../../include/gpt_types.h"
+#include "pt_vec.h"
+
+namespace pt {
+
+struct alignas(16) DevNode {
+    float bmin[3];
+    float bmax[3];
+    // Threaded preorder traversal (fixed left-first order == the reference's
+    // stack discipline, src/pathtracer.cu:221-252):
+    //   inner: link = index to continue at when the box is missed ("escape":
+    //          first node after this subtree in preorder); last = -1
+    //   leaf : link = first primitive; last = last primitive (inclusive, >= 0)
+    // A hit inner node continues at idx+1; a leaf always continues at idx+1.
+    int32_t link;
+    int32_t last;
+};
+static_assert(sizeof(DevNode) == 32, "DevNode");
+
+struct alignas(16) DevTri {
+    float v1[3]; float e1x;
+    float e1yz[2]; float e2xy[2];
+    float e2z; float pad[3];
+};
+static_assert(sizeof(DevTri) == 48, "DevTri");
+
+struct alignas(16) DevShade {
+    float n1[3], n2[3], n3[3];   // vertex normals
+    float uv1[2], uv2[2], uv3[2];
+    float ndpdv[3];              // normalize(dpdv) of src/mesh.h:71-83,91
+    int32_t matIdx;
+    int32_t lightIdx;
+};
+static_assert(sizeof(DevShade) == 80, "DevShade");
+
+struct alignas(16) DevLight {
+    float radiance[3];
+    float area;                  // Triangle::GetSurfaceArea, src/mesh.h:39-43
+    float v1[3], v2[3], v3[3];
+    float n1[3], n2[3], n3[3];
+    float pad[2];
+};
+static_assert(sizeof(DevLight) == 96, "DevLight");
+
+struct DevTexture {
+    const gpt_uchar4 *data;
+    int32_t width, height;
+};
+
+struct DevInfinite {
+    const float *data;           // float3[w*h]
+    int32_t width, height;
+    float radius;
+    float u[3], v[3], w[3];
+    int32_t isvalid;
+};
+
+// kernel arguments (by value in the kernarg segment)
+struct DevParams {
+    const DevNode *nodes;
+    const DevTri *tris;
+    const DevShade *shade;
+    const gpt_material *materials;
+    const DevLight *lights;
+    const float *light_cdf;
+    const DevTexture *textures;
+    DevInfinite inf;
+    int32_t n_nodes;
+    int32_t n_lights;
+    int32_t n_cdf;
+    int32_t max_depth;
+    float eps;
+    gpt_camera cam;
+    // film
+    float *acc;                  // kernel_acc_image
+    float *color;                // kernel_color
+    float *out;                  // tonemapped output or nullptr
+    uint32_t stride;             // 32*(W/32): row stride of the reference's pixel index
+    uint32_t rows;               // 4*(H/4)
+    uint32_t tiles_x;            // 8x8 tiles per row
+    uint32_t n_tiles;            // all tiles
+    uint32_t rank, n_ranks;      // tile ownership: t % n_ranks == rank
+    uint32_t iter_first, iter_count;
+    int32_t reset;
+    // scheduler
+    uint32_t *tile_counter;      // work queue head (zeroed before every launch)
+    unsigned long long *counters;  // 6 work counters (counting build only)
+};
+
+}  // namespace pt

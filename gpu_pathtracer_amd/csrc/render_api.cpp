@@ -1,0 +1,547 @@
+// render_api.cpp — host half of the render API: the C ABI of include/gpt.h
+// (gpt_begin / gpt_render / gpt_end ...), replacing the host side of the
+// reference's BeginRender / Render / EndRender (reference
+// src/pathtracer.cu:2568-2750).
+//
+// Differences from the reference, by design:
+//   * state lives in a gpt_ctx, not in file-scope globals (re-entrant, one
+//     context per GPU / per process rank);
+//   * the scene is re-laid-out for the GPU once (pt_layout.h) instead of
+//     uploading host structs verbatim;
+//   * one launch per BATCH of iterations (the reference launches Path + Output
+//     and does a synchronous 104-byte camera cudaMemcpy per spp); the camera
+//     travels in the kernel arguments;
+//   * errors come back as codes + gpt_last_error(), never __debugbreak().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpt.h"
+#include "host_util.h"
+#include "pt_layout.h"
+
+namespace pt {
+hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream);
+hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_t rows, uint32_t iter, int filmic,
+                          hipStream_t stream);
+hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
+hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream);
+int render_kernel_blocks_per_cu(bool count);
+}  // namespace pt
+
+using namespace pt;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            gpt_set_error("%s in %s at line %d", hipGetErrorString(e_), __FILE__, __LINE__);   \
+            return GPT_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+struct gpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t width = 0, height = 0;
+    std::vector<void *> allocs;       // everything to hipFree in gpt_end
+    DevParams P{};                    // scene pointers + constants; per-call fields filled in gpt_render
+    float *acc = nullptr, *color = nullptr;
+    uint32_t *tile_counter = nullptr;
+    unsigned long long *counters = nullptr;
+    bool count_next = false;
+    int n_cus = 256;
+    int blocks_per_cu[2] = {4, 4};
+    // timing of the path kernel on its own stream
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    uint32_t timed_launches = 0;
+    double timed_ms = 0.0;
+};
+
+namespace {
+
+template <class T>
+int dev_upload(gpt_ctx *ctx, const T *host, size_t n, const T **out)
+{
+    *out = nullptr;
+    if (n == 0) return GPT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+    ctx->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(p);
+    return GPT_OK;
+}
+
+int fold_events(gpt_ctx *ctx)
+{
+    for (auto &ev : ctx->events) {
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        ctx->timed_ms += ms;
+        ctx->timed_launches++;
+        ctx->free_events.push_back(ev);
+    }
+    ctx->events.clear();
+    return GPT_OK;
+}
+
+// ---- scene re-layout (see pt_layout.h) ----------------------------------------
+V3 f3(const gpt_float3 &a) { return V3{a.x, a.y, a.z}; }
+void st3(float *d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+// wrap.h:6-16
+void make_coordinate(V3 n, V3 &u, V3 &w)
+{
+    if (std::fabs(n.x) > std::fabs(n.y)) {
+        float invLen = 1.0f / sqrt_rn(n.x * n.x + n.z * n.z);
+        w = v3(n.z * invLen, 0.0f, -n.x * invLen);
+    } else {
+        float invLen = 1.0f / sqrt_rn(n.y * n.y + n.z * n.z);
+        w = v3(0.0f, n.z * invLen, -n.y * invLen);
+    }
+    u = cross(w, n);
+}
+
+void pack_triangle(const gpt_triangle &t, DevTri &dt, DevShade &ds)
+{
+    const V3 v1 = f3(t.v1.v), v2 = f3(t.v2.v), v3_ = f3(t.v3.v);
+    const V3 e1 = v2 - v1;          // mesh.h:46-47
+    const V3 e2 = v3_ - v1;
+    std::memset(&dt, 0, sizeof(dt));
+    st3(dt.v1, v1);
+    dt.e1x = e1.x; dt.e1yz[0] = e1.y; dt.e1yz[1] = e1.z;
+    dt.e2xy[0] = e2.x; dt.e2xy[1] = e2.y; dt.e2z = e2.z;
+
+    // mesh.h:69-83: dp/dv depends only on the triangle
+    V3 dpdu, dpdv;
+    const V2 duv1 = V2{t.v2.uv.x - t.v1.uv.x, t.v2.uv.y - t.v1.uv.y};
+    const V2 duv2 = V2{t.v3.uv.x - t.v1.uv.x, t.v3.uv.y - t.v1.uv.y};
+    const float det = duv1.x * duv2.y - duv1.y * duv2.x;
+    if ((double)std::fabs(det) < 1e-8) {
+        V3 nn = normalize(cross(e1, e2));
+        make_coordinate(nn, dpdu, dpdv);
+    } else {
+        float invDet = 1 / det;
+        dpdu = (duv2.y * e1 - duv1.y * e2) * invDet;
+        dpdv = (-duv2.x * e1 + duv1.x * e2) * invDet;
+    }
+    (void)dpdu;
+    std::memset(&ds, 0, sizeof(ds));
+    st3(ds.n1, f3(t.v1.n)); st3(ds.n2, f3(t.v2.n)); st3(ds.n3, f3(t.v3.n));
+    ds.uv1[0] = t.v1.uv.x; ds.uv1[1] = t.v1.uv.y;
+    ds.uv2[0] = t.v2.uv.x; ds.uv2[1] = t.v2.uv.y;
+    ds.uv3[0] = t.v3.uv.x; ds.uv3[1] = t.v3.uv.y;
+    st3(ds.ndpdv, normalize(dpdv));  // mesh.h:91 normalize(dpdv)
+    ds.matIdx = t.matIdx;
+    ds.lightIdx = t.lightIdx;
+}
+
+// Threaded links: escape(i) = first preorder index after subtree(i).
+void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
+{
+    out.resize((size_t)n);
+    std::vector<int> escape((size_t)n, n);
+    // preorder: children of i are i+1 (left) and second_child_offset (right)
+    for (int i = 0; i < n; ++i) {
+        const gpt_bvh_node &nd = nodes[i];
+        if (!nd.is_leaf && nd.second_child_offset > 0) {
+            if (i + 1 < n) escape[(size_t)i + 1] = nd.second_child_offset;
+            if (nd.second_child_offset < n) escape[(size_t)nd.second_child_offset] = escape[(size_t)i];
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const gpt_bvh_node &nd = nodes[i];
+        DevNode &d = out[(size_t)i];
+        d.bmin[0] = nd.fmin.x; d.bmin[1] = nd.fmin.y; d.bmin[2] = nd.fmin.z;
+        d.bmax[0] = nd.fmax.x; d.bmax[1] = nd.fmax.y; d.bmax[2] = nd.fmax.z;
+        if (nd.is_leaf) {
+            d.link = nd.start;
+            d.last = nd.end;
+        } else {
+            d.link = escape[(size_t)i];
+            d.last = -1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gpt_version(void) { return "gpu_pathtracer_amd 0.1 (gfx950)"; }
+
+int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, float epsilon, int device, gpt_ctx **out)
+{
+    if (!scene || !out || width == 0 || height == 0) {
+        gpt_set_error("gpt_begin: null scene/out or empty frame");
+        return GPT_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    if (scene->integrator_type != GPT_IT_PT) {
+        gpt_set_error("gpt_begin: integrator type %d is not supported (only \"pt\")", scene->integrator_type);
+        return GPT_ERR_UNSUPPORTED;
+    }
+    if (scene->n_prims < 0 || scene->n_nodes < 0 || scene->n_materials <= 0 || scene->n_light_distribution < 1) {
+        gpt_set_error("gpt_begin: inconsistent scene counts");
+        return GPT_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < scene->n_prims; ++i) {
+        if (scene->prims[i].type != GPT_GT_TRIANGLE) {
+            gpt_set_error("gpt_begin: primitive %d has type %d; only triangles are supported", i, scene->prims[i].type);
+            return GPT_ERR_UNSUPPORTED;
+        }
+        const int m = scene->prims[i].triangle.matIdx;
+        if (m < 0 || m >= scene->n_materials) {
+            gpt_set_error("gpt_begin: primitive %d has material index %d outside [0,%d)", i, m, scene->n_materials);
+            return GPT_ERR_INVALID_ARG;
+        }
+        const int l = scene->prims[i].triangle.lightIdx;
+        if (l < -1 || l >= scene->n_lights) {
+            gpt_set_error("gpt_begin: primitive %d has light index %d outside [-1,%d)", i, l, scene->n_lights);
+            return GPT_ERR_INVALID_ARG;
+        }
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        gpt_set_error("gpt_begin: no HIP device visible (this library has no CPU fallback)");
+        return GPT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) {
+        gpt_set_error("gpt_begin: device %d out of range (%d visible)", device, n_dev);
+        return GPT_ERR_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+
+    gpt_ctx *ctx = new gpt_ctx();
+    ctx->device = device;
+    ctx->width = width;
+    ctx->height = height;
+    int rc = GPT_OK;
+    auto fail = [&](int code) {
+        gpt_end(ctx);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        gpt_set_error("gpt_begin: hipStreamCreate failed");
+        return fail(GPT_ERR_HIP);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+    ctx->blocks_per_cu[0] = render_kernel_blocks_per_cu(false);
+    ctx->blocks_per_cu[1] = render_kernel_blocks_per_cu(true);
+
+    // ---- geometry
+    std::vector<DevTri> tris((size_t)scene->n_prims);
+    std::vector<DevShade> shade((size_t)scene->n_prims);
+    for (int i = 0; i < scene->n_prims; ++i) pack_triangle(scene->prims[i].triangle, tris[(size_t)i], shade[(size_t)i]);
+    std::vector<DevNode> nodes;
+    thread_nodes(scene->nodes, scene->n_nodes, nodes);
+    std::vector<DevLight> lights((size_t)scene->n_lights);
+    for (int i = 0; i < scene->n_lights; ++i) {
+        const gpt_area &a = scene->lights[i];
+        DevLight &L = lights[(size_t)i];
+        std::memset(&L, 0, sizeof(L));
+        st3(L.radiance, f3(a.radiance));
+        const V3 v1 = f3(a.triangle.v1.v), v2 = f3(a.triangle.v2.v), v3_ = f3(a.triangle.v3.v);
+        L.area = length(cross(v2 - v1, v3_ - v1)) * 0.5f;       // mesh.h:39-43
+        st3(L.v1, v1); st3(L.v2, v2); st3(L.v3, v3_);
+        st3(L.n1, f3(a.triangle.v1.n)); st3(L.n2, f3(a.triangle.v2.n)); st3(L.n3, f3(a.triangle.v3.n));
+    }
+
+    DevParams &P = ctx->P;
+    if ((rc = dev_upload(ctx, nodes.data(), nodes.size(), &P.nodes)) != GPT_OK) return fail(rc);
+    if ((rc = dev_upload(ctx, tris.data(), tris.size(), &P.tris)) != GPT_OK) return fail(rc);
+    if ((rc = dev_upload(ctx, shade.data(), shade.size(), &P.shade)) != GPT_OK) return fail(rc);
+    if ((rc = dev_upload(ctx, scene->materials, (size_t)scene->n_materials, &P.materials)) != GPT_OK) return fail(rc);
+    if ((rc = dev_upload(ctx, lights.data(), lights.size(), &P.lights)) != GPT_OK) return fail(rc);
+    if ((rc = dev_upload(ctx, scene->light_distribution, (size_t)scene->n_light_distribution, &P.light_cdf)) != GPT_OK)
+        return fail(rc);
+
+    // ---- textures
+    std::vector<DevTexture> texs((size_t)scene->n_textures);
+    for (int i = 0; i < scene->n_textures; ++i) {
+        const gpt_texture &t = scene->textures[i];
+        if (t.width <= 0 || t.height <= 0 || !t.data) {
+            gpt_set_error("gpt_begin: texture %d is empty", i);
+            return fail(GPT_ERR_INVALID_ARG);
+        }
+        if ((rc = dev_upload(ctx, t.data, (size_t)t.width * (size_t)t.height, &texs[(size_t)i].data)) != GPT_OK) return fail(rc);
+        texs[(size_t)i].width = t.width;
+        texs[(size_t)i].height = t.height;
+    }
+    if ((rc = dev_upload(ctx, texs.data(), texs.size(), &P.textures)) != GPT_OK) return fail(rc);
+    for (int i = 0; i < scene->n_materials; ++i) {
+        const int ti = scene->materials[i].textureIdx;
+        if (ti < -1 || ti >= scene->n_textures) {
+            gpt_set_error("gpt_begin: material %d has texture index %d outside [-1,%d)", i, ti, scene->n_textures);
+            return fail(GPT_ERR_INVALID_ARG);
+        }
+    }
+
+    // ---- environment light
+    std::memset(&P.inf, 0, sizeof(P.inf));
+    if (scene->infinite && scene->infinite->isvalid) {
+        const gpt_infinite &I = *scene->infinite;
+        if (I.width <= 0 || I.height <= 0 || !I.data) {
+            gpt_set_error("gpt_begin: infinite light has no data");
+            return fail(GPT_ERR_INVALID_ARG);
+        }
+        const float *envd = nullptr;
+        if ((rc = dev_upload(ctx, reinterpret_cast<const float *>(I.data), (size_t)I.width * (size_t)I.height * 3, &envd)) != GPT_OK)
+            return fail(rc);
+        P.inf.data = envd;
+        P.inf.width = I.width;
+        P.inf.height = I.height;
+        P.inf.radius = I.radius;
+        st3(P.inf.u, f3(I.u)); st3(P.inf.v, f3(I.v)); st3(P.inf.w, f3(I.w));
+        P.inf.isvalid = 1;
+    }
+    const int expect_cdf = scene->n_lights + 1 + (P.inf.isvalid ? 1 : 0);
+    if (scene->n_light_distribution != expect_cdf) {
+        gpt_set_error("gpt_begin: light distribution has %d entries, expected %d", scene->n_light_distribution, expect_cdf);
+        return fail(GPT_ERR_INVALID_ARG);
+    }
+
+    P.n_nodes = scene->n_nodes;
+    P.n_lights = scene->n_lights;
+    P.n_cdf = scene->n_light_distribution;
+    P.max_depth = scene->max_depth;
+    P.eps = epsilon;
+
+    // ---- film: reference launch geometry (pathtracer.cu:2707-2709, 881-883)
+    P.stride = 32u * (width / 32u);
+    P.rows = 4u * (height / 4u);
+    P.tiles_x = (P.stride + 7u) / 8u;
+    P.n_tiles = P.tiles_x * ((P.rows + 7u) / 8u);
+    P.rank = 0;
+    P.n_ranks = 1;
+    const size_t film_bytes = (size_t)width * height * 3 * sizeof(float);
+    void *p = nullptr;
+    if (hipMalloc(&p, film_bytes) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(acc) failed"); return fail(GPT_ERR_HIP); }
+    ctx->allocs.push_back(p);
+    ctx->acc = static_cast<float *>(p);
+    if (hipMalloc(&p, film_bytes) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(color) failed"); return fail(GPT_ERR_HIP); }
+    ctx->allocs.push_back(p);
+    ctx->color = static_cast<float *>(p);
+    if (hipMalloc(&p, 256) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(queue) failed"); return fail(GPT_ERR_HIP); }
+    ctx->allocs.push_back(p);
+    ctx->tile_counter = static_cast<uint32_t *>(p);
+    ctx->counters = reinterpret_cast<unsigned long long *>(static_cast<char *>(p) + 64);
+    if (hipMemset(ctx->acc, 0, film_bytes) != hipSuccess || hipMemset(ctx->color, 0, film_bytes) != hipSuccess ||
+        hipMemset(p, 0, 256) != hipSuccess) {
+        gpt_set_error("gpt_begin: hipMemset failed");
+        return fail(GPT_ERR_HIP);
+    }
+    P.acc = ctx->acc;
+    P.color = ctx->color;
+    P.tile_counter = ctx->tile_counter;
+    P.counters = ctx->counters;
+    if (hipDeviceSynchronize() != hipSuccess) { gpt_set_error("gpt_begin: device sync failed"); return fail(GPT_ERR_HIP); }
+    *out = ctx;
+    return GPT_OK;
+}
+
+int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks)
+{
+    if (!ctx || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        gpt_set_error("gpt_set_tile_owner: invalid rank %d of %d", rank, n_ranks);
+        return GPT_ERR_INVALID_ARG;
+    }
+    ctx->P.rank = (uint32_t)rank;
+    ctx->P.n_ranks = (uint32_t)n_ranks;
+    return GPT_OK;
+}
+
+int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint32_t iter_count, int reset,
+               float *out_tonemapped_dev)
+{
+    if (!ctx || !camera) {
+        gpt_set_error("gpt_render: null context or camera");
+        return GPT_ERR_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevParams P = ctx->P;
+    P.cam = *camera;
+    P.iter_first = iter_first;
+    P.iter_count = iter_count;
+    P.reset = reset ? 1 : 0;
+    P.out = out_tonemapped_dev;
+    const bool count = ctx->count_next;
+    HIP_TRY(hipMemsetAsync(ctx->tile_counter, 0, 64, ctx->stream));
+    if (count) HIP_TRY(hipMemsetAsync(ctx->counters, 0, 6 * sizeof(unsigned long long), ctx->stream));
+
+    const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
+    if (n_owned == 0) return GPT_OK;
+    // persistent grid: as many 4-wave workgroups as stay resident, no more than the work
+    const long resident = (long)ctx->n_cus * ctx->blocks_per_cu[count ? 1 : 0];
+    const long needed = ((long)n_owned + 3) / 4;
+    const int n_blocks = (int)(needed < resident ? needed : resident);
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!ctx->free_events.empty()) {
+        ev = ctx->free_events.back();
+        ctx->free_events.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&ev.first));
+        HIP_TRY(hipEventCreate(&ev.second));
+    }
+    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+    HIP_TRY(launch_render(P, count, n_blocks, ctx->stream));
+    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+    ctx->events.push_back(ev);
+    if (ctx->events.size() > 2048) {
+        int rc = fold_events(ctx);
+        if (rc != GPT_OK) return rc;
+    }
+    return GPT_OK;
+}
+
+int gpt_tonemap(gpt_ctx *ctx, uint32_t iter, int filmic, float *out_dev)
+{
+    if (!ctx || !out_dev || iter == 0) {
+        gpt_set_error("gpt_tonemap: invalid argument");
+        return GPT_ERR_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(launch_tonemap(ctx->acc, out_dev, ctx->P.stride, ctx->P.rows, iter, filmic, ctx->stream));
+    return GPT_OK;
+}
+
+int gpt_synchronize(gpt_ctx *ctx)
+{
+    if (!ctx) { gpt_set_error("gpt_synchronize: null context"); return GPT_ERR_INVALID_ARG; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GPT_OK;
+}
+
+float *gpt_accum_device_ptr(gpt_ctx *ctx) { return ctx ? ctx->acc : nullptr; }
+float *gpt_color_device_ptr(gpt_ctx *ctx) { return ctx ? ctx->color : nullptr; }
+
+int gpt_copy_to_host(gpt_ctx *ctx, const float *dev, float *host, size_t n_floats)
+{
+    if (!ctx || !dev || !host) { gpt_set_error("gpt_copy_to_host: null argument"); return GPT_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(host, dev, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return GPT_OK;
+}
+
+int gpt_read_accum(gpt_ctx *ctx, float *host_rgb)
+{
+    if (!ctx) { gpt_set_error("gpt_read_accum: null context"); return GPT_ERR_INVALID_ARG; }
+    return gpt_copy_to_host(ctx, ctx->acc, host_rgb, (size_t)ctx->width * ctx->height * 3);
+}
+
+int gpt_read_color(gpt_ctx *ctx, float *host_rgb)
+{
+    if (!ctx) { gpt_set_error("gpt_read_color: null context"); return GPT_ERR_INVALID_ARG; }
+    return gpt_copy_to_host(ctx, ctx->color, host_rgb, (size_t)ctx->width * ctx->height * 3);
+}
+
+int gpt_write_state(gpt_ctx *ctx, const float *host_acc, const float *host_color)
+{
+    if (!ctx || !host_acc || !host_color) { gpt_set_error("gpt_write_state: null argument"); return GPT_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t bytes = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    HIP_TRY(hipMemcpy(ctx->acc, host_acc, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->color, host_color, bytes, hipMemcpyHostToDevice));
+    return GPT_OK;
+}
+
+int gpt_end(gpt_ctx *ctx)
+{
+    if (!ctx) return GPT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GPT_OK;
+}
+
+int gpt_kernel_time(gpt_ctx *ctx, uint32_t *launches, double *total_ms)
+{
+    if (!ctx) { gpt_set_error("gpt_kernel_time: null context"); return GPT_ERR_INVALID_ARG; }
+    int rc = fold_events(ctx);
+    if (rc != GPT_OK) return rc;
+    if (launches) *launches = ctx->timed_launches;
+    if (total_ms) *total_ms = ctx->timed_ms;
+    return GPT_OK;
+}
+
+int gpt_kernel_time_reset(gpt_ctx *ctx)
+{
+    if (!ctx) { gpt_set_error("gpt_kernel_time_reset: null context"); return GPT_ERR_INVALID_ARG; }
+    int rc = fold_events(ctx);
+    ctx->timed_launches = 0;
+    ctx->timed_ms = 0.0;
+    return rc;
+}
+
+int gpt_enable_counters(gpt_ctx *ctx, int enable)
+{
+    if (!ctx) { gpt_set_error("gpt_enable_counters: null context"); return GPT_ERR_INVALID_ARG; }
+    ctx->count_next = enable != 0;
+    return GPT_OK;
+}
+
+int gpt_read_counters(gpt_ctx *ctx, uint64_t out6[6])
+{
+    if (!ctx || !out6) { gpt_set_error("gpt_read_counters: null argument"); return GPT_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long tmp[6];
+    HIP_TRY(hipMemcpy(tmp, ctx->counters, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) out6[i] = tmp[i];
+    return GPT_OK;
+}
+
+int gpt_debug_math(int device, int fn, const float *x, const float *y, float *out, int n)
+{
+    if (!x || !out || n <= 0) { gpt_set_error("gpt_debug_math: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { gpt_set_error("gpt_debug_math: no HIP device"); return GPT_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    HIP_TRY(hipMalloc((void **)&dx, bytes));
+    HIP_TRY(hipMalloc((void **)&dy, bytes));
+    HIP_TRY(hipMalloc((void **)&dout, bytes));
+    HIP_TRY(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, y ? y : x, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(launch_debug_math(fn, dx, dy, dout, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return GPT_OK;
+}
+
+int gpt_debug_rng(int device, uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n)
+{
+    if (!seed_out || !u_out || n <= 0) { gpt_set_error("gpt_debug_rng: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { gpt_set_error("gpt_debug_rng: no HIP device"); return GPT_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *dseed = nullptr;
+    float *du = nullptr;
+    HIP_TRY(hipMalloc((void **)&dseed, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&du, (size_t)n * sizeof(float)));
+    HIP_TRY(launch_debug_rng(pixel, iter, dseed, du, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(seed_out, dseed, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(u_out, du, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dseed); (void)hipFree(du);
+    return GPT_OK;
+}
+
+}  // extern "C"

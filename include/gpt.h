@@ -1,0 +1,155 @@
+/*
+ * gpt.h — C ABI of the MI355X path-tracing integrator.
+ *
+ * This is the drop-in boundary for the reference's render API
+ * (reference src/pathtracer.h:10-12):
+ *
+ *     void BeginRender(Scene& scene, unsigned width, unsigned height, float ep);
+ *     void Render(Scene& scene, unsigned width, unsigned height, Camera* camera,
+ *                 unsigned iter, bool reset, float3* output);
+ *     void EndRender();
+ *
+ * and for the host-side steps that produce what BeginRender() uploads
+ * (Scene::Init, reference src/scene.h:50-83; BVH::build, src/bvh.cpp:18-36;
+ * Camera constructor/Lookat, src/camera.h:31-46,123-128; LoadScene,
+ * src/parsescene.h:26).  Entry points take plain pointers and sizes; records
+ * are the reference's own struct layouts (gpt_types.h).  Every function returns
+ * GPT_OK or a negative error code and never aborts; gpt_last_error() returns a
+ * thread-local message for the last failure.
+ *
+ * The C++ signatures above are provided on top of this ABI by
+ * gpu_pathtracer_amd/csrc/pathtracer.h for callers that link as C++.
+ */
+#ifndef GPT_H
+#define GPT_H
+
+#include "gpt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported even when the library is built with -fvisibility=hidden */
+#pragma GCC visibility push(default)
+
+#define GPT_OK                 0
+#define GPT_ERR_INVALID_ARG   -1
+#define GPT_ERR_UNSUPPORTED   -2   /* integrator other than "pt", non-triangle primitive */
+#define GPT_ERR_HIP           -3   /* a HIP runtime call failed (message has file:line) */
+#define GPT_ERR_NO_DEVICE     -4
+#define GPT_ERR_IO            -5
+#define GPT_ERR_PARSE         -6
+
+typedef struct gpt_ctx gpt_ctx;      /* one renderer: scene in HBM + film state */
+typedef struct gpt_scene gpt_scene;  /* host-side Scene built by the loader */
+
+const char *gpt_last_error(void);
+const char *gpt_version(void);
+
+/* ---- render API --------------------------------------------------------- */
+
+/* BeginRender (src/pathtracer.cu:2568-2695): copy the scene out of the caller's
+ * arrays, lay it out for the GPU, allocate the W*H*3 accumulator
+ * (kernel_acc_image) and last-sample (kernel_color) planes, both zeroed.
+ * `device` is the HIP device ordinal.  The caller keeps ownership of `scene`. */
+int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, float epsilon,
+              int device, gpt_ctx **out);
+
+/* Multi-GPU tile ownership: this context renders only the 8x8 pixel tiles t
+ * (row-major tile index) with t % n_ranks == rank; other pixels stay untouched
+ * (zero), so a sum-reduce of the accumulators over ranks equals the 1-GPU image
+ * bit for bit.  Default rank 0 of 1. */
+int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks);
+
+/* Render (src/pathtracer.cu:2705-2750), batched: for iter = iter_first ..
+ * iter_first+iter_count-1 add one sample per pixel, seeded by (pixel, iter),
+ * into the accumulator, exactly as iter_count successive reference calls would
+ * (iter_count = 1 is the reference call).  `reset` clears the accumulator first
+ * (reference: reset on the first call after a camera move).  `camera` is read
+ * on every call like the reference's per-call cudaMemcpy.  If
+ * `out_tonemapped_dev` is not NULL it must be a DEVICE pointer to W*H*3 floats
+ * (the reference's mapped GL buffer) and receives tonemap(acc / last_iter).
+ * Asynchronous: returns after enqueueing on the context's stream. */
+int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint32_t iter_count,
+               int reset, float *out_tonemapped_dev);
+
+/* Output pass alone (src/pathtracer.cu:2516-2531 without the accumulate):
+ * out = tonemap(acc / iter).  Used on the root rank after the framebuffer
+ * reduce.  `out_dev` is a device pointer. */
+int gpt_tonemap(gpt_ctx *ctx, uint32_t iter, int filmic, float *out_dev);
+
+int gpt_synchronize(gpt_ctx *ctx);
+
+/* Film state.  Device pointers stay valid until gpt_end(); W*H*3 floats each,
+ * row-major, row 0 = bottom (reference convention, src/imageio.cpp:66). */
+float *gpt_accum_device_ptr(gpt_ctx *ctx);   /* kernel_acc_image: running SUM of samples */
+float *gpt_color_device_ptr(gpt_ctx *ctx);   /* kernel_color: last finite sample */
+int gpt_read_accum(gpt_ctx *ctx, float *host_rgb);        /* synchronises */
+int gpt_read_color(gpt_ctx *ctx, float *host_rgb);
+int gpt_write_state(gpt_ctx *ctx, const float *host_acc, const float *host_color); /* resume */
+int gpt_copy_to_host(gpt_ctx *ctx, const float *dev, float *host, size_t n_floats);
+
+/* EndRender (src/pathtracer.cu:2697-2703); frees everything gpt_begin allocated. */
+int gpt_end(gpt_ctx *ctx);
+
+/* ---- measurement ---------------------------------------------------------- */
+
+/* HIP-event time of the path kernel launches since the last reset, measured on
+ * the stream the kernel runs on.  Synchronises. */
+int gpt_kernel_time(gpt_ctx *ctx, uint32_t *launches, double *total_ms);
+int gpt_kernel_time_reset(gpt_ctx *ctx);
+
+/* Work counters of the NEXT gpt_render call (it runs the counting build of the
+ * kernel): out6 = node visits, primitive tests, bounce iterations, shadow rays,
+ * closest-hit rays, samples — the terms of SURVEY.md §8(d) B_alg. */
+int gpt_enable_counters(gpt_ctx *ctx, int enable);
+int gpt_read_counters(gpt_ctx *ctx, uint64_t out6[6]);
+
+/* Device-side evaluation of the elementary float operations the kernel relies
+ * on, for parity tests against the CPU oracle: fn 0 sin, 1 cos, 2 tan, 3 atan,
+ * 4 acos, 5 pow(x,y), 6 x/y, 7 sqrt, 8 1/sqrt.  Host pointers. */
+int gpt_debug_math(int device, int fn, const float *x, const float *y, float *out, int n);
+/* first n uniform draws of the (pixel, iter) stream, evaluated on the device */
+int gpt_debug_rng(int device, uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n);
+
+/* ---- host-side scene preparation (CPU; no GPU needed) ---------------------- */
+
+/* BVH::build (src/bvh.cpp:18-173): binned-SAH build + preorder flatten.
+ * prims_out holds n records, nodes_out at least 2*n.  root_box6 = min.xyz,max.xyz */
+int gpt_bvh_build(const gpt_primitive *prims_in, int32_t n, gpt_primitive *prims_out,
+                  gpt_bvh_node *nodes_out, int32_t *n_nodes_out, float root_box6[6]);
+
+/* Scene::Init light power CDF (src/scene.h:65-82); cdf_out holds n_lights+2 floats */
+int gpt_light_distribution(const gpt_area *lights, int32_t n_lights, const gpt_infinite *infinite,
+                           float *cdf_out, int32_t *n_out);
+
+/* Infinite::Init (src/infinite.h:61-63) */
+int gpt_infinite_init(gpt_infinite *infinite, const float root_box6[6]);
+
+/* Camera::Lookat + constructor (src/camera.h:31-46,123-128; called as main.cpp:268-270) */
+int gpt_camera_init(gpt_camera *camera, const float position[3], const float lookat[3], const float up[3],
+                    float res_x, float res_y, float distance, float fov_degrees, float aperture_radius,
+                    float focal_distance, int filmic, int environment);
+
+/* LoadScene + InitScene (src/parsescene.cpp:45-590, src/main.cpp:261-278):
+ * parse a scene JSON, read its OBJ meshes, build the BVH and the light CDF. */
+int gpt_scene_load(const char *json_path, gpt_scene **out);
+int gpt_scene_get_desc(const gpt_scene *scene, gpt_scene_desc *desc_out);
+int gpt_scene_get_config(const gpt_scene *scene, int32_t *width, int32_t *height, float *epsilon,
+                         gpt_camera *camera_out);
+int gpt_scene_set_integrator(gpt_scene *scene, int32_t integrator_type, int32_t max_depth);
+int gpt_scene_free(gpt_scene *scene);
+
+/* ImageIO::SavePng (src/imageio.cpp:61-78): flip Y, clamp, truncate to 8 bit.
+ * `rgb` is W*H*3 host floats, row 0 = bottom. */
+int gpt_save_png(const char *path, int32_t width, int32_t height, const float *rgb);
+/* linear radiance as PFM (little-endian float32, bottom-up) */
+int gpt_save_pfm(const char *path, int32_t width, int32_t height, const float *rgb);
+
+#pragma GCC visibility pop
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GPT_H */
