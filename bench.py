@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the path-tracing hot path on the BASELINE.json configuration.
+
+Workload (config.workload): BASELINE.json configs[1] — cornell_box, 1920x1080, 8 bounces, area light + MIS,
+1024 spp — rendered as K steps of SPP_PER_STEP iterations (default 16 x 64 = 1024 spp).  A "step" is one
+gpt_render() call = one launch of the path kernel over the whole frame for SPP_PER_STEP iterations.
+Inputs (scene, camera, film) are resident in HBM before the timed region starts.
+
+N GPUs (launched by torch.distributed.run, one rank per GPU): every rank holds the whole scene, owns the 8x8
+pixel tiles t with t % N == rank, and the timed region ends with ONE RCCL sum-reduce of the float3 accumulator
+to rank 0 (disjoint supports, so the result is bit-identical to 1 GPU).  Total work is fixed as N grows
+("strong").
+
+Prints one JSON line on rank 0.  Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, MAX_DEPTH, EPS = 1920, 1080, 8, 0.001
+SPP_PER_STEP = 64
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_sample(c):
+    """reference-layout bytes the reference's algorithm touches per sample:
+    40 B per node visit (LinearBVHNode) + 176 B per primitive test (Primitive) + 72 B per bounce
+    (Material) + 192 B per shadow ray (Area) + 60 B of film traffic (12 B kernel_color write + Output's
+    12 R + 12 R + 12 W + 12 W)."""
+    s = float(c["samples"])
+    return (40.0 * c["node_visits"] + 176.0 * c["prim_tests"] + 72.0 * c["bounce_iters"] + 192.0 * c["shadow_rays"]) / s + 60.0
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the same algorithm, same BVH) on ONE host core, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    scene, meta = ol.load_cornell(MAX_DEPTH)
+    cam = ol.cornell_camera(meta, WIDTH, HEIGHT)
+    spp = 2
+    t = time.perf_counter()
+    ol.render(scene, cam, WIDTH, HEIGHT, EPS, 1, spp, kind="soft", threads=1)
+    dt = time.perf_counter() - t
+    return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"same scene/camera/frame, iterations 1-{spp} ({WIDTH * HEIGHT * spp} samples), "
+                      f"oracle/liboracle_soft.so single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from gpu_pathtracer_amd import api, host
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
+    cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
+    n_floats = WIDTH * HEIGHT * 3
+    # the film IS the reduce buffer: torch tensors bound as accumulator / last-sample planes
+    acc = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+    col = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+    out = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    r = api.Renderer(scene.desc, WIDTH, HEIGHT, EPS, device=local_rank)
+    r.bind_film(acc.data_ptr(), col.data_ptr())
+    r.set_tile_owner(rank, world)
+
+    def barrier():
+        r.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def job(steps):
+        for k in range(steps):
+            r.render(cam, 1 + k * SPP_PER_STEP, SPP_PER_STEP, reset=(k == 0))
+        r.synchronize()
+        if dist is not None:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)     # the one collective: float3 framebuffer over xGMI
+        if rank == 0:
+            r.tonemap(steps * SPP_PER_STEP, bool(cam.filmic), out.data_ptr())   # Output on the root
+            r.synchronize()
+
+    if args.warmup > 0:
+        job(args.warmup)
+    barrier()
+    r.kernel_time_reset()
+    t0 = time.perf_counter()
+    job(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = r.kernel_time()
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
+    if rank == 0:
+        img = acc.cpu().numpy().reshape(-1, 3) / np.float32(args.steps * SPP_PER_STEP)
+        finite = bool(np.isfinite(img).all())
+        # algorithmic bytes: count the work of this exact workload with the counting build of the kernel
+        rc = api.Renderer(scene.desc, WIDTH, HEIGHT, EPS, device=local_rank)
+        rc.enable_counters(True)
+        rc.render(cam, 1, 4, reset=True)
+        counters = rc.read_counters()
+        rc.close()
+        b_alg = algorithmic_bytes_per_sample(counters)
+        # this rank's launches cover its own tiles: samples per launch on this rank
+        samples_per_launch = WIDTH * HEIGHT * SPP_PER_STEP / world
+        avg_ms = kernel_ms / max(1, launches)
+        achieved = b_alg * samples_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Msamples/s at 1920x1080, 8-bounce PT",
+            "value": samples / dt_max / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cornell_box 1920x1080, 8 bounces, area light + MIS, "
+                                   f"{args.steps * SPP_PER_STEP} spp ({args.steps} steps x {SPP_PER_STEP} iterations)",
+                       "scene": "cornell_pt (36 triangles, 27 BVH nodes)", "spp_per_step": SPP_PER_STEP,
+                       "tiles": "8x8 pixels, tile % n_gpus == rank", "all_finite": finite,
+                       "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "pt::pt_render_kernel<false>", "avg_launch_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_sample": b_alg,
+                         "note": "algorithmic = reference-layout bytes (SURVEY.md 8d); the 7.4 KB scene is "
+                                 "cache-resident, so this logical figure can exceed the HBM peak"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

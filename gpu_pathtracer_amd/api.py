@@ -28,6 +28,15 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GptError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no fallback path")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.  If libgpt.so pulled in the
+    # system copy first, a later torch.cuda initialisation in the same process fails ("No HIP GPUs are
+    # available").  Loading torch first makes both share the runtime torch ships.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, u32, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
     lib.gpt_last_error.restype = C.c_char_p
@@ -42,6 +51,7 @@ def load():
         "gpt_read_color": [vp, vp],
         "gpt_write_state": [vp, vp, vp],
         "gpt_copy_to_host": [vp, vp, vp, C.c_size_t],
+        "gpt_bind_film": [vp, vp, vp],
         "gpt_end": [vp],
         "gpt_kernel_time": [vp, C.POINTER(u32), C.POINTER(C.c_double)],
         "gpt_kernel_time_reset": [vp],
@@ -151,6 +161,9 @@ class Renderer:
         acc = np.ascontiguousarray(acc, dtype=np.float32)
         color = np.ascontiguousarray(color, dtype=np.float32)
         check(self.lib.gpt_write_state(self.ctx, st.ptr(acc), st.ptr(color)))
+
+    def bind_film(self, acc_dev=None, color_dev=None):
+        check(self.lib.gpt_bind_film(self.ctx, acc_dev, color_dev))
 
     def kernel_time(self):
         n, ms = C.c_uint32(0), C.c_double(0)

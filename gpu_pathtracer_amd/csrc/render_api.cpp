@@ -376,6 +376,11 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     const bool count = ctx->count_next;
     HIP_TRY(hipMemsetAsync(ctx->tile_counter, 0, 64, ctx->stream));
     if (count) HIP_TRY(hipMemsetAsync(ctx->counters, 0, 6 * sizeof(unsigned long long), ctx->stream));
+    // reset clears the accumulator of EVERY pixel (Output, pathtracer.cu:2521).  With tile ownership the
+    // kernel only touches its own tiles, so the rest is cleared here: the sum-reduce over ranks then sees
+    // zeros outside each rank's support.
+    if (reset && P.n_ranks > 1)
+        HIP_TRY(hipMemsetAsync(ctx->acc, 0, (size_t)ctx->width * ctx->height * 3 * sizeof(float), ctx->stream));
 
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     if (n_owned == 0) return GPT_OK;
@@ -453,6 +458,15 @@ int gpt_write_state(gpt_ctx *ctx, const float *host_acc, const float *host_color
     const size_t bytes = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
     HIP_TRY(hipMemcpy(ctx->acc, host_acc, bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->color, host_color, bytes, hipMemcpyHostToDevice));
+    return GPT_OK;
+}
+
+int gpt_bind_film(gpt_ctx *ctx, float *acc_dev, float *color_dev)
+{
+    if (!ctx) { gpt_set_error("gpt_bind_film: null context"); return GPT_ERR_INVALID_ARG; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (acc_dev) { ctx->acc = acc_dev; ctx->P.acc = acc_dev; }
+    if (color_dev) { ctx->color = color_dev; ctx->P.color = color_dev; }
     return GPT_OK;
 }
 

@@ -89,6 +89,13 @@ int gpt_read_color(gpt_ctx *ctx, float *host_rgb);
 int gpt_write_state(gpt_ctx *ctx, const float *host_acc, const float *host_color); /* resume */
 int gpt_copy_to_host(gpt_ctx *ctx, const float *dev, float *host, size_t n_floats);
 
+/* Use caller-owned DEVICE buffers (W*H*3 floats each, zero them first) as the
+ * accumulator / last-sample planes instead of the ones gpt_begin allocated —
+ * like the reference, where the caller owns the device `output` buffer
+ * (src/main.cpp:136-137).  Lets a framework tensor (e.g. the send buffer of
+ * the RCCL framebuffer reduce) be the film itself.  NULL keeps the current one. */
+int gpt_bind_film(gpt_ctx *ctx, float *acc_dev, float *color_dev);
+
 /* EndRender (src/pathtracer.cu:2697-2703); frees everything gpt_begin allocated. */
 int gpt_end(gpt_ctx *ctx);
 

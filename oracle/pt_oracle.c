@@ -1079,7 +1079,8 @@ static inline f3 tonemap(f3 color, int filmic)
  * receives tonemap(acc/iter) of the last iteration.  `reset` zeroes acc before
  * the first iteration of this call.  Pixel addressing follows the reference's
  * launch geometry: stride = 32*(W/32), rows = 4*(H/4) (pathtracer.cu:881-883,2709).
- * Only rows with (y/4) % n_ranks == rank are rendered (multi-GPU tile ownership;
+ * Only 8x8-pixel tiles t (row-major tile index) with t % n_ranks == rank are
+ * rendered (multi-GPU tile ownership, same rule as gpt_set_tile_owner;
  * rank=0,n_ranks=1 renders everything).
  */
 API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_t width, uint32_t height,
@@ -1093,6 +1094,7 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     if (desc->infinite) sc.inf = *desc->infinite; else { memset(&sc.inf, 0, sizeof(sc.inf)); }
     uint32_t stride = 32u * (width / 32u);
     uint32_t rows = 4u * (height / 4u);
+    uint32_t tiles_x = (stride + 7u) / 8u;
     int maxDepth = desc->max_depth;
     int filmic = cam->filmic;
     if (n_threads < 1) n_threads = 1;
@@ -1103,8 +1105,9 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
         memset(&t_cnt, 0, sizeof(t_cnt));
 #pragma omp for schedule(dynamic, 1)
         for (uint32_t y = 0; y < rows; ++y) {
-            if ((int)((y / 4u) % (uint32_t)n_ranks) != rank) continue;
             for (uint32_t x = 0; x < stride; ++x) {
+                uint32_t tile = (x / 8u) + (y / 8u) * tiles_x;
+                if ((int)(tile % (uint32_t)n_ranks) != rank) continue;
                 uint32_t pixel = x + y * stride;
                 f3 a = mk3(acc[3 * pixel], acc[3 * pixel + 1], acc[3 * pixel + 2]);
                 f3 c = mk3(color[3 * pixel], color[3 * pixel + 1], color[3 * pixel + 2]);

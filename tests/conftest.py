@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    import oracle_lib
+    oracle_lib.build_oracle()
+
+
+@pytest.fixture(scope="session")
+def gpt():
+    """The HIP library through its C ABI; the GPU tests fail loudly if it is not built."""
+    from gpu_pathtracer_amd import api
+    api.load()
+    return api

@@ -1,0 +1,150 @@
+"""Pins the CPU oracle against the reference's known answers (no GPU).
+
+Golden sources:
+  tests/golden/survey_appendix_b.json  values produced by the reference's own code
+  tests/golden/rng_table.json          produced from the real thrust headers (tools/gen_rng_golden.cpp)
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpu_pathtracer_amd import scene_types as st
+
+GOLD = json.load(open(os.path.join(ol.GOLDEN, "survey_appendix_b.json")))
+RNG = json.load(open(os.path.join(ol.GOLDEN, "rng_table.json")))
+
+
+def nine(x):
+    """the survey printed 9 significant digits, which identifies a float32"""
+    return float(f"{float(x):.9g}")
+
+
+@pytest.mark.parametrize("kind", ["libm", "soft"])
+def test_rng_matches_thrust(kind):
+    lib = ol.load(kind)
+    for row in RNG:
+        if "pixel" not in row:
+            continue
+        seed = C.c_uint32()
+        u = np.zeros(16, np.float32)
+        lib.oracle_rng_table(row["pixel"], row["iter"], C.byref(seed), st.ptr(u), 16)
+        assert seed.value == row["seed"]
+        assert u.view(np.uint32).tolist() == row["u_bits"]
+
+
+def test_rng_matches_survey_table():
+    lib = ol.load("libm")
+    for row in GOLD["rng"]:
+        seed = C.c_uint32()
+        u = np.zeros(4, np.float32)
+        lib.oracle_rng_table(row["pixel"], row["iter"], C.byref(seed), st.ptr(u), 4)
+        assert seed.value == row["seed"]
+        assert [nine(x) for x in u] == row["u"]
+
+
+def test_uniform_can_reach_one():
+    # float(x-1)/2^31 rounds to 1.0f for x-1 >= 2147483584
+    assert np.float32(2147483584) / np.float32(2147483648.0) == np.float32(1.0)
+
+
+def test_cornell_bvh_listing():
+    scene, _ = ol.load_cornell(4, ol.load("libm"))
+    g = GOLD["cornell_bvh"]
+    assert len(scene.prims) == g["n_prims"] and len(scene.nodes) == g["n_nodes"]
+    assert 32 + 176 * len(scene.prims) + 40 * len(scene.nodes) == g["cache_bytes"]
+    assert np.allclose(scene.root_box, g["root_box"], atol=1e-9)
+    for row in g["nodes"]:
+        n = scene.nodes[row[0]]
+        if row[1] == "I":
+            assert not n["is_leaf"] and n["second_child_offset"] == row[2]
+        else:
+            assert n["is_leaf"] and (n["start"], n["end"]) == (row[2], row[3])
+    tri = scene.prims["triangle"]
+    assert [i for i in range(36) if tri["lightIdx"][i] >= 0] == g["light_prims"]
+    assert all(tri["matIdx"][i] == g["light_matIdx"] for i in g["light_prims"])
+    assert [i for i in range(36) if tri["matIdx"][i] == 0] == g["matIdx_0_prims"]
+    assert [i for i in range(36) if tri["matIdx"][i] == 1] == g["matIdx_1_prims"]
+    assert scene.cdf.tolist() == g["light_cdf"]
+    # every primitive reachable exactly once
+    seen = []
+    for n in scene.nodes:
+        if n["is_leaf"]:
+            seen += list(range(n["start"], n["end"] + 1))
+    assert sorted(seen) == list(range(36))
+
+
+@pytest.mark.parametrize("case", GOLD["radiance_clang_nofma"], ids=lambda c: f"spp{c['spp']}")
+def test_cornell_radiance_matches_reference_values(case):
+    lib = ol.load("libm")
+    scene, meta = ol.load_cornell(case["depth"], lib)
+    cam = ol.cornell_camera(meta, 512, 512, lib)
+    acc, _ = ol.render(scene, cam, 512, 512, meta["epsilon"], 1, case["spp"], kind="libm")
+    img = acc.reshape(-1, 3) / np.float32(case["spp"])
+    for p, rgb in case["pixels"].items():
+        assert [nine(x) for x in img[int(p)]] == rgb, f"pixel {p}"
+    mean = img.astype(np.float64).mean(0)
+    assert [nine(x) for x in mean] == case["mean"]
+
+
+def test_work_counters_match_survey():
+    """B_alg inputs.  The survey counted with a g++ build (right-to-left
+    draws), so agreement is statistical (<0.5 %), not exact."""
+    lib = ol.load("libm")
+    scene, meta = ol.load_cornell(4, lib)
+    cam = ol.cornell_camera(meta, 512, 512, lib)
+    ol.render(scene, cam, 512, 512, meta["epsilon"], 1, 2, kind="libm")
+    c = ol.counters("libm")
+    g = GOLD["work_per_sample_gxx"]["cornell_depth4_512"]
+    s = c["samples"]
+    assert s == 512 * 512 * 2
+    for key, name in (("bounce", "bounce_iters"), ("closest", "closest_rays"), ("shadow", "shadow_rays"),
+                      ("node", "node_visits"), ("prim", "prim_tests")):
+        assert abs(c[name] / s - g[key]) / g[key] < 5e-3, key
+
+
+def test_soft_and_libm_builds_agree_statistically():
+    """Same algorithm, different last-bit rounding of sin/cos: images differ only in rare pixels."""
+    scene, meta = ol.load_cornell(4)
+    cam = ol.cornell_camera(meta, 128, 128)
+    a, _ = ol.render(scene, cam, 128, 128, 0.001, 1, 16, kind="soft")
+    b, _ = ol.render(scene, cam, 128, 128, 0.001, 1, 16, kind="libm")
+    rms = np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2))
+    assert rms < 1e-3
+    assert np.count_nonzero(a != b) < 0.05 * a.size
+
+
+def test_render_is_deterministic_and_thread_independent():
+    scene, meta = ol.load_cornell(8)
+    cam = ol.cornell_camera(meta, 64, 64)
+    a, _ = ol.render(scene, cam, 64, 64, 0.001, 1, 8, threads=1)
+    b, _ = ol.render(scene, cam, 64, 64, 0.001, 1, 8, threads=8)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_batched_iterations_equal_single_calls():
+    """iter_count=N in one call == N reference-style calls with iter = 1..N."""
+    scene, meta = ol.load_cornell(5)
+    cam = ol.cornell_camera(meta, 64, 64)
+    a, ca = ol.render(scene, cam, 64, 64, 0.001, 1, 6)
+    acc = np.zeros(64 * 64 * 3, np.float32)
+    col = np.zeros(64 * 64 * 3, np.float32)
+    for it in range(1, 7):
+        ol.render(scene, cam, 64, 64, 0.001, it, 1, reset=(it == 1), acc=acc, color=col)
+    assert a.tobytes() == acc.tobytes() and ca.tobytes() == col.tobytes()
+
+
+def test_tile_ownership_partitions_the_frame():
+    scene, meta = ol.load_cornell(4)
+    W, H = 96, 64
+    cam = ol.cornell_camera(meta, W, H)
+    full, _ = ol.render(scene, cam, W, H, 0.001, 1, 3)
+    parts = [ol.render(scene, cam, W, H, 0.001, 1, 3, rank=r, n_ranks=3)[0] for r in range(3)]
+    s = parts[0] + parts[1] + parts[2]
+    assert s.tobytes() == full.tobytes()
+    # supports are disjoint
+    nz = [(p.reshape(-1, 3) != 0).any(1) for p in parts]
+    assert not (nz[0] & nz[1]).any() and not (nz[0] & nz[2]).any() and not (nz[1] & nz[2]).any()
