@@ -12,7 +12,7 @@ import numpy as np
 from . import scene_types as st
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpt.so")
+LIB_PATH = os.environ.get("GPT_LIB_PATH") or os.path.join(_HERE, "libgpt.so")   # override: kernel experiments only
 
 _lib = None
 
@@ -57,6 +57,7 @@ def load():
         "gpt_kernel_time_reset": [vp],
         "gpt_enable_counters": [vp, C.c_int],
         "gpt_read_counters": [vp, vp],
+        "gpt_read_probe_counters": [vp, vp],
         "gpt_debug_math": [C.c_int, C.c_int, vp, vp, vp, C.c_int],
         "gpt_debug_rng": [C.c_int, u32, u32, vp, vp, C.c_int],
         "gpt_bvh_build": [vp, i32, vp, vp, C.POINTER(i32), vp],
@@ -180,6 +181,13 @@ class Renderer:
         c = np.zeros(6, dtype=np.uint64)
         check(self.lib.gpt_read_counters(self.ctx, st.ptr(c)))
         names = ["node_visits", "prim_tests", "bounce_iters", "shadow_rays", "closest_rays", "samples"]
+        return dict(zip(names, map(int, c)))
+
+    def read_probe_counters(self):
+        c = np.zeros(16, dtype=np.uint64)
+        check(self.lib.gpt_read_probe_counters(self.ctx, st.ptr(c)))
+        names = ["node_visits", "prim_tests", "bounce_iters", "shadow_rays", "closest_rays", "samples",
+                 "w_node", "w_prim", "w_trip", "l_trip", "w_shade", "l_shade", "w_nee", "l_nee"]
         return dict(zip(names, map(int, c)))
 
     def close(self):

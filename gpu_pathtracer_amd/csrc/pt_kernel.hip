@@ -82,91 +82,223 @@ struct Hit {
 };
 struct Counters {
     uint32_t node_visits, prim_tests, bounce_iters, shadow_rays, closest_rays, samples;
+    // utilisation probes (counting build): wave-level trips, incremented by one lane per wave per trip
+    uint32_t w_node, w_prim, w_trip, l_trip, w_shade, l_shade, w_nee, l_nee;
 };
+__device__ __forceinline__ bool first_active_lane()
+{
+    const unsigned long long m = __ballot(1);
+    return (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m);
+}
 
 __device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 rcp3(V3 d) { return V3{1.f / d.x, 1.f / d.y, 1.f / d.z}; }
 
 // ------------------------------------------------------------ traversal ------
-// Closest hit (ANY=false): shrinks tmax, records (prim, b1, b2).  Any hit
-// (ANY=true): returns at the first accepted triangle.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const DevParams &P, const Ray &ray, float &tmax_io, int &hit_prim,
-                                         float &hit_b1, float &hit_b2, Counters &cnt)
+// Rays live in an LDS pool that belongs to ONE wavefront (no workgroup barrier
+// is ever needed).  Each bounce, every lane (= one path) deposits up to three
+// rays that share its shading point: the path ray (closest hit), the MIS light
+// ray (closest hit) and the shadow ray (any hit).  __ballot/mbcnt compaction
+// packs them densely — path rays first, then MIS rays, then shadow rays, i.e.
+// longest first — and the traversal loop below drains the pool with dynamic
+// fetch: a lane whose ray is finished writes its result into the ray's slot and
+// takes the next untraced ray, whichever path it belongs to.  The reference
+// traces the same rays one kind at a time with every thread waiting for the
+// slowest ray of its warp (src/pathtracer.cu:905,942,960).
+//
+// Inside the loop the wave votes each trip between a node step and a triangle
+// step (whichever more lanes are waiting for).  Per ray the visit order is
+// exactly the reference's: threaded preorder == its push-right/push-left stack
+// (pathtracer.cu:221-252), leaf triangles in index order; arithmetic is
+// bbox.h:77-96 and mesh.h:45-67.
+constexpr int kPoolSlots = 192;                    // 3 rays x 64 lanes
+constexpr int kWaveLdsFloat4 = 2 * kPoolSlots + 64;   // slots (2 x float4) + one origin per lane
+#ifndef PT_FETCH_T
+#define PT_FETCH_T 12
+#endif
+constexpr int kFetchThreshold = PT_FETCH_T;        // idle lanes that trigger a refill
+
+struct RaySet {        // what one lane deposits
+    V3 org;
+    V3 dir_p, dir_m, dir_s;
+    float tmax_s;
+    bool has_p, has_m, has_s;
+};
+struct PoolLayout {    // wave-uniform: where each kind starts, from the ballots
+    unsigned long long m_p, m_m, m_s;
+    int n_p, n_m, n_rays;
+};
+struct RayResult {
+    int prim;          // -1 = miss
+    float t, b1, b2;
+};
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask)   // number of set bits below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave execute in issue order; this only stops the compiler from
+    // moving LDS accesses across the hand-off between lanes.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// slot = { dir.xyz, tmax } { 1/dir.xyz, bits(owner lane | any_hit << 8) }
+__device__ __forceinline__ void pool_put(float4 *pool, int slot, V3 dir, float tmax, unsigned owner, bool any_hit)
+{
+    // bbox.h:79 computes 1/d at every node visit; the quotient is the same every time
+    pool[2 * slot] = make_float4(dir.x, dir.y, dir.z, tmax);
+    pool[2 * slot + 1] = make_float4(1.f / dir.x, 1.f / dir.y, 1.f / dir.z, __int_as_float((int)(owner | (any_hit ? 256u : 0u))));
+}
+
+__device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &rs, unsigned lane)
+{
+    PoolLayout L;
+    L.m_p = __ballot(rs.has_p);
+    L.m_m = __ballot(rs.has_m);
+    L.m_s = __ballot(rs.has_s);
+    L.n_p = __builtin_popcountll(L.m_p);
+    L.n_m = __builtin_popcountll(L.m_m);
+    L.n_rays = L.n_p + L.n_m + __builtin_popcountll(L.m_s);
+    pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
+    if (rs.has_p) pool_put(pool, lane_rank(L.m_p), rs.dir_p, __builtin_inff(), lane, false);
+    if (rs.has_m) pool_put(pool, L.n_p + lane_rank(L.m_m), rs.dir_m, __builtin_inff(), lane, false);
+    if (rs.has_s) pool_put(pool, L.n_p + L.n_m + lane_rank(L.m_s), rs.dir_s, rs.tmax_s, lane, true);
+    return L;
+}
+
+__device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
+{
+    const float4 r = pool[2 * slot];
+    RayResult out;
+    out.prim = __float_as_int(r.x);
+    out.t = r.y;
+    out.b1 = r.z;
+    out.b2 = r.w;
+    return out;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt)
 {
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
     const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(P.tris);
-    const V3 o = ray.o, d = ray.d;
-    // bbox.h:79 computes 1/d per node visit; the quotient is the same every time
-    const V3 inv = V3{1.f / d.x, 1.f / d.y, 1.f / d.z};
-    const float tmin_ray = ray.tmin;
-    float tmax = tmax_io;
-    bool hit = false;
-    int idx = 0;
     const int end = P.n_nodes;
-    while (idx < end) {
-        // ---- node phase: walk until a leaf whose box is hit --------------------
-        int leaf_first = 0, leaf_last = -1;
-        while (idx < end) {
-            const float4 a = nodes[2 * idx];
-            const float4 b = nodes[2 * idx + 1];
-            if (COUNT) cnt.node_visits++;
-            const float t1 = (a.x - o.x) * inv.x;
-            const float t2 = (a.w - o.x) * inv.x;
-            const float t3 = (a.y - o.y) * inv.y;
-            const float t4 = (b.x - o.y) * inv.y;
-            const float t5 = (a.z - o.z) * inv.z;
-            const float t6 = (b.y - o.z) * inv.z;
-            const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
-            const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
-            // bbox.h:91-95, with the reference's comparison senses (NaN passes)
-            const bool box = !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
-            const int link = __float_as_int(b.z);
-            const int last = __float_as_int(b.w);
-            const bool leaf = last >= 0;
-            const int next = (box || leaf) ? idx + 1 : link;
-            idx = next;
-            if (box && leaf) {
-                leaf_first = link;
-                leaf_last = last;
-                break;
-            }
+    const float tmin_ray = P.eps;          // every ray of the integrator starts at epsilon
+
+    int next = 0;                          // wave-uniform: first slot nobody has taken yet
+    bool busy = false;
+    int slot = 0;
+    bool any_hit = false;
+    V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
+    float tmax = 0.f;
+    int idx = end, tri = 0, tri_last = -1;
+    int hprim = -1;
+    float hb1 = 0.f, hb2 = 0.f;
+
+    for (;;) {
+        bool want_tri = busy && tri <= tri_last;
+        bool want_node = busy && !want_tri && idx < end;
+        if (busy && !want_tri && !want_node) {
+            // ray finished: the result overwrites the first half of its slot
+            pool[2 * slot] = make_float4(__int_as_float(hprim), tmax, hb1, hb2);
+            busy = false;
         }
-        // ---- leaf phase: Moeller-Trumbore, mesh.h:45-67 ------------------------
-        for (int i = leaf_first; i <= leaf_last; ++i) {
-            const float4 q0 = tris[3 * i];
-            const float4 q1 = tris[3 * i + 1];
-            const float e2z = reinterpret_cast<const float *>(tris + 3 * i + 2)[0];
-            if (COUNT) cnt.prim_tests++;
-            const V3 v1 = V3{q0.x, q0.y, q0.z};
-            const V3 e1 = V3{q0.w, q1.x, q1.y};
-            const V3 e2 = V3{q1.z, q1.w, e2z};
-            const V3 s1 = cross(d, e2);
-            const float divisor = dot(s1, e1);
-            if (fabs_(divisor) < 1e-8f) continue;
-            // reference: float invDivisor = 1.0 / divisor (double divide, rounded to
-            // float) == the correctly rounded float quotient (53 >= 2*24+2 bits)
-            const float invDivisor = 1.0f / divisor;
-            const V3 s = o - v1;
-            const float b1 = dot(s, s1) * invDivisor;
-            if (b1 < 0.0f || b1 > 1.0f) continue;
-            const V3 s2 = cross(s, e1);
-            const float b2 = dot(d, s2) * invDivisor;
-            if (b2 < 0.0f || b1 + b2 > 1.0f) continue;
-            const float tt = dot(e2, s2) * invDivisor;
-            if (tt < tmin_ray || tt > tmax) continue;
-            tmax = tt;
-            hit = true;
-            if (ANY) {
-                tmax_io = tmax;
-                return true;
+        unsigned long long m_busy = __ballot(busy);
+        const int n_idle = 64 - __builtin_popcountll(m_busy);
+        if (next < n_rays && (n_idle >= kFetchThreshold || m_busy == 0ull)) {
+            // ---- refill: idle lanes take the next slots, in lane order ------------------
+            const int mine = next + lane_rank(~m_busy);
+            if (!busy && mine < n_rays) {
+                const float4 r0 = pool[2 * mine];
+                const float4 r1 = pool[2 * mine + 1];
+                const int tag = __float_as_int(r1.w);
+                const float4 ro = pool[2 * kPoolSlots + (tag & 255)];
+                slot = mine;
+                any_hit = (tag & 256) != 0;
+                o = V3{ro.x, ro.y, ro.z};
+                d = V3{r0.x, r0.y, r0.z};
+                inv = V3{r1.x, r1.y, r1.z};
+                tmax = r0.w;
+                idx = 0;
+                tri = 0;
+                tri_last = -1;
+                hprim = -1;
+                hb1 = hb2 = 0.f;
+                busy = true;
+                want_tri = false;
+                want_node = end > 0;
             }
-            hit_prim = i;
-            hit_b1 = b1;
-            hit_b2 = b2;
+            next += n_idle;
+            m_busy = __ballot(busy);
+        }
+        if (m_busy == 0ull) break;
+
+        const unsigned long long m_tri = __ballot(want_tri);
+        const unsigned long long m_node = __ballot(want_node);
+        if (__builtin_popcountll(m_node) >= __builtin_popcountll(m_tri)) {
+            if (want_node) {
+                // ---- one node --------------------------------------------------------------
+                const float4 a = nodes[2 * idx];
+                const float4 b = nodes[2 * idx + 1];
+                if (COUNT) { cnt.node_visits++; if (first_active_lane()) cnt.w_node++; }
+                const float t1 = (a.x - o.x) * inv.x;
+                const float t2 = (a.w - o.x) * inv.x;
+                const float t3 = (a.y - o.y) * inv.y;
+                const float t4 = (b.x - o.y) * inv.y;
+                const float t5 = (a.z - o.z) * inv.z;
+                const float t6 = (b.y - o.z) * inv.z;
+                const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
+                const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
+                // the reference's comparison senses (NaN passes)
+                const bool box = !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
+                const int link = __float_as_int(b.z);
+                const int last = __float_as_int(b.w);
+                const bool leaf = last >= 0;
+                idx = (box || leaf) ? idx + 1 : link;
+                if (box && leaf) {
+                    tri = link;
+                    tri_last = last;
+                }
+            }
+        } else {
+            if (want_tri) {
+                // ---- one triangle ----------------------------------------------------------
+                const int i = tri++;
+                const float4 q0 = tris[3 * i];
+                const float4 q1 = tris[3 * i + 1];
+                const float e2z = reinterpret_cast<const float *>(tris + 3 * i + 2)[0];
+                if (COUNT) { cnt.prim_tests++; if (first_active_lane()) cnt.w_prim++; }
+                const V3 v1 = V3{q0.x, q0.y, q0.z};
+                const V3 e1 = V3{q0.w, q1.x, q1.y};
+                const V3 e2 = V3{q1.z, q1.w, e2z};
+                const V3 s1 = cross(d, e2);
+                const float divisor = dot(s1, e1);
+                // reference: float invDivisor = 1.0 / divisor (double divide rounded to float)
+                // == the correctly rounded float quotient (53 >= 2*24+2 bits)
+                const float invDivisor = 1.0f / divisor;
+                const V3 s = o - v1;
+                const float b1 = dot(s, s1) * invDivisor;
+                const V3 s2 = cross(s, e1);
+                const float b2 = dot(d, s2) * invDivisor;
+                const float tt = dot(e2, s2) * invDivisor;
+                const bool accept = !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) &&
+                                    !(b2 < 0.0f || b1 + b2 > 1.0f) && !(tt < tmin_ray || tt > tmax);
+                if (accept) {
+                    tmax = tt;
+                    hprim = i;
+                    hb1 = b1;
+                    hb2 = b2;
+                    if (any_hit) {      // IntersectP: the first accepted triangle ends the ray
+                        idx = end;
+                        tri_last = -1;
+                    }
+                }
+            }
         }
     }
-    tmax_io = tmax;
-    return hit;
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -790,12 +922,37 @@ __device__ __forceinline__ V3 tonemap(V3 in, bool filmic)   // pathtracer.cu:187
 }
 
 // ----------------------------------------------------- the render kernel -----
-template <bool COUNT>
-__global__ void __launch_bounds__(256) pt_render_kernel(const DevParams P)
+// normal + light index of a hit, for the MIS light ray (mesh.h:87-90): the
+// other Intersection fields are not read at pathtracer.cu:960-976
+__device__ __forceinline__ void make_light_hit(const DevParams &P, int prim, float b1, float b2, V3 &nor, int &lightIdx)
 {
+    const float4 *__restrict__ sp = reinterpret_cast<const float4 *>(P.shade) + 5 * prim;
+    const float4 s0 = sp[0], s1 = sp[1];
+    const float n3z = reinterpret_cast<const float *>(sp + 2)[0];
+    lightIdx = __float_as_int(reinterpret_cast<const float *>(sp + 4)[3]);
+    const V3 n1 = V3{s0.x, s0.y, s0.z}, n2 = V3{s0.w, s1.x, s1.y}, n3 = V3{s1.z, s1.w, n3z};
+    nor = normalize(n1 * (1.f - b1 - b2) + n2 * b1 + n3 * b2);
+}
+
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4
+#endif
+struct RayResults {    // this lane's own rays, read back from the pool
+    bool occluded;
+    int prim_m;
+    float t_m, b1_m, b2_m;
+    int prim_p;
+    float t_p, b1_p, b2_p;
+};
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P)
+{
+    __shared__ float4 lds_pool[4 * kWaveLdsFloat4];     // one private ray pool per wavefront
+    float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveLdsFloat4;
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
-    Counters cnt = {0, 0, 0, 0, 0, 0};
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
         // ---- persistent scheduler: one atomic per wave per tile -----------------
@@ -816,24 +973,185 @@ __global__ void __launch_bounds__(256) pt_render_kernel(const DevParams P)
             if (!P.reset) acc = V3{P.acc[3 * pixel], P.acc[3 * pixel + 1], P.acc[3 * pixel + 2]};
         }
         const uint32_t hash_pixel = wang_hash(pixel);
-
         uint32_t iter = P.iter_first;
         uint32_t left = valid ? P.iter_count : 0u;
-        bool alive = false;
 
-        // per-path state
+        // ---- per-path state ---------------------------------------------------------
         Rng rng;
         rng.x = 1;
-        Ray r;
-        r.o = r.d = v3(0.f);
-        r.tmin = P.eps;
-        r.tmax = 0.f;
         V3 Li = v3(0.f), beta = v3(1.f);
         bool specular = false;
         int bounces = 0;
+        // direct light waiting for its shadow / MIS rays (pathtracer.cu:942-994)
+        V3 beta_ld = v3(0.f);      // throughput to apply to Ld
+        V3 cand = v3(0.f);         // light-sample term, added if the shadow ray is unoccluded
+        V3 mis_fr = v3(0.f);       // BSDF-sample term pieces
+        float mis_cos = 0.f, mis_pdf = 1.f;
+        bool ending = false;       // the path has no continuation; the sample ends once Ld is resolved
+        bool alive = false;
 
-        while (__any(alive || left > 0)) {
-            // ---- regenerate: pathtracer.cu:888-903 -------------------------------
+        RaySet q;
+        q.org = q.dir_s = q.dir_m = q.dir_p = v3(0.f);
+        q.tmax_s = 0.f;
+        q.has_s = q.has_m = q.has_p = false;
+        RayResults res;
+        res.occluded = false;
+        res.prim_m = res.prim_p = -1;
+        res.t_m = res.b1_m = res.b2_m = res.t_p = res.b1_p = res.b2_p = 0.f;
+
+        for (;;) {
+            bool finish = false;
+            if (alive) {
+                // ---- resolve the direct light of the previous bounce ------------------
+                if (q.has_s || q.has_m) {
+                    V3 Ld = v3(0.f, 0.f, 0.f);
+                    if (q.has_s && !res.occluded) Ld += cand;
+                    if (q.has_m) {
+                        if (res.prim_m >= 0) {
+                            V3 n;
+                            int lightIdx;
+                            make_light_hit(P, res.prim_m, res.b1_m, res.b2_m, n, lightIdx);
+                            V3 radiance = v3(0.f, 0.f, 0.f);
+                            if (lightIdx != -1) radiance = area_le(P.lights[lightIdx], n, -q.dir_m);
+                            if (!is_black(radiance)) {
+                                V3 p = q.org + res.t_m * q.dir_m;
+                                float pdfA = 1.f / P.lights[lightIdx].area;              // area.h:28-32
+                                float choicePdf = pdf_from_light_distribution(P, lightIdx);
+                                float lenSquare = dot(p - q.org, p - q.org);
+                                float costheta = fabs_(dot(n, q.dir_m));
+                                float lPdf = pdfA * lenSquare / (costheta);
+                                float weight = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
+                                Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
+                            }
+                        } else if (P.inf.isvalid) {
+                            V3 radiance = inf_le(P.inf, q.dir_m);
+                            float choicePdf = pdf_from_light_distribution(P, P.n_lights);
+                            float lightPdf = ONE_OVER_FOUR_PI;                             // infinite.h:38-41
+                            float weight = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
+                            Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
+                        }
+                    }
+                    Li += beta_ld * Ld;
+                }
+                if (ending) finish = true;
+
+                // ---- the path ray came back: pathtracer.cu:905-1016 ----------------------
+                if (!finish && q.has_p) {
+                    if (res.prim_p < 0) {
+                        if ((bounces == 0 || specular) && P.inf.isvalid)
+                            Li += beta * inf_le(P.inf, q.dir_p);
+                        finish = true;
+                    } else {
+                        Ray r;
+                        r.o = q.org;
+                        r.d = q.dir_p;
+                        const Hit isect = make_hit(P, r, res.t_p, res.prim_p, res.b1_p, res.b2_p);
+                        const V3 pos = isect.pos;
+                        const V3 nor = isect.nor;
+                        const V2 uv = isect.uv;
+                        const V3 dpdu = isect.dpdu;
+                        const V3 wo = -q.dir_p;
+                        const gpt_material material = P.materials[isect.matIdx];
+                        q.has_s = q.has_m = q.has_p = false;
+
+                        if ((bounces == 0 || specular) && isect.lightIdx != -1) {
+                            Li += beta * area_le(P.lights[isect.lightIdx], nor, wo);
+                            finish = true;
+                        } else {
+                            q.org = pos;
+                            // direct light with multiple importance sampling: everything that
+                            // does not depend on visibility is evaluated now
+                            if (!is_delta(material.type)) {
+                                float u = rng_uniform(rng);
+                                float choicePdf;
+                                int idx = lookup_light_distribution(P, u, choicePdf);
+                                bool inf = idx == P.n_lights;
+                                float u1x = rng_uniform(rng);
+                                float u1y = rng_uniform(rng);
+                                V2 u1 = v2(u1x, u1y);
+                                V3 radiance = v3(0.f), lightNor;
+                                Ray shadowRay;
+                                shadowRay.o = pos;
+                                shadowRay.d = v3(0.f);
+                                shadowRay.tmin = P.eps;
+                                shadowRay.tmax = 0.f;
+                                float lightPdf = 0.f;
+                                if (idx >= 0) {
+                                    if (!inf)
+                                        area_sample_light(P.lights[idx], pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                    else
+                                        inf_sample_light(P.inf, pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                }
+                                if (!is_black(radiance)) {
+                                    V3 fr;
+                                    float samplePdf;
+                                    eval_bsdf(P, material, wo, shadowRay.d, nor, uv, dpdu, fr, samplePdf);
+                                    float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                                    cand = weight * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
+                                    q.dir_s = shadowRay.d;
+                                    q.tmax_s = shadowRay.tmax;
+                                    q.has_s = true;
+                                }
+                                float usx = rng_uniform(rng);
+                                float usy = rng_uniform(rng);
+                                float usz = rng_uniform(rng);
+                                V3 out, fr;
+                                float pdf;
+                                sample_bsdf(P, material, wo, nor, uv, dpdu, v3(usx, usy, usz), out, fr, pdf);
+                                if (!(is_black(fr) || pdf == 0)) {
+                                    mis_fr = fr;
+                                    mis_cos = fabs_(dot(out, nor));
+                                    mis_pdf = pdf;
+                                    q.dir_m = out;
+                                    q.has_m = true;
+                                }
+                                beta_ld = beta;
+                            }
+                            // continuation.  The reference also samples it on the last bounce and
+                            // then leaves the loop; nothing of that sample reaches Li, so it is skipped.
+                            ending = true;
+                            if (bounces + 1 < P.max_depth) {
+                                float ux = rng_uniform(rng);
+                                float uy = rng_uniform(rng);
+                                float uz = rng_uniform(rng);
+                                V3 out, fr;
+                                float pdf;
+                                sample_bsdf(P, material, wo, nor, uv, dpdu, v3(ux, uy, uz), out, fr, pdf);
+                                if (!is_black(fr)) {
+                                    beta *= fr * fabs_(dot(nor, out)) / pdf;
+                                    specular = is_delta(material.type);
+                                    bool kill = false;
+                                    if (bounces > 3) {
+                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                        if (rng_uniform(rng) < illumate)
+                                            kill = true;
+                                        else
+                                            beta /= (1 - illumate);
+                                    }
+                                    if (!kill) {
+                                        q.dir_p = out;
+                                        q.has_p = true;
+                                        ending = false;
+                                        bounces++;
+                                    }
+                                }
+                            }
+                            if (ending && !q.has_s && !q.has_m) finish = true;
+                        }
+                    }
+                }
+            }
+
+            if (finish) {
+                // pathtracer.cu:1019-1020 (a non-finite sample leaves the previous value in
+                // kernel_color) + Output's accumulate (:2523-2525)
+                if (!is_inf(Li) && !is_nan(Li)) col = Li;
+                acc += col;
+                alive = false;
+                iter++;
+                q.has_s = q.has_m = q.has_p = false;
+            }
+            // ---- regenerate: pathtracer.cu:888-903 ---------------------------------------
             if (!alive && left > 0) {
                 rng_seed(rng, hash_pixel + wang_hash(iter));
                 float offsetx = rng_uniform(rng) - 0.5f;
@@ -843,159 +1161,43 @@ __global__ void __launch_bounds__(256) pt_render_kernel(const DevParams P)
                 float rr = sqrt_rn(du1);                  // UniformDisk, wrap.h:78-85
                 float phi = TWOPI * du2;
                 V2 aperture = v2(rr * gpt_cosf(phi), rr * gpt_sinf(phi));
-                r = primary_ray(P.cam, x + offsetx, y + offsety, aperture);
-                r.tmin = P.eps;
+                Ray r = primary_ray(P.cam, x + offsetx, y + offsety, aperture);
+                q.org = r.o;
+                q.dir_p = r.d;
+                q.has_p = true;
+                q.has_s = q.has_m = false;
                 Li = v3(0.f, 0.f, 0.f);
                 beta = v3(1.f, 1.f, 1.f);
                 specular = false;
                 bounces = 0;
+                ending = false;
                 alive = true;
                 left--;
                 if (COUNT) cnt.samples++;
             }
-            if (!alive) continue;
+            if (!__any(alive)) break;
 
-            // ---- one bounce: pathtracer.cu:904-1017 -------------------------------
-            bool finish = false;
-            if (COUNT) { cnt.bounce_iters++; cnt.closest_rays++; }
-            int hp = 0;
-            float hb1 = 0.f, hb2 = 0.f;
-            float tmax = r.tmax;
-            if (!traverse<false, COUNT>(P, r, tmax, hp, hb1, hb2, cnt)) {
-                if ((bounces == 0 || specular) && P.inf.isvalid)
-                    Li += beta * inf_le(P.inf, r.d);
-                finish = true;
-            } else {
-                const Hit isect = make_hit(P, r, tmax, hp, hb1, hb2);
-                const V3 pos = isect.pos;
-                const V3 nor = isect.nor;
-                const V2 uv = isect.uv;
-                const V3 dpdu = isect.dpdu;
-                const gpt_material material = P.materials[isect.matIdx];
-
-                if ((bounces == 0 || specular) && isect.lightIdx != -1) {
-                    Li += beta * area_le(P.lights[isect.lightIdx], nor, -r.d);
-                    finish = true;
-                } else {
-                    // direct light with multiple importance sampling
-                    if (!is_delta(material.type)) {
-                        V3 Ld = v3(0.f, 0.f, 0.f);
-                        float u = rng_uniform(rng);
-                        float choicePdf;
-                        int idx = lookup_light_distribution(P, u, choicePdf);
-                        bool inf = idx == P.n_lights;
-                        float u1x = rng_uniform(rng);
-                        float u1y = rng_uniform(rng);
-                        V2 u1 = v2(u1x, u1y);
-                        V3 radiance = v3(0.f), lightNor;
-                        Ray shadowRay;
-                        shadowRay.o = pos;
-                        shadowRay.d = v3(0.f);
-                        shadowRay.tmin = P.eps;
-                        shadowRay.tmax = 0.f;
-                        float lightPdf = 0.f;
-                        if (idx >= 0) {
-                            if (!inf)
-                                area_sample_light(P.lights[idx], pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
-                            else
-                                inf_sample_light(P.inf, pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
-                        }
-                        if (!is_black(radiance)) {
-                            if (COUNT) cnt.shadow_rays++;
-                            int d0;
-                            float d1, d2;
-                            float stmax = shadowRay.tmax;
-                            if (!traverse<true, COUNT>(P, shadowRay, stmax, d0, d1, d2, cnt)) {
-                                V3 fr;
-                                float samplePdf;
-                                eval_bsdf(P, material, -r.d, shadowRay.d, nor, uv, dpdu, fr, samplePdf);
-                                float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
-                                Ld += weight * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
-                            }
-                        }
-
-                        float usx = rng_uniform(rng);
-                        float usy = rng_uniform(rng);
-                        float usz = rng_uniform(rng);
-                        V3 us = v3(usx, usy, usz);
-                        V3 out, fr;
-                        float pdf;
-                        sample_bsdf(P, material, -r.d, nor, uv, dpdu, us, out, fr, pdf);
-                        if (!(is_black(fr) || pdf == 0)) {
-                            Ray lightRay;
-                            lightRay.o = pos;
-                            lightRay.d = out;
-                            lightRay.tmin = P.eps;
-                            lightRay.tmax = __builtin_inff();
-                            int lp = 0;
-                            float lb1 = 0.f, lb2 = 0.f;
-                            float ltmax = lightRay.tmax;
-                            if (COUNT) cnt.closest_rays++;
-                            if (traverse<false, COUNT>(P, lightRay, ltmax, lp, lb1, lb2, cnt)) {
-                                const Hit lightIsect = make_hit(P, lightRay, ltmax, lp, lb1, lb2);
-                                V3 p = lightIsect.pos;
-                                V3 n = lightIsect.nor;
-                                V3 radiance2 = v3(0.f, 0.f, 0.f);
-                                if (lightIsect.lightIdx != -1)
-                                    radiance2 = area_le(P.lights[lightIsect.lightIdx], n, -lightRay.d);
-                                if (!is_black(radiance2)) {
-                                    float pdfA = 1.f / P.lights[lightIsect.lightIdx].area;   // area.h:28-32
-                                    float choicePdf2 = pdf_from_light_distribution(P, lightIsect.lightIdx);
-                                    float lenSquare = dot(p - pos, p - pos);
-                                    float costheta = fabs_(dot(n, lightRay.d));
-                                    float lPdf = pdfA * lenSquare / (costheta);
-                                    float weight = power_heuristic(1, pdf, 1, lPdf * choicePdf2);
-                                    Ld += weight * fr * radiance2 * fabs_(dot(out, nor)) / pdf;
-                                }
-                            } else if (P.inf.isvalid) {
-                                V3 radiance2 = inf_le(P.inf, lightRay.d);
-                                float choicePdf2 = pdf_from_light_distribution(P, P.n_lights);
-                                float lightPdf2 = ONE_OVER_FOUR_PI;                           // infinite.h:38-41
-                                float weight = power_heuristic(1, pdf, 1, lightPdf2 * choicePdf2);
-                                Ld += weight * fr * radiance2 * fabs_(dot(out, nor)) / pdf;
-                            }
-                        }
-                        Li += beta * Ld;
-                    }
-
-                    float ux = rng_uniform(rng);
-                    float uy = rng_uniform(rng);
-                    float uz = rng_uniform(rng);
-                    V3 u = v3(ux, uy, uz);
-                    V3 out, fr;
-                    float pdf;
-                    sample_bsdf(P, material, -r.d, nor, uv, dpdu, u, out, fr, pdf);
-                    if (is_black(fr)) {
-                        finish = true;
-                    } else {
-                        beta *= fr * fabs_(dot(nor, out)) / pdf;
-                        specular = is_delta(material.type);
-                        r.o = pos;
-                        r.d = out;
-                        r.tmin = P.eps;
-                        r.tmax = __builtin_inff();
-                        if (bounces > 3) {
-                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
-                            if (rng_uniform(rng) < illumate) {
-                                finish = true;
-                            } else {
-                                beta /= (1 - illumate);
-                            }
-                        }
-                        bounces++;
-                        if (bounces >= P.max_depth) finish = true;
-                    }
-                }
+            if (COUNT && alive) {
+                if (q.has_p) { cnt.bounce_iters++; cnt.closest_rays++; }
+                if (q.has_m) cnt.closest_rays++;
+                if (q.has_s) cnt.shadow_rays++;
             }
-
-            if (finish) {
-                // pathtracer.cu:1019-1020 (a non-finite sample leaves the previous
-                // value in kernel_color) + Output's accumulate (:2523-2525)
-                if (!is_inf(Li) && !is_nan(Li)) col = Li;
-                acc += col;
-                alive = false;
-                iter++;
+            // ---- deposit this bounce's rays, drain the pool, pick up the results -----------------
+            if (!alive) q.has_p = q.has_m = q.has_s = false;
+            const PoolLayout L = pool_deposit(pool, q, lane);
+            wave_lds_fence();
+            trace_pool<COUNT>(P, pool, L.n_rays, cnt);
+            wave_lds_fence();
+            if (q.has_p) {
+                const RayResult rr = pool_result(pool, lane_rank(L.m_p));
+                res.prim_p = rr.prim; res.t_p = rr.t; res.b1_p = rr.b1; res.b2_p = rr.b2;
             }
+            if (q.has_m) {
+                const RayResult rr = pool_result(pool, L.n_p + lane_rank(L.m_m));
+                res.prim_m = rr.prim; res.t_m = rr.t; res.b1_m = rr.b1; res.b2_m = rr.b2;
+            }
+            if (q.has_s) res.occluded = pool_result(pool, L.n_p + L.n_m + lane_rank(L.m_s)).prim >= 0;
+            wave_lds_fence();
         }
 
         if (valid) {
@@ -1022,6 +1224,14 @@ __global__ void __launch_bounds__(256) pt_render_kernel(const DevParams P)
         atomicAdd(&P.counters[3], (unsigned long long)cnt.shadow_rays);
         atomicAdd(&P.counters[4], (unsigned long long)cnt.closest_rays);
         atomicAdd(&P.counters[5], (unsigned long long)cnt.samples);
+        atomicAdd(&P.counters[6], (unsigned long long)cnt.w_node);
+        atomicAdd(&P.counters[7], (unsigned long long)cnt.w_prim);
+        atomicAdd(&P.counters[8], (unsigned long long)cnt.w_trip);
+        atomicAdd(&P.counters[9], (unsigned long long)cnt.l_trip);
+        atomicAdd(&P.counters[10], (unsigned long long)cnt.w_shade);
+        atomicAdd(&P.counters[11], (unsigned long long)cnt.l_shade);
+        atomicAdd(&P.counters[12], (unsigned long long)cnt.w_nee);
+        atomicAdd(&P.counters[13], (unsigned long long)cnt.l_nee);
     }
 }
 

@@ -375,7 +375,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     P.out = out_tonemapped_dev;
     const bool count = ctx->count_next;
     HIP_TRY(hipMemsetAsync(ctx->tile_counter, 0, 64, ctx->stream));
-    if (count) HIP_TRY(hipMemsetAsync(ctx->counters, 0, 6 * sizeof(unsigned long long), ctx->stream));
+    if (count) HIP_TRY(hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
     // reset clears the accumulator of EVERY pixel (Output, pathtracer.cu:2521).  With tile ownership the
     // kernel only touches its own tiles, so the rest is cleared here: the sum-reduce over ranks then sees
     // zeros outside each rank's support.
@@ -506,6 +506,17 @@ int gpt_enable_counters(gpt_ctx *ctx, int enable)
 {
     if (!ctx) { gpt_set_error("gpt_enable_counters: null context"); return GPT_ERR_INVALID_ARG; }
     ctx->count_next = enable != 0;
+    return GPT_OK;
+}
+
+int gpt_read_probe_counters(gpt_ctx *ctx, uint64_t out16[16])
+{
+    if (!ctx || !out16) { gpt_set_error("gpt_read_probe_counters: null argument"); return GPT_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long tmp[16];
+    HIP_TRY(hipMemcpy(tmp, ctx->counters, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; ++i) out16[i] = tmp[i];
     return GPT_OK;
 }
 

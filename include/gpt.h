@@ -111,6 +111,10 @@ int gpt_kernel_time_reset(gpt_ctx *ctx);
  * closest-hit rays, samples — the terms of SURVEY.md §8(d) B_alg. */
 int gpt_enable_counters(gpt_ctx *ctx, int enable);
 int gpt_read_counters(gpt_ctx *ctx, uint64_t out6[6]);
+/* The 6 counters above plus SIMD-utilisation probes of the counting build: [6] wave-level node-loop
+ * trips, [7] wave-level triangle-loop trips, [8]/[9] wave/lane bounce trips, [10]/[11] wave/lane
+ * hit-shading trips, [12]/[13] wave/lane direct-light trips.  lanes/(64*waves) = lane utilisation. */
+int gpt_read_probe_counters(gpt_ctx *ctx, uint64_t out16[16]);
 
 /* Device-side evaluation of the elementary float operations the kernel relies
  * on, for parity tests against the CPU oracle: fn 0 sin, 1 cos, 2 tan, 3 atan,

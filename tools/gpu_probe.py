@@ -1,0 +1,14 @@
+import sys, os
+sys.path.insert(0, '.')
+from gpu_pathtracer_amd import api, host
+W, H, D = 1920, 1080, 8
+scene, meta = host.load_baked("tests/golden/cornell_pt.npz", D)
+cam = host.camera_from_meta(meta, W, H)
+r = api.Renderer(scene.desc, W, H, 0.001)
+r.enable_counters(True); r.render(cam, 1, 16, reset=True); r.synchronize()
+c = r.read_probe_counters(); print(c)
+u = lambda l, w: c[l] / (64.0 * c[w]) if c[w] else float('nan')
+print("lane utilisation: node loop %.3f  triangle loop %.3f  bounce trip %.3f  hit shading %.3f  direct light %.3f" %
+      (u("node_visits", "w_node"), u("prim_tests", "w_prim"), u("l_trip", "w_trip"), u("l_shade", "w_shade"), u("l_nee", "w_nee")))
+print("per sample: wave node trips x64 = %.1f lane-slots (useful %.1f); tri %.1f (useful %.1f); trips %.2f" % (
+    64.0*c["w_node"]/c["samples"], c["node_visits"]/c["samples"], 64.0*c["w_prim"]/c["samples"], c["prim_tests"]/c["samples"], 64.0*c["w_trip"]/c["samples"]))
