@@ -64,6 +64,13 @@ def load():
         "gpt_light_distribution": [vp, i32, vp, vp, C.POINTER(i32)],
         "gpt_infinite_init": [vp, vp],
         "gpt_camera_init": [vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, C.c_int, C.c_int],
+        "gpt_scene_load": [C.c_char_p, C.POINTER(vp)],
+        "gpt_scene_get_desc": [vp, vp],
+        "gpt_scene_get_config": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), vp],
+        "gpt_scene_set_integrator": [vp, i32, i32],
+        "gpt_scene_free": [vp],
+        "gpt_save_png": [C.c_char_p, i32, i32, vp],
+        "gpt_save_pfm": [C.c_char_p, i32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -112,6 +119,54 @@ def camera_init(position, lookat, up=(0, 1, 0), res=(512, 512), fov=60.0, apertu
     check(load().gpt_camera_init(C.byref(cam), p, la, u, float(res[0]), float(res[1]), float(distance), float(fov),
                                  float(aperture), float(focal), int(filmic), int(environment)))
     return cam
+
+
+class LoadedScene:
+    """gpt_scene_load: LoadScene + InitScene of the reference (src/parsescene.cpp:45, src/main.cpp:261-278)."""
+
+    def __init__(self, json_path):
+        self.lib = load()
+        self.handle = C.c_void_p()
+        check(self.lib.gpt_scene_load(os.fsencode(json_path), C.byref(self.handle)))
+        self.desc = st.SceneDesc()
+        check(self.lib.gpt_scene_get_desc(self.handle, C.byref(self.desc)))
+        w, h, eps = C.c_int32(), C.c_int32(), C.c_float()
+        self.camera = st.Camera()
+        check(self.lib.gpt_scene_get_config(self.handle, C.byref(w), C.byref(h), C.byref(eps), C.byref(self.camera)))
+        self.width, self.height, self.epsilon = w.value, h.value, eps.value
+
+    def set_integrator(self, integrator_type, max_depth):
+        check(self.lib.gpt_scene_set_integrator(self.handle, integrator_type, max_depth))
+        check(self.lib.gpt_scene_get_desc(self.handle, C.byref(self.desc)))
+
+    def array(self, name, count_name, dtype):
+        n = getattr(self.desc, count_name)
+        ptr_ = getattr(self.desc, name)
+        if not n or not ptr_:
+            return np.zeros(0, dtype=dtype)
+        raw = np.ctypeslib.as_array(C.cast(ptr_, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dtype).itemsize,))
+        return raw.view(dtype)
+
+    def close(self):
+        if self.handle:
+            self.lib.gpt_scene_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def save_png(path, width, height, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    check(load().gpt_save_png(os.fsencode(path), width, height, st.ptr(rgb)))
+
+
+def save_pfm(path, width, height, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    check(load().gpt_save_pfm(os.fsencode(path), width, height, st.ptr(rgb)))
 
 
 # ---- renderer --------------------------------------------------------------------

@@ -1,0 +1,848 @@
+// scene_loader.cpp — host-side scene loading for the path: the reference's
+//   LoadScene            src/parsescene.cpp:45-590   (the keys the "pt" path reads)
+//   Mesh::processMesh    src/mesh.cpp:29-111         (vertex transform, tangents, triangle soup)
+//   Scene::Init          src/scene.h:50-83           (BVH, env bounding sphere, light power CDF)
+//   BVH::LoadOrBuildBVH  src/bvh.cpp:189-218         (bvh.cache, same file layout)
+//   Camera               src/camera.h:31-46,123-128
+// re-implemented without the reference's third-party stack: own JSON reader (rapidjson there), own OBJ
+// reader (assimp there; the Windows .lib is all the reference vendors), own 4x4 transform code (glm
+// there — the operation ORDER of glm's translate/rotate/scale/operator* is followed so transformed
+// vertices round the same way).
+//
+// OBJ rule (what assimp does for aiProcess_Triangulate on the meshes the reference ships): one vertex
+// per face corner, polygons fan-triangulated, no vertex joining.  For files WITHOUT `vn`
+// (aiProcess_GenSmoothNormals) the declared rule is: normal of a position index = normalize(sum of the
+// un-normalised face normals cross(p1-p0, p2-p0) of every triangle that uses that index).  assimp's exact
+// smoothing (it also merges coincident positions with different indices) is not pinned — DESIGN.md.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "host_util.h"
+#include "imageio.h"
+#include "pathtracer.h"
+#include "pt_vec.h"
+
+using pt::V3;
+
+// ================================================================= JSON ==========
+namespace {
+
+struct Json {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    double num = 0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+
+    bool has(const char *k) const
+    {
+        for (auto &kv : obj) if (kv.first == k) return true;
+        return false;
+    }
+    const Json &at(const char *k) const
+    {
+        static const Json null_json;
+        for (auto &kv : obj) if (kv.first == k) return kv.second;
+        return null_json;
+    }
+    double number(double dflt) const { return kind == Num ? num : dflt; }
+};
+
+struct JsonParser {
+    const char *p, *end;
+    std::string err;
+    void ws()
+    {
+        for (;;) {
+            while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+            if (p + 1 < end && p[0] == '/' && p[1] == '/') { while (p < end && *p != '\n') ++p; continue; }
+            break;
+        }
+    }
+    bool fail(const char *m) { if (err.empty()) err = m; return false; }
+    bool parse(Json &j)
+    {
+        ws();
+        if (p >= end) return fail("unexpected end");
+        char c = *p;
+        if (c == '{') {
+            ++p; j.kind = Json::Obj;
+            ws();
+            if (p < end && *p == '}') { ++p; return true; }
+            for (;;) {
+                ws();
+                Json k;
+                if (p >= end || *p != '"' || !parse(k)) return fail("expected key");
+                ws();
+                if (p >= end || *p != ':') return fail("expected ':'");
+                ++p;
+                Json v;
+                if (!parse(v)) return false;
+                j.obj.emplace_back(k.str, std::move(v));
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            ++p; j.kind = Json::Arr;
+            ws();
+            if (p < end && *p == ']') { ++p; return true; }
+            for (;;) {
+                Json v;
+                if (!parse(v)) return false;
+                j.arr.push_back(std::move(v));
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') {
+            ++p; j.kind = Json::Str;
+            while (p < end && *p != '"') {
+                if (*p == '\\' && p + 1 < end) {
+                    ++p;
+                    switch (*p) {
+                    case 'n': j.str += '\n'; break;
+                    case 't': j.str += '\t'; break;
+                    case 'r': j.str += '\r'; break;
+                    case 'u': j.str += '?'; p += (end - p > 4) ? 4 : 0; break;
+                    default: j.str += *p; break;
+                    }
+                    ++p;
+                } else j.str += *p++;
+            }
+            if (p >= end) return fail("unterminated string");
+            ++p;
+            return true;
+        }
+        if (!std::strncmp(p, "true", 4)) { p += 4; j.kind = Json::Bool; j.b = true; return true; }
+        if (!std::strncmp(p, "false", 5)) { p += 5; j.kind = Json::Bool; j.b = false; return true; }
+        if (!std::strncmp(p, "null", 4)) { p += 4; j.kind = Json::Null; return true; }
+        char *e = nullptr;
+        double v = std::strtod(p, &e);
+        if (e == p) return fail("unexpected character");
+        p = e;
+        j.kind = Json::Num;
+        j.num = v;
+        return true;
+    }
+};
+
+// ================================================================= mat4 (glm order) ===
+struct M4 {
+    float c[4][4];   // c[column][row]
+};
+M4 identity()
+{
+    M4 m;
+    std::memset(&m, 0, sizeof(m));
+    m.c[0][0] = m.c[1][1] = m.c[2][2] = m.c[3][3] = 1.f;
+    return m;
+}
+void col_madd3(float out[4], const M4 &m, float a, float b, float c)   // m[0]*a + m[1]*b + m[2]*c
+{
+    for (int r = 0; r < 4; ++r) out[r] = m.c[0][r] * a + m.c[1][r] * b + m.c[2][r] * c;
+}
+M4 translate(const M4 &m, float x, float y, float z)   // glm::translate: Result[3] = m[0]*v0 + m[1]*v1 + m[2]*v2 + m[3]
+{
+    M4 r = m;
+    for (int k = 0; k < 4; ++k) r.c[3][k] = m.c[0][k] * x + m.c[1][k] * y + m.c[2][k] * z + m.c[3][k];
+    return r;
+}
+M4 scale(const M4 &m, float x, float y, float z)
+{
+    M4 r = m;
+    for (int k = 0; k < 4; ++k) { r.c[0][k] = m.c[0][k] * x; r.c[1][k] = m.c[1][k] * y; r.c[2][k] = m.c[2][k] * z; }
+    return r;
+}
+M4 rotate(const M4 &m, float angle, float ax, float ay, float az)   // glm::rotate (axis already unit here)
+{
+    const float c = std::cos(angle), s = std::sin(angle);
+    const float axis[3] = {ax, ay, az};
+    const float temp[3] = {(1.f - c) * ax, (1.f - c) * ay, (1.f - c) * az};
+    float R[3][3];
+    R[0][0] = c + temp[0] * axis[0];
+    R[0][1] = temp[0] * axis[1] + s * axis[2];
+    R[0][2] = temp[0] * axis[2] - s * axis[1];
+    R[1][0] = temp[1] * axis[0] - s * axis[2];
+    R[1][1] = c + temp[1] * axis[1];
+    R[1][2] = temp[1] * axis[2] + s * axis[0];
+    R[2][0] = temp[2] * axis[0] + s * axis[1];
+    R[2][1] = temp[2] * axis[1] - s * axis[0];
+    R[2][2] = c + temp[2] * axis[2];
+    M4 r;
+    col_madd3(r.c[0], m, R[0][0], R[0][1], R[0][2]);
+    col_madd3(r.c[1], m, R[1][0], R[1][1], R[1][2]);
+    col_madd3(r.c[2], m, R[2][0], R[2][1], R[2][2]);
+    for (int k = 0; k < 4; ++k) r.c[3][k] = m.c[3][k];
+    return r;
+}
+M4 mul(const M4 &a, const M4 &b)   // glm operator*(mat4, mat4)
+{
+    M4 r;
+    for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < 4; ++k)
+            r.c[j][k] = a.c[0][k] * b.c[j][0] + a.c[1][k] * b.c[j][1] + a.c[2][k] * b.c[j][2] + a.c[3][k] * b.c[j][3];
+    return r;
+}
+void mulv(const M4 &m, const float v[4], float out[4])   // glm operator*(mat4, vec4): (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
+{
+    for (int k = 0; k < 4; ++k) out[k] = (m.c[0][k] * v[0] + m.c[1][k] * v[1]) + (m.c[2][k] * v[2] + m.c[3][k] * v[3]);
+}
+M4 transpose(const M4 &m)
+{
+    M4 r;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.c[i][j] = m.c[j][i];
+    return r;
+}
+M4 inverse(const M4 &m)   // cofactor expansion (glm::inverse computes the same adjugate / determinant)
+{
+    const float *a = &m.c[0][0];
+    float inv[16];
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    float det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    float id = 1.0f / det;
+    M4 r;
+    for (int i = 0; i < 16; ++i) (&r.c[0][0])[i] = inv[i] * id;
+    return r;
+}
+float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+
+M4 trs_matrix(const float scale_[3], const float translate_[3], const float rotate_[3])   // parsescene.cpp:346-352
+{
+    M4 s = scale(identity(), scale_[0], scale_[1], scale_[2]);
+    M4 t = translate(identity(), translate_[0], translate_[1], translate_[2]);
+    M4 r = rotate(identity(), radians(rotate_[0]), 1, 0, 0);
+    r = rotate(r, radians(rotate_[1]), 0, 1, 0);
+    r = rotate(r, radians(rotate_[2]), 0, 0, 1);
+    return mul(mul(t, r), s);
+}
+
+// ================================================================= OBJ =================
+struct ObjMesh {
+    std::vector<V3> v, vn;
+    std::vector<pt::V2> vt;
+    struct Corner { int v, vt, vn; };
+    std::vector<Corner> corners;   // 3 per triangle
+};
+
+bool read_obj(const std::string &path, ObjMesh &m)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char line[4096];
+    std::vector<ObjMesh::Corner> face;
+    while (std::fgets(line, sizeof(line), f)) {
+        char *p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            V3 a{0, 0, 0};
+            char *e = p + 1;
+            a.x = std::strtof(e, &e); a.y = std::strtof(e, &e); a.z = std::strtof(e, &e);
+            m.v.push_back(a);
+        } else if (p[0] == 'v' && p[1] == 'n') {
+            V3 a{0, 0, 0};
+            char *e = p + 2;
+            a.x = std::strtof(e, &e); a.y = std::strtof(e, &e); a.z = std::strtof(e, &e);
+            m.vn.push_back(a);
+        } else if (p[0] == 'v' && p[1] == 't') {
+            pt::V2 a{0, 0};
+            char *e = p + 2;
+            a.x = std::strtof(e, &e); a.y = std::strtof(e, &e);
+            m.vt.push_back(a);
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            face.clear();
+            char *e = p + 1;
+            for (;;) {
+                while (*e == ' ' || *e == '\t') ++e;
+                if (*e == 0 || *e == '\n' || *e == '\r' || *e == '#') break;
+                ObjMesh::Corner c{0, 0, 0};
+                c.v = (int)std::strtol(e, &e, 10);
+                if (*e == '/') {
+                    ++e;
+                    if (*e != '/') c.vt = (int)std::strtol(e, &e, 10);
+                    if (*e == '/') { ++e; c.vn = (int)std::strtol(e, &e, 10); }
+                }
+                if (c.v < 0) c.v = (int)m.v.size() + c.v + 1;
+                if (c.vt < 0) c.vt = (int)m.vt.size() + c.vt + 1;
+                if (c.vn < 0) c.vn = (int)m.vn.size() + c.vn + 1;
+                if (c.v <= 0 || c.v > (int)m.v.size()) { std::fclose(f); return false; }
+                if (c.vt > (int)m.vt.size() || c.vn > (int)m.vn.size()) { std::fclose(f); return false; }
+                face.push_back(c);
+            }
+            for (size_t k = 1; k + 1 < face.size(); ++k) {
+                m.corners.push_back(face[0]);
+                m.corners.push_back(face[k]);
+                m.corners.push_back(face[k + 1]);
+            }
+        }
+    }
+    std::fclose(f);
+    return true;
+}
+
+gpt_float3 g3(V3 a) { return gpt_float3{a.x, a.y, a.z}; }
+V3 v3of(gpt_float3 a) { return V3{a.x, a.y, a.z}; }
+
+// wrap.h:6-16
+void make_coordinate(V3 n, V3 &u, V3 &w)
+{
+    if (std::fabs(n.x) > std::fabs(n.y)) {
+        float invLen = 1.0f / pt::sqrt_rn(n.x * n.x + n.z * n.z);
+        w = pt::v3(n.z * invLen, 0.0f, -n.x * invLen);
+    } else {
+        float invLen = 1.0f / pt::sqrt_rn(n.y * n.y + n.z * n.z);
+        w = pt::v3(0.0f, n.z * invLen, -n.y * invLen);
+    }
+    u = pt::cross(w, n);
+}
+
+// Mesh::genTangent, src/mesh.cpp:93-111
+V3 gen_tangent(const gpt_vertex &v1, const gpt_vertex &v2, const gpt_vertex &v3)
+{
+    const pt::V2 duv1{v2.uv.x - v1.uv.x, v2.uv.y - v1.uv.y}, duv2{v3.uv.x - v1.uv.x, v3.uv.y - v1.uv.y};
+    const V3 e1 = v3of(v2.v) - v3of(v1.v), e2 = v3of(v3.v) - v3of(v1.v);
+    const float det = duv1.x * duv2.y - duv1.y * duv2.x;
+    if (!((double)std::fabs(det) < 1e-8)) {
+        float invdet = 1.f / det;
+        return pt::normalize((-duv2.x * e1 + duv1.y * e2) * invdet);
+    }
+    V3 uu, ww;
+    V3 nn = pt::normalize(pt::cross(e1, e2));
+    make_coordinate(nn, uu, ww);
+    return uu;
+}
+
+// Mesh::LoadObjFromFile + processMesh (src/mesh.cpp:4-91) for one OBJ file
+bool load_mesh(const std::string &path, const M4 &trs, int matIdx, int bssrdfIdx, std::vector<Triangle> &out)
+{
+    ObjMesh m;
+    if (!read_obj(path, m)) {
+        gpt_set_error("Error when import model: cannot read \"%s\"", path.c_str());
+        return false;
+    }
+    const size_t ntri = m.corners.size() / 3;
+    std::vector<V3> smooth;
+    if (m.vn.empty()) {   // aiProcess_GenSmoothNormals stand-in (see file header)
+        smooth.assign(m.v.size(), V3{0, 0, 0});
+        for (size_t t = 0; t < ntri; ++t) {
+            const V3 p0 = m.v[(size_t)m.corners[3 * t].v - 1], p1 = m.v[(size_t)m.corners[3 * t + 1].v - 1],
+                     p2 = m.v[(size_t)m.corners[3 * t + 2].v - 1];
+            const V3 fn = pt::cross(p1 - p0, p2 - p0);
+            for (int k = 0; k < 3; ++k) smooth[(size_t)m.corners[3 * t + k].v - 1] += fn;
+        }
+        for (auto &n : smooth) {
+            float d = pt::dot(n, n);
+            n = d > 0.f ? pt::normalize(n) : V3{0, 1, 0};
+        }
+    }
+    // one vertex per face corner
+    std::vector<gpt_vertex> verts(m.corners.size());
+    const M4 invT = transpose(inverse(trs));
+    for (size_t i = 0; i < m.corners.size(); ++i) {
+        const ObjMesh::Corner &c = m.corners[i];
+        gpt_vertex vx;
+        std::memset(&vx, 0, sizeof(vx));
+        const V3 p = m.v[(size_t)c.v - 1];
+        const V3 n = c.vn > 0 ? m.vn[(size_t)c.vn - 1] : (m.vn.empty() ? smooth[(size_t)c.v - 1] : V3{0, 1, 0});
+        float pv[4] = {p.x, p.y, p.z, 1.f}, nv[4] = {n.x, n.y, n.z, 0.f}, o[4];
+        mulv(trs, pv, o);
+        vx.v = gpt_float3{o[0], o[1], o[2]};
+        mulv(invT, nv, o);
+        vx.n = g3(pt::normalize(V3{o[0], o[1], o[2]}));
+        if (c.vt > 0) { vx.uv.x = m.vt[(size_t)c.vt - 1].x; vx.uv.y = m.vt[(size_t)c.vt - 1].y; }
+        verts[i] = vx;
+    }
+    // tangents: accumulate per vertex, normalise (mesh.cpp:62-76); unique corners => one face each
+    for (size_t t = 0; t < ntri; ++t) {
+        V3 tg = gen_tangent(verts[3 * t], verts[3 * t + 1], verts[3 * t + 2]);
+        for (int k = 0; k < 3; ++k) verts[3 * t + k].t = g3(pt::normalize(tg));
+    }
+    out.reserve(out.size() + ntri);
+    for (size_t t = 0; t < ntri; ++t) {
+        Triangle tri;
+        std::memset(&tri, 0, sizeof(tri));
+        tri.v1 = verts[3 * t]; tri.v2 = verts[3 * t + 1]; tri.v3 = verts[3 * t + 2];
+        tri.matIdx = matIdx;
+        tri.bssrdfIdx = bssrdfIdx;
+        tri.lightIdx = -1;
+        tri.mediumInside = tri.mediumOutside = -1;
+        out.push_back(tri);
+    }
+    std::fprintf(stdout, "Load Model sucessfully: %s\nMerge [%d] triangles\n", path.c_str(), (int)ntri);
+    return true;
+}
+
+void get3(const Json &j, const char *key, const float dflt[3], float out[3])
+{
+    out[0] = dflt[0]; out[1] = dflt[1]; out[2] = dflt[2];
+    if (j.has(key) && j.at(key).kind == Json::Arr)
+        for (size_t i = 0; i < 3 && i < j.at(key).arr.size(); ++i) out[i] = (float)j.at(key).arr[i].num;
+}
+float getf(const Json &j, const char *key, float dflt) { return j.has(key) ? (float)j.at(key).number(dflt) : dflt; }
+bool getb(const Json &j, const char *key, bool dflt) { return j.has(key) && j.at(key).kind == Json::Bool ? j.at(key).b : dflt; }
+std::string gets(const Json &j, const char *key, const char *dflt) { return j.has(key) && j.at(key).kind == Json::Str ? j.at(key).str : dflt; }
+
+uint64_t fnv1a(const void *data, size_t n)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+}  // namespace
+
+// ================================================================= Camera ================
+Camera::Camera() { std::memset(static_cast<gpt_camera *>(this), 0, sizeof(gpt_camera)); medium = -1; }
+
+Camera::Camera(float3_t pos, float3_t uu, float3_t vv, float3_t ww, float2_t res, float dis, float angle, float radius,
+               float focal, bool filmic_, int medium_)
+{
+    std::memset(static_cast<gpt_camera *>(this), 0, sizeof(gpt_camera));
+    position = pos; u = uu; v = vv; w = ww;
+    resolution = res; distance = dis; fov = angle;
+    apertureRadius = radius; focalDistance = focal;
+    filmic = filmic_ ? 1 : 0;
+    medium = medium_;
+    float half_fov = fov * .5f;                                           // camera.h:38-45
+    float rad = (float)(half_fov / 180.0 * pt::PI);                      // DegreesToRadians, common.h:46-49
+    height = std::tan(rad) * distance;
+    width = height * resolution.x / resolution.y;
+    area = 4.f * width * height;
+    pixel2screen.x = 2.f * width / resolution.x;
+    pixel2screen.y = 2.f * height / resolution.y;
+    ratio = focalDistance / distance;
+}
+
+void Camera::Lookat(const float3_t &eye_pos, const float3_t &dest, const float3_t &up)   // camera.h:123-128
+{
+    position = eye_pos;
+    V3 ww = pt::normalize(v3of(eye_pos) - v3of(dest));
+    V3 uu = pt::normalize(pt::cross(v3of(up), ww));
+    V3 vv = pt::normalize(pt::cross(ww, uu));
+    w = g3(ww); u = g3(uu); v = g3(vv);
+}
+
+// ================================================================= BVH ====================
+BVH::~BVH() { delete[] linear_root; }
+
+void BVH::Build(std::vector<Primitive> &primitives)
+{
+    delete[] linear_root;
+    linear_root = nullptr;
+    total_nodes = 0;
+    const int n = (int)primitives.size();
+    prims.assign((size_t)n, Primitive());
+    if (n == 0) return;
+    linear_root = new LinearBVHNode[(size_t)2 * n];
+    float box[6];
+    int32_t nn = 0;
+    if (gpt_bvh_build(primitives.data(), n, prims.data(), linear_root, &nn, box) != GPT_OK) {
+        prims.clear();
+        return;
+    }
+    total_nodes = nn;
+    root_box.fmin = gpt_float3{box[0], box[1], box[2]};
+    root_box.fmax = gpt_float3{box[3], box[4], box[5]};
+    primitives.clear();   // bvh.cpp:30
+}
+
+// bvh.cache: int total_nodes, int nprims, float[3] min, float[3] max, Primitive[nprims], LinearBVHNode[total_nodes]
+// (src/bvh.cpp:189-218), followed here by an 8-byte FNV-1a hash of the INPUT primitives.  The reference keys
+// the cache by directory only and silently reuses a stale one; here a cache is used only when the primitive
+// count matches and, if the trailing hash is present, the hash matches too.
+void BVH::LoadOrBuildBVH(std::vector<Primitive> &primitives, std::string file)
+{
+    const std::string base = file.substr(0, file.find_last_of('/') + 1);
+    const std::string bvhfile = base + "bvh.cache";
+    const uint64_t want = fnv1a(primitives.data(), primitives.size() * sizeof(Primitive));
+    FILE *fp = std::fopen(bvhfile.c_str(), "rb");
+    if (fp) {
+        int nodes = 0, size = 0;
+        float mn[3], mx[3];
+        bool ok = std::fread(&nodes, sizeof(int), 1, fp) == 1 && std::fread(&size, sizeof(int), 1, fp) == 1 &&
+                  std::fread(mn, sizeof(float) * 3, 1, fp) == 1 && std::fread(mx, sizeof(float) * 3, 1, fp) == 1;
+        ok = ok && size == (int)primitives.size() && nodes > 0 && nodes <= 2 * size;
+        std::vector<Primitive> p;
+        LinearBVHNode *lr = nullptr;
+        if (ok) {
+            p.resize((size_t)size);
+            lr = new LinearBVHNode[(size_t)nodes];
+            ok = std::fread(p.data(), sizeof(Primitive), (size_t)size, fp) == (size_t)size &&
+                 std::fread(lr, sizeof(LinearBVHNode), (size_t)nodes, fp) == (size_t)nodes;
+            uint64_t have = 0;
+            if (ok && std::fread(&have, sizeof(have), 1, fp) == 1) ok = have == want;
+        }
+        std::fclose(fp);
+        if (ok) {
+            delete[] linear_root;
+            linear_root = lr;
+            total_nodes = nodes;
+            prims.swap(p);
+            root_box.fmin = gpt_float3{mn[0], mn[1], mn[2]};
+            root_box.fmax = gpt_float3{mx[0], mx[1], mx[2]};
+            primitives.clear();
+            return;
+        }
+        delete[] lr;
+    }
+    Build(primitives);
+    fp = std::fopen(bvhfile.c_str(), "wb");
+    if (fp) {
+        int size = (int)prims.size();
+        std::fwrite(&total_nodes, sizeof(int), 1, fp);
+        std::fwrite(&size, sizeof(int), 1, fp);
+        std::fwrite(&root_box.fmin.x, sizeof(float) * 3, 1, fp);
+        std::fwrite(&root_box.fmax.x, sizeof(float) * 3, 1, fp);
+        if (size) std::fwrite(prims.data(), sizeof(Primitive), (size_t)size, fp);
+        if (total_nodes) std::fwrite(linear_root, sizeof(LinearBVHNode), (size_t)total_nodes, fp);
+        std::fwrite(&want, sizeof(want), 1, fp);
+        std::fclose(fp);
+    }
+}
+
+// ================================================================= Scene ==================
+Scene::Scene()
+{
+    std::memset(&infinite, 0, sizeof(infinite));
+    integrator.maxDepth = 5;
+}
+
+void Scene::Init(Camera *cam, std::string file)   // scene.h:50-83
+{
+    camera = cam;
+    if (use_bvh_cache) bvh.LoadOrBuildBVH(primitives, file);
+    else bvh.Build(primitives);
+    std::printf("Bvh total nodes:%d\n", bvh.total_nodes);
+    std::printf("Scene Bounds [%.3f, %.3f, %.3f]-[%.3f, %.3f, %.3f]\n", bvh.root_box.fmin.x, bvh.root_box.fmin.y,
+                bvh.root_box.fmin.z, bvh.root_box.fmax.x, bvh.root_box.fmax.y, bvh.root_box.fmax.z);
+    if (infinite.isvalid) {
+        infinite.data = infinite_data.data();
+        float box[6] = {bvh.root_box.fmin.x, bvh.root_box.fmin.y, bvh.root_box.fmin.z,
+                        bvh.root_box.fmax.x, bvh.root_box.fmax.y, bvh.root_box.fmax.z};
+        gpt_infinite_init(&infinite, box);
+    }
+    lightDistribution.assign(lights.size() + 2, 0.f);
+    int32_t n = 0;
+    gpt_light_distribution(lights.data(), (int32_t)lights.size(), infinite.isvalid ? &infinite : nullptr,
+                           lightDistribution.data(), &n);
+    lightDistribution.resize((size_t)n);
+}
+
+void Scene::Describe(gpt_scene_desc &d, std::vector<gpt_texture> &tex) const
+{
+    std::memset(&d, 0, sizeof(d));
+    d.prims = bvh.prims.data();
+    d.n_prims = (int32_t)bvh.prims.size();
+    d.nodes = bvh.linear_root;
+    d.n_nodes = bvh.total_nodes;
+    d.materials = materials.data();
+    d.n_materials = (int32_t)materials.size();
+    d.lights = lights.data();
+    d.n_lights = (int32_t)lights.size();
+    d.light_distribution = lightDistribution.data();
+    d.n_light_distribution = (int32_t)lightDistribution.size();
+    d.infinite = infinite.isvalid ? &infinite : nullptr;
+    tex.resize(textures.size());
+    for (size_t i = 0; i < textures.size(); ++i) {
+        tex[i].data = textures[i].data.data();
+        tex[i].width = textures[i].width;
+        tex[i].height = textures[i].height;
+    }
+    d.textures = tex.empty() ? nullptr : tex.data();
+    d.n_textures = (int32_t)tex.size();
+    d.integrator_type = (int32_t)integrator.type;
+    d.max_depth = integrator.maxDepth;
+}
+
+// ================================================================= LoadScene ==============
+bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
+{
+    const std::string file = filename;
+    const std::string base = file.substr(0, file.find_last_of('/') + 1);
+    FILE *f = std::fopen(filename, "rb");
+    if (!f) {
+        gpt_set_error("Scene file [\"%s\"] is not good", filename);
+        return false;
+    }
+    std::string text;
+    char buf[65536];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+    std::fclose(f);
+    Json doc;
+    JsonParser jp{text.data(), text.data() + text.size(), ""};
+    if (!jp.parse(doc) || doc.kind != Json::Obj) {
+        gpt_set_error("Parse scene error: %s (offset %ld)", jp.err.c_str(), (long)(jp.p - text.data()));
+        return false;
+    }
+    const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
+
+    // media are out of scope for the "pt" path; their names only matter because a mesh that names an
+    // inside/outside medium and no material is legal in the reference (parsescene.cpp:359-380)
+    std::vector<std::string> mediumName;
+    if (doc.has("medium") && doc.at("medium").kind == Json::Arr)
+        for (auto &m : doc.at("medium").arr) mediumName.push_back(gets(m, "name", ""));
+    auto getMedium = [&](const std::string &m) {
+        for (size_t i = 0; i < mediumName.size(); ++i) if (mediumName[i] == m) return (int)i;
+        return -1;
+    };
+
+    // ---- global config (parsescene.cpp:150-181)
+    if (doc.has("screen_width") && doc.has("screen_height")) {
+        config.width = (int)doc.at("screen_width").num;
+        config.height = (int)doc.at("screen_height").num;
+    } else {
+        config.width = 512;
+        config.height = 512;
+    }
+    config.epsilon = getf(doc, "epsilon", 0.001f);
+    if (!doc.has("camera")) {
+        gpt_set_error("Scene file must define camera");
+        return false;
+    }
+    {
+        const Json &cam = doc.at("camera");
+        float pos[3], up[3], lookat[3];
+        const float up_d[3] = {0, 1, 0}, la_d[3] = {0, 0, -1};
+        get3(cam, "position", zero3, pos);
+        get3(cam, "up", up_d, up);
+        get3(cam, "lookat", la_d, lookat);
+        config.camera.environment = getb(cam, "environment", false) ? 1 : 0;
+        config.camera.fov = getf(cam, "fov", 60.f);
+        config.camera.Lookat(gpt_float3{pos[0], pos[1], pos[2]}, gpt_float3{lookat[0], lookat[1], lookat[2]},
+                             gpt_float3{up[0], up[1], up[2]});
+        config.camera.apertureRadius = getf(cam, "apertureRadius", 0.f);
+        config.camera.focalDistance = getf(cam, "focalDistance", 0.f);
+        config.camera_move_speed = getf(cam, "move_speed", 0.1f);
+        config.camera.filmic = getb(cam, "filmicTonemap", true) ? 1 : 0;
+        config.camera.medium = getMedium(gets(cam, "medium", ""));
+    }
+
+    // ---- integrator (parsescene.cpp:184-226)
+    {
+        const std::string in = gets(doc, "integrator", "pt");
+        static const std::map<std::string, IntegratorType> types = {
+            {"ao", IT_AO}, {"pt", IT_PT}, {"vpt", IT_VPT}, {"lt", IT_LT}, {"bdpt", IT_BDPT}, {"mlt", IT_MLT}, {"sppm", IT_SPPM}, {"ir", IT_IR}};
+        auto it = types.find(in);
+        if (it == types.end()) {
+            gpt_set_error("Unsupport integrator [%s]; choose one of [ao, pt, vpt, lt, bdpt, mlt, sppm, ir]", in.c_str());
+            return false;
+        }
+        scene.integrator.type = it->second;
+        if (it->second == IT_AO) scene.integrator.maxDist = getf(doc, "maxDist", 0.5f);
+        else scene.integrator.maxDepth = doc.has("maxDepth") ? (int)doc.at("maxDepth").num : 5;
+    }
+
+    // ---- materials (parsescene.cpp:231-330)
+    std::vector<std::string> matName, bssrdfName;
+    if (doc.has("material")) {
+        const Json &mats = doc.at("material");
+        if (mats.kind != Json::Arr) {
+            gpt_set_error("Invalid material format");
+            return false;
+        }
+        std::map<std::string, int> matMap = {{"lambertian", GPT_MT_LAMBERTIAN}, {"mirror", GPT_MT_MIRROR},
+                                             {"dielectric", GPT_MT_DIELECTRIC}, {"roughdielectric", GPT_MT_ROUGHDIELECTRIC},
+                                             {"roughconduct", GPT_MT_ROUGHCONDUCTOR}, {"substrate", GPT_MT_SUBSTRATE}};
+        std::map<std::string, int> texMap;
+        for (auto &m : mats.arr) {
+            if (m.has("bssrdf")) {   // BSSRDF tables are not on this path; keep the name so lookups behave
+                bssrdfName.push_back(gets(m, "name", ""));
+                continue;
+            }
+            float alphaU, alphaV;
+            if (m.has("alpha")) {
+                alphaU = (float)m.at("alpha").num;
+                alphaV = alphaU;
+            } else {
+                alphaU = getf(m, "alphaU", 0.01f);
+                alphaV = getf(m, "alphaV", 0.01f);
+            }
+            if (getb(m, "remap", false)) {
+                auto Remap = [](float roughness) -> float {   // parsescene.cpp:282-288
+                    roughness = std::max(roughness, (float)1e-3);
+                    float x = std::log(roughness);
+                    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x + 0.000640711f * x * x * x * x;
+                };
+                alphaU = Remap(alphaU);
+                alphaV = Remap(alphaV);
+            }
+            Material mat;
+            std::memset(&mat, 0, sizeof(mat));
+            mat.type = matMap[gets(m, "bsdf", "")];   // unknown names map to 0 like std::map::operator[]
+            mat.alphaU = alphaU;
+            mat.alphaV = alphaV;
+            mat.insideIOR = getf(m, "insideIOR", 1.f);
+            mat.outsideIOR = getf(m, "outsideIOR", 1.f);
+            float t[3];
+            get3(m, "k", zero3, t); mat.k = gpt_float3{t[0], t[1], t[2]};
+            get3(m, "eta", zero3, t); mat.eta = gpt_float3{t[0], t[1], t[2]};
+            get3(m, "specular", one3, t); mat.specular = gpt_float3{t[0], t[1], t[2]};
+            mat.diffuse = gpt_float3{1.f, 1.f, 1.f};
+            mat.textureIdx = -1;
+            if (m.has("diffuse")) {
+                if (m.at("diffuse").kind == Json::Str) {
+                    const std::string tf = m.at("diffuse").str;
+                    if (texMap.find(tf) == texMap.end()) {
+                        Texture tex;
+                        if (!imageio::load_texture_png((base + tf).c_str(), tex.width, tex.height, tex.data)) {
+                            gpt_set_error("Error when load texture [%s] (8-bit non-interlaced PNG is supported)", (base + tf).c_str());
+                            return false;
+                        }
+                        scene.textures.push_back(std::move(tex));
+                        texMap[tf] = (int)scene.textures.size() - 1;
+                    }
+                    mat.textureIdx = texMap[tf];
+                } else {
+                    get3(m, "diffuse", one3, t);
+                    mat.diffuse = gpt_float3{t[0], t[1], t[2]};
+                }
+            }
+            scene.materials.push_back(mat);
+            matName.push_back(gets(m, "name", ""));
+        }
+    }
+    auto find_material = [&](const std::string &name, int &matIdx, int &bssrdfIdx) {   // first match wins
+        for (size_t i = 0; i < matName.size(); ++i) if (matName[i] == name) { matIdx = (int)i; return true; }
+        for (size_t i = 0; i < bssrdfName.size(); ++i) if (bssrdfName[i] == name) { bssrdfIdx = (int)i; return true; }
+        gpt_set_error("There is no material named:[\"%s\"]", name.c_str());
+        return false;
+    };
+
+    // ---- scene (parsescene.cpp:333-489)
+    if (doc.has("scene") && doc.at("scene").kind == Json::Arr) {
+        for (auto &unit : doc.at("scene").arr) {
+            if (unit.has("mesh")) {
+                float sc[3], tr[3], ro[3];
+                get3(unit, "scale", one3, sc);
+                get3(unit, "translate", zero3, tr);
+                get3(unit, "rotate", zero3, ro);
+                const std::string mat_name = gets(unit, "material", "");
+                const int mi = getMedium(gets(unit, "inside", "")), mo = getMedium(gets(unit, "outside", ""));
+                int matIdx = -1, bssrdfIdx = -1;
+                if (mat_name != "" || !(mi != -1 || mo != -1))
+                    if (!find_material(mat_name, matIdx, bssrdfIdx)) return false;
+                std::vector<Triangle> tris;
+                if (!load_mesh(base + unit.at("mesh").str, trs_matrix(sc, tr, ro), matIdx, bssrdfIdx, tris)) return false;
+                for (auto &t : tris) {
+                    Primitive p;
+                    std::memset(&p, 0, sizeof(p));
+                    p.type = GPT_GT_TRIANGLE;
+                    p.triangle = t;
+                    p.triangle.mediumInside = mi;
+                    p.triangle.mediumOutside = mo;
+                    scene.primitives.push_back(p);
+                }
+            } else if (unit.has("line") || unit.has("sphere")) {
+                gpt_set_error("scene unit \"%s\": line and sphere primitives are outside the triangle path tracer",
+                              unit.has("line") ? "line" : "sphere");
+                return false;
+            } else {
+                gpt_set_error("Error scene file format");
+                return false;
+            }
+        }
+    } else {
+        std::fprintf(stderr, "There is no primitives in the scene\n");
+    }
+
+    // ---- lights (parsescene.cpp:492-586)
+    if (doc.has("light") && doc.at("light").kind == Json::Arr) {
+        for (auto &unit : doc.at("light").arr) {
+            if (unit.has("mesh")) {
+                float sc[3], tr[3], ro[3], rad[3];
+                get3(unit, "scale", one3, sc);
+                get3(unit, "translate", zero3, tr);
+                get3(unit, "rotate", zero3, ro);
+                get3(unit, "radiance", zero3, rad);
+                int matIdx = -1, bssrdfIdx = -1;
+                const std::string mat_name = gets(unit, "material", "matte");
+                bool found = false;
+                for (size_t i = 0; i < matName.size(); ++i) if (matName[i] == mat_name) { matIdx = (int)i; found = true; break; }
+                if (!found) {
+                    gpt_set_error("There is no material named:[\"%s\"]", mat_name.c_str());
+                    return false;
+                }
+                std::vector<Triangle> tris;
+                if (!load_mesh(base + unit.at("mesh").str, trs_matrix(sc, tr, ro), matIdx, bssrdfIdx, tris)) return false;
+                for (auto &t : tris) {
+                    t.lightIdx = (int)scene.lights.size();
+                    Primitive p;
+                    std::memset(&p, 0, sizeof(p));
+                    p.type = GPT_GT_TRIANGLE;
+                    p.triangle = t;
+                    scene.primitives.push_back(p);
+                    Area area;
+                    std::memset(&area, 0, sizeof(area));
+                    area.radiance = gpt_float3{rad[0], rad[1], rad[2]};
+                    area.triangle = t;
+                    area.medium = getMedium(gets(unit, "medium", ""));
+                    scene.lights.push_back(area);
+                }
+            } else if (unit.has("infinite")) {
+                const std::string ef = unit.at("infinite").str;
+                int w = 0, h = 0;
+                if (!imageio::read_pfm_top_down((base + ef).c_str(), w, h, scene.infinite_data)) {
+                    gpt_set_error("Couldn't load hdr file \"%s\" (this build reads .pfm; OpenEXR decoding is not implemented)", ef.c_str());
+                    return false;
+                }
+                // the reference leaves u,v,w unset without "rotate"/"matrix"; identity axes here
+                float uu[4] = {1, 0, 0, 0}, vv[4] = {0, 1, 0, 0}, ww[4] = {0, 0, 1, 0};
+                auto apply = [&](const M4 &rs) {
+                    const float ex[4] = {1, 0, 0, 0}, ey[4] = {0, 1, 0, 0}, ez[4] = {0, 0, 1, 0};
+                    mulv(rs, ex, uu); mulv(rs, ey, vv); mulv(rs, ez, ww);
+                };
+                if (unit.has("rotate")) {
+                    float r[3];
+                    get3(unit, "rotate", zero3, r);
+                    M4 rs = rotate(identity(), radians(r[0]), 1, 0, 0);
+                    rs = rotate(rs, radians(r[1]), 0, 1, 0);
+                    rs = rotate(rs, radians(r[2]), 0, 0, 1);
+                    apply(rs);
+                }
+                if (unit.has("matrix") && unit.at("matrix").arr.size() == 16) {
+                    M4 rs;
+                    for (int i = 0; i < 16; ++i) (&rs.c[0][0])[i] = (float)unit.at("matrix").arr[(size_t)i].num;
+                    apply(inverse(rs));
+                }
+                std::memset(&scene.infinite, 0, sizeof(scene.infinite));
+                scene.infinite.u = gpt_float3{uu[0], uu[1], uu[2]};
+                scene.infinite.v = gpt_float3{vv[0], vv[1], vv[2]};
+                scene.infinite.w = gpt_float3{ww[0], ww[1], ww[2]};
+                scene.infinite.width = w;
+                scene.infinite.height = h;
+                scene.infinite.data = scene.infinite_data.data();
+                scene.infinite.isvalid = 1;
+            } else {
+                std::fprintf(stderr, "Only support area and infinite light\n");
+            }
+        }
+    }
+    return true;
+}

@@ -1,0 +1,126 @@
+"""Host half of the product (libgpt.so, CPU code paths only) against the oracle, plus the C ABI surface.
+No GPU: nothing here launches a kernel."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+from gpu_pathtracer_amd import api, host, scene_types as st
+
+ROOT = ol.ROOT
+
+
+def nodes_equal(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = api.load()
+    header = open(os.path.join(ROOT, "include", "gpt.h")).read()
+    names = set(re.findall(r"\b(gpt_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 25
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert missing == [], f"declared in include/gpt.h but not exported: {missing}"
+
+
+def test_record_layouts_match_reference_sizes():
+    assert st.VERTEX.itemsize == 48 and st.TRIANGLE.itemsize == 168 and st.PRIMITIVE.itemsize == 176
+    assert st.BVH_NODE.itemsize == 40 and st.MATERIAL.itemsize == 72 and st.AREA.itemsize == 192
+    assert C.sizeof(st.Infinite) == 72 and C.sizeof(st.Camera) == 104
+    assert st.PRIMITIVE.fields["triangle"][1] == 8 and st.AREA.fields["triangle"][1] == 16
+    assert st.TRIANGLE.fields["lightIdx"][1] == 152 and st.MATERIAL.fields["textureIdx"][1] == 68
+
+
+def test_cornell_bvh_equals_oracle_and_survey():
+    prims, _, _ = scenes.cornell_raw()
+    po, no, bo = ol.bvh_build(prims)
+    pg, ng, bg = api.bvh_build(prims)
+    assert po.tobytes() == pg.tobytes() and nodes_equal(no, ng) and np.array_equal(bo, bg)
+    assert len(ng) == 27
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (4, 1), (5, 2), (37, 3), (1000, 4), (20000, 5)])
+def test_random_soup_bvh_equals_oracle(n, seed):
+    soup = scenes.random_soup(n, seed)
+    po, no, bo = ol.bvh_build(soup)
+    pg, ng, bg = api.bvh_build(soup)
+    assert po.tobytes() == pg.tobytes() and nodes_equal(no, ng) and np.array_equal(bo, bg)
+    # every primitive in exactly one leaf, preorder child links consistent
+    seen = np.zeros(n, int)
+    for i, nd in enumerate(ng):
+        if nd["is_leaf"]:
+            seen[nd["start"]:nd["end"] + 1] += 1
+        else:
+            assert i + 1 < nd["second_child_offset"] < len(ng)
+    assert (seen == 1).all()
+
+
+def test_degenerate_inputs():
+    # coplanar, axis-aligned quad soup: a bbox thinner than 1e-4 makes a leaf with more than 4 primitives
+    flat = scenes.random_soup(40, 7, lo=(-1, 0.5, -1), hi=(1, 0.5, 1), size=0.0)
+    for k in range(40):
+        for v in ("v1", "v2", "v3"):
+            flat[k]["triangle"][v]["v"]["y"] = np.float32(0.5)
+    po, no, _ = ol.bvh_build(flat)
+    pg, ng, _ = api.bvh_build(flat)
+    assert nodes_equal(no, ng) and po.tobytes() == pg.tobytes()
+    assert len(ng) == 1 and ng[0]["is_leaf"] and ng[0]["end"] == 39
+    # identical triangles: no split can beat the leaf cost
+    dup = scenes.concat([scenes.random_soup(1, 11)] * 9)
+    po, no, _ = ol.bvh_build(dup)
+    pg, ng, _ = api.bvh_build(dup)
+    assert nodes_equal(no, ng)
+    # empty scene
+    pg, ng, _ = api.bvh_build(np.zeros(0, dtype=st.PRIMITIVE))
+    assert len(ng) == 0
+
+
+def test_light_distribution_camera_and_env_sphere():
+    scene_o, meta = scenes.zoo_scene(with_env=True)
+    hs = host.HostScene(scene_o.prims, scene_o.materials, meta["light_radiance"], 8, env=scene_o.env,
+                        env_uvw=((np.float32(np.cos(np.pi / 6)), 0.0, -np.float32(np.sin(np.pi / 6))), (0, 1, 0),
+                                 (np.float32(np.sin(np.pi / 6)), 0.0, np.float32(np.cos(np.pi / 6)))),
+                        textures=scene_o.textures)
+    assert np.array_equal(hs.cdf, scene_o.cdf) and len(hs.cdf) == 4
+    assert hs.infinite.radius == scene_o.infinite.radius
+    assert bytes(hs.infinite)[16:32] == bytes(scene_o.infinite)[16:32]
+    for res in ((512, 512), (1920, 1080), (100, 70)):
+        for fov, ap in ((19.5, 0.0), (60.0, 0.2)):
+            a = ol.make_camera((0, 1, 6.8), (0, 1, 0), (0, 1, 0), res, fov, ap, 7.0)
+            b = api.camera_init((0, 1, 6.8), (0, 1, 0), (0, 1, 0), res, fov, ap, 7.0)
+            assert bytes(a) == bytes(b)
+
+
+def test_errors_are_codes_with_messages():
+    lib = api.load()
+    assert lib.gpt_bvh_build(None, 3, None, None, C.byref(C.c_int32()), None) == -1
+    assert b"gpt_bvh_build" in lib.gpt_last_error()
+    bad = scenes.random_soup(2, 1)
+    bad[1]["type"] = 2           # a sphere: out of scope, must be refused, not skipped
+    out = np.zeros(2, dtype=st.PRIMITIVE)
+    nodes = np.zeros(4, dtype=st.BVH_NODE)
+    assert lib.gpt_bvh_build(st.ptr(bad), 2, st.ptr(out), st.ptr(nodes), C.byref(C.c_int32()), None) == -2
+    assert lib.gpt_camera_init(None, None, None, None, 1.0, 1.0, 0.1, 60.0, 0.0, 0.0, 1, 0) == -1
+
+
+def test_begin_without_gpu_fails_loudly():
+    """There is no CPU fallback: without a device gpt_begin must return an error, not render."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    scene, meta = ol.load_cornell(4)
+    with pytest.raises(api.GptError) as e:
+        api.Renderer(scene.desc, 64, 64, 0.001)
+    assert "no HIP device" in str(e.value) or "gpt error -4" in str(e.value) or "gpt error -3" in str(e.value)
+
+
+def test_unsupported_integrator_is_refused():
+    scene, _ = ol.load_cornell(4)
+    scene.desc.integrator_type = 2      # "vpt": out of scope for this library
+    ctx = C.c_void_p()
+    rc = api.load().gpt_begin(C.byref(scene.desc), 64, 64, C.c_float(0.001), 0, C.byref(ctx))
+    assert rc == -2 and b"integrator" in api.load().gpt_last_error()

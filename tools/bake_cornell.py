@@ -58,9 +58,14 @@ def normalize32(n):
     return (n * inv).astype(np.float32)
 
 
+RAW_NORMALS = []   # OBJ normals before normalisation, one (3,3) block per triangle, for tools/export_cornell_scene.py
+
+
 def mesh_prims(path, mat_idx, light_base=None):
     v, vn, vt, faces = read_obj(path)
     prims = np.zeros(len(faces), dtype=st.PRIMITIVE)
+    for face in faces:
+        RAW_NORMALS.append(np.array([vn[c[2] - 1] for c in face], dtype=np.float32))
     for i, face in enumerate(faces):
         tri = prims[i]["triangle"]
         for name, (iv, it, inn) in zip(("v1", "v2", "v3"), face):
@@ -109,7 +114,8 @@ def main():
     out = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "cornell_pt.npz")
     # raw bytes: np.save would re-pack the padded record layouts
     np.savez_compressed(out, prims=np.frombuffer(prims.tobytes(), np.uint8),
-                        materials=np.frombuffer(mats.tobytes(), np.uint8), meta=json.dumps(meta))
+                        materials=np.frombuffer(mats.tobytes(), np.uint8), meta=json.dumps(meta),
+                        raw_normals=np.stack(RAW_NORMALS))
     print("wrote", out, len(prims), "prims")
 
 
