@@ -14,11 +14,14 @@
 // pixel-sample, one launch per spp, a 64-int private stack and 176-byte AoS
 // primitive fetches):
 //   * ONE launch renders a whole batch of iterations.  Waves are persistent:
-//     each 64-lane wavefront pulls 8x8-pixel tiles from a global atomic queue
-//     and one lane owns one pixel for all iterations of the batch, so the
-//     accumulator (acc += sample, in iteration order, exactly the reference's
-//     fp32 summation order) lives in registers; the film is read and written
-//     once per launch instead of 48 B/pixel/spp.
+//     each 64-lane wavefront pulls (8x8-pixel tile, iteration chunk) work items
+//     from a global atomic queue; one lane owns one pixel for the iterations of
+//     its chunk.  Every finished sample is written to its iteration's plane in
+//     HBM (one 16-B store per sample; a 64-iteration 1080p batch is 2.1 GB of the 288 GB), so
+//     work items are completely independent of each other, and
+//     pt_output_kernel then folds the planes into the accumulator in iteration
+//     order — exactly the reference's fp32 summation order (its Output kernel
+//     runs once per spp, pathtracer.cu:2516-2531).
 //   * Path regeneration: a lane whose path ends starts its next sample in the
 //     same loop trip, so every lane carries a live path into every
 //     closest-hit traversal.
@@ -954,27 +957,27 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+    const uint32_t n_items = n_owned * P.n_chunks;
     for (;;) {
-        // ---- persistent scheduler: one atomic per wave per tile -----------------
+        // ---- persistent scheduler: one atomic per wave per work item -------------------------
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= n_owned) break;
-        const uint32_t tile = P.rank + t * P.n_ranks;
+        if (t >= n_items) break;
+        const uint32_t chunk = t / n_owned;
+        const uint32_t tile_local = t - chunk * n_owned;
+        const uint32_t tile = P.rank + tile_local * P.n_ranks;
         const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
         const uint32_t x = tx * 8u + (lane & 7u);
         const uint32_t y = ty * 8u + (lane >> 3);
         const bool valid = x < P.stride && y < P.rows;
         const uint32_t pixel = x + y * P.stride;       // pathtracer.cu:881-883
+        const uint32_t chunk_first = P.iter_first + chunk * P.chunk_iters;
+        const uint32_t chunk_count = (chunk + 1u == P.n_chunks) ? P.iter_count - chunk * P.chunk_iters : P.chunk_iters;
 
-        V3 acc = v3(0.f), col = v3(0.f);
-        if (valid) {
-            col = V3{P.color[3 * pixel], P.color[3 * pixel + 1], P.color[3 * pixel + 2]};
-            if (!P.reset) acc = V3{P.acc[3 * pixel], P.acc[3 * pixel + 1], P.acc[3 * pixel + 2]};
-        }
         const uint32_t hash_pixel = wang_hash(pixel);
-        uint32_t iter = P.iter_first;
-        uint32_t left = valid ? P.iter_count : 0u;
+        uint32_t iter = chunk_first;
+        uint32_t left = valid ? chunk_count : 0u;
 
         // ---- per-path state ---------------------------------------------------------
         Rng rng;
@@ -1143,10 +1146,11 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             }
 
             if (finish) {
-                // pathtracer.cu:1019-1020 (a non-finite sample leaves the previous value in
-                // kernel_color) + Output's accumulate (:2523-2525)
-                if (!is_inf(Li) && !is_nan(Li)) col = Li;
-                acc += col;
+                // The sample goes to its iteration's plane as is; the finite-guard of pathtracer.cu:1019-1020
+                // and the accumulation run in iteration order in pt_output_kernel.
+                // one 16-byte store per sample: stores are written through to the fabric per request
+                float4 *dst = reinterpret_cast<float4 *>(P.samples) + (uint64_t)(iter - P.iter_first) * P.plane + pixel;
+                *dst = make_float4(Li.x, Li.y, Li.z, 0.f);
                 alive = false;
                 iter++;
                 q.has_s = q.has_m = q.has_p = false;
@@ -1199,22 +1203,6 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             if (q.has_s) res.occluded = pool_result(pool, L.n_p + L.n_m + lane_rank(L.m_s)).prim >= 0;
             wave_lds_fence();
         }
-
-        if (valid) {
-            P.acc[3 * pixel] = acc.x;
-            P.acc[3 * pixel + 1] = acc.y;
-            P.acc[3 * pixel + 2] = acc.z;
-            P.color[3 * pixel] = col.x;
-            P.color[3 * pixel + 1] = col.y;
-            P.color[3 * pixel + 2] = col.z;
-            if (P.out != nullptr && P.iter_count > 0) {
-                const uint32_t last = P.iter_first + P.iter_count - 1u;
-                V3 o = tonemap(acc / (float)(int)last, P.cam.filmic != 0);   // Output: acc / iter, iter is int
-                P.out[3 * pixel] = o.x;
-                P.out[3 * pixel + 1] = o.y;
-                P.out[3 * pixel + 2] = o.z;
-            }
-        }
     }
 
     if (COUNT) {
@@ -1232,6 +1220,43 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         atomicAdd(&P.counters[11], (unsigned long long)cnt.l_shade);
         atomicAdd(&P.counters[12], (unsigned long long)cnt.w_nee);
         atomicAdd(&P.counters[13], (unsigned long long)cnt.l_nee);
+    }
+}
+
+// Output (pathtracer.cu:2516-2531) for a batch: per pixel, in iteration order,
+//   if the sample is finite it becomes kernel_color (:1019-1020: a non-finite sample leaves the previous
+//   value there), kernel_acc_image += kernel_color; after the last iteration out = tonemap(acc / iter).
+// Streaming: 16 B per pixel per iteration read, 48 B per pixel read/written once.
+__global__ void __launch_bounds__(256) pt_output_kernel(const DevParams P)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.stride * P.rows) return;
+    const uint32_t x = i % P.stride, y = i / P.stride;
+    const uint32_t tile = (x >> 3) + (y >> 3) * P.tiles_x;
+    if (tile % P.n_ranks != P.rank) return;
+    const uint32_t pixel = x + y * P.stride;
+    V3 col = V3{P.color[3 * pixel], P.color[3 * pixel + 1], P.color[3 * pixel + 2]};
+    V3 acc = v3(0.f);
+    if (!P.reset) acc = V3{P.acc[3 * pixel], P.acc[3 * pixel + 1], P.acc[3 * pixel + 2]};
+    const float4 *s = reinterpret_cast<const float4 *>(P.samples) + pixel;
+    for (uint32_t k = 0; k < P.iter_count; ++k, s += P.plane) {
+        const float4 sv = *s;
+        const V3 Li = V3{sv.x, sv.y, sv.z};
+        if (!is_inf(Li) && !is_nan(Li)) col = Li;
+        acc += col;
+    }
+    P.acc[3 * pixel] = acc.x;
+    P.acc[3 * pixel + 1] = acc.y;
+    P.acc[3 * pixel + 2] = acc.z;
+    P.color[3 * pixel] = col.x;
+    P.color[3 * pixel + 1] = col.y;
+    P.color[3 * pixel + 2] = col.z;
+    if (P.out != nullptr && P.iter_count > 0) {
+        const uint32_t last = P.iter_first + P.iter_count - 1u;
+        V3 o = tonemap(acc / (float)(int)last, P.cam.filmic != 0);   // Output: acc / iter, iter is int
+        P.out[3 * pixel] = o.x;
+        P.out[3 * pixel + 1] = o.y;
+        P.out[3 * pixel + 2] = o.z;
     }
 }
 
@@ -1300,6 +1325,13 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream
         hipLaunchKernelGGL(pt_render_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, P);
     else
         hipLaunchKernelGGL(pt_render_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_output(const DevParams &P, hipStream_t stream)
+{
+    const uint32_t n = P.stride * P.rows;
+    hipLaunchKernelGGL(pt_output_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 

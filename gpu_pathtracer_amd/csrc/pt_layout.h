@@ -94,9 +94,11 @@ struct DevParams {
     float eps;
     gpt_camera cam;
     // film
-    float *acc;                  // kernel_acc_image
+    float *acc;                  // kernel_acc_image (read/written by the output kernel)
     float *color;                // kernel_color
     float *out;                  // tonemapped output or nullptr
+    float *samples;              // per-iteration sample planes of float4: plane index = iter - iter_first
+    uint64_t plane;              // float4 per plane = W*H
     uint32_t stride;             // 32*(W/32): row stride of the reference's pixel index
     uint32_t rows;               // 4*(H/4)
     uint32_t tiles_x;            // 8x8 tiles per row
@@ -104,9 +106,11 @@ struct DevParams {
     uint32_t rank, n_ranks;      // tile ownership: t % n_ranks == rank
     uint32_t iter_first, iter_count;
     int32_t reset;
-    // scheduler
+    // scheduler: independent work items w = (chunk, tile), chunk = w / n_owned
+    uint32_t chunk_iters;        // iterations per work item
+    uint32_t n_chunks;           // ceil(iter_count / chunk_iters)
     uint32_t *tile_counter;      // work queue head (zeroed before every launch)
-    unsigned long long *counters;  // 6 work counters (counting build only)
+    unsigned long long *counters;  // work counters (counting build only)
 };
 
 }  // namespace pt

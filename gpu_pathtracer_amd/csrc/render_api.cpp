@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,6 +27,7 @@
 
 namespace pt {
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream);
+hipError_t launch_output(const DevParams &P, hipStream_t stream);
 hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_t rows, uint32_t iter, int filmic,
                           hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
@@ -53,6 +55,10 @@ struct gpt_ctx {
     float *acc = nullptr, *color = nullptr;
     uint32_t *tile_counter = nullptr;
     unsigned long long *counters = nullptr;
+    uint32_t chunk_override = 0;          // GPT_CHUNK_ITERS (experiments)
+    float *samples = nullptr;             // per-iteration sample planes, grown on demand
+    uint32_t sample_planes = 0;           // planes allocated
+    uint32_t max_batch = 64;              // iterations per path-kernel launch (GPT_MAX_BATCH)
     bool count_next = false;
     int n_cus = 256;
     int blocks_per_cu[2] = {4, 4};
@@ -330,6 +336,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     if (hipMalloc(&p, film_bytes) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(color) failed"); return fail(GPT_ERR_HIP); }
     ctx->allocs.push_back(p);
     ctx->color = static_cast<float *>(p);
+    if (const char *e = std::getenv("GPT_CHUNK_ITERS")) ctx->chunk_override = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("GPT_MAX_BATCH")) { int v = std::atoi(e); if (v > 0) ctx->max_batch = (uint32_t)v; }
     if (hipMalloc(&p, 256) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(queue) failed"); return fail(GPT_ERR_HIP); }
     ctx->allocs.push_back(p);
     ctx->tile_counter = static_cast<uint32_t *>(p);
@@ -342,6 +350,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.acc = ctx->acc;
     P.color = ctx->color;
     P.tile_counter = ctx->tile_counter;
+    P.plane = (uint64_t)width * height;
     P.counters = ctx->counters;
     if (hipDeviceSynchronize() != hipSuccess) { gpt_set_error("gpt_begin: device sync failed"); return fail(GPT_ERR_HIP); }
     *out = ctx;
@@ -367,43 +376,79 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         return GPT_ERR_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    DevParams P = ctx->P;
-    P.cam = *camera;
-    P.iter_first = iter_first;
-    P.iter_count = iter_count;
-    P.reset = reset ? 1 : 0;
-    P.out = out_tonemapped_dev;
     const bool count = ctx->count_next;
-    HIP_TRY(hipMemsetAsync(ctx->tile_counter, 0, 64, ctx->stream));
     if (count) HIP_TRY(hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    const uint32_t n_tiles = ctx->P.n_tiles, rank = ctx->P.rank, n_ranks = ctx->P.n_ranks;
+    const uint32_t n_owned = (n_tiles > rank) ? (n_tiles - rank + n_ranks - 1) / n_ranks : 0u;
     // reset clears the accumulator of EVERY pixel (Output, pathtracer.cu:2521).  With tile ownership the
-    // kernel only touches its own tiles, so the rest is cleared here: the sum-reduce over ranks then sees
+    // kernels only touch their own tiles, so the rest is cleared here: the sum-reduce over ranks then sees
     // zeros outside each rank's support.
-    if (reset && P.n_ranks > 1)
+    if (reset && n_ranks > 1)
         HIP_TRY(hipMemsetAsync(ctx->acc, 0, (size_t)ctx->width * ctx->height * 3 * sizeof(float), ctx->stream));
+    if (n_owned == 0 || iter_count == 0) return GPT_OK;
 
-    const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
-    if (n_owned == 0) return GPT_OK;
-    // persistent grid: as many 4-wave workgroups as stay resident, no more than the work
-    const long resident = (long)ctx->n_cus * ctx->blocks_per_cu[count ? 1 : 0];
-    const long needed = ((long)n_owned + 3) / 4;
-    const int n_blocks = (int)(needed < resident ? needed : resident);
-
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (!ctx->free_events.empty()) {
-        ev = ctx->free_events.back();
-        ctx->free_events.pop_back();
-    } else {
-        HIP_TRY(hipEventCreate(&ev.first));
-        HIP_TRY(hipEventCreate(&ev.second));
+    // sample planes for one launch (grown on demand, never shrunk)
+    const uint32_t batch_cap = iter_count < ctx->max_batch ? iter_count : ctx->max_batch;
+    if (ctx->sample_planes < batch_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->samples) {
+            HIP_TRY(hipFree(ctx->samples));
+            for (auto &a : ctx->allocs) if (a == ctx->samples) a = nullptr;
+            ctx->samples = nullptr;
+            ctx->sample_planes = 0;
+        }
+        void *ps = nullptr;
+        HIP_TRY(hipMalloc(&ps, (size_t)ctx->P.plane * 4 * sizeof(float) * batch_cap));
+        ctx->allocs.push_back(ps);
+        ctx->samples = static_cast<float *>(ps);
+        ctx->sample_planes = batch_cap;
     }
-    HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-    HIP_TRY(launch_render(P, count, n_blocks, ctx->stream));
-    HIP_TRY(hipEventRecord(ev.second, ctx->stream));
-    ctx->events.push_back(ev);
-    if (ctx->events.size() > 2048) {
-        int rc = fold_events(ctx);
-        if (rc != GPT_OK) return rc;
+
+    const long resident_waves = (long)ctx->n_cus * ctx->blocks_per_cu[count ? 1 : 0] * 4;
+    for (uint32_t done = 0; done < iter_count; done += batch_cap) {
+        DevParams P = ctx->P;
+        P.cam = *camera;
+        P.samples = ctx->samples;
+        P.iter_first = iter_first + done;
+        P.iter_count = iter_count - done < batch_cap ? iter_count - done : batch_cap;
+        P.reset = (reset && done == 0) ? 1 : 0;
+        P.out = (done + P.iter_count == iter_count) ? out_tonemapped_dev : nullptr;
+        // Work items = (iteration chunk, tile), all independent.  The batch is cut into chunks until there
+        // are about kItemsPerWave items per resident wave (small frames and multi-GPU shards would otherwise
+        // wait for their slowest tile); a chunk is never shorter than kMinChunk iterations because lanes idle
+        // while a wave drains at the end of each item.
+        const long kItemsPerWave = 8, kMinChunk = 8;
+        long n_chunks = (kItemsPerWave * resident_waves + n_owned - 1) / n_owned;
+        const long max_chunks = P.iter_count / kMinChunk > 0 ? P.iter_count / kMinChunk : 1;
+        if (n_chunks > max_chunks) n_chunks = max_chunks;
+        if (n_chunks < 1) n_chunks = 1;
+        uint32_t chunk_iters = (uint32_t)((P.iter_count + n_chunks - 1) / n_chunks);
+        if (ctx->chunk_override) chunk_iters = ctx->chunk_override < P.iter_count ? ctx->chunk_override : P.iter_count;
+        P.chunk_iters = chunk_iters;
+        P.n_chunks = (P.iter_count + chunk_iters - 1) / chunk_iters;
+        // persistent grid: as many 4-wave workgroups as stay resident, no more than the work
+        const long needed = ((long)n_owned * P.n_chunks + 3) / 4;
+        const long resident = resident_waves / 4;
+        const int n_blocks = (int)(needed < resident ? needed : resident);
+
+        HIP_TRY(hipMemsetAsync(ctx->tile_counter, 0, 64, ctx->stream));
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!ctx->free_events.empty()) {
+            ev = ctx->free_events.back();
+            ctx->free_events.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ev.first));
+            HIP_TRY(hipEventCreate(&ev.second));
+        }
+        HIP_TRY(hipEventRecord(ev.first, ctx->stream));
+        HIP_TRY(launch_render(P, count, n_blocks, ctx->stream));
+        HIP_TRY(hipEventRecord(ev.second, ctx->stream));
+        ctx->events.push_back(ev);
+        HIP_TRY(launch_output(P, ctx->stream));
+        if (ctx->events.size() > 2048) {
+            int rc = fold_events(ctx);
+            if (rc != GPT_OK) return rc;
+        }
     }
     return GPT_OK;
 }
@@ -477,7 +522,7 @@ int gpt_end(gpt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (void *p : ctx->allocs) (void)hipFree(p);
+    for (void *p : ctx->allocs) if (p) (void)hipFree(p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GPT_OK;

@@ -203,6 +203,19 @@ def test_tonemapped_output(gpt):
             assert_bit_exact(out2.cpu().numpy(), out_o, f"tonemap pass filmic={filmic}")
 
 
+def test_scene_file_through_the_loader(gpt):
+    """scenes/cornell_pt/scene.json -> gpt_scene_load -> gpt_begin: same film as the baked fixture + oracle."""
+    import os
+    ls = gpt.LoadedScene(os.path.join(ol.ROOT, "scenes", "cornell_pt", "scene.json"))
+    scene, meta = ol.load_cornell(8)
+    W, H = 128, 128
+    cam = ol.cornell_camera(meta, W, H)
+    ref, _ = ol.render(scene, cam, W, H, ls.epsilon, 1, 4)
+    with gpt.Renderer(ls.desc, W, H, ls.epsilon) as r:
+        r.render(cam, 1, 4, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "loader scene")
+
+
 # ---- Render() call semantics ----------------------------------------------------------------
 
 def test_single_iteration_calls_equal_batch(gpt):
