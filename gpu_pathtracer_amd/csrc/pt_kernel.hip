@@ -238,6 +238,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
             m_busy = __ballot(busy);
         }
         if (m_busy == 0ull) break;
+        if (COUNT && first_active_lane()) { cnt.w_trip++; cnt.l_trip += (uint32_t)__builtin_popcountll(m_busy); }
 
         const unsigned long long m_tri = __ballot(want_tri);
         const unsigned long long m_node = __ballot(want_node);
@@ -347,7 +348,9 @@ __device__ __forceinline__ V3 uniform_sphere(float u1, float u2, float &pdf)    
 }
 
 // --------------------------------------------------------------- camera ------
-__device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y, V2 xy)   // camera.h:48-84
+// `du1, du2` are the two draws of UniformDisk (pathtracer.cu:895, wrap.h:78-85).  The reference always
+// evaluates the disk sample; only the thin-lens branch reads it, so its sin/cos is evaluated there.
+__device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y, float du1, float du2)   // camera.h:48-84
 {
     const V3 cu = V3{c.u.x, c.u.y, c.u.z}, cv = V3{c.v.x, c.v.y, c.v.z}, cw = V3{c.w.x, c.w.y, c.w.z};
     Ray ray;
@@ -367,6 +370,9 @@ __device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y
     float yy = y * c.pixel2screen.y - c.height;
     V3 dir;
     if (c.apertureRadius > 0.00001f) {
+        float rr = sqrt_rn(du1);                  // UniformDisk
+        float phi = TWOPI * du2;
+        V2 xy = v2(rr * gpt_cosf(phi), rr * gpt_sinf(phi));
         V2 aperture_xy = xy * c.apertureRadius;
         float focal_x = c.ratio * xx;
         float focal_y = c.ratio * yy;
@@ -1162,10 +1168,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 float offsety = rng_uniform(rng) - 0.5f;
                 float du1 = rng_uniform(rng);
                 float du2 = rng_uniform(rng);
-                float rr = sqrt_rn(du1);                  // UniformDisk, wrap.h:78-85
-                float phi = TWOPI * du2;
-                V2 aperture = v2(rr * gpt_cosf(phi), rr * gpt_sinf(phi));
-                Ray r = primary_ray(P.cam, x + offsetx, y + offsety, aperture);
+                Ray r = primary_ray(P.cam, x + offsetx, y + offsety, du1, du2);
                 q.org = r.o;
                 q.dir_p = r.d;
                 q.has_p = true;

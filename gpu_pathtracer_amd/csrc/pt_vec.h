@@ -72,8 +72,15 @@ PT_HD float rsqrt_rn(float x) { return 1.0f / sqrt_rn(x); }
 PT_HD float length(V3 v) { return sqrt_rn(dot(v, v)); }
 PT_HD V3 normalize(V3 v) { float invLen = rsqrt_rn(dot(v, v)); return v * invLen; }
 
-PT_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }   // minNum: NaN operand loses
+// minNum / maxNum (a NaN operand loses), like CUDA's fminf/fmaxf.  On the device this is one v_min_f32 /
+// v_max_f32; on the host the builtin would be a libm call, so the same rule is spelled out inline.
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 PT_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
+PT_HD float fmin_(float a, float b) { return gpt_fminf(a, b); }
+PT_HD float fmax_(float a, float b) { return gpt_fmaxf(a, b); }
+#endif
 PT_HD float clamp(float f, float a, float b) { return fmax_(a, fmin_(f, b)); }
 PT_HD float fabs_(float x) { return __builtin_fabsf(x); }
 PT_HD bool is_black(V3 c) { return c.x == 0 && c.y == 0 && c.z == 0; }

@@ -143,3 +143,61 @@ def zoo_scene(max_depth=8, with_env=False, with_area_light=True, assign=None, ex
     scene = ol.make_scene(allp, mats, light_radiance=meta["light_radiance"], max_depth=max_depth, env=env,
                           env_rotate_uvw=uvw, textures=[checker_texture()])
     return scene, meta
+
+
+def displaced_sphere(center, radius, mat, nu, nv, amp=0.08, freq=9.0):
+    """dense smooth-shaded blob: 2*nu*(nv-1) triangles, vectorised (used for the 250k-triangle stress scene)"""
+    c = np.asarray(center, np.float32)
+    j, i = np.meshgrid(np.arange(nv + 1, dtype=np.float32), np.arange(nu + 1, dtype=np.float32), indexing="ij")
+    th = np.float32(np.pi) * j / np.float32(nv)
+    ph = np.float32(2 * np.pi) * i / np.float32(nu)
+    d = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).astype(np.float32)
+    r = (np.float32(radius) * (1 + np.float32(amp) * np.sin(np.float32(freq) * th) * np.cos(np.float32(freq) * ph))).astype(np.float32)
+    pos = (c + d * r[..., None]).astype(np.float32)
+    nrm = d / np.sqrt((d * d).sum(-1, keepdims=True), dtype=np.float32)
+    uv = np.stack([i / np.float32(nu), j / np.float32(nv)], -1).astype(np.float32)
+    quads = [(jj, ii) for jj in range(nv) for ii in range(nu)]
+    tris = []
+    for jj, ii in quads:
+        a, b, cc, dd = (jj, ii), (jj, ii + 1), (jj + 1, ii + 1), (jj + 1, ii)
+        if jj != 0:
+            tris.append((a, b, cc))
+        if jj != nv - 1:
+            tris.append((a, cc, dd))
+    out = np.zeros(len(tris), dtype=st.PRIMITIVE)
+    idx = np.array(tris)            # (T, 3, 2)
+    for k, name in enumerate(("v1", "v2", "v3")):
+        jj, ii = idx[:, k, 0], idx[:, k, 1]
+        for ax, comp in enumerate("xyz"):
+            out["triangle"][name]["v"][comp] = pos[jj, ii, ax]
+            out["triangle"][name]["n"][comp] = nrm[jj, ii, ax]
+        out["triangle"][name]["uv"] = uv[jj, ii]
+    out["triangle"]["matIdx"] = mat
+    out["triangle"]["bssrdfIdx"] = -1
+    out["triangle"]["lightIdx"] = -1
+    out["triangle"]["mediumInside"] = -1
+    out["triangle"]["mediumOutside"] = -1
+    return out
+
+
+def stress_parts(scale=1.0):
+    """Cornell walls + three dense blobs (mirror-ish metal, glass, substrate): ~250k triangles at scale=1
+    (stand-in for BASELINE config 5 "sponza": the reference ships no such mesh)."""
+    n1 = max(8, int(182 * scale))
+    n2 = max(8, int(140 * scale))
+    n3 = max(8, int(105 * scale))
+    return concat([
+        displaced_sphere((-0.35, 0.55, -0.25), 0.45, 13, 2 * n1, n1),
+        displaced_sphere((0.45, 0.4, 0.3), 0.35, 7, 2 * n2, n2, amp=0.05, freq=13.0),
+        displaced_sphere((-0.1, 1.45, 0.1), 0.3, 10, 2 * n3, n3, amp=0.12, freq=7.0),
+    ])
+
+
+def stress_scene(scale=1.0, max_depth=16):
+    prims, _, meta = cornell_raw()
+    keep = concat([prims[0:10], prims[34:36]])      # walls + light, no boxes
+    keep["triangle"]["lightIdx"][10:] = [0, 1]
+    allp = concat([keep, stress_parts(scale)])
+    scene = ol.make_scene(allp, material_table(), light_radiance=meta["light_radiance"], max_depth=max_depth,
+                          textures=[checker_texture()])
+    return scene, meta

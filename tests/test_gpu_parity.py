@@ -305,6 +305,26 @@ def test_work_counters_match_oracle(gpt):
     assert cg == co
 
 
+def test_stress_scene_250k_triangles(gpt):
+    """Stand-in for BASELINE config 5 (the reference ships no sponza mesh): Cornell walls + three dense
+    displaced blobs (rough conductor, glass, substrate), 253 300 triangles, 156 061 BVH nodes, depth 29,
+    16 bounces.  ~460 node visits per sample: the memory-system-bound case."""
+    scene, meta = scenes.stress_scene(1.0, max_depth=16)
+    assert len(scene.prims) > 250_000
+    W, H = 256, 256
+    cam = ol.cornell_camera(meta, W, H)
+    ag, cg, ao, co = render_both(gpt, scene, cam, W, H, 0.001, 1, 4)
+    assert_bit_exact(ag, ao, "stress acc")
+    # 4K frame of the same scene: oracle-checked on 1/256 of the tiles
+    W, H = 3840, 2160
+    cam = ol.cornell_camera(meta, W, H)
+    po, _ = ol.render(scene, cam, W, H, 0.001, 1, 1, rank=77, n_ranks=256)
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        r.set_tile_owner(77, 256)
+        r.render(cam, 1, 1, reset=True)
+        assert r.read_accum().tobytes() == po.tobytes()
+
+
 # ---- BASELINE.json full size: size-independent properties -------------------------------------
 
 def test_full_hd_properties(gpt):

@@ -10,5 +10,6 @@ c = r.read_probe_counters(); print(c)
 u = lambda l, w: c[l] / (64.0 * c[w]) if c[w] else float('nan')
 print("lane utilisation: node loop %.3f  triangle loop %.3f  bounce trip %.3f  hit shading %.3f  direct light %.3f" %
       (u("node_visits", "w_node"), u("prim_tests", "w_prim"), u("l_trip", "w_trip"), u("l_shade", "w_shade"), u("l_nee", "w_nee")))
+print("traversal trips per sample: %.3f wave-trips, busy lanes per trip %.1f/64" % (c["w_trip"]/c["samples"]*1.0, c["l_trip"]/max(1,c["w_trip"])))
 print("per sample: wave node trips x64 = %.1f lane-slots (useful %.1f); tri %.1f (useful %.1f); trips %.2f" % (
     64.0*c["w_node"]/c["samples"], c["node_visits"]/c["samples"], 64.0*c["w_prim"]/c["samples"], c["prim_tests"]/c["samples"], 64.0*c["w_trip"]/c["samples"]))
