@@ -892,6 +892,26 @@ __device__ __forceinline__ void inf_sample_light(const DevInfinite &I, V3 pos, V
     rad = inf_le(I, dir);
 }
 
+// Would Triangle::Intersect (mesh.h:45-67) accept this ray on the emitter's triangle, with tmax = inf?
+// Same operations, same order as the traversal's triangle step.
+__device__ __forceinline__ bool emitter_accepts(const DevLight &L, V3 o, V3 d, float tmin)
+{
+    const V3 v1 = ld3(L.v1);
+    const V3 e1 = ld3(L.v2) - v1;
+    const V3 e2 = ld3(L.v3) - v1;
+    const V3 s1 = cross(d, e2);
+    const float divisor = dot(s1, e1);
+    const float invDivisor = 1.0f / divisor;
+    const V3 s = o - v1;
+    const float b1 = dot(s, s1) * invDivisor;
+    const V3 s2 = cross(s, e1);
+    const float b2 = dot(d, s2) * invDivisor;
+    const float tt = dot(e2, s2) * invDivisor;
+    return !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) && !(b2 < 0.0f || b1 + b2 > 1.0f) &&
+           !(tt < tmin || tt > __builtin_inff());
+}
+constexpr int kEmitterPretestMax = 8;
+
 // pathtracer.cu:172-181 (no match — only for NaN u — returns -1 here; the
 // reference falls off the end of a non-void function)
 __device__ __forceinline__ int lookup_light_distribution(const DevParams &P, float u, float &pdf)
@@ -996,6 +1016,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         V3 cand = v3(0.f);         // light-sample term, added if the shadow ray is unoccluded
         V3 mis_fr = v3(0.f);       // BSDF-sample term pieces
         float mis_cos = 0.f, mis_pdf = 1.f;
+        bool direct = false;       // a non-delta bounce is waiting for `Li += beta*Ld` (pathtracer.cu:994)
         bool ending = false;       // the path has no continuation; the sample ends once Ld is resolved
         bool alive = false;
 
@@ -1012,7 +1033,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             bool finish = false;
             if (alive) {
                 // ---- resolve the direct light of the previous bounce ------------------
-                if (q.has_s || q.has_m) {
+                if (direct) {
                     V3 Ld = v3(0.f, 0.f, 0.f);
                     if (q.has_s && !res.occluded) Ld += cand;
                     if (q.has_m) {
@@ -1040,7 +1061,10 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                             Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
                         }
                     }
+                    // executed even when both rays were skipped: beta * 0 is NaN for a non-finite
+                    // throughput, and the reference then discards the sample (pathtracer.cu:994,1019)
                     Li += beta_ld * Ld;
+                    direct = false;
                 }
                 if (ending) finish = true;
 
@@ -1097,9 +1121,13 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                     eval_bsdf(P, material, wo, shadowRay.d, nor, uv, dpdu, fr, samplePdf);
                                     float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
                                     cand = weight * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
-                                    q.dir_s = shadowRay.d;
-                                    q.tmax_s = shadowRay.tmax;
-                                    q.has_s = true;
+                                    // an exactly-zero term (e.g. the light is below the horizon of a lambertian
+                                    // surface: Fr returns 0) adds nothing whether or not the light is visible
+                                    if (!is_black(cand)) {
+                                        q.dir_s = shadowRay.d;
+                                        q.tmax_s = shadowRay.tmax;
+                                        q.has_s = true;
+                                    }
                                 }
                                 float usx = rng_uniform(rng);
                                 float usy = rng_uniform(rng);
@@ -1108,13 +1136,27 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 float pdf;
                                 sample_bsdf(P, material, wo, nor, uv, dpdu, v3(usx, usy, usz), out, fr, pdf);
                                 if (!(is_black(fr) || pdf == 0)) {
-                                    mis_fr = fr;
-                                    mis_cos = fabs_(dot(out, nor));
-                                    mis_pdf = pdf;
-                                    q.dir_m = out;
-                                    q.has_m = true;
+                                    // The BSDF-sampled light ray contributes only if its CLOSEST hit is an emitter
+                                    // triangle (pathtracer.cu:964-976) or, with an environment light, if it escapes
+                                    // (:978-990).  Without an environment light and with few emitters, test the
+                                    // emitters' triangles first: if Triangle::Intersect would reject all of them, no
+                                    // traversal order can make an emitter the closest hit and the ray is not traced.
+                                    bool useful = true;
+                                    if (!P.inf.isvalid && P.n_lights <= kEmitterPretestMax) {
+                                        useful = false;
+                                        for (int li = 0; li < P.n_lights; ++li)
+                                            useful = useful || emitter_accepts(P.lights[li], pos, out, P.eps);
+                                    }
+                                    if (useful) {
+                                        mis_fr = fr;
+                                        mis_cos = fabs_(dot(out, nor));
+                                        mis_pdf = pdf;
+                                        q.dir_m = out;
+                                        q.has_m = true;
+                                    }
                                 }
                                 beta_ld = beta;
+                                direct = true;
                             }
                             // continuation.  The reference also samples it on the last bounce and
                             // then leaves the loop; nothing of that sample reaches Li, so it is skipped.
@@ -1145,7 +1187,13 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                     }
                                 }
                             }
-                            if (ending && !q.has_s && !q.has_m) finish = true;
+                            if (ending && !q.has_s && !q.has_m) {
+                                if (direct) {      // nothing to wait for: Ld = 0
+                                    Li += beta_ld * v3(0.f, 0.f, 0.f);
+                                    direct = false;
+                                }
+                                finish = true;
+                            }
                         }
                     }
                 }
@@ -1178,6 +1226,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 specular = false;
                 bounces = 0;
                 ending = false;
+                direct = false;
                 alive = true;
                 left--;
                 if (COUNT) cnt.samples++;

@@ -288,41 +288,49 @@ def test_tile_ownership_sums_to_full_frame(gpt):
         assert total.tobytes() == full.tobytes()
 
 
-def test_work_counters_match_oracle(gpt):
+def test_work_counters_against_oracle(gpt):
+    """Counting build: same film; path-level counts equal the oracle's (= the reference algorithm's);
+    ray-level counts can only be lower, because the kernel does not trace rays that provably cannot
+    contribute (zero light-sample term; BSDF-sampled light ray that misses every emitter triangle)."""
     scene, meta = ol.load_cornell(8)
     W, H = 128, 128
     cam = ol.cornell_camera(meta, W, H)
-    ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft")
+    ref, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft")
     co = ol.counters("soft")
     with gpt.Renderer(scene.desc, W, H, 0.001) as r:
         r.enable_counters(True)
         r.render(cam, 1, 4, reset=True)
         cg = r.read_counters()
-        acc_count = r.read_accum()
-        r.enable_counters(False)
-        r.render(cam, 1, 4, reset=True)
-        assert acc_count.tobytes() == r.read_accum().tobytes()
-    assert cg == co
+        assert_bit_exact(r.read_accum(), ref, "counting build")
+    assert cg["samples"] == co["samples"] and cg["bounce_iters"] == co["bounce_iters"]
+    for k in ("shadow_rays", "closest_rays", "node_visits", "prim_tests"):
+        assert 0 < cg[k] <= co[k], k
+    assert cg["closest_rays"] < 0.8 * co["closest_rays"]       # most MIS light rays miss the small Cornell light
 
 
-def test_stress_scene_250k_triangles(gpt):
-    """Stand-in for BASELINE config 5 (the reference ships no sponza mesh): Cornell walls + three dense
-    displaced blobs (rough conductor, glass, substrate), 253 300 triangles, 156 061 BVH nodes, depth 29,
-    16 bounces.  ~460 node visits per sample: the memory-system-bound case."""
-    scene, meta = scenes.stress_scene(1.0, max_depth=16)
-    assert len(scene.prims) > 250_000
-    W, H = 256, 256
+def test_emitter_pretest_is_exact_with_many_lights_and_env(gpt):
+    """The MIS-ray pre-test is only used without an environment light and with <= 8 emitter triangles;
+    both sides of that switch must give the oracle's film."""
+    prims, _, meta = scenes.cornell_raw()
+    # 12 emitter triangles: the short box becomes a second light (pre-test off)
+    a, b = scenes.CORNELL_PARTS["short"]
+    prims["triangle"]["lightIdx"][a:b] = np.arange(2, 2 + (b - a))
+    prims["triangle"]["matIdx"][a:b] = 4
+    rad = np.array([[17.0, 12.0, 4.0]] * 2 + [[0.5, 0.9, 1.4]] * (b - a), np.float32)
+    scene = ol.make_scene(prims, scenes.material_table(), light_radiance=rad, max_depth=6, textures=[scenes.checker_texture()])
+    assert len(scene.lights) == 14
+    W, H = 128, 128
     cam = ol.cornell_camera(meta, W, H)
-    ag, cg, ao, co = render_both(gpt, scene, cam, W, H, 0.001, 1, 4)
-    assert_bit_exact(ag, ao, "stress acc")
-    # 4K frame of the same scene: oracle-checked on 1/256 of the tiles
-    W, H = 3840, 2160
-    cam = ol.cornell_camera(meta, W, H)
-    po, _ = ol.render(scene, cam, W, H, 0.001, 1, 1, rank=77, n_ranks=256)
-    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
-        r.set_tile_owner(77, 256)
-        r.render(cam, 1, 1, reset=True)
-        assert r.read_accum().tobytes() == po.tobytes()
+    ag, cg, ao, co = render_both(gpt, scene, cam, W, H, 0.001, 1, 6)
+    assert_bit_exact(ag, ao, "14 emitter triangles")
+    # 3 emitter triangles (pre-test on), one of them large and close to surfaces
+    prims, _, meta = scenes.cornell_raw()
+    prims["triangle"]["lightIdx"][a] = 2
+    prims["triangle"]["matIdx"][a] = 4
+    scene = ol.make_scene(prims, scenes.material_table(), light_radiance=np.array([[17, 12, 4]] * 2 + [[3, 3, 3]], np.float32),
+                          max_depth=9, textures=[scenes.checker_texture()])
+    ag, cg, ao, co = render_both(gpt, scene, cam, W, H, 0.001, 1, 8)
+    assert_bit_exact(ag, ao, "3 emitter triangles")
 
 
 # ---- BASELINE.json full size: size-independent properties -------------------------------------
