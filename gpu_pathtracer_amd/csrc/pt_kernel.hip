@@ -126,6 +126,7 @@ struct RaySet {        // what one lane deposits
     V3 dir_p, dir_m, dir_s;
     float tmax_s;
     bool has_p, has_m, has_s;
+    bool mis_any;      // the MIS ray only needs hit / no hit (no emitter can be its closest hit)
 };
 struct PoolLayout {    // wave-uniform: where each kind starts, from the ballots
     unsigned long long m_p, m_m, m_s;
@@ -167,7 +168,7 @@ __device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &r
     L.n_rays = L.n_p + L.n_m + __builtin_popcountll(L.m_s);
     pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
     if (rs.has_p) pool_put(pool, lane_rank(L.m_p), rs.dir_p, __builtin_inff(), lane, false);
-    if (rs.has_m) pool_put(pool, L.n_p + lane_rank(L.m_m), rs.dir_m, __builtin_inff(), lane, false);
+    if (rs.has_m) pool_put(pool, L.n_p + lane_rank(L.m_m), rs.dir_m, __builtin_inff(), lane, rs.mis_any);
     if (rs.has_s) pool_put(pool, L.n_p + L.n_m + lane_rank(L.m_s), rs.dir_s, rs.tmax_s, lane, true);
     return L;
 }
@@ -1024,6 +1025,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         q.org = q.dir_s = q.dir_m = q.dir_p = v3(0.f);
         q.tmax_s = 0.f;
         q.has_s = q.has_m = q.has_p = false;
+        q.mis_any = false;
         RayResults res;
         res.occluded = false;
         res.prim_m = res.prim_p = -1;
@@ -1038,6 +1040,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                     if (q.has_s && !res.occluded) Ld += cand;
                     if (q.has_m) {
                         if (res.prim_m >= 0) {
+                          if (!q.mis_any) {
                             V3 n;
                             int lightIdx;
                             make_light_hit(P, res.prim_m, res.b1_m, res.b2_m, n, lightIdx);
@@ -1053,6 +1056,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 float weight = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
                                 Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
                             }
+                          }
                         } else if (P.inf.isvalid) {
                             V3 radiance = inf_le(P.inf, q.dir_m);
                             float choicePdf = pdf_from_light_distribution(P, P.n_lights);
@@ -1138,14 +1142,21 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 if (!(is_black(fr) || pdf == 0)) {
                                     // The BSDF-sampled light ray contributes only if its CLOSEST hit is an emitter
                                     // triangle (pathtracer.cu:964-976) or, with an environment light, if it escapes
-                                    // (:978-990).  Without an environment light and with few emitters, test the
-                                    // emitters' triangles first: if Triangle::Intersect would reject all of them, no
-                                    // traversal order can make an emitter the closest hit and the ray is not traced.
+                                    // (:978-990).  With few emitters, test their triangles first: if
+                                    // Triangle::Intersect would reject all of them, no traversal order can make an
+                                    // emitter the closest hit.  Then, without an environment light the ray is not
+                                    // traced at all; with one, only hit / no hit matters and the ray is traced as an
+                                    // any-hit ray (the first accepted triangle is the same in both traversals).
                                     bool useful = true;
-                                    if (!P.inf.isvalid && P.n_lights <= kEmitterPretestMax) {
-                                        useful = false;
+                                    q.mis_any = false;
+                                    if (P.n_lights <= kEmitterPretestMax) {
+                                        bool emitter = false;
                                         for (int li = 0; li < P.n_lights; ++li)
-                                            useful = useful || emitter_accepts(P.lights[li], pos, out, P.eps);
+                                            emitter = emitter || emitter_accepts(P.lights[li], pos, out, P.eps);
+                                        if (!emitter) {
+                                            useful = P.inf.isvalid != 0;
+                                            q.mis_any = true;
+                                        }
                                     }
                                     if (useful) {
                                         mis_fr = fr;
