@@ -965,7 +965,7 @@ __device__ __forceinline__ void make_light_hit(const DevParams &P, int prim, flo
 }
 
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 4
+#define PT_MIN_WAVES 3
 #endif
 struct RayResults {    // this lane's own rays, read back from the pool
     bool occluded;
