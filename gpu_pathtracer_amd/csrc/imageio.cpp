@@ -10,14 +10,16 @@
 // Here: a PNG writer (stored-deflate, no compression needed for a checker
 // output), a PNG reader (8-bit grey / grey+alpha / RGB / RGBA / palette,
 // non-interlaced) on a small inflate, and PFM (little- or big-endian float32)
-// for linear radiance and environment maps.  JPEG and OpenEXR decoding are not
-// implemented yet (DESIGN.md "Next").
+// for linear radiance and environment maps, an OpenEXR scanline reader (NONE / RLE / ZIPS / ZIP,
+// half / float) for the reference's environment maps, and a baseline JPEG reader for textures.
+// Progressive JPEG and EXR PIZ are not implemented (DESIGN.md "Next").
 #include "imageio.h"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../include/gpt.h"
 #include "host_util.h"
@@ -318,13 +320,243 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
     return true;
 }
 
+// ---- baseline JPEG (sequential DCT, Huffman, 8-bit, 1 or 3 components, any h/v sampling, restart
+// intervals).  Chroma is up-sampled by replication and the inverse DCT is evaluated in float; stb_image, which
+// the reference uses, has its own fixed-point IDCT and smooth chroma filter, so texel values can differ from
+// the reference's by a few 8-bit steps (parity of JPEG textures is unpinned — DESIGN.md).  Progressive and
+// arithmetic-coded files are refused.
+namespace {
+struct JpegHuff {
+    unsigned char bits[17] = {0};
+    unsigned char vals[256] = {0};
+    int mincode[17], maxcode[18], valptr[17];
+    void build()
+    {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            valptr[l] = k;
+            mincode[l] = code;
+            code += bits[l];
+            k += bits[l];
+            maxcode[l] = bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+    }
+};
+struct JpegBits {
+    const unsigned char *p;
+    size_t n, pos;
+    uint32_t buf = 0;
+    int cnt = 0;
+    bool eof = false;
+    int bit()
+    {
+        if (cnt == 0) {
+            unsigned char c = 0;
+            if (pos < n) {
+                c = p[pos++];
+                if (c == 0xff) {
+                    if (pos < n && p[pos] == 0) ++pos;
+                    else { --pos; c = 0; eof = true; }     // a marker: feed zeros
+                }
+            } else eof = true;
+            buf = c;
+            cnt = 8;
+        }
+        --cnt;
+        return (buf >> cnt) & 1;
+    }
+    int receive(int s)
+    {
+        int v = 0;
+        for (int i = 0; i < s; ++i) v = (v << 1) | bit();
+        return v;
+    }
+    int decode(const JpegHuff &h)
+    {
+        int code = 0;
+        for (int l = 1; l <= 16; ++l) {
+            code = (code << 1) | bit();
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+        }
+        return -1;
+    }
+    void reset() { cnt = 0; eof = false; }
+};
+int jpeg_extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+void jpeg_idct(const float in[64], unsigned char *out, int stride)
+{
+    static float c[8][8];
+    static bool init = false;
+    if (!init) {
+        for (int x = 0; x < 8; ++x)
+            for (int u = 0; u < 8; ++u) c[x][u] = (u == 0 ? 0.35355339059f : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
+        init = true;
+    }
+    float tmp[64];
+    for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) {
+            float s = 0;
+            for (int u = 0; u < 8; ++u) s += c[x][u] * in[y * 8 + u];
+            tmp[y * 8 + x] = s;
+        }
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y) {
+            float s = 0;
+            for (int v = 0; v < 8; ++v) s += c[y][v] * tmp[v * 8 + x];
+            int q = (int)std::floor(s + 128.5f);
+            out[y * stride + x] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+}
+}  // namespace
+
+bool read_jpeg(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
+{
+    static const unsigned char zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    std::vector<unsigned char> d;
+    if (!read_file(path, d) || d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return false;
+    float qt[4][64] = {{0}};
+    JpegHuff hdc[4], hac[4];
+    struct Comp { int id, h, v, tq, td, ta, pred; std::vector<unsigned char> plane; int pw, ph; } comp[3];
+    int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
+    width = height = 0;
+    size_t pos = 2;
+    while (pos + 4 <= d.size()) {
+        if (d[pos] != 0xff) { ++pos; continue; }
+        const int marker = d[pos + 1];
+        pos += 2;
+        if (marker == 0xd8 || (marker >= 0xd0 && marker <= 0xd7) || marker == 0x01 || marker == 0xff) continue;
+        if (marker == 0xd9) break;
+        if (pos + 2 > d.size()) return false;
+        const size_t len = (size_t)d[pos] << 8 | d[pos + 1];
+        if (len < 2 || pos + len > d.size()) return false;
+        const unsigned char *seg = &d[pos + 2];
+        const size_t seglen = len - 2;
+        if (marker == 0xdb) {
+            size_t q = 0;
+            while (q < seglen) {
+                const int pq = seg[q] >> 4, tq = seg[q] & 15;
+                ++q;
+                if (tq > 3 || q + (pq ? 128u : 64u) > seglen) return false;
+                for (int i = 0; i < 64; ++i) { qt[tq][zigzag[i]] = pq ? (float)(seg[q] << 8 | seg[q + 1]) : (float)seg[q]; q += pq ? 2 : 1; }
+            }
+        } else if (marker == 0xc4) {
+            size_t q = 0;
+            while (q + 17 <= seglen) {
+                const int tc = seg[q] >> 4, th = seg[q] & 15;
+                if (th > 3) return false;
+                JpegHuff &h = tc ? hac[th] : hdc[th];
+                int total = 0;
+                for (int l = 1; l <= 16; ++l) { h.bits[l] = seg[q + (size_t)l]; total += h.bits[l]; }
+                q += 17;
+                if (total > 256 || q + (size_t)total > seglen) return false;
+                std::memcpy(h.vals, seg + q, (size_t)total);
+                q += (size_t)total;
+                h.build();
+            }
+        } else if (marker == 0xc0 || marker == 0xc1) {
+            if (seglen < 6 || seg[0] != 8) return false;
+            height = seg[1] << 8 | seg[2];
+            width = seg[3] << 8 | seg[4];
+            ncomp = seg[5];
+            if ((ncomp != 1 && ncomp != 3) || seglen < 6 + 3 * (size_t)ncomp || width <= 0 || height <= 0) return false;
+            for (int i = 0; i < ncomp; ++i) {
+                comp[i].id = seg[6 + 3 * i];
+                comp[i].h = seg[7 + 3 * i] >> 4;
+                comp[i].v = seg[7 + 3 * i] & 15;
+                comp[i].tq = seg[8 + 3 * i];
+                if (comp[i].h < 1 || comp[i].v < 1 || comp[i].tq > 3) return false;
+                if (comp[i].h > hmax) hmax = comp[i].h;
+                if (comp[i].v > vmax) vmax = comp[i].v;
+            }
+        } else if (marker == 0xc2 || (marker >= 0xc5 && marker <= 0xcf && marker != 0xc8 && marker != 0xcc)) {
+            return false;    // progressive / lossless / arithmetic
+        } else if (marker == 0xdd) {
+            if (seglen < 2) return false;
+            restart = seg[0] << 8 | seg[1];
+        } else if (marker == 0xda) {
+            if (!width || seglen < 1 || seg[0] != ncomp) return false;
+            for (int i = 0; i < ncomp; ++i) {
+                const int cid = seg[1 + 2 * i];
+                for (int k = 0; k < ncomp; ++k)
+                    if (comp[k].id == cid) { comp[k].td = seg[2 + 2 * i] >> 4; comp[k].ta = seg[2 + 2 * i] & 15; }
+            }
+            const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (int i = 0; i < ncomp; ++i) {
+                comp[i].pw = mcux * comp[i].h * 8;
+                comp[i].ph = mcuy * comp[i].v * 8;
+                comp[i].plane.assign((size_t)comp[i].pw * comp[i].ph, 0);
+                comp[i].pred = 0;
+                if (comp[i].td > 3 || comp[i].ta > 3) return false;
+            }
+            JpegBits br{d.data(), d.size(), pos + len};
+            int count = 0;
+            for (int my = 0; my < mcuy; ++my)
+                for (int mx = 0; mx < mcux; ++mx) {
+                    if (restart && count && count % restart == 0) {
+                        br.reset();
+                        while (br.pos + 1 < br.n && !(br.p[br.pos] == 0xff && br.p[br.pos + 1] >= 0xd0 && br.p[br.pos + 1] <= 0xd7)) ++br.pos;
+                        br.pos += 2;
+                        for (int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+                    }
+                    ++count;
+                    for (int i = 0; i < ncomp; ++i)
+                        for (int by = 0; by < comp[i].v; ++by)
+                            for (int bx = 0; bx < comp[i].h; ++bx) {
+                                float blk[64] = {0};
+                                int t = br.decode(hdc[comp[i].td]);
+                                if (t < 0 || t > 16) return false;
+                                comp[i].pred += jpeg_extend(br.receive(t), t);
+                                blk[0] = comp[i].pred * qt[comp[i].tq][0];
+                                for (int k = 1; k < 64;) {
+                                    const int rs = br.decode(hac[comp[i].ta]);
+                                    if (rs < 0) return false;
+                                    const int r = rs >> 4, sz = rs & 15;
+                                    if (sz == 0) {
+                                        if (r != 15) break;
+                                        k += 16;
+                                        continue;
+                                    }
+                                    k += r;
+                                    if (k > 63) return false;
+                                    blk[zigzag[k]] = jpeg_extend(br.receive(sz), sz) * qt[comp[i].tq][zigzag[k]];
+                                    ++k;
+                                }
+                                jpeg_idct(blk, &comp[i].plane[(size_t)((my * comp[i].v + by) * 8) * comp[i].pw + (size_t)(mx * comp[i].h + bx) * 8], comp[i].pw);
+                            }
+                }
+            break;
+        }
+        pos += len;
+    }
+    if (!width || comp[0].plane.empty()) return false;
+    components = ncomp;
+    rgba.resize((size_t)width * height * 4);
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            auto at = [&](int i) { return (float)comp[i].plane[(size_t)(y * comp[i].v / vmax) * comp[i].pw + (size_t)(x * comp[i].h / hmax)]; };
+            unsigned char *o = &rgba[((size_t)y * width + x) * 4];
+            if (ncomp == 1) { o[0] = o[1] = o[2] = (unsigned char)at(0); }
+            else {
+                const float Y = at(0), cb = at(1) - 128.f, cr = at(2) - 128.f;
+                const float r = Y + 1.402f * cr, g = Y - 0.344136f * cb - 0.714136f * cr, b = Y + 1.772f * cb;
+                auto cl = [](float v) { int q = (int)std::floor(v + 0.5f); return (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q)); };
+                o[0] = cl(r); o[1] = cl(g); o[2] = cl(b);
+            }
+            o[3] = 255;
+        }
+    return true;
+}
+
 // ImageIO::LoadTexture + Texture::Texture (src/imageio.cpp:11-59, src/texture.h:15-27):
 // flip vertically, 1/255, sRGB -> linear by powf(x, 2.2f) on r,g,b, then truncate x*255 back to uchar.
-bool load_texture_png(const char *path, int &width, int &height, std::vector<gpt_uchar4> &texels)
+bool load_texture(const char *path, int &width, int &height, std::vector<gpt_uchar4> &texels)
 {
     std::vector<unsigned char> rgba;
     int comp = 0;
-    if (!read_png(path, width, height, comp, rgba)) return false;
+    if (!read_png(path, width, height, comp, rgba) && !read_jpeg(path, width, height, comp, rgba)) return false;
     texels.resize((size_t)width * height);
     const float inv = 1.f / 255.f;
     for (int y = 0; y < height; ++y) {
@@ -390,6 +622,162 @@ bool read_pfm_top_down(const char *path, int &width, int &height, std::vector<gp
             else { c.x = c.y = c.z = rd(src); }
             out[(size_t)y * width + x] = c;
         }
+    return true;
+}
+
+// ---- OpenEXR, scanline images (what ImageIO::LoadExr hands the reference through tinyexr's LoadEXR:
+// float RGB, row 0 = top).  Supported: single-part scanline files, compression NONE / RLE / ZIPS / ZIP,
+// HALF / FLOAT / UINT channels named R,G,B (or a single luminance channel Y), sampling 1x1.  Not supported
+// (returns false): tiled or multi-part files, PIZ / PXR24 / B44 / DWA compression.
+namespace {
+float half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400u));
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | (man & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | man << 13;
+    else bits = sign | (exp + 112u) << 23 | man << 13;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+bool exr_rle_decode(const unsigned char *in, size_t n, std::vector<unsigned char> &out, size_t expect)
+{
+    out.clear();
+    size_t i = 0;
+    while (i < n) {
+        int c = (signed char)in[i++];
+        if (c < 0) {
+            size_t cnt = (size_t)(-c);
+            if (i + cnt > n) return false;
+            out.insert(out.end(), in + i, in + i + cnt);
+            i += cnt;
+        } else {
+            if (i >= n) return false;
+            out.insert(out.end(), (size_t)c + 1, in[i++]);
+        }
+        if (out.size() > expect) return false;
+    }
+    return out.size() == expect;
+}
+void exr_unpredict(std::vector<unsigned char> &buf, std::vector<unsigned char> &tmp)
+{
+    for (size_t i = 1; i < buf.size(); ++i) buf[i] = (unsigned char)(buf[i - 1] + buf[i] - 128);
+    tmp.resize(buf.size());
+    const size_t half = (buf.size() + 1) / 2;
+    for (size_t i = 0, a = 0, b = half; i < buf.size();) {
+        tmp[i++] = buf[a++];
+        if (i < buf.size()) tmp[i++] = buf[b++];
+    }
+    buf.swap(tmp);
+}
+}  // namespace
+
+bool read_exr_rgb_top_down(const char *path, int &width, int &height, std::vector<gpt_float3> &out)
+{
+    std::vector<unsigned char> d;
+    if (!read_file(path, d) || d.size() < 16) return false;
+    auto le32 = [&](size_t p) { return (uint32_t)d[p] | (uint32_t)d[p + 1] << 8 | (uint32_t)d[p + 2] << 16 | (uint32_t)d[p + 3] << 24; };
+    if (le32(0) != 20000630u) return false;
+    const uint32_t version = le32(4);
+    if ((version & 0xff) != 2 || (version & 0x1a00u)) return false;     // tiled / deep / multipart
+    size_t pos = 8;
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1, xmin = 0, ymin = 0, xmax = -1, ymax = -1;
+    while (pos < d.size() && d[pos] != 0) {
+        std::string name, type;
+        while (pos < d.size() && d[pos]) name += (char)d[pos++];
+        ++pos;
+        while (pos < d.size() && d[pos]) type += (char)d[pos++];
+        ++pos;
+        if (pos + 4 > d.size()) return false;
+        const uint32_t size = le32(pos);
+        pos += 4;
+        if (pos + size > d.size()) return false;
+        if (name == "channels") {
+            size_t q = pos;
+            while (q < pos + size && d[q] != 0) {
+                Chan c;
+                while (q < d.size() && d[q]) c.name += (char)d[q++];
+                ++q;
+                if (q + 16 > d.size()) return false;
+                c.type = (int)le32(q);
+                const uint32_t xs = le32(q + 8), ys = le32(q + 12);
+                if (xs != 1 || ys != 1) return false;
+                q += 16;
+                chans.push_back(c);
+            }
+        } else if (name == "compression") compression = d[pos];
+        else if (name == "dataWindow" && size == 16) {
+            xmin = (int)le32(pos); ymin = (int)le32(pos + 4); xmax = (int)le32(pos + 8); ymax = (int)le32(pos + 12);
+        }
+        pos += size;
+    }
+    ++pos;
+    width = xmax - xmin + 1;
+    height = ymax - ymin + 1;
+    if (width <= 0 || height <= 0 || chans.empty() || compression < 0 || compression > 3) return false;
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int n_blocks = (height + lines_per_block - 1) / lines_per_block;
+    if (pos + (size_t)n_blocks * 8 > d.size()) return false;
+    std::vector<size_t> choff(chans.size());
+    size_t line_bytes = 0;
+    int ir = -1, ig = -1, ib = -1, iy = -1;
+    for (size_t c = 0; c < chans.size(); ++c) {
+        choff[c] = line_bytes;
+        line_bytes += (size_t)width * (chans[c].type == 1 ? 2 : 4);
+        if (chans[c].name == "R") ir = (int)c;
+        else if (chans[c].name == "G") ig = (int)c;
+        else if (chans[c].name == "B") ib = (int)c;
+        else if (chans[c].name == "Y") iy = (int)c;
+    }
+    if ((ir < 0 || ig < 0 || ib < 0) && iy < 0) return false;
+    out.assign((size_t)width * height, gpt_float3{0, 0, 0});
+    std::vector<unsigned char> raw, tmp;
+    auto sample = [&](const unsigned char *line, int c, int x) -> float {
+        const unsigned char *p = line + choff[(size_t)c];
+        if (chans[(size_t)c].type == 1) { uint16_t h = (uint16_t)(p[2 * x] | p[2 * x + 1] << 8); return half_to_float(h); }
+        uint32_t u = (uint32_t)p[4 * x] | (uint32_t)p[4 * x + 1] << 8 | (uint32_t)p[4 * x + 2] << 16 | (uint32_t)p[4 * x + 3] << 24;
+        if (chans[(size_t)c].type == 0) return (float)u;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    for (int b = 0; b < n_blocks; ++b) {
+        uint64_t off = 0;
+        for (int k = 7; k >= 0; --k) off = off << 8 | d[pos + (size_t)b * 8 + (size_t)k];
+        if (off + 8 > d.size()) return false;
+        const int y0 = (int)le32((size_t)off) - ymin;
+        const uint32_t csize = le32((size_t)off + 4);
+        if (off + 8 + csize > d.size() || y0 < 0 || y0 >= height) return false;
+        const int lines = y0 + lines_per_block <= height ? lines_per_block : height - y0;
+        const size_t expect = line_bytes * (size_t)lines;
+        const unsigned char *src = &d[(size_t)off + 8];
+        if (compression == 0 || csize == expect) raw.assign(src, src + csize);
+        else if (compression == 1) {
+            if (!exr_rle_decode(src, csize, raw, expect)) return false;
+            exr_unpredict(raw, tmp);
+        } else {
+            raw.clear();
+            if (csize < 6 || !inflate_raw(src + 2, csize - 2, raw)) return false;
+            exr_unpredict(raw, tmp);
+        }
+        if (raw.size() < expect) return false;
+        for (int l = 0; l < lines; ++l) {
+            const unsigned char *line = raw.data() + line_bytes * (size_t)l;
+            gpt_float3 *row = &out[(size_t)(y0 + l) * width];
+            for (int x = 0; x < width; ++x) {
+                if (ir >= 0 && ig >= 0 && ib >= 0) row[x] = gpt_float3{sample(line, ir, x), sample(line, ig, x), sample(line, ib, x)};
+                else { float v = sample(line, iy, x); row[x] = gpt_float3{v, v, v}; }
+            }
+        }
+    }
     return true;
 }
 

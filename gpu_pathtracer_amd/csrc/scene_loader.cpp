@@ -711,8 +711,8 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
                     const std::string tf = m.at("diffuse").str;
                     if (texMap.find(tf) == texMap.end()) {
                         Texture tex;
-                        if (!imageio::load_texture_png((base + tf).c_str(), tex.width, tex.height, tex.data)) {
-                            gpt_set_error("Error when load texture [%s] (8-bit non-interlaced PNG is supported)", (base + tf).c_str());
+                        if (!imageio::load_texture((base + tf).c_str(), tex.width, tex.height, tex.data)) {
+                            gpt_set_error("Error when load texture [%s] (supported: 8-bit non-interlaced PNG, baseline JPEG)", (base + tf).c_str());
                             return false;
                         }
                         scene.textures.push_back(std::move(tex));
@@ -808,8 +808,11 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
             } else if (unit.has("infinite")) {
                 const std::string ef = unit.at("infinite").str;
                 int w = 0, h = 0;
-                if (!imageio::read_pfm_top_down((base + ef).c_str(), w, h, scene.infinite_data)) {
-                    gpt_set_error("Couldn't load hdr file \"%s\" (this build reads .pfm; OpenEXR decoding is not implemented)", ef.c_str());
+                const bool is_exr = ef.size() >= 4 && ef.compare(ef.size() - 4, 4, ".exr") == 0;
+                const bool ok = is_exr ? imageio::read_exr_rgb_top_down((base + ef).c_str(), w, h, scene.infinite_data)
+                                       : imageio::read_pfm_top_down((base + ef).c_str(), w, h, scene.infinite_data);
+                if (!ok) {
+                    gpt_set_error("Couldn't load hdr file \"%s\" (supported: scanline .exr with NONE/RLE/ZIPS/ZIP compression, .pfm)", ef.c_str());
                     return false;
                 }
                 // the reference leaves u,v,w unset without "rotate"/"matrix"; identity axes here

@@ -117,6 +117,109 @@ def test_transform_defaults_textures_env_and_materials(scene_dir):
     assert np.array_equal(data, env)
 
 
+def write_exr(path, img, compression, pixel_type):
+    """Minimal scanline OpenEXR writer (test helper, written from the file-format description):
+    img (H, W, 3) float32, rows top-down; compression 0 NONE, 1 RLE, 2 ZIPS, 3 ZIP; pixel_type 1 HALF, 2 FLOAT."""
+    h, w, _ = img.shape
+    names = ["B", "G", "R"]                      # channels are stored in alphabetical order
+    chan = {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2]}
+    dt = np.float16 if pixel_type == 1 else np.float32
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pixel_type, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    header = (attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression])) +
+              attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) +
+              attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) +
+              attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) +
+              attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    lines_per = 16 if compression == 3 else 1
+    chunks = []
+    for y0 in range(0, h, lines_per):
+        raw = b"".join(chan[n][y].astype(dt).tobytes() for y in range(y0, min(h, y0 + lines_per)) for n in names)
+        data = raw
+        if compression:
+            b = np.frombuffer(raw, np.uint8)
+            half = (len(b) + 1) // 2
+            t = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)        # split even/odd bytes
+            assert len(t[:half]) == half
+            p = t.copy()
+            p[1:] = (t[1:] - t[:-1] + 128 + 256) % 256                     # predictor
+            pre = p.astype(np.uint8).tobytes()
+            if compression == 1:                                           # RLE: runs of 3..127 equal bytes, else literals
+                out, i = bytearray(), 0
+                while i < len(pre):
+                    run = 1
+                    while i + run < len(pre) and pre[i + run] == pre[i] and run < 127:
+                        run += 1
+                    if run >= 3:
+                        out += bytes([run - 1, pre[i]])
+                        i += run
+                    else:
+                        j = i
+                        while j < len(pre) and j - i < 127 and not (j + 2 < len(pre) and pre[j] == pre[j + 1] == pre[j + 2]):
+                            j += 1
+                        j = max(j, i + 1)
+                        out += bytes([(256 - (j - i)) & 0xff]) + pre[i:j]
+                        i = j
+                comp = bytes(out)
+            else:
+                comp = zlib.compress(pre, 6)
+            data = comp if len(comp) < len(raw) else raw
+        chunks.append(struct.pack("<ii", y0, len(data)) + data)
+    head = struct.pack("<ii", 20000630, 2) + header
+    off = len(head) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", off)
+        off += len(c)
+    open(path, "wb").write(head + table + b"".join(chunks))
+
+
+@pytest.mark.parametrize("compression,pixel_type", [(0, 2), (0, 1), (1, 1), (2, 2), (3, 1), (3, 2)])
+def test_exr_environment_map(scene_dir, compression, pixel_type):
+    """"infinite": "<file>.exr" (reference src/parsescene.cpp:543-550 -> ImageIO::LoadExr): float RGB, row 0 = top."""
+    import ctypes as C
+    env = scenes.sky_env(40, 21)                  # 21 rows: the last 16-line ZIP block is short
+    if pixel_type == 1:
+        env = env.astype(np.float16).astype(np.float32)
+    write_exr(str(scene_dir / "sky.exr"), env, compression, pixel_type)
+    js = json.load(open(scene_dir / "scene.json"))
+    js["light"].append({"infinite": "sky.exr"})
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    ls = api.LoadedScene(str(scene_dir / "scene.json"))
+    inf = C.cast(ls.desc.infinite, C.POINTER(st.Infinite))[0]
+    assert inf.isvalid and (inf.width, inf.height) == (40, 21)
+    data = np.ctypeslib.as_array(C.cast(inf.data, C.POINTER(C.c_float)), shape=(21, 40, 3))
+    assert np.array_equal(data, env)
+    assert (inf.u.x, inf.v.y, inf.w.z) == (1.0, 1.0, 1.0)      # no "rotate": identity axes (documented deviation)
+
+
+@pytest.mark.parametrize("subsampling,quality", [(0, 95), (1, 90), (2, 85)])
+def test_jpeg_texture(scene_dir, subsampling, quality):
+    """Baseline JPEG textures (the reference's sponza uses .jpg): decoded within a few 8-bit steps of an
+    independent decoder (PIL); exact agreement with stb_image's fixed-point IDCT is not claimed."""
+    import ctypes as C
+    from PIL import Image
+    yy, xx = np.mgrid[0:37, 0:50]
+    img = np.stack([(xx * 5) % 256, (yy * 7) % 256, ((xx + yy) * 3) % 256], -1).astype(np.uint8)
+    img = (img // 2 + 60).astype(np.uint8)
+    Image.fromarray(img).save(scene_dir / "tex.jpg", quality=quality, subsampling=subsampling)
+    ref = np.asarray(Image.open(scene_dir / "tex.jpg").convert("RGB")).astype(np.float32)
+    js = json.load(open(scene_dir / "scene.json"))
+    js["material"].append({"name": "jpg", "bsdf": "lambertian", "diffuse": "tex.jpg"})
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    ls = api.LoadedScene(str(scene_dir / "scene.json"))
+    trec = C.cast(ls.desc.textures, C.POINTER(st.Texture))[0]
+    assert (trec.width, trec.height) == (50, 37)
+    got = np.ctypeslib.as_array(C.cast(trec.data, C.POINTER(C.c_uint8)), shape=(37, 50, 4))[..., :3].astype(np.float32)
+    want = np.floor(np.power(ref[::-1] / 255.0, 2.2) * 255.0)       # flip + sRGB->linear + truncate, as LoadTexture
+    tol = 6 if subsampling == 0 else 40                               # chroma replication vs PIL's smooth upsampling
+    assert np.abs(got - want).mean() < (1.0 if subsampling == 0 else 3.0)
+    assert np.abs(got - want).max() <= tol
+
+
 def test_loader_errors(tmp_path, scene_dir):
     lib = api.load()
     with pytest.raises(api.GptError) as e:
