@@ -72,7 +72,7 @@ def main():
     from gpu_pathtracer_amd import api, host
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("GPT_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -83,7 +83,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # "nccl" is RCCL on ROCm.  GPT_BENCH_BACKEND=gloo + GPT_BENCH_SHARE_GPU=1 runs the same N-rank code
+        # path with every rank on GPU 0 (functional check on a 1-GPU box; RCCL refuses duplicate devices).
+        backend = os.environ.get("GPT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
     cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
@@ -110,6 +116,7 @@ def main():
         r.synchronize()
         if dist is not None:
             dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)     # the one collective: float3 framebuffer over xGMI
+            torch.cuda.synchronize()                           # the reduce runs on torch's streams, Output on ours
         if rank == 0:
             r.tonemap(steps * SPP_PER_STEP, bool(cam.filmic), out.data_ptr())   # Output on the root
             r.synchronize()
@@ -133,6 +140,8 @@ def main():
     if rank == 0:
         img = acc.cpu().numpy().reshape(-1, 3) / np.float32(args.steps * SPP_PER_STEP)
         finite = bool(np.isfinite(img).all())
+        import hashlib
+        frame_sha1 = hashlib.sha1(acc.cpu().numpy().tobytes()).hexdigest()[:16]
         cpu = None
         b_alg = B_ALG_CONFIG2
         if world == 1 and not args.no_cpu_baseline:
@@ -161,6 +170,7 @@ def main():
                                    f"{args.steps * SPP_PER_STEP} spp ({args.steps} steps x {SPP_PER_STEP} iterations)",
                        "scene": "cornell_pt (36 triangles, 27 BVH nodes)", "spp_per_step": SPP_PER_STEP,
                        "tiles": "8x8 pixels, tile % n_gpus == rank", "all_finite": finite,
+                       "accumulator_sha1": frame_sha1,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
