@@ -174,7 +174,7 @@ def main():
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pt::pt_render_kernel<false>", "avg_launch_ms": avg_ms, "launches": launches,
+                         "kernel": "pt::pt_render_kernel<false, true> (counting off, BVH staged in LDS)", "avg_launch_ms": avg_ms, "launches": launches,
                          "algorithmic_bytes_per_sample": b_alg,
                          "note": "algorithmic = reference-layout bytes (SURVEY.md 8d); the 7.4 KB scene is "
                                  "cache-resident, so this logical figure can exceed the HBM peak"},

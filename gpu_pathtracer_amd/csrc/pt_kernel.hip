@@ -38,6 +38,7 @@
 // Draw order inside argument lists is left to right.
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pt_layout.h"
 
 namespace pt {
@@ -184,11 +185,10 @@ __device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
     return out;
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt)
+template <bool COUNT, class NodePtr, class TriPtr>
+__device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, NodePtr nodes,
+                                           TriPtr tris)
 {
-    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *__restrict__ tris = reinterpret_cast<const float4 *>(P.tris);
     const int end = P.n_nodes;
     const float tmin_ray = P.eps;          // every ray of the integrator starts at epsilon
 
@@ -274,7 +274,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
                 const int i = tri++;
                 const float4 q0 = tris[3 * i];
                 const float4 q1 = tris[3 * i + 1];
-                const float e2z = reinterpret_cast<const float *>(tris + 3 * i + 2)[0];
+                const float e2z = tris[3 * i + 2].x;
                 if (COUNT) { cnt.prim_tests++; if (first_active_lane()) cnt.w_prim++; }
                 const V3 v1 = V3{q0.x, q0.y, q0.z};
                 const V3 e1 = V3{q0.w, q1.x, q1.y};
@@ -975,14 +975,27 @@ struct RayResults {    // this lane's own rays, read back from the pool
     float t_p, b1_p, b2_p;
 };
 
-template <bool COUNT>
+// Scenes whose BVH fits kSmallSceneFloat4 (nodes: 2 float4 each, triangles: 3 float4 each) are staged in LDS once
+// per workgroup; the traversal then reads ds_read_b128 instead of going through the vector-memory pipe.
+constexpr int kSmallSceneFloat4 = 512;                  // 8 KB
+
+template <bool COUNT, bool SMALL>
 __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P)
 {
+    __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
+    if (SMALL) {
+        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
+        const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
+        for (int i = threadIdx.x; i < 2 * P.n_nodes; i += 256) lds_scene[i] = gn[i];
+        for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[2 * P.n_nodes + i] = gt[i];
+        __syncthreads();
+    }
     __shared__ float4 lds_pool[4 * kWaveLdsFloat4];     // one private ray pool per wavefront
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveLdsFloat4;
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
 
     const uint32_t n_items = n_owned * P.n_chunks;
     for (;;) {
@@ -1253,7 +1266,20 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             if (!alive) q.has_p = q.has_m = q.has_s = false;
             const PoolLayout L = pool_deposit(pool, q, lane);
             wave_lds_fence();
-            trace_pool<COUNT>(P, pool, L.n_rays, cnt);
+            unsigned long long c0 = 0;
+            if (COUNT) {
+                c0 = __builtin_readcyclecounter();
+                if (lane == 0) cyc_shade += c0 - cyc_mark;
+            }
+            if (SMALL)
+                trace_pool<COUNT>(P, pool, L.n_rays, cnt, (const float4 *)lds_scene, (const float4 *)(lds_scene + 2 * P.n_nodes));
+            else
+                trace_pool<COUNT>(P, pool, L.n_rays, cnt, reinterpret_cast<const float4 *>(P.nodes),
+                                  reinterpret_cast<const float4 *>(P.tris));
+            if (COUNT) {
+                cyc_mark = __builtin_readcyclecounter();
+                if (lane == 0) cyc_trace += cyc_mark - c0;
+            }
             wave_lds_fence();
             if (q.has_p) {
                 const RayResult rr = pool_result(pool, lane_rank(L.m_p));
@@ -1283,6 +1309,10 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         atomicAdd(&P.counters[11], (unsigned long long)cnt.l_shade);
         atomicAdd(&P.counters[12], (unsigned long long)cnt.w_nee);
         atomicAdd(&P.counters[13], (unsigned long long)cnt.l_nee);
+        if (lane == 0) {
+            atomicAdd(&P.counters[14], cyc_trace);     // shader-clock cycles this wave spent draining pools
+            atomicAdd(&P.counters[15], cyc_shade);     // ... and everywhere else (shading, regeneration, deposit)
+        }
     }
 }
 
@@ -1375,8 +1405,8 @@ namespace pt {
 int render_kernel_blocks_per_cu(bool count)
 {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true>, 256, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false>, 256, 0);
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true>, 256, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true>, 256, 0);
     if (e != hipSuccess || n < 1) n = 2;
     if (n > 8) n = 8;
     return n;
@@ -1384,10 +1414,11 @@ int render_kernel_blocks_per_cu(bool count)
 
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream)
 {
-    if (count)
-        hipLaunchKernelGGL(pt_render_kernel<true>, dim3(n_blocks), dim3(256), 0, stream, P);
-    else
-        hipLaunchKernelGGL(pt_render_kernel<false>, dim3(n_blocks), dim3(256), 0, stream, P);
+    const bool small = 2 * P.n_nodes + 3 * P.n_prims <= kSmallSceneFloat4 && !getenv("GPT_NO_LDS_SCENE");
+    if (count && small) hipLaunchKernelGGL((pt_render_kernel<true, true>), dim3(n_blocks), dim3(256), 0, stream, P);
+    else if (count) hipLaunchKernelGGL((pt_render_kernel<true, false>), dim3(n_blocks), dim3(256), 0, stream, P);
+    else if (small) hipLaunchKernelGGL((pt_render_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((pt_render_kernel<false, false>), dim3(n_blocks), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 

@@ -88,6 +88,7 @@ struct DevParams {
     const DevTexture *textures;
     DevInfinite inf;
     int32_t n_nodes;
+    int32_t n_prims;
     int32_t n_lights;
     int32_t n_cdf;
     int32_t max_depth;

@@ -13,3 +13,5 @@ print("lane utilisation: node loop %.3f  triangle loop %.3f  bounce trip %.3f  h
 print("traversal trips per sample: %.3f wave-trips, busy lanes per trip %.1f/64" % (c["w_trip"]/c["samples"]*1.0, c["l_trip"]/max(1,c["w_trip"])))
 print("per sample: wave node trips x64 = %.1f lane-slots (useful %.1f); tri %.1f (useful %.1f); trips %.2f" % (
     64.0*c["w_node"]/c["samples"], c["node_visits"]/c["samples"], 64.0*c["w_prim"]/c["samples"], c["prim_tests"]/c["samples"], 64.0*c["w_trip"]/c["samples"]))
+print("wave time split (s_memtime, counting build): traversal %.1f %%  shading+rest %.1f %%" % (
+    100.0 * c["cyc_trace"] / (c["cyc_trace"] + c["cyc_shade"]), 100.0 * c["cyc_shade"] / (c["cyc_trace"] + c["cyc_shade"])))

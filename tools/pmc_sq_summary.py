@@ -3,7 +3,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "pt_render_kernel<false>" in row.get("Kernel_Name", "") or "pt_render_kernelILb0" in row.get("Kernel_Name", ""):
+        if "pt_render_kernel<false" in row.get("Kernel_Name", "") or "pt_render_kernelILb0" in row.get("Kernel_Name", ""):
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 for k in sorted(m): print(f"{k:28s} {m[k]:18.1f}  (n={len(acc[k])})")

@@ -17,7 +17,7 @@ for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     vals = []
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "pt_render_kernel<false>" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+            if "pt_render_kernel<false" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                 vals.append(float(row["Counter_Value"]))
     if vals:
         res[counter] = {"launches": len(vals), "mean_KiB_per_launch": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
