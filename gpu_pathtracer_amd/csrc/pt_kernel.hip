@@ -975,20 +975,36 @@ struct RayResults {    // this lane's own rays, read back from the pool
     float t_p, b1_p, b2_p;
 };
 
-// Scenes whose BVH fits kSmallSceneFloat4 (nodes: 2 float4 each, triangles: 3 float4 each) are staged in LDS once
-// per workgroup; the traversal then reads ds_read_b128 instead of going through the vector-memory pipe.
-constexpr int kSmallSceneFloat4 = 512;                  // 8 KB
+// Scenes that fit kSmallSceneFloat4 (nodes 2 float4 each, triangles 3, shading records 5, lights 6, materials
+// 72 B) are staged in LDS once per workgroup; traversal and shading then read LDS instead of going through
+// the vector-memory pipe.
+constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray pools exactly 4 workgroups per CU
 
 template <bool COUNT, bool SMALL>
-__global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P)
+__global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
     __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
+    DevParams P = P_in;
     if (SMALL) {
-        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
-        const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
+        // layout: nodes | triangles | shading records | lights | materials (all 16-byte multiples except the
+        // 72-byte materials, which come last)
+        const float4 *gn = reinterpret_cast<const float4 *>(P_in.nodes);
+        const float4 *gt = reinterpret_cast<const float4 *>(P_in.tris);
+        const float4 *gs = reinterpret_cast<const float4 *>(P_in.shade);
+        const float4 *gl = reinterpret_cast<const float4 *>(P_in.lights);
+        const uint32_t *gm = reinterpret_cast<const uint32_t *>(P_in.materials);
+        const int o_tri = 2 * P.n_nodes, o_shade = o_tri + 3 * P.n_prims, o_light = o_shade + 5 * P.n_prims,
+                  o_mat = o_light + 6 * P.n_lights;
         for (int i = threadIdx.x; i < 2 * P.n_nodes; i += 256) lds_scene[i] = gn[i];
-        for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[2 * P.n_nodes + i] = gt[i];
+        for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[o_tri + i] = gt[i];
+        for (int i = threadIdx.x; i < 5 * P.n_prims; i += 256) lds_scene[o_shade + i] = gs[i];
+        for (int i = threadIdx.x; i < 6 * P.n_lights; i += 256) lds_scene[o_light + i] = gl[i];
+        uint32_t *lm = reinterpret_cast<uint32_t *>(lds_scene + o_mat);
+        for (int i = threadIdx.x; i < 18 * P.n_materials; i += 256) lm[i] = gm[i];
         __syncthreads();
+        P.shade = reinterpret_cast<const DevShade *>(lds_scene + o_shade);
+        P.lights = reinterpret_cast<const DevLight *>(lds_scene + o_light);
+        P.materials = reinterpret_cast<const gpt_material *>(lds_scene + o_mat);
     }
     __shared__ float4 lds_pool[4 * kWaveLdsFloat4];     // one private ray pool per wavefront
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveLdsFloat4;
@@ -1414,7 +1430,8 @@ int render_kernel_blocks_per_cu(bool count)
 
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream)
 {
-    const bool small = 2 * P.n_nodes + 3 * P.n_prims <= kSmallSceneFloat4 && !getenv("GPT_NO_LDS_SCENE");
+    const bool small = 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4 &&
+                       !getenv("GPT_NO_LDS_SCENE");
     if (count && small) hipLaunchKernelGGL((pt_render_kernel<true, true>), dim3(n_blocks), dim3(256), 0, stream, P);
     else if (count) hipLaunchKernelGGL((pt_render_kernel<true, false>), dim3(n_blocks), dim3(256), 0, stream, P);
     else if (small) hipLaunchKernelGGL((pt_render_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P);

@@ -89,6 +89,7 @@ struct DevParams {
     DevInfinite inf;
     int32_t n_nodes;
     int32_t n_prims;
+    int32_t n_materials;
     int32_t n_lights;
     int32_t n_cdf;
     int32_t max_depth;

@@ -317,6 +317,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
 
     P.n_nodes = scene->n_nodes;
     P.n_prims = scene->n_prims;
+    P.n_materials = scene->n_materials;
     P.n_lights = scene->n_lights;
     P.n_cdf = scene->n_light_distribution;
     P.max_depth = scene->max_depth;
