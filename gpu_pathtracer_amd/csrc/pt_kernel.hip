@@ -1024,16 +1024,15 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         const uint32_t tile_local = t - chunk * n_owned;
         const uint32_t tile = P.rank + tile_local * P.n_ranks;
         const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-        const uint32_t x = tx * 8u + (lane & 7u);
-        const uint32_t y = ty * 8u + (lane >> 3);
-        const bool valid = x < P.stride && y < P.rows;
-        const uint32_t pixel = x + y * P.stride;       // pathtracer.cu:881-883
         const uint32_t chunk_first = P.iter_first + chunk * P.chunk_iters;
         const uint32_t chunk_count = (chunk + 1u == P.n_chunks) ? P.iter_count - chunk * P.chunk_iters : P.chunk_iters;
-
-        const uint32_t hash_pixel = wang_hash(pixel);
-        uint32_t iter = chunk_first;
-        uint32_t left = valid ? chunk_count : 0u;
+        // The item's samples (64 pixels x chunk_count iterations, all independent: each goes to its own slot of
+        // its iteration's plane) are handed out dynamically: a lane whose path ends takes the next sample of the
+        // tile, whichever pixel it belongs to, so cheap pixels do not leave their lanes idle.
+        // sample s -> pixel s % 64 of the tile, iteration chunk_first + s / 64.
+        const uint32_t n_item_samples = 64u * chunk_count;
+        uint32_t next_sample = 0;                       // wave-uniform
+        uint32_t x = 0, y = 0, pixel = 0, iter = chunk_first;
 
         // ---- per-path state ---------------------------------------------------------
         Rng rng;
@@ -1246,12 +1245,24 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 float4 *dst = reinterpret_cast<float4 *>(P.samples) + (uint64_t)(iter - P.iter_first) * P.plane + pixel;
                 *dst = make_float4(Li.x, Li.y, Li.z, 0.f);
                 alive = false;
-                iter++;
                 q.has_s = q.has_m = q.has_p = false;
             }
-            // ---- regenerate: pathtracer.cu:888-903 ---------------------------------------
-            if (!alive && left > 0) {
-                rng_seed(rng, hash_pixel + wang_hash(iter));
+            // ---- regenerate: pathtracer.cu:881-903 ---------------------------------------
+            bool start = false;
+            if (next_sample < n_item_samples) {
+                const unsigned long long m_idle = __ballot(!alive);
+                const uint32_t s = next_sample + (uint32_t)lane_rank(m_idle);
+                next_sample += (uint32_t)__builtin_popcountll(m_idle);
+                if (!alive && s < n_item_samples) {
+                    x = tx * 8u + (s & 7u);
+                    y = ty * 8u + ((s >> 3) & 7u);
+                    iter = chunk_first + (s >> 6);
+                    pixel = x + y * P.stride;          // pathtracer.cu:881-883
+                    start = x < P.stride && y < P.rows;
+                }
+            }
+            if (start) {
+                rng_seed(rng, wang_hash(pixel) + wang_hash(iter));
                 float offsetx = rng_uniform(rng) - 0.5f;
                 float offsety = rng_uniform(rng) - 0.5f;
                 float du1 = rng_uniform(rng);
@@ -1268,10 +1279,12 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 ending = false;
                 direct = false;
                 alive = true;
-                left--;
                 if (COUNT) cnt.samples++;
             }
-            if (!__any(alive)) break;
+            if (!__any(alive)) {
+                if (next_sample >= n_item_samples) break;
+                continue;                              // only samples of pixels outside the frame were drawn
+            }
 
             if (COUNT && alive) {
                 if (q.has_p) { cnt.bounce_iters++; cnt.closest_rays++; }

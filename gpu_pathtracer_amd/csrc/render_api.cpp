@@ -416,10 +416,10 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         P.reset = (reset && done == 0) ? 1 : 0;
         P.out = (done + P.iter_count == iter_count) ? out_tonemapped_dev : nullptr;
         // Work items = (iteration chunk, tile), all independent.  The batch is cut into chunks until there
-        // are about kItemsPerWave items per resident wave (small frames and multi-GPU shards would otherwise
+        // are about kItemsPerWave (24) items per resident wave (small frames and multi-GPU shards would otherwise
         // wait for their slowest tile); a chunk is never shorter than kMinChunk iterations because lanes idle
         // while a wave drains at the end of each item.
-        const long kItemsPerWave = 8, kMinChunk = 8;
+        const long kItemsPerWave = 24, kMinChunk = 8;
         long n_chunks = (kItemsPerWave * resident_waves + n_owned - 1) / n_owned;
         const long max_chunks = P.iter_count / kMinChunk > 0 ? P.iter_count / kMinChunk : 1;
         if (n_chunks > max_chunks) n_chunks = max_chunks;
