@@ -71,6 +71,7 @@ def load():
         "gpt_scene_free": [vp],
         "gpt_save_png": [C.c_char_p, i32, i32, vp],
         "gpt_save_pfm": [C.c_char_p, i32, i32, vp],
+        "gpt_save_exr": [C.c_char_p, i32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -162,6 +163,11 @@ class LoadedScene:
 def save_png(path, width, height, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     check(load().gpt_save_png(os.fsencode(path), width, height, st.ptr(rgb)))
+
+
+def save_exr(path, width, height, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    check(load().gpt_save_exr(os.fsencode(path), width, height, st.ptr(rgb)))
 
 
 def save_pfm(path, width, height, rgb):

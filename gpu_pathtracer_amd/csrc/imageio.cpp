@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <string>
 
 #include "../../include/gpt.h"
@@ -800,6 +801,91 @@ int gpt_save_png(const char *path, int32_t width, int32_t height, const float *r
             }
         }
     if (!imageio::write_png_rgb8(path, width, height, px.data())) { gpt_set_error("gpt_save_png: cannot write %s", path); return GPT_ERR_IO; }
+    return GPT_OK;
+}
+
+// ImageIO::SaveExr (src/imageio.cpp:104-161): the reference stores B, G, R as HALF through tinyexr.  Same
+// channels and pixel type here, scanline, uncompressed; rows are written top-down from the bottom-up film.
+static uint16_t float_to_half(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t man = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = (uint32_t)exp << 10 | man >> 13;
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;      // round to nearest even; may carry into the exponent
+    return (uint16_t)(sign | h);
+}
+
+int gpt_save_exr(const char *path, int32_t width, int32_t height, const float *rgb)
+{
+    if (!path || !rgb || width <= 0 || height <= 0) { gpt_set_error("gpt_save_exr: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    std::vector<unsigned char> out;
+    auto put32 = [&](uint32_t v) { for (int k = 0; k < 4; ++k) out.push_back((unsigned char)(v >> (8 * k))); };
+    auto puts = [&](const char *s) { while (*s) out.push_back((unsigned char)*s++); out.push_back(0); };
+    auto attr = [&](const char *name, const char *type, const std::vector<unsigned char> &v) {
+        puts(name); puts(type); put32((uint32_t)v.size()); out.insert(out.end(), v.begin(), v.end());
+    };
+    auto le = [](std::initializer_list<uint32_t> vals) {
+        std::vector<unsigned char> v;
+        for (uint32_t x : vals) for (int k = 0; k < 4; ++k) v.push_back((unsigned char)(x >> (8 * k)));
+        return v;
+    };
+    put32(20000630u);
+    put32(2u);
+    std::vector<unsigned char> ch;
+    for (const char *n : {"B", "G", "R"}) {
+        ch.push_back((unsigned char)n[0]); ch.push_back(0);
+        for (uint32_t x : {1u, 0u, 1u, 1u}) for (int k = 0; k < 4; ++k) ch.push_back((unsigned char)(x >> (8 * k)));   // HALF, pLinear+reserved, 1x1
+    }
+    ch.push_back(0);
+    attr("channels", "chlist", ch);
+    attr("compression", "compression", {0});
+    attr("dataWindow", "box2i", le({0u, 0u, (uint32_t)(width - 1), (uint32_t)(height - 1)}));
+    attr("displayWindow", "box2i", le({0u, 0u, (uint32_t)(width - 1), (uint32_t)(height - 1)}));
+    attr("lineOrder", "lineOrder", {0});
+    const float one = 1.f, zero = 0.f;
+    uint32_t one_bits, zero_bits;
+    std::memcpy(&one_bits, &one, 4);
+    std::memcpy(&zero_bits, &zero, 4);
+    attr("pixelAspectRatio", "float", le({one_bits}));
+    attr("screenWindowCenter", "v2f", le({zero_bits, zero_bits}));
+    attr("screenWindowWidth", "float", le({one_bits}));
+    out.push_back(0);
+    const size_t line_bytes = (size_t)width * 3 * 2, chunk = 8 + line_bytes;
+    const size_t table = out.size();
+    for (int y = 0; y < height; ++y) {
+        const uint64_t off = table + (size_t)height * 8 + (size_t)y * chunk;
+        for (int k = 0; k < 8; ++k) out.push_back((unsigned char)(off >> (8 * k)));
+    }
+    for (int y = 0; y < height; ++y) {
+        put32((uint32_t)y);
+        put32((uint32_t)line_bytes);
+        const float *row = rgb + (size_t)(height - 1 - y) * width * 3;      // film row 0 = bottom
+        for (int c = 2; c >= 0; --c)                                          // B, G, R
+            for (int x = 0; x < width; ++x) {
+                const uint16_t h = float_to_half(row[3 * x + c]);
+                out.push_back((unsigned char)h); out.push_back((unsigned char)(h >> 8));
+            }
+    }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { gpt_set_error("gpt_save_exr: cannot write %s", path); return GPT_ERR_IO; }
+    const size_t w = std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    if (w != out.size()) { gpt_set_error("gpt_save_exr: short write to %s", path); return GPT_ERR_IO; }
     return GPT_OK;
 }
 

@@ -5,6 +5,7 @@
 // Like the reference, the three C++ calls keep ONE renderer per process in file-scope state
 // (src/pathtracer.cu:9-20); callers that need several renderers use the gpt_ctx API directly.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "host_util.h"
@@ -62,6 +63,8 @@ int gpt_scene_load(const char *json_path, gpt_scene **out)
     if (!json_path || !out) { gpt_set_error("gpt_scene_load: null argument"); return GPT_ERR_INVALID_ARG; }
     *out = nullptr;
     gpt_scene *s = new gpt_scene();
+    // the reference always reads/writes <scene dir>/bvh.cache (src/bvh.cpp:189-218); here it is opt-in
+    if (const char *e = std::getenv("GPT_BVH_CACHE")) s->scene.use_bvh_cache = e[0] == '1';
     if (!LoadScene(json_path, s->config, s->scene)) {
         delete s;
         return std::strstr(gpt_last_error(), "Parse scene error") ? GPT_ERR_PARSE : GPT_ERR_IO;

@@ -154,6 +154,8 @@ int gpt_scene_free(gpt_scene *scene);
 /* ImageIO::SavePng (src/imageio.cpp:61-78): flip Y, clamp, truncate to 8 bit.
  * `rgb` is W*H*3 host floats, row 0 = bottom. */
 int gpt_save_png(const char *path, int32_t width, int32_t height, const float *rgb);
+/* ImageIO::SaveExr (src/imageio.cpp:104-161): linear radiance as OpenEXR, channels B,G,R stored as HALF */
+int gpt_save_exr(const char *path, int32_t width, int32_t height, const float *rgb);
 /* linear radiance as PFM (little-endian float32, bottom-up) */
 int gpt_save_pfm(const char *path, int32_t width, int32_t height, const float *rgb);
 

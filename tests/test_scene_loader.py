@@ -220,6 +220,51 @@ def test_jpeg_texture(scene_dir, subsampling, quality):
     assert np.abs(got - want).max() <= tol
 
 
+def test_exr_writer_roundtrip_through_the_reader(scene_dir):
+    """gpt_save_exr (HALF B,G,R like the reference's SaveExr) -> read back as an environment map."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    film = (rng.random((9, 14, 3)) * np.array([40.0, 3.0, 0.01])).astype(np.float32)      # row 0 = bottom
+    film[0, 0] = [0.0, 65504.0, 1e-7]
+    api.save_exr(str(scene_dir / "out.exr"), 14, 9, film)
+    js = json.load(open(scene_dir / "scene.json"))
+    js["light"].append({"infinite": "out.exr"})
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    ls = api.LoadedScene(str(scene_dir / "scene.json"))
+    inf = C.cast(ls.desc.infinite, C.POINTER(st.Infinite))[0]
+    data = np.ctypeslib.as_array(C.cast(inf.data, C.POINTER(C.c_float)), shape=(9, 14, 3))
+    assert np.array_equal(data, film[::-1].astype(np.float16).astype(np.float32))          # top-down, half precision
+
+
+def test_bvh_cache_roundtrip_and_staleness(scene_dir, monkeypatch):
+    """bvh.cache in the reference's layout (src/bvh.cpp:189-218) + a content hash: reused when the primitives
+    match, rebuilt when the scene changed (the reference silently reuses a stale cache)."""
+    monkeypatch.setenv("GPT_BVH_CACHE", "1")
+    path = str(scene_dir / "scene.json")
+    a = api.LoadedScene(path)
+    cache = scene_dir / "bvh.cache"
+    assert cache.exists()
+    raw = cache.read_bytes()
+    n_nodes, n_prims = struct.unpack("<ii", raw[:8])
+    assert (n_nodes, n_prims) == (27, 36) and len(raw) == 32 + 36 * 176 + 27 * 40 + 8
+    prims_a = a.array("prims", "n_prims", st.PRIMITIVE).tobytes()
+    mtime = cache.stat().st_mtime_ns
+    b = api.LoadedScene(path)                                   # second load: served from the cache
+    assert cache.stat().st_mtime_ns == mtime
+    assert b.array("prims", "n_prims", st.PRIMITIVE).tobytes() == prims_a
+    assert b.desc.n_nodes == 27
+    # change the geometry: the stale cache must not be used
+    obj = (scene_dir / "geometry" / "tall.obj").read_text().replace("v 0.", "v 0.1", 1)
+    (scene_dir / "geometry" / "tall.obj").write_text(obj)
+    c = api.LoadedScene(path)
+    assert c.array("prims", "n_prims", st.PRIMITIVE).tobytes() != prims_a
+    assert cache.read_bytes() != raw                             # rewritten for the new primitives
+    # a cache written by the reference has no trailing hash: accepted when the primitive count matches
+    cache.write_bytes(cache.read_bytes()[:-8])
+    d = api.LoadedScene(path)
+    assert d.desc.n_nodes == c.desc.n_nodes
+
+
 def test_loader_errors(tmp_path, scene_dir):
     lib = api.load()
     with pytest.raises(api.GptError) as e:
