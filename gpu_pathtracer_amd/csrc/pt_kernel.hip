@@ -89,9 +89,17 @@ struct Counters {
     // utilisation probes (counting build): wave-level trips, incremented by one lane per wave per trip
     uint32_t w_node, w_prim, w_trip, l_trip, w_shade, l_shade, w_nee, l_nee;
 };
+// Wave votes.  The builtin takes the i1 directly (HIP's __ballot(int) widens the predicate to a VGPR and
+// compares it again: two VALU instructions per vote in the traversal loop), and counting the halves
+// separately keeps every comparison of counts on the scalar unit (a 64-bit ctpop is compared as u64 on VALU).
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int popc(unsigned long long m)
+{
+    return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
+}
 __device__ __forceinline__ bool first_active_lane()
 {
-    const unsigned long long m = __ballot(1);
+    const unsigned long long m = ballot(true);
     return (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m);
 }
 
@@ -150,7 +158,7 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
-// slot = { dir.xyz, tmax } { 1/dir.xyz, bits(owner lane | any_hit << 8) }
+// slot = { dir.xyz, tmax } { 1/dir.xyz, bits(owner lane | any_hit << 8) }; the result replaces the second half
 __device__ __forceinline__ void pool_put(float4 *pool, int slot, V3 dir, float tmax, unsigned owner, bool any_hit)
 {
     // bbox.h:79 computes 1/d at every node visit; the quotient is the same every time
@@ -161,12 +169,12 @@ __device__ __forceinline__ void pool_put(float4 *pool, int slot, V3 dir, float t
 __device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &rs, unsigned lane)
 {
     PoolLayout L;
-    L.m_p = __ballot(rs.has_p);
-    L.m_m = __ballot(rs.has_m);
-    L.m_s = __ballot(rs.has_s);
-    L.n_p = __builtin_popcountll(L.m_p);
-    L.n_m = __builtin_popcountll(L.m_m);
-    L.n_rays = L.n_p + L.n_m + __builtin_popcountll(L.m_s);
+    L.m_p = ballot(rs.has_p);
+    L.m_m = ballot(rs.has_m);
+    L.m_s = ballot(rs.has_s);
+    L.n_p = popc(L.m_p);
+    L.n_m = popc(L.m_m);
+    L.n_rays = L.n_p + L.n_m + popc(L.m_s);
     pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
     if (rs.has_p) pool_put(pool, lane_rank(L.m_p), rs.dir_p, __builtin_inff(), lane, false);
     if (rs.has_m) pool_put(pool, L.n_p + lane_rank(L.m_m), rs.dir_m, __builtin_inff(), lane, rs.mis_any);
@@ -176,7 +184,7 @@ __device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &r
 
 __device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
 {
-    const float4 r = pool[2 * slot];
+    const float4 r = pool[2 * slot + 1];
     RayResult out;
     out.prim = __float_as_int(r.x);
     out.t = r.y;
@@ -185,17 +193,54 @@ __device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
     return out;
 }
 
-template <bool COUNT, class NodePtr, class TriPtr>
-__device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, NodePtr nodes,
-                                           TriPtr tris)
+// Every cursor is a BYTE offset: DevNode.link/last are stored pre-scaled (pt_layout.h), so a visit is "load
+// at cursor" with no address arithmetic.  Two memory spaces:
+//   GlobalScene  cursors are offsets from the node / triangle arrays in HBM
+//   LdsScene     the scene was staged into LDS with every link rebased to an absolute LDS address
+struct GlobalScene {
+    const char *nodes, *tris;
+    int first, end;                        // cursor of node 0, cursor one past the last node
+    int tri_bias;                          // cursor of triangle 0
+    __device__ __forceinline__ float4 node4(int c) const { return *reinterpret_cast<const float4 *>(nodes + (unsigned)c); }
+    __device__ __forceinline__ float4 tri4(int c) const { return *reinterpret_cast<const float4 *>(tris + (unsigned)c); }
+    __device__ __forceinline__ float tri1(int c) const { return *reinterpret_cast<const float *>(tris + (unsigned)c); }
+};
+struct LdsScene {
+    int first, end, tri_bias;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float native4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ float4 node4(int c) const
+    {
+        const native4 v = *(const __attribute__((address_space(3))) native4 *)(unsigned)c;
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    __device__ __forceinline__ float4 tri4(int c) const { return node4(c); }
+    __device__ __forceinline__ float tri1(int c) const { return *(const __attribute__((address_space(3))) float *)(unsigned)c; }
+#else
+    float4 node4(int) const { return float4(); }
+    float4 tri4(int) const { return float4(); }
+    float tri1(int) const { return 0.f; }
+#endif
+};
+__device__ __forceinline__ unsigned lds_address(const void *p)      // LDS byte address of a __shared__ object
 {
-    const int end = P.n_nodes;
+    return (unsigned)(unsigned long long)p;                          // low half of the flat (shared aperture) address
+}
+
+template <bool COUNT, class Mem>
+__device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, const Mem mem)
+{
+    const int end = mem.end;
+    const int tri_bias = mem.tri_bias;
     const float tmin_ray = P.eps;          // every ray of the integrator starts at epsilon
 
+    // Loop-carried lane state is integers only; every predicate is a compare made in the trip that uses it,
+    // so a vote is one v_cmp into an SGPR pair and the mask algebra stays on the scalar unit.  (A bool
+    // carried around the loop lives in an SGPR lane mask that the compiler re-materialises through a VGPR
+    // for every ballot.)  An idle lane has slot < 0, idx == end and tri > tri_last.
     int next = 0;                          // wave-uniform: first slot nobody has taken yet
-    bool busy = false;
-    int slot = 0;
-    bool any_hit = false;
+    int slot = -1;
+    int any_hit = 0;
     V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
     float tmax = 0.f;
     int idx = end, tri = 0, tri_last = -1;
@@ -203,51 +248,54 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
     float hb1 = 0.f, hb2 = 0.f;
 
     for (;;) {
-        bool want_tri = busy && tri <= tri_last;
-        bool want_node = busy && !want_tri && idx < end;
-        if (busy && !want_tri && !want_node) {
-            // ray finished: the result overwrites the first half of its slot
-            pool[2 * slot] = make_float4(__int_as_float(hprim), tmax, hb1, hb2);
-            busy = false;
+        const bool want_tri = tri <= tri_last;
+        const bool more_nodes = idx < end;
+        const unsigned long long m_tri = ballot(want_tri);
+        const unsigned long long m_more = ballot(more_nodes);
+        const unsigned long long m_has = ballot(slot >= 0);
+        const unsigned long long m_fin = m_has & ~(m_tri | m_more);
+        if (m_fin != 0ull) {
+            if (slot >= 0 && !want_tri && !more_nodes) {
+                // ray finished: the result overwrites the second half of its slot (the direction stays)
+                const int prim = hprim < 0 ? -1 : (int)((unsigned)(hprim - tri_bias) / 48u);
+                pool[2 * slot + 1] = make_float4(__int_as_float(prim), tmax, hb1, hb2);
+                slot = -1;
+            }
         }
-        unsigned long long m_busy = __ballot(busy);
-        const int n_idle = 64 - __builtin_popcountll(m_busy);
-        if (next < n_rays && (n_idle >= kFetchThreshold || m_busy == 0ull)) {
+        const unsigned long long m_busy = m_has & ~m_fin;
+        const int n_idle = 64 - popc(m_busy);
+        if (next < n_rays && n_idle >= kFetchThreshold) {       // (an empty wave has 64 idle lanes)
             // ---- refill: idle lanes take the next slots, in lane order ------------------
             const int mine = next + lane_rank(~m_busy);
-            if (!busy && mine < n_rays) {
+            if (slot < 0 && mine < n_rays) {
                 const float4 r0 = pool[2 * mine];
                 const float4 r1 = pool[2 * mine + 1];
                 const int tag = __float_as_int(r1.w);
                 const float4 ro = pool[2 * kPoolSlots + (tag & 255)];
                 slot = mine;
-                any_hit = (tag & 256) != 0;
+                any_hit = tag & 256;
                 o = V3{ro.x, ro.y, ro.z};
                 d = V3{r0.x, r0.y, r0.z};
                 inv = V3{r1.x, r1.y, r1.z};
                 tmax = r0.w;
-                idx = 0;
+                idx = mem.first;
                 tri = 0;
                 tri_last = -1;
                 hprim = -1;
                 hb1 = hb2 = 0.f;
-                busy = true;
-                want_tri = false;
-                want_node = end > 0;
             }
-            next += n_idle;
-            m_busy = __ballot(busy);
-        }
+            next += n_idle;               // next trip votes with the new rays on board
+        } else {
         if (m_busy == 0ull) break;
-        if (COUNT && first_active_lane()) { cnt.w_trip++; cnt.l_trip += (uint32_t)__builtin_popcountll(m_busy); }
+        if (COUNT && first_active_lane()) { cnt.w_trip++; cnt.l_trip += (uint32_t)popc(m_busy); }
 
-        const unsigned long long m_tri = __ballot(want_tri);
-        const unsigned long long m_node = __ballot(want_node);
-        if (__builtin_popcountll(m_node) >= __builtin_popcountll(m_tri)) {
-            if (want_node) {
+        const unsigned long long m_node = m_more & ~m_tri;
+        const bool node_trip = popc(m_node) >= popc(m_tri);
+        {
+            if (node_trip && more_nodes && !want_tri) {
                 // ---- one node --------------------------------------------------------------
-                const float4 a = nodes[2 * idx];
-                const float4 b = nodes[2 * idx + 1];
+                const float4 a = mem.node4(idx);
+                const float4 b = mem.node4(idx + 16);
                 if (COUNT) { cnt.node_visits++; if (first_active_lane()) cnt.w_node++; }
                 const float t1 = (a.x - o.x) * inv.x;
                 const float t2 = (a.w - o.x) * inv.x;
@@ -262,19 +310,21 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
                 const int link = __float_as_int(b.z);
                 const int last = __float_as_int(b.w);
                 const bool leaf = last >= 0;
-                idx = (box || leaf) ? idx + 1 : link;
+                idx = (box || leaf) ? idx + 32 : link;
                 if (box && leaf) {
                     tri = link;
                     tri_last = last;
                 }
             }
-        } else {
-            if (want_tri) {
+        }
+        {
+            if (!node_trip && want_tri) {
                 // ---- one triangle ----------------------------------------------------------
-                const int i = tri++;
-                const float4 q0 = tris[3 * i];
-                const float4 q1 = tris[3 * i + 1];
-                const float e2z = tris[3 * i + 2].x;
+                const int i = tri;
+                tri += 48;
+                const float4 q0 = mem.tri4(i);
+                const float4 q1 = mem.tri4(i + 16);
+                const float e2z = mem.tri1(i + 32);
                 if (COUNT) { cnt.prim_tests++; if (first_active_lane()) cnt.w_prim++; }
                 const V3 v1 = V3{q0.x, q0.y, q0.z};
                 const V3 e1 = V3{q0.w, q1.x, q1.y};
@@ -296,14 +346,256 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
                     hprim = i;
                     hb1 = b1;
                     hb2 = b2;
-                    if (any_hit) {      // IntersectP: the first accepted triangle ends the ray
+                    if (any_hit != 0) {      // IntersectP: the first accepted triangle ends the ray
                         idx = end;
                         tri_last = -1;
                     }
                 }
             }
         }
+        }
     }
+}
+
+// ---- the same loop, hand-scheduled for a scene staged in LDS ---------------------------------------------
+// trace_pool<> above is the specification; this is its instruction-for-instruction twin with the control
+// skeleton the compiler cannot be talked into.  Measured on gfx950 (tools/micro/issue_rate.hip): a wave issues
+// one dependent instruction every ~9 cycles, VALU or SALU alike, and with 4 waves per SIMD that - not VALU
+// throughput - bounds this loop.  The compiler spends ~54 scalar instructions per trip on lane-mask phis,
+// saveexec pairs and uniform-bool round trips; written by hand the skeleton is 16.  All floating-point
+// instructions (and their order of evaluation) are the ones the compiler emits for trace_pool<>, so the two
+// are bit-identical; tests/test_gpu_parity.py runs both (the counting build uses trace_pool<>).
+//
+// Register map (all clobbered, nothing is live across):
+//   v[80:82] origin   v[84:86] dir  v87 (tmax as loaded)   v[88:90] 1/dir  v91 tag
+//   v92 node cursor  v93 triangle cursor  v94 last triangle  v95 slot address (-1 = idle lane)
+//   v[100:103] result {triangle cursor / index, tmax, b1, b2}   v[104:112] node or triangle data
+//   v113..v123 temporaries (40 VGPRs in all)
+//   s[60:61] m_tri  s[62:63] m_more / m_node  s[64:65] m_has / m_busy  s[66:69] scratch masks
+//   s70 next  s71 s72 counts  s76 1e-8f
+// The kernel always runs full wavefronts (256-thread workgroups, wave-uniform control flow), so exec is
+// restored to all ones.
+// gfx950 hazards honoured by hand: >= 2 wait states between a VALU write of VCC/SGPR and a VALU read of it
+// (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
+__device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps)
+{
+    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
+    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
+    const int s_end = __builtin_amdgcn_readfirstlane(mem.end);
+    const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
+    const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
+    asm volatile(
+        "s_mov_b32 s70, 0\n"
+        "s_mov_b32 s76, 0x322bcc77\n"
+        "v_mov_b32_e32 v92, %[end]\n"
+        "v_mov_b32_e32 v93, 0\n"
+        "v_mov_b32_e32 v94, -1\n"
+        "v_mov_b32_e32 v95, -1\n"
+        "TP_LOOP_%=:\n"
+        "v_cmp_le_i32_e64 s[60:61], v93, v94\n"             // want_tri
+        "v_cmp_gt_i32_e64 s[62:63], %[end], v92\n"          // more_nodes
+        "v_cmp_lt_i32_e64 s[64:65], -1, v95\n"              // has a ray
+        "s_or_b64 s[66:67], s[60:61], s[62:63]\n"
+        "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n"        // finished: has && !want_tri && !more_nodes
+        "s_cbranch_scc0 TP_NOFIN_%=\n"
+        // ---- store results ----
+        "s_mov_b64 exec, s[68:69]\n"
+        "s_mov_b32 s72, 0xaaaaaaab\n"
+        "v_cmp_gt_i32_e32 vcc, 0, v100\n"
+        "v_subrev_u32_e32 v113, %[bias], v100\n"
+        "v_mul_hi_u32 v113, v113, s72\n"
+        "v_lshrrev_b32_e32 v113, 5, v113\n"                 // (cursor - bias) / 48
+        "v_cndmask_b32_e64 v100, v113, -1, vcc\n"
+        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"        // m_busy
+        "ds_write_b128 v95, v[100:103] offset:16\n"
+        "v_mov_b32_e32 v95, -1\n"
+        "s_mov_b64 exec, -1\n"
+        "TP_NOFIN_%=:\n"
+        "s_cmp_ge_i32 s70, %[rays]\n"
+        "s_cbranch_scc1 TP_NOREFILL_%=\n"
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
+        "s_cmp_gt_u32 s71, %[maxbusy]\n"
+        "s_cbranch_scc1 TP_NOREFILL_%=\n"
+        // ---- refill: idle lanes take the next slots in lane order ----
+        "s_not_b64 s[66:67], s[64:65]\n"
+        "v_mbcnt_lo_u32_b32 v113, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v113, s67, v113\n"
+        "v_add_u32_e32 v113, s70, v113\n"
+        "v_cmp_gt_i32_e32 vcc, %[rays], v113\n"
+        "s_and_b64 s[66:67], vcc, s[66:67]\n"
+        "s_sub_i32 s71, 64, s71\n"
+        "s_add_i32 s70, s70, s71\n"
+        "s_mov_b64 exec, s[66:67]\n"
+        "v_lshl_add_u32 v95, v113, 5, %[pool]\n"
+        "ds_read_b128 v[84:87], v95\n"
+        "ds_read_b128 v[88:91], v95 offset:16\n"
+        "v_mov_b32_e32 v92, %[first]\n"
+        "v_mov_b32_e32 v93, 0\n"
+        "v_mov_b32_e32 v94, -1\n"
+        "v_mov_b32_e32 v100, -1\n"
+        "v_mov_b32_e32 v102, 0\n"
+        "v_mov_b32_e32 v103, 0\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32_e32 v113, 0xff, v91\n"
+        "v_lshl_add_u32 v113, v113, 4, %[pool]\n"
+        "ds_read_b96 v[80:82], v113 offset:%[org]\n"
+        "v_mov_b32_e32 v101, v87\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TP_LOOP_%=\n"
+        "TP_NOREFILL_%=:\n"
+        "s_cmp_eq_u64 s[64:65], 0\n"
+        "s_cbranch_scc1 TP_DONE_%=\n"
+        // ---- vote ----
+        "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n"        // m_node
+        "s_bcnt1_i32_b64 s71, s[62:63]\n"
+        "s_bcnt1_i32_b64 s72, s[60:61]\n"
+        "s_cmp_ge_u32 s71, s72\n"
+        "s_cbranch_scc0 TP_TRI_%=\n"
+        // ---- one node ----
+        "s_mov_b64 exec, s[62:63]\n"
+        "ds_read_b128 v[104:107], v92\n"
+        "ds_read_b128 v[108:111], v92 offset:16\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_sub_f32_e32 v113, v104, v80\n"
+        "v_sub_f32_e32 v114, v107, v80\n"
+        "v_sub_f32_e32 v115, v105, v81\n"
+        "v_sub_f32_e32 v117, v106, v82\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_sub_f32_e32 v116, v108, v81\n"
+        "v_sub_f32_e32 v118, v109, v82\n"
+        "v_mul_f32_e32 v113, v88, v113\n"
+        "v_mul_f32_e32 v114, v88, v114\n"
+        "v_mul_f32_e32 v115, v89, v115\n"
+        "v_mul_f32_e32 v116, v89, v116\n"
+        "v_mul_f32_e32 v117, v90, v117\n"
+        "v_mul_f32_e32 v118, v90, v118\n"
+        "v_min_f32_e32 v119, v113, v114\n"
+        "v_min_f32_e32 v120, v115, v116\n"
+        "v_min_f32_e32 v121, v117, v118\n"
+        "v_max_f32_e32 v113, v113, v114\n"
+        "v_max_f32_e32 v115, v115, v116\n"
+        "v_max_f32_e32 v117, v117, v118\n"
+        "v_min3_f32 v113, v113, v115, v117\n"               // t far
+        "v_max3_f32 v119, v119, v120, v121\n"               // t near
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v113\n"         // !(tf <= 1e-5)
+        "v_min_f32_e32 v113, v113, v101\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v113, v119\n"          // !(tn > tf) && !(tn > tmax)
+        "s_and_b64 s[66:67], s[66:67], vcc\n"               // box
+        "v_cmp_lt_i32_e32 vcc, -1, v111\n"                  // leaf
+        "v_add_u32_e32 v113, 32, v92\n"
+        "s_or_b64 s[68:69], vcc, s[66:67]\n"
+        "s_and_b64 vcc, vcc, s[66:67]\n"
+        "v_cndmask_b32_e64 v92, v110, v113, s[68:69]\n"     // (box || leaf) ? next node : escape link
+        "v_cndmask_b32_e32 v94, v94, v111, vcc\n"           // box && leaf: its triangles
+        "v_cndmask_b32_e32 v93, v93, v110, vcc\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TP_LOOP_%=\n"
+        // ---- one triangle ----
+        "TP_TRI_%=:\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        "ds_read_b128 v[108:111], v93 offset:16\n"
+        "ds_read_b32 v112, v93 offset:32\n"
+        "ds_read_b128 v[104:107], v93\n"
+        "v_add_u32_e32 v93, 48, v93\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_mul_f32_e32 v113, v85, v112\n"                   // s1 = cross(d, e2)
+        "v_mul_f32_e32 v122, v86, v111\n"
+        "v_sub_f32_e32 v113, v113, v122\n"
+        "v_mul_f32_e32 v114, v86, v110\n"
+        "v_mul_f32_e32 v122, v84, v112\n"
+        "v_sub_f32_e32 v114, v114, v122\n"
+        "v_mul_f32_e32 v115, v84, v111\n"
+        "v_mul_f32_e32 v122, v85, v110\n"
+        "v_sub_f32_e32 v115, v115, v122\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_mul_f32_e32 v116, v113, v107\n"                  // divisor = dot(s1, e1)
+        "v_mul_f32_e32 v122, v114, v108\n"
+        "v_add_f32_e32 v116, v116, v122\n"
+        "v_mul_f32_e32 v122, v115, v109\n"
+        "v_add_f32_e32 v116, v116, v122\n"
+        "v_div_scale_f32 v117, s[66:67], v116, v116, 1.0\n" // 1.0f / divisor, IEEE
+        "v_rcp_f32_e32 v118, v117\n"
+        "v_sub_f32_e32 v104, v80, v104\n"                   // s = o - v1
+        "v_sub_f32_e32 v105, v81, v105\n"
+        "v_sub_f32_e32 v106, v82, v106\n"
+        "v_fma_f32 v121, -v117, v118, 1.0\n"
+        "v_fmac_f32_e32 v118, v121, v118\n"
+        "v_div_scale_f32 v119, vcc, 1.0, v116, 1.0\n"
+        "v_mul_f32_e32 v120, v119, v118\n"
+        "v_fma_f32 v121, -v117, v120, v119\n"
+        "v_fmac_f32_e32 v120, v121, v118\n"
+        "v_fma_f32 v117, -v117, v120, v119\n"
+        "v_div_fmas_f32 v117, v117, v118, v120\n"
+        "v_mul_f32_e32 v123, v104, v113\n"                  // dot(s, s1)
+        "v_mul_f32_e32 v122, v105, v114\n"
+        "v_add_f32_e32 v123, v123, v122\n"
+        "v_mul_f32_e32 v122, v106, v115\n"
+        "v_add_f32_e32 v123, v123, v122\n"
+        "v_div_fixup_f32 v117, v117, v116, 1.0\n"           // invDivisor
+        "v_mul_f32_e32 v113, v105, v109\n"                  // s2 = cross(s, e1)
+        "v_mul_f32_e32 v122, v106, v108\n"
+        "v_sub_f32_e32 v113, v113, v122\n"
+        "v_mul_f32_e32 v114, v106, v107\n"
+        "v_mul_f32_e32 v122, v104, v109\n"
+        "v_sub_f32_e32 v114, v114, v122\n"
+        "v_mul_f32_e32 v115, v104, v108\n"
+        "v_mul_f32_e32 v122, v105, v107\n"
+        "v_sub_f32_e32 v115, v115, v122\n"
+        "v_mul_f32_e32 v123, v123, v117\n"                  // b1
+        "v_mul_f32_e32 v118, v84, v113\n"                    // dot(d, s2)
+        "v_mul_f32_e32 v122, v85, v114\n"
+        "v_add_f32_e32 v118, v118, v122\n"
+        "v_mul_f32_e32 v122, v86, v115\n"
+        "v_add_f32_e32 v118, v118, v122\n"
+        "v_mul_f32_e32 v118, v118, v117\n"                    // b2
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v116), s76\n"      // !(|divisor| < 1e-8)
+        "v_cmp_ngt_f32_e32 vcc, 0, v123\n"                  // !(b1 < 0)
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v123\n"                // !(b1 > 1)
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v118\n"                   // !(b2 < 0)
+        "v_add_f32_e32 v122, v123, v118\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v122\n"                 // !(b1 + b2 > 1)
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TP_TRI_END_%=\n"
+        "v_mul_f32_e32 v119, v110, v113\n"                   // dot(e2, s2)
+        "v_mul_f32_e32 v122, v111, v114\n"
+        "v_add_f32_e32 v119, v119, v122\n"
+        "v_mul_f32_e32 v122, v112, v115\n"
+        "v_add_f32_e32 v119, v119, v122\n"
+        "v_mul_f32_e32 v119, v119, v117\n"                    // t
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v119\n"              // !(t < tmin)
+        "v_cmp_ngt_f32_e64 s[66:67], v119, v101\n"           // !(t > tmax)
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TP_TRI_END_%=\n"
+        // accepted: new closest hit (any-hit rays stop here)
+        "v_and_b32_e32 v122, 0x100, v91\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v122\n"
+        "v_mov_b32_e32 v104, %[end]\n"
+        "v_mov_b32_e32 v101, v119\n"
+        "v_subrev_u32_e32 v100, 48, v93\n"
+        "v_mov_b32_e32 v102, v123\n"
+        "v_mov_b32_e32 v103, v118\n"
+        "v_cndmask_b32_e32 v92, v92, v104, vcc\n"
+        "v_cndmask_b32_e64 v94, v94, -1, vcc\n"
+        "TP_TRI_END_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TP_LOOP_%=\n"
+        "TP_DONE_%=:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        :
+        : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias),
+          [eps] "s"(s_eps), [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16)
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+          "s72", "s76", "v80", "v81", "v82", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+          "v95", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+          "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -965,7 +1257,7 @@ __device__ __forceinline__ void make_light_hit(const DevParams &P, int prim, flo
 }
 
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 3
+#define PT_MIN_WAVES 4
 #endif
 struct RayResults {    // this lane's own rays, read back from the pool
     bool occluded;
@@ -995,7 +1287,19 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         const uint32_t *gm = reinterpret_cast<const uint32_t *>(P_in.materials);
         const int o_tri = 2 * P.n_nodes, o_shade = o_tri + 3 * P.n_prims, o_light = o_shade + 5 * P.n_prims,
                   o_mat = o_light + 6 * P.n_lights;
-        for (int i = threadIdx.x; i < 2 * P.n_nodes; i += 256) lds_scene[i] = gn[i];
+        const int lds_nodes = (int)lds_address(lds_scene), lds_tris = lds_nodes + o_tri * 16;
+        for (int i = threadIdx.x; i < 2 * P.n_nodes; i += 256) {
+            float4 v = gn[i];
+            if (i & 1) {                                      // links become absolute LDS addresses
+                if (__float_as_int(v.w) >= 0) {               // leaf: first / last triangle
+                    v.z = __int_as_float(__float_as_int(v.z) + lds_tris);
+                    v.w = __int_as_float(__float_as_int(v.w) + lds_tris);
+                } else {
+                    v.z = __int_as_float(__float_as_int(v.z) + lds_nodes);
+                }
+            }
+            lds_scene[i] = v;
+        }
         for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[o_tri + i] = gt[i];
         for (int i = threadIdx.x; i < 5 * P.n_prims; i += 256) lds_scene[o_shade + i] = gs[i];
         for (int i = threadIdx.x; i < 6 * P.n_lights; i += 256) lds_scene[o_light + i] = gl[i];
@@ -1250,9 +1554,9 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             // ---- regenerate: pathtracer.cu:881-903 ---------------------------------------
             bool start = false;
             if (next_sample < n_item_samples) {
-                const unsigned long long m_idle = __ballot(!alive);
+                const unsigned long long m_idle = ballot(!alive);
                 const uint32_t s = next_sample + (uint32_t)lane_rank(m_idle);
-                next_sample += (uint32_t)__builtin_popcountll(m_idle);
+                next_sample += (uint32_t)popc(m_idle);
                 if (!alive && s < n_item_samples) {
                     x = tx * 8u + (s & 7u);
                     y = ty * 8u + ((s >> 3) & 7u);
@@ -1300,22 +1604,47 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 c0 = __builtin_readcyclecounter();
                 if (lane == 0) cyc_shade += c0 - cyc_mark;
             }
-            if (SMALL)
-                trace_pool<COUNT>(P, pool, L.n_rays, cnt, (const float4 *)lds_scene, (const float4 *)(lds_scene + 2 * P.n_nodes));
-            else
-                trace_pool<COUNT>(P, pool, L.n_rays, cnt, reinterpret_cast<const float4 *>(P.nodes),
-                                  reinterpret_cast<const float4 *>(P.tris));
+            if (SMALL) {
+                LdsScene mem;
+                mem.first = (int)lds_address(lds_scene);
+                mem.end = mem.first + 32 * P.n_nodes;
+                mem.tri_bias = mem.end;
+                if (COUNT)
+                    trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
+                else
+                    trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
+            } else {
+                GlobalScene mem;
+                mem.nodes = reinterpret_cast<const char *>(P.nodes);
+                mem.tris = reinterpret_cast<const char *>(P.tris);
+                mem.first = 0;
+                mem.end = 32 * P.n_nodes;
+                mem.tri_bias = 0;
+                trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
+            }
             if (COUNT) {
                 cyc_mark = __builtin_readcyclecounter();
                 if (lane == 0) cyc_trace += cyc_mark - c0;
             }
             wave_lds_fence();
+            // The origin and the directions come back from the pool as well (same bits), so they do not
+            // occupy registers while the pool is drained.
+            {
+                const float4 ro = pool[2 * kPoolSlots + lane];
+                q.org = V3{ro.x, ro.y, ro.z};
+            }
             if (q.has_p) {
-                const RayResult rr = pool_result(pool, lane_rank(L.m_p));
+                const int sl = lane_rank(L.m_p);
+                const RayResult rr = pool_result(pool, sl);
+                const float4 rd = pool[2 * sl];
+                q.dir_p = V3{rd.x, rd.y, rd.z};
                 res.prim_p = rr.prim; res.t_p = rr.t; res.b1_p = rr.b1; res.b2_p = rr.b2;
             }
             if (q.has_m) {
-                const RayResult rr = pool_result(pool, L.n_p + lane_rank(L.m_m));
+                const int sl = L.n_p + lane_rank(L.m_m);
+                const RayResult rr = pool_result(pool, sl);
+                const float4 rd = pool[2 * sl];
+                q.dir_m = V3{rd.x, rd.y, rd.z};
                 res.prim_m = rr.prim; res.t_m = rr.t; res.b1_m = rr.b1; res.b2_m = rr.b2;
             }
             if (q.has_s) res.occluded = pool_result(pool, L.n_p + L.n_m + lane_rank(L.m_s)).prim >= 0;

@@ -30,10 +30,12 @@ struct alignas(16) DevNode {
     float bmax[3];
     // Threaded preorder traversal (fixed left-first order == the reference's
     // stack discipline, src/pathtracer.cu:221-252):
-    //   inner: link = index to continue at when the box is missed ("escape":
+    //   inner: link = where to continue when the box is missed ("escape":
     //          first node after this subtree in preorder); last = -1
     //   leaf : link = first primitive; last = last primitive (inclusive, >= 0)
-    // A hit inner node continues at idx+1; a leaf always continues at idx+1.
+    // A hit inner node continues at the next node; a leaf always does.
+    // Both are stored as BYTE offsets (node index * 32, primitive index * 48)
+    // so the traversal loop does no address arithmetic.
     int32_t link;
     int32_t last;
 };

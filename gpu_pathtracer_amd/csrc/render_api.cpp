@@ -168,10 +168,10 @@ void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
         d.bmin[0] = nd.fmin.x; d.bmin[1] = nd.fmin.y; d.bmin[2] = nd.fmin.z;
         d.bmax[0] = nd.fmax.x; d.bmax[1] = nd.fmax.y; d.bmax[2] = nd.fmax.z;
         if (nd.is_leaf) {
-            d.link = nd.start;
-            d.last = nd.end;
+            d.link = nd.start * (int32_t)sizeof(DevTri);
+            d.last = nd.end * (int32_t)sizeof(DevTri);
         } else {
-            d.link = escape[(size_t)i];
+            d.link = escape[(size_t)i] * (int32_t)sizeof(DevNode);
             d.last = -1;
         }
     }
@@ -197,6 +197,11 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     if (scene->n_prims < 0 || scene->n_nodes < 0 || scene->n_materials <= 0 || scene->n_light_distribution < 1) {
         gpt_set_error("gpt_begin: inconsistent scene counts");
         return GPT_ERR_INVALID_ARG;
+    }
+    // traversal cursors are 32-bit byte offsets into the packed node / triangle arrays (pt_layout.h)
+    if ((int64_t)scene->n_nodes * (int64_t)sizeof(DevNode) > INT32_MAX || (int64_t)scene->n_prims * (int64_t)sizeof(DevTri) > INT32_MAX) {
+        gpt_set_error("gpt_begin: scene too large (%d nodes, %d primitives; limits 67108863 / 44739242)", scene->n_nodes, scene->n_prims);
+        return GPT_ERR_UNSUPPORTED;
     }
     for (int i = 0; i < scene->n_prims; ++i) {
         if (scene->prims[i].type != GPT_GT_TRIANGLE) {
