@@ -128,6 +128,15 @@ constexpr int kWaveLdsFloat4 = 2 * kPoolSlots + 64;   // slots (2 x float4) + on
 #ifndef PT_FETCH_T
 #define PT_FETCH_T 12
 #endif
+#ifndef PT_ASM_IN_COUNT
+#define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
+#endif
+#ifndef PT_VOTE_NODE_SHIFT
+#define PT_VOTE_NODE_SHIFT 1      // a node trip costs half a triangle trip: 2 * node-waiters >= triangle-waiters
+#endif
+#ifndef PT_VOTE_TRI_SHIFT
+#define PT_VOTE_TRI_SHIFT 0
+#endif
 constexpr int kFetchThreshold = PT_FETCH_T;        // idle lanes that trigger a refill
 
 struct RaySet {        // what one lane deposits
@@ -290,7 +299,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         if (COUNT && first_active_lane()) { cnt.w_trip++; cnt.l_trip += (uint32_t)popc(m_busy); }
 
         const unsigned long long m_node = m_more & ~m_tri;
-        const bool node_trip = popc(m_node) >= popc(m_tri);
+        const bool node_trip = (popc(m_node) << PT_VOTE_NODE_SHIFT) >= (popc(m_tri) << PT_VOTE_TRI_SHIFT);
         {
             if (node_trip && more_nodes && !want_tri) {
                 // ---- one node --------------------------------------------------------------
@@ -367,16 +376,19 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 // are bit-identical; tests/test_gpu_parity.py runs both (the counting build uses trace_pool<>).
 //
 // Register map (all clobbered, nothing is live across):
-//   v[80:82] origin   v[84:86] dir  v87 (tmax as loaded)   v[88:90] 1/dir  v91 tag
-//   v92 node cursor  v93 triangle cursor  v94 last triangle  v95 slot address (-1 = idle lane)
-//   v[100:103] result {triangle cursor / index, tmax, b1, b2}   v[104:112] node or triangle data
-//   v113..v123 temporaries (40 VGPRs in all)
+//   v[0:2] origin   v[4:6] dir  v7 (tmax as loaded)   v[8:10] 1/dir  v11 tag
+//   v12 node cursor  v13 triangle cursor  v14 last triangle  v15 slot address (-1 = idle lane)
+//   v[20:23] result {triangle cursor / index, tmax, b1, b2}   v[24:32] node or triangle data
+//   v33..v43 temporaries (40 VGPRs in all).  The block sits at the
+//   bottom of the register file: with v80..v123 the allocator spilled 17 dwords per lane, here none.
 //   s[60:61] m_tri  s[62:63] m_more / m_node  s[64:65] m_has / m_busy  s[66:69] scratch masks
-//   s70 next  s71 s72 counts  s76 1e-8f
+//   s70 next  s71 s72 counts  s76 1e-8f  s77 2^100
 // The kernel always runs full wavefronts (256-thread workgroups, wave-uniform control flow), so exec is
 // restored to all ones.
 // gfx950 hazards honoured by hand: >= 2 wait states between a VALU write of VCC/SGPR and a VALU read of it
 // (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
+#define PT_STR2(x) #x
+#define PT_STR(x) PT_STR2(x)
 __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
@@ -388,204 +400,228 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     asm volatile(
         "s_mov_b32 s70, 0\n"
         "s_mov_b32 s76, 0x322bcc77\n"
-        "v_mov_b32_e32 v92, %[end]\n"
-        "v_mov_b32_e32 v93, 0\n"
-        "v_mov_b32_e32 v94, -1\n"
-        "v_mov_b32_e32 v95, -1\n"
+        "s_mov_b32 s77, 0x71800000\n"
+        "s_mov_b64 s[64:65], 0\n"
+        "v_mov_b32_e32 v12, %[end]\n"
+        "v_mov_b32_e32 v13, 0\n"
+        "v_mov_b32_e32 v14, -1\n"
+        "v_mov_b32_e32 v15, -1\n"
+        "s_branch TP_FILL_%=\n"                              // every lane is idle: first refill
         "TP_LOOP_%=:\n"
-        "v_cmp_le_i32_e64 s[60:61], v93, v94\n"             // want_tri
-        "v_cmp_gt_i32_e64 s[62:63], %[end], v92\n"          // more_nodes
-        "v_cmp_lt_i32_e64 s[64:65], -1, v95\n"              // has a ray
+        "v_cmp_le_i32_e64 s[60:61], v13, v14\n"             // want_tri
+        "v_cmp_gt_i32_e64 s[62:63], %[end], v12\n"          // more_nodes
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"              // has a ray
         "s_or_b64 s[66:67], s[60:61], s[62:63]\n"
         "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n"        // finished: has && !want_tri && !more_nodes
-        "s_cbranch_scc0 TP_NOFIN_%=\n"
-        // ---- store results ----
-        "s_mov_b64 exec, s[68:69]\n"
-        "s_mov_b32 s72, 0xaaaaaaab\n"
-        "v_cmp_gt_i32_e32 vcc, 0, v100\n"
-        "v_subrev_u32_e32 v113, %[bias], v100\n"
-        "v_mul_hi_u32 v113, v113, s72\n"
-        "v_lshrrev_b32_e32 v113, 5, v113\n"                 // (cursor - bias) / 48
-        "v_cndmask_b32_e64 v100, v113, -1, vcc\n"
-        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"        // m_busy
-        "ds_write_b128 v95, v[100:103] offset:16\n"
-        "v_mov_b32_e32 v95, -1\n"
-        "s_mov_b64 exec, -1\n"
-        "TP_NOFIN_%=:\n"
-        "s_cmp_ge_i32 s70, %[rays]\n"
-        "s_cbranch_scc1 TP_NOREFILL_%=\n"
-        "s_bcnt1_i32_b64 s71, s[64:65]\n"
-        "s_cmp_gt_u32 s71, %[maxbusy]\n"
-        "s_cbranch_scc1 TP_NOREFILL_%=\n"
-        // ---- refill: idle lanes take the next slots in lane order ----
-        "s_not_b64 s[66:67], s[64:65]\n"
-        "v_mbcnt_lo_u32_b32 v113, s66, 0\n"
-        "v_mbcnt_hi_u32_b32 v113, s67, v113\n"
-        "v_add_u32_e32 v113, s70, v113\n"
-        "v_cmp_gt_i32_e32 vcc, %[rays], v113\n"
-        "s_and_b64 s[66:67], vcc, s[66:67]\n"
-        "s_sub_i32 s71, 64, s71\n"
-        "s_add_i32 s70, s70, s71\n"
-        "s_mov_b64 exec, s[66:67]\n"
-        "v_lshl_add_u32 v95, v113, 5, %[pool]\n"
-        "ds_read_b128 v[84:87], v95\n"
-        "ds_read_b128 v[88:91], v95 offset:16\n"
-        "v_mov_b32_e32 v92, %[first]\n"
-        "v_mov_b32_e32 v93, 0\n"
-        "v_mov_b32_e32 v94, -1\n"
-        "v_mov_b32_e32 v100, -1\n"
-        "v_mov_b32_e32 v102, 0\n"
-        "v_mov_b32_e32 v103, 0\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_and_b32_e32 v113, 0xff, v91\n"
-        "v_lshl_add_u32 v113, v113, 4, %[pool]\n"
-        "ds_read_b96 v[80:82], v113 offset:%[org]\n"
-        "v_mov_b32_e32 v101, v87\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, -1\n"
-        "s_branch TP_LOOP_%=\n"
-        "TP_NOREFILL_%=:\n"
-        "s_cmp_eq_u64 s[64:65], 0\n"
-        "s_cbranch_scc1 TP_DONE_%=\n"
+        "s_cbranch_scc1 TP_FIN_%=\n"
+        "TP_VOTE_%=:\n"
         // ---- vote ----
         "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n"        // m_node
         "s_bcnt1_i32_b64 s71, s[62:63]\n"
         "s_bcnt1_i32_b64 s72, s[60:61]\n"
+#if PT_VOTE_NODE_SHIFT
+        "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n"
+#endif
+#if PT_VOTE_TRI_SHIFT
+        "s_lshl_b32 s72, s72, " PT_STR(PT_VOTE_TRI_SHIFT) "\n"
+#endif
         "s_cmp_ge_u32 s71, s72\n"
         "s_cbranch_scc0 TP_TRI_%=\n"
         // ---- one node ----
         "s_mov_b64 exec, s[62:63]\n"
-        "ds_read_b128 v[104:107], v92\n"
-        "ds_read_b128 v[108:111], v92 offset:16\n"
+        "ds_read_b128 v[24:27], v12\n"
+        "ds_read_b128 v[28:31], v12 offset:16\n"
         "s_waitcnt lgkmcnt(1)\n"
-        "v_sub_f32_e32 v113, v104, v80\n"
-        "v_sub_f32_e32 v114, v107, v80\n"
-        "v_sub_f32_e32 v115, v105, v81\n"
-        "v_sub_f32_e32 v117, v106, v82\n"
+        "v_sub_f32_e32 v33, v24, v0\n"
+        "v_sub_f32_e32 v34, v27, v0\n"
+        "v_sub_f32_e32 v35, v25, v1\n"
+        "v_sub_f32_e32 v37, v26, v2\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_sub_f32_e32 v116, v108, v81\n"
-        "v_sub_f32_e32 v118, v109, v82\n"
-        "v_mul_f32_e32 v113, v88, v113\n"
-        "v_mul_f32_e32 v114, v88, v114\n"
-        "v_mul_f32_e32 v115, v89, v115\n"
-        "v_mul_f32_e32 v116, v89, v116\n"
-        "v_mul_f32_e32 v117, v90, v117\n"
-        "v_mul_f32_e32 v118, v90, v118\n"
-        "v_min_f32_e32 v119, v113, v114\n"
-        "v_min_f32_e32 v120, v115, v116\n"
-        "v_min_f32_e32 v121, v117, v118\n"
-        "v_max_f32_e32 v113, v113, v114\n"
-        "v_max_f32_e32 v115, v115, v116\n"
-        "v_max_f32_e32 v117, v117, v118\n"
-        "v_min3_f32 v113, v113, v115, v117\n"               // t far
-        "v_max3_f32 v119, v119, v120, v121\n"               // t near
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v113\n"         // !(tf <= 1e-5)
-        "v_min_f32_e32 v113, v113, v101\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v113, v119\n"          // !(tn > tf) && !(tn > tmax)
+        "v_sub_f32_e32 v36, v28, v1\n"
+        "v_sub_f32_e32 v38, v29, v2\n"
+        "v_mul_f32_e32 v33, v8, v33\n"
+        "v_mul_f32_e32 v34, v8, v34\n"
+        "v_mul_f32_e32 v35, v9, v35\n"
+        "v_mul_f32_e32 v36, v9, v36\n"
+        "v_mul_f32_e32 v37, v10, v37\n"
+        "v_mul_f32_e32 v38, v10, v38\n"
+        "v_min_f32_e32 v39, v33, v34\n"
+        "v_min_f32_e32 v40, v35, v36\n"
+        "v_min_f32_e32 v41, v37, v38\n"
+        "v_max_f32_e32 v33, v33, v34\n"
+        "v_max_f32_e32 v35, v35, v36\n"
+        "v_max_f32_e32 v37, v37, v38\n"
+        "v_min3_f32 v33, v33, v35, v37\n"               // t far
+        "v_max3_f32 v39, v39, v40, v41\n"               // t near
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v33\n"         // !(tf <= 1e-5)
+        "v_min_f32_e32 v33, v33, v21\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v33, v39\n"          // !(tn > tf) && !(tn > tmax)
         "s_and_b64 s[66:67], s[66:67], vcc\n"               // box
-        "v_cmp_lt_i32_e32 vcc, -1, v111\n"                  // leaf
-        "v_add_u32_e32 v113, 32, v92\n"
+        "v_cmp_lt_i32_e32 vcc, -1, v31\n"                  // leaf
+        "v_add_u32_e32 v33, 32, v12\n"
         "s_or_b64 s[68:69], vcc, s[66:67]\n"
         "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v92, v110, v113, s[68:69]\n"     // (box || leaf) ? next node : escape link
-        "v_cndmask_b32_e32 v94, v94, v111, vcc\n"           // box && leaf: its triangles
-        "v_cndmask_b32_e32 v93, v93, v110, vcc\n"
+        "v_cndmask_b32_e64 v12, v30, v33, s[68:69]\n"     // (box || leaf) ? next node : escape link
+        "v_cndmask_b32_e32 v14, v14, v31, vcc\n"           // box && leaf: its triangles
+        "v_cndmask_b32_e32 v13, v13, v30, vcc\n"
         "s_mov_b64 exec, -1\n"
         "s_branch TP_LOOP_%=\n"
         // ---- one triangle ----
         "TP_TRI_%=:\n"
         "s_mov_b64 exec, s[60:61]\n"
-        "ds_read_b128 v[108:111], v93 offset:16\n"
-        "ds_read_b32 v112, v93 offset:32\n"
-        "ds_read_b128 v[104:107], v93\n"
-        "v_add_u32_e32 v93, 48, v93\n"
+        "ds_read_b128 v[28:31], v13 offset:16\n"
+        "ds_read_b32 v32, v13 offset:32\n"
+        "ds_read_b128 v[24:27], v13\n"
+        "v_add_u32_e32 v13, 48, v13\n"
         "s_waitcnt lgkmcnt(1)\n"
-        "v_mul_f32_e32 v113, v85, v112\n"                   // s1 = cross(d, e2)
-        "v_mul_f32_e32 v122, v86, v111\n"
-        "v_sub_f32_e32 v113, v113, v122\n"
-        "v_mul_f32_e32 v114, v86, v110\n"
-        "v_mul_f32_e32 v122, v84, v112\n"
-        "v_sub_f32_e32 v114, v114, v122\n"
-        "v_mul_f32_e32 v115, v84, v111\n"
-        "v_mul_f32_e32 v122, v85, v110\n"
-        "v_sub_f32_e32 v115, v115, v122\n"
+        "v_mul_f32_e32 v33, v5, v32\n"                   // s1 = cross(d, e2)
+        "v_mul_f32_e32 v42, v6, v31\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v6, v30\n"
+        "v_mul_f32_e32 v42, v4, v32\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v4, v31\n"
+        "v_mul_f32_e32 v42, v5, v30\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_mul_f32_e32 v116, v113, v107\n"                  // divisor = dot(s1, e1)
-        "v_mul_f32_e32 v122, v114, v108\n"
-        "v_add_f32_e32 v116, v116, v122\n"
-        "v_mul_f32_e32 v122, v115, v109\n"
-        "v_add_f32_e32 v116, v116, v122\n"
-        "v_div_scale_f32 v117, s[66:67], v116, v116, 1.0\n" // 1.0f / divisor, IEEE
-        "v_rcp_f32_e32 v118, v117\n"
-        "v_sub_f32_e32 v104, v80, v104\n"                   // s = o - v1
-        "v_sub_f32_e32 v105, v81, v105\n"
-        "v_sub_f32_e32 v106, v82, v106\n"
-        "v_fma_f32 v121, -v117, v118, 1.0\n"
-        "v_fmac_f32_e32 v118, v121, v118\n"
-        "v_div_scale_f32 v119, vcc, 1.0, v116, 1.0\n"
-        "v_mul_f32_e32 v120, v119, v118\n"
-        "v_fma_f32 v121, -v117, v120, v119\n"
-        "v_fmac_f32_e32 v120, v121, v118\n"
-        "v_fma_f32 v117, -v117, v120, v119\n"
-        "v_div_fmas_f32 v117, v117, v118, v120\n"
-        "v_mul_f32_e32 v123, v104, v113\n"                  // dot(s, s1)
-        "v_mul_f32_e32 v122, v105, v114\n"
-        "v_add_f32_e32 v123, v123, v122\n"
-        "v_mul_f32_e32 v122, v106, v115\n"
-        "v_add_f32_e32 v123, v123, v122\n"
-        "v_div_fixup_f32 v117, v117, v116, 1.0\n"           // invDivisor
-        "v_mul_f32_e32 v113, v105, v109\n"                  // s2 = cross(s, e1)
-        "v_mul_f32_e32 v122, v106, v108\n"
-        "v_sub_f32_e32 v113, v113, v122\n"
-        "v_mul_f32_e32 v114, v106, v107\n"
-        "v_mul_f32_e32 v122, v104, v109\n"
-        "v_sub_f32_e32 v114, v114, v122\n"
-        "v_mul_f32_e32 v115, v104, v108\n"
-        "v_mul_f32_e32 v122, v105, v107\n"
-        "v_sub_f32_e32 v115, v115, v122\n"
-        "v_mul_f32_e32 v123, v123, v117\n"                  // b1
-        "v_mul_f32_e32 v118, v84, v113\n"                    // dot(d, s2)
-        "v_mul_f32_e32 v122, v85, v114\n"
-        "v_add_f32_e32 v118, v118, v122\n"
-        "v_mul_f32_e32 v122, v86, v115\n"
-        "v_add_f32_e32 v118, v118, v122\n"
-        "v_mul_f32_e32 v118, v118, v117\n"                    // b2
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v116), s76\n"      // !(|divisor| < 1e-8)
-        "v_cmp_ngt_f32_e32 vcc, 0, v123\n"                  // !(b1 < 0)
+        "v_mul_f32_e32 v36, v33, v27\n"                  // divisor = dot(s1, e1)
+        "v_mul_f32_e32 v42, v34, v28\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_mul_f32_e32 v42, v35, v29\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        // 1.0f / divisor: one Newton step from v_rcp_f32 IS the IEEE quotient for 2^-100 <= |x| <= 2^100
+        // (all 2^32 inputs checked on gfx950, tools/micro/rcp_exact.hip).  Larger, infinite or NaN divisors
+        // take the IEEE sequence; smaller ones are rejected by the 1e-8 test below whatever the quotient is.
+        "v_rcp_f32_e32 v38, v36\n"
+        "v_sub_f32_e32 v24, v0, v24\n"                   // s = o - v1
+        "v_sub_f32_e32 v25, v1, v25\n"
+        "v_sub_f32_e32 v26, v2, v26\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
+        "v_fma_f32 v41, -v36, v38, 1.0\n"
+        "v_fma_f32 v37, v41, v38, v38\n"                // invDivisor
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TP_DIV_IEEE_%=\n"
+        "TP_DIV_DONE_%=:\n"
+        "v_mul_f32_e32 v43, v24, v33\n"                  // dot(s, s1)
+        "v_mul_f32_e32 v42, v25, v34\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v42, v26, v35\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v33, v25, v29\n"                  // s2 = cross(s, e1)
+        "v_mul_f32_e32 v42, v26, v28\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v26, v27\n"
+        "v_mul_f32_e32 v42, v24, v29\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v24, v28\n"
+        "v_mul_f32_e32 v42, v25, v27\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v43, v43, v37\n"                  // b1
+        "v_mul_f32_e32 v38, v4, v33\n"                    // dot(d, s2)
+        "v_mul_f32_e32 v42, v5, v34\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v42, v6, v35\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v38, v38, v37\n"                    // b2
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"      // !(|divisor| < 1e-8)
+        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"                  // !(b1 < 0)
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v123\n"                // !(b1 > 1)
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"                // !(b1 > 1)
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v118\n"                   // !(b2 < 0)
-        "v_add_f32_e32 v122, v123, v118\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"                   // !(b2 < 0)
+        "v_add_f32_e32 v42, v43, v38\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v122\n"                 // !(b1 + b2 > 1)
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"                 // !(b1 + b2 > 1)
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_and_b64 exec, exec, s[66:67]\n"
         "s_cbranch_scc0 TP_TRI_END_%=\n"
-        "v_mul_f32_e32 v119, v110, v113\n"                   // dot(e2, s2)
-        "v_mul_f32_e32 v122, v111, v114\n"
-        "v_add_f32_e32 v119, v119, v122\n"
-        "v_mul_f32_e32 v122, v112, v115\n"
-        "v_add_f32_e32 v119, v119, v122\n"
-        "v_mul_f32_e32 v119, v119, v117\n"                    // t
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v119\n"              // !(t < tmin)
-        "v_cmp_ngt_f32_e64 s[66:67], v119, v101\n"           // !(t > tmax)
+        "v_mul_f32_e32 v39, v30, v33\n"                   // dot(e2, s2)
+        "v_mul_f32_e32 v42, v31, v34\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v42, v32, v35\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v39, v39, v37\n"                    // t
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"              // !(t < tmin)
+        "v_cmp_ngt_f32_e64 s[66:67], v39, v21\n"           // !(t > tmax)
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_and_b64 exec, exec, s[66:67]\n"
         "s_cbranch_scc0 TP_TRI_END_%=\n"
         // accepted: new closest hit (any-hit rays stop here)
-        "v_and_b32_e32 v122, 0x100, v91\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v122\n"
-        "v_mov_b32_e32 v104, %[end]\n"
-        "v_mov_b32_e32 v101, v119\n"
-        "v_subrev_u32_e32 v100, 48, v93\n"
-        "v_mov_b32_e32 v102, v123\n"
-        "v_mov_b32_e32 v103, v118\n"
-        "v_cndmask_b32_e32 v92, v92, v104, vcc\n"
-        "v_cndmask_b32_e64 v94, v94, -1, vcc\n"
+        "v_and_b32_e32 v42, 0x100, v11\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v42\n"
+        "v_mov_b32_e32 v24, %[end]\n"
+        "v_mov_b32_e32 v21, v39\n"
+        "v_subrev_u32_e32 v20, 48, v13\n"
+        "v_mov_b32_e32 v22, v43\n"
+        "v_mov_b32_e32 v23, v38\n"
+        "v_cndmask_b32_e32 v12, v12, v24, vcc\n"
+        "v_cndmask_b32_e64 v14, v14, -1, vcc\n"
         "TP_TRI_END_%=:\n"
         "s_mov_b64 exec, -1\n"
         "s_branch TP_LOOP_%=\n"
+        "TP_DIV_IEEE_%=:\n"
+        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
+        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
+        "v_rcp_f32_e32 v38, v37\n"
+        "s_nop 0\n"
+        "v_fma_f32 v41, -v37, v38, 1.0\n"
+        "v_fmac_f32_e32 v38, v41, v38\n"
+        "v_mul_f32_e32 v40, v39, v38\n"
+        "v_fma_f32 v41, -v37, v40, v39\n"
+        "v_fmac_f32_e32 v40, v41, v38\n"
+        "v_fma_f32 v37, -v37, v40, v39\n"
+        "v_div_fmas_f32 v37, v37, v38, v40\n"
+        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
+        "s_branch TP_DIV_DONE_%=\n"
+        // ---- some rays finished: store results; the idle count only changes here, so does the refill test ----
+        "TP_FIN_%=:\n"
+        "s_mov_b64 exec, s[68:69]\n"
+        "s_mov_b32 s72, 0xaaaaaaab\n"
+        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
+        "v_subrev_u32_e32 v33, %[bias], v20\n"
+        "v_mul_hi_u32 v33, v33, s72\n"
+        "v_lshrrev_b32_e32 v33, 5, v33\n"                 // (cursor - bias) / 48
+        "v_cndmask_b32_e64 v20, v33, -1, vcc\n"
+        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"        // m_busy
+        "ds_write_b128 v15, v[20:23] offset:16\n"
+        "v_mov_b32_e32 v15, -1\n"
+        "s_mov_b64 exec, -1\n"
+        "TP_FILL_%=:\n"
+        "s_cmp_ge_i32 s70, %[rays]\n"
+        "s_cbranch_scc1 TP_EMPTY_%=\n"
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
+        "s_cmp_gt_u32 s71, %[maxbusy]\n"
+        "s_cbranch_scc1 TP_VOTE_%=\n"
+        // refill: idle lanes take the next slots in lane order
+        "s_not_b64 s[66:67], s[64:65]\n"
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
+        "v_add_u32_e32 v33, s70, v33\n"
+        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
+        "s_and_b64 s[66:67], vcc, s[66:67]\n"
+        "s_sub_i32 s71, 64, s71\n"
+        "s_add_i32 s70, s70, s71\n"
+        "s_mov_b64 exec, s[66:67]\n"
+        "v_lshl_add_u32 v15, v33, 5, %[pool]\n"
+        "ds_read_b128 v[4:7], v15\n"
+        "ds_read_b128 v[8:11], v15 offset:16\n"
+        "v_mov_b32_e32 v12, %[first]\n"
+        "v_mov_b32_e32 v13, 0\n"
+        "v_mov_b32_e32 v14, -1\n"
+        "v_mov_b32_e32 v20, -1\n"
+        "v_mov_b32_e32 v22, 0\n"
+        "v_mov_b32_e32 v23, 0\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32_e32 v33, 0xff, v11\n"
+        "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
+        "ds_read_b96 v[0:2], v33 offset:%[org]\n"
+        "v_mov_b32_e32 v21, v7\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TP_LOOP_%=\n"
+        "TP_EMPTY_%=:\n"                                     // nothing left to fetch
+        "s_cmp_lg_u64 s[64:65], 0\n"
+        "s_cbranch_scc1 TP_VOTE_%=\n"
         "TP_DONE_%=:\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
@@ -593,9 +629,9 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias),
           [eps] "s"(s_eps), [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-          "s72", "s76", "v80", "v81", "v82", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
-          "v95", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
-          "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
+          "s72", "s76", "s77", "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14",
+          "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32",
+          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -1609,7 +1645,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 mem.first = (int)lds_address(lds_scene);
                 mem.end = mem.first + 32 * P.n_nodes;
                 mem.tri_bias = mem.end;
-                if (COUNT)
+                if (COUNT && !PT_ASM_IN_COUNT)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);

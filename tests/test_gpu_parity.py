@@ -192,12 +192,14 @@ def test_tonemapped_output(gpt):
         cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, filmic=filmic)
         _, _, out_o = ol.render(scene, cam, W, H, 0.001, 1, 5, kind="soft", want_out=True)
         out_t = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()        # torch fills on its own stream; the renderer has its own
         with gpt.Renderer(scene.desc, W, H, 0.001) as r:
             r.render(cam, 1, 5, reset=True, out_dev=out_t.data_ptr())
             r.synchronize()
             out_g = out_t.cpu().numpy()
             assert_bit_exact(out_g, out_o, f"fused tonemap filmic={filmic}")
             out2 = torch.zeros_like(out_t)
+            torch.cuda.synchronize()
             r.tonemap(5, filmic, out2.data_ptr())
             r.synchronize()
             assert_bit_exact(out2.cpu().numpy(), out_o, f"tonemap pass filmic={filmic}")
