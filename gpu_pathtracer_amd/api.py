@@ -248,7 +248,7 @@ class Renderer:
         c = np.zeros(16, dtype=np.uint64)
         check(self.lib.gpt_read_probe_counters(self.ctx, st.ptr(c)))
         names = ["node_visits", "prim_tests", "bounce_iters", "shadow_rays", "closest_rays", "samples",
-                 "w_node", "w_prim", "w_trip", "l_trip", "w_shade", "l_shade", "w_nee", "l_nee", "cyc_trace", "cyc_shade"]
+                 "w_node", "w_prim", "w_trip", "l_trip", "cyc_direct", "cyc_hit", "cyc_regen", "unused13", "cyc_trace", "cyc_shade"]
         return dict(zip(names, map(int, c)))
 
     def close(self):

@@ -131,6 +131,9 @@ constexpr int kWaveLdsFloat4 = 2 * kPoolSlots + 64;   // slots (2 x float4) + on
 #ifndef PT_ASM_IN_COUNT
 #define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
 #endif
+#ifndef PT_SUBPROBES
+#define PT_SUBPROBES 0            // 1 (with PT_ASM_IN_COUNT): finer time split of the hit-shading block
+#endif
 #ifndef PT_VOTE_NODE_SHIFT
 #define PT_VOTE_NODE_SHIFT 1      // a node trip costs half a triangle trip: 2 * node-waiters >= triangle-waiters
 #endif
@@ -1352,6 +1355,28 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
+    unsigned long long cyc_direct = 0, cyc_hit = 0, cyc_regen = 0, cyc_sub = 0;                                // ... split of cyc_shade
+#define PT_SUBPHASE(acc)                                                                     \
+    if (COUNT) {                                                                             \
+        const unsigned long long now_ = __builtin_readcyclecounter();                        \
+        if (lane == 0) acc += now_ - cyc_sub;                                                \
+        cyc_sub = now_;                                                                      \
+    }
+    // PT_SUBPROBES (probe builds only): marks inside divergent code, booked by whichever lane is first active
+    // through a per-wave LDS record {mark, h[0..6]}
+#if PT_SUBPROBES
+    __shared__ unsigned long long lds_probe[4 * 8];
+    unsigned long long *probe = lds_probe + (threadIdx.x >> 6) * 8;
+    if (lane < 8) probe[lane] = 0;
+#define PT_MARK(i)                                                                           \
+    if (first_active_lane()) {                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter();                        \
+        probe[1 + (i)] += now_ - probe[0];                                                   \
+        probe[0] = now_;                                                                     \
+    }
+#else
+#define PT_MARK(i)
+#endif
 
     const uint32_t n_items = n_owned * P.n_chunks;
     for (;;) {
@@ -1401,6 +1426,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
 
         for (;;) {
             bool finish = false;
+            if (COUNT) cyc_sub = __builtin_readcyclecounter();
+            PT_MARK(0)
             if (alive) {
                 // ---- resolve the direct light of the previous bounce ------------------
                 if (direct) {
@@ -1439,6 +1466,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                     direct = false;
                 }
                 if (ending) finish = true;
+                PT_SUBPHASE(cyc_direct)
 
                 // ---- the path ray came back: pathtracer.cu:905-1016 ----------------------
                 if (!finish && q.has_p) {
@@ -1458,6 +1486,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                         const V3 wo = -q.dir_p;
                         const gpt_material material = P.materials[isect.matIdx];
                         q.has_s = q.has_m = q.has_p = false;
+                        PT_MARK(1)
 
                         if ((bounces == 0 || specular) && isect.lightIdx != -1) {
                             Li += beta * area_le(P.lights[isect.lightIdx], nor, wo);
@@ -1501,6 +1530,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                         q.has_s = true;
                                     }
                                 }
+                                PT_MARK(2)
                                 float usx = rng_uniform(rng);
                                 float usy = rng_uniform(rng);
                                 float usz = rng_uniform(rng);
@@ -1536,6 +1566,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 }
                                 beta_ld = beta;
                                 direct = true;
+                                PT_MARK(3)
                             }
                             // continuation.  The reference also samples it on the last bounce and
                             // then leaves the loop; nothing of that sample reaches Li, so it is skipped.
@@ -1566,6 +1597,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                     }
                                 }
                             }
+                            PT_MARK(4)
                             if (ending && !q.has_s && !q.has_m) {
                                 if (direct) {      // nothing to wait for: Ld = 0
                                     Li += beta_ld * v3(0.f, 0.f, 0.f);
@@ -1578,6 +1610,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 }
             }
 
+            PT_SUBPHASE(cyc_hit)
             if (finish) {
                 // The sample goes to its iteration's plane as is; the finite-guard of pathtracer.cu:1019-1020
                 // and the accumulation run in iteration order in pt_output_kernel.
@@ -1621,6 +1654,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 alive = true;
                 if (COUNT) cnt.samples++;
             }
+            PT_SUBPHASE(cyc_regen)
             if (!__any(alive)) {
                 if (next_sample >= n_item_samples) break;
                 continue;                              // only samples of pixels outside the frame were drawn
@@ -1699,10 +1733,20 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         atomicAdd(&P.counters[7], (unsigned long long)cnt.w_prim);
         atomicAdd(&P.counters[8], (unsigned long long)cnt.w_trip);
         atomicAdd(&P.counters[9], (unsigned long long)cnt.l_trip);
-        atomicAdd(&P.counters[10], (unsigned long long)cnt.w_shade);
-        atomicAdd(&P.counters[11], (unsigned long long)cnt.l_shade);
-        atomicAdd(&P.counters[12], (unsigned long long)cnt.w_nee);
-        atomicAdd(&P.counters[13], (unsigned long long)cnt.l_nee);
+#if PT_SUBPROBES
+        if (lane == 0) {
+            atomicAdd(&P.counters[6], probe[2]);    // make_hit + material      (reuses w_node..l_trip, unused with the asm loop)
+            atomicAdd(&P.counters[7], probe[3]);    // light sample + BSDF eval
+            atomicAdd(&P.counters[8], probe[4]);    // MIS sample + emitter pre-test
+            atomicAdd(&P.counters[9], probe[5]);    // continuation sample + roulette
+            atomicAdd(&P.counters[13], probe[1]);   // everything between the last mark of a round and the first of the next
+        }
+#endif
+        if (lane == 0) {     // split of cyc_shade: direct-light resolution | hit shading | finish + regeneration | (rest: pool)
+            atomicAdd(&P.counters[10], cyc_direct);
+            atomicAdd(&P.counters[11], cyc_hit);
+            atomicAdd(&P.counters[12], cyc_regen);
+        }
         if (lane == 0) {
             atomicAdd(&P.counters[14], cyc_trace);     // shader-clock cycles this wave spent draining pools
             atomicAdd(&P.counters[15], cyc_shade);     // ... and everywhere else (shading, regeneration, deposit)
