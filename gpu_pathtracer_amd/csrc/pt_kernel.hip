@@ -234,6 +234,12 @@ struct LdsScene {
     float tri1(int) const { return 0.f; }
 #endif
 };
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)      // wave-uniform value -> SGPR pair
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned lds_address(const void *p)      // LDS byte address of a __shared__ object
 {
     return (unsigned)(unsigned long long)p;                          // low half of the flat (shared aperture) address
@@ -392,6 +398,228 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 // (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
+// The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
+// loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
+#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, ...) \
+    asm volatile( \
+        "s_mov_b32 s70, 0\n" \
+        "s_mov_b32 s76, 0x322bcc77\n" \
+        "s_mov_b32 s77, 0x71800000\n" \
+        "s_mov_b64 s[64:65], 0\n" \
+        "v_mov_b32_e32 v12, %[end]\n" \
+        "v_mov_b32_e32 v13, 0\n" \
+        "v_mov_b32_e32 v14, -1\n" \
+        "v_mov_b32_e32 v15, -1\n" \
+        "s_branch TP_FILL_%=\n" \
+        "TP_LOOP_%=:\n" \
+        "v_cmp_le_i32_e64 s[60:61], v13, v14\n" \
+        "v_cmp_gt_i32_e64 s[62:63], %[end], v12\n" \
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n" \
+        "s_or_b64 s[66:67], s[60:61], s[62:63]\n" \
+        "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n" \
+        "s_cbranch_scc1 TP_FIN_%=\n" \
+        "TP_VOTE_%=:\n" \
+        "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n" \
+        "s_bcnt1_i32_b64 s71, s[62:63]\n" \
+        "s_bcnt1_i32_b64 s72, s[60:61]\n" \
+        "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n" \
+        "s_cmp_ge_u32 s71, s72\n" \
+        "s_cbranch_scc0 TP_TRI_%=\n" \
+        "s_mov_b64 exec, s[62:63]\n" \
+        LD_NODE \
+        WAIT_1 \
+        "v_sub_f32_e32 v33, v24, v0\n" \
+        "v_sub_f32_e32 v34, v27, v0\n" \
+        "v_sub_f32_e32 v35, v25, v1\n" \
+        "v_sub_f32_e32 v37, v26, v2\n" \
+        WAIT_0 \
+        "v_sub_f32_e32 v36, v28, v1\n" \
+        "v_sub_f32_e32 v38, v29, v2\n" \
+        "v_mul_f32_e32 v33, v8, v33\n" \
+        "v_mul_f32_e32 v34, v8, v34\n" \
+        "v_mul_f32_e32 v35, v9, v35\n" \
+        "v_mul_f32_e32 v36, v9, v36\n" \
+        "v_mul_f32_e32 v37, v10, v37\n" \
+        "v_mul_f32_e32 v38, v10, v38\n" \
+        "v_min_f32_e32 v39, v33, v34\n" \
+        "v_min_f32_e32 v40, v35, v36\n" \
+        "v_min_f32_e32 v41, v37, v38\n" \
+        "v_max_f32_e32 v33, v33, v34\n" \
+        "v_max_f32_e32 v35, v35, v36\n" \
+        "v_max_f32_e32 v37, v37, v38\n" \
+        "v_min3_f32 v33, v33, v35, v37\n" \
+        "v_max3_f32 v39, v39, v40, v41\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v33\n" \
+        "v_min_f32_e32 v33, v33, v21\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], v33, v39\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_lt_i32_e32 vcc, -1, v31\n" \
+        "v_add_u32_e32 v33, 32, v12\n" \
+        "s_or_b64 s[68:69], vcc, s[66:67]\n" \
+        "s_and_b64 vcc, vcc, s[66:67]\n" \
+        "v_cndmask_b32_e64 v12, v30, v33, s[68:69]\n" \
+        "v_cndmask_b32_e32 v14, v14, v31, vcc\n" \
+        "v_cndmask_b32_e32 v13, v13, v30, vcc\n" \
+        "s_mov_b64 exec, -1\n" \
+        "s_branch TP_LOOP_%=\n" \
+        "TP_TRI_%=:\n" \
+        "s_mov_b64 exec, s[60:61]\n" \
+        LD_TRI \
+        "v_add_u32_e32 v13, 48, v13\n" \
+        WAIT_1 \
+        "v_mul_f32_e32 v33, v5, v32\n" \
+        "v_mul_f32_e32 v42, v6, v31\n" \
+        "v_sub_f32_e32 v33, v33, v42\n" \
+        "v_mul_f32_e32 v34, v6, v30\n" \
+        "v_mul_f32_e32 v42, v4, v32\n" \
+        "v_sub_f32_e32 v34, v34, v42\n" \
+        "v_mul_f32_e32 v35, v4, v31\n" \
+        "v_mul_f32_e32 v42, v5, v30\n" \
+        "v_sub_f32_e32 v35, v35, v42\n" \
+        WAIT_0 \
+        "v_mul_f32_e32 v36, v33, v27\n" \
+        "v_mul_f32_e32 v42, v34, v28\n" \
+        "v_add_f32_e32 v36, v36, v42\n" \
+        "v_mul_f32_e32 v42, v35, v29\n" \
+        "v_add_f32_e32 v36, v36, v42\n" \
+        "v_rcp_f32_e32 v38, v36\n" \
+        "v_sub_f32_e32 v24, v0, v24\n" \
+        "v_sub_f32_e32 v25, v1, v25\n" \
+        "v_sub_f32_e32 v26, v2, v26\n" \
+        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n" \
+        "v_fma_f32 v41, -v36, v38, 1.0\n" \
+        "v_fma_f32 v37, v41, v38, v38\n" \
+        "s_cmp_lg_u64 s[66:67], 0\n" \
+        "s_cbranch_scc1 TP_DIV_IEEE_%=\n" \
+        "TP_DIV_DONE_%=:\n" \
+        "v_mul_f32_e32 v43, v24, v33\n" \
+        "v_mul_f32_e32 v42, v25, v34\n" \
+        "v_add_f32_e32 v43, v43, v42\n" \
+        "v_mul_f32_e32 v42, v26, v35\n" \
+        "v_add_f32_e32 v43, v43, v42\n" \
+        "v_mul_f32_e32 v33, v25, v29\n" \
+        "v_mul_f32_e32 v42, v26, v28\n" \
+        "v_sub_f32_e32 v33, v33, v42\n" \
+        "v_mul_f32_e32 v34, v26, v27\n" \
+        "v_mul_f32_e32 v42, v24, v29\n" \
+        "v_sub_f32_e32 v34, v34, v42\n" \
+        "v_mul_f32_e32 v35, v24, v28\n" \
+        "v_mul_f32_e32 v42, v25, v27\n" \
+        "v_sub_f32_e32 v35, v35, v42\n" \
+        "v_mul_f32_e32 v43, v43, v37\n" \
+        "v_mul_f32_e32 v38, v4, v33\n" \
+        "v_mul_f32_e32 v42, v5, v34\n" \
+        "v_add_f32_e32 v38, v38, v42\n" \
+        "v_mul_f32_e32 v42, v6, v35\n" \
+        "v_add_f32_e32 v38, v38, v42\n" \
+        "v_mul_f32_e32 v38, v38, v37\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v43\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v38\n" \
+        "v_add_f32_e32 v42, v43, v38\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TP_TRI_END_%=\n" \
+        "v_mul_f32_e32 v39, v30, v33\n" \
+        "v_mul_f32_e32 v42, v31, v34\n" \
+        "v_add_f32_e32 v39, v39, v42\n" \
+        "v_mul_f32_e32 v42, v32, v35\n" \
+        "v_add_f32_e32 v39, v39, v42\n" \
+        "v_mul_f32_e32 v39, v39, v37\n" \
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n" \
+        "v_cmp_ngt_f32_e64 s[66:67], v39, v21\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TP_TRI_END_%=\n" \
+        "v_and_b32_e32 v42, 0x100, v11\n" \
+        "v_cmp_ne_u32_e32 vcc, 0, v42\n" \
+        "v_mov_b32_e32 v24, %[end]\n" \
+        "v_mov_b32_e32 v21, v39\n" \
+        "v_subrev_u32_e32 v20, 48, v13\n" \
+        "v_mov_b32_e32 v22, v43\n" \
+        "v_mov_b32_e32 v23, v38\n" \
+        "v_cndmask_b32_e32 v12, v12, v24, vcc\n" \
+        "v_cndmask_b32_e64 v14, v14, -1, vcc\n" \
+        "TP_TRI_END_%=:\n" \
+        "s_mov_b64 exec, -1\n" \
+        "s_branch TP_LOOP_%=\n" \
+        "TP_DIV_IEEE_%=:\n" \
+        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n" \
+        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n" \
+        "v_rcp_f32_e32 v38, v37\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v41, -v37, v38, 1.0\n" \
+        "v_fmac_f32_e32 v38, v41, v38\n" \
+        "v_mul_f32_e32 v40, v39, v38\n" \
+        "v_fma_f32 v41, -v37, v40, v39\n" \
+        "v_fmac_f32_e32 v40, v41, v38\n" \
+        "v_fma_f32 v37, -v37, v40, v39\n" \
+        "v_div_fmas_f32 v37, v37, v38, v40\n" \
+        "v_div_fixup_f32 v37, v37, v36, 1.0\n" \
+        "s_branch TP_DIV_DONE_%=\n" \
+        "TP_FIN_%=:\n" \
+        "s_mov_b64 exec, s[68:69]\n" \
+        "s_mov_b32 s72, 0xaaaaaaab\n" \
+        "v_cmp_gt_i32_e32 vcc, 0, v20\n" \
+        "v_subrev_u32_e32 v33, %[bias], v20\n" \
+        "v_mul_hi_u32 v33, v33, s72\n" \
+        "v_lshrrev_b32_e32 v33, 5, v33\n" \
+        "v_cndmask_b32_e64 v20, v33, -1, vcc\n" \
+        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n" \
+        "ds_write_b128 v15, v[20:23] offset:16\n" \
+        "v_mov_b32_e32 v15, -1\n" \
+        "s_mov_b64 exec, -1\n" \
+        "TP_FILL_%=:\n" \
+        "s_cmp_ge_i32 s70, %[rays]\n" \
+        "s_cbranch_scc1 TP_EMPTY_%=\n" \
+        "s_bcnt1_i32_b64 s71, s[64:65]\n" \
+        "s_cmp_gt_u32 s71, %[maxbusy]\n" \
+        "s_cbranch_scc1 TP_VOTE_%=\n" \
+        "s_not_b64 s[66:67], s[64:65]\n" \
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n" \
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n" \
+        "v_add_u32_e32 v33, s70, v33\n" \
+        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n" \
+        "s_and_b64 s[66:67], vcc, s[66:67]\n" \
+        "s_sub_i32 s71, 64, s71\n" \
+        "s_add_i32 s70, s70, s71\n" \
+        "s_mov_b64 exec, s[66:67]\n" \
+        "v_lshl_add_u32 v15, v33, 5, %[pool]\n" \
+        "ds_read_b128 v[4:7], v15\n" \
+        "ds_read_b128 v[8:11], v15 offset:16\n" \
+        "v_mov_b32_e32 v12, %[first]\n" \
+        "v_mov_b32_e32 v13, 0\n" \
+        "v_mov_b32_e32 v14, -1\n" \
+        "v_mov_b32_e32 v20, -1\n" \
+        "v_mov_b32_e32 v22, 0\n" \
+        "v_mov_b32_e32 v23, 0\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "v_and_b32_e32 v33, 0xff, v11\n" \
+        "v_lshl_add_u32 v33, v33, 4, %[pool]\n" \
+        "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
+        "v_mov_b32_e32 v21, v7\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_mov_b64 exec, -1\n" \
+        "s_branch TP_LOOP_%=\n" \
+        "TP_EMPTY_%=:\n" \
+        "s_cmp_lg_u64 s[64:65], 0\n" \
+        "s_cbranch_scc1 TP_VOTE_%=\n" \
+        "TP_DONE_%=:\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_mov_b64 exec, -1\n" \
+        : \
+        : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias), \
+          [eps] "s"(s_eps), __VA_ARGS__, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", \
+          "s72", "s76", "s77", "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
+          "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
+          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
+
 __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
@@ -400,241 +628,25 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
     const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    asm volatile(
-        "s_mov_b32 s70, 0\n"
-        "s_mov_b32 s76, 0x322bcc77\n"
-        "s_mov_b32 s77, 0x71800000\n"
-        "s_mov_b64 s[64:65], 0\n"
-        "v_mov_b32_e32 v12, %[end]\n"
-        "v_mov_b32_e32 v13, 0\n"
-        "v_mov_b32_e32 v14, -1\n"
-        "v_mov_b32_e32 v15, -1\n"
-        "s_branch TP_FILL_%=\n"                              // every lane is idle: first refill
-        "TP_LOOP_%=:\n"
-        "v_cmp_le_i32_e64 s[60:61], v13, v14\n"             // want_tri
-        "v_cmp_gt_i32_e64 s[62:63], %[end], v12\n"          // more_nodes
-        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"              // has a ray
-        "s_or_b64 s[66:67], s[60:61], s[62:63]\n"
-        "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n"        // finished: has && !want_tri && !more_nodes
-        "s_cbranch_scc1 TP_FIN_%=\n"
-        "TP_VOTE_%=:\n"
-        // ---- vote ----
-        "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n"        // m_node
-        "s_bcnt1_i32_b64 s71, s[62:63]\n"
-        "s_bcnt1_i32_b64 s72, s[60:61]\n"
-#if PT_VOTE_NODE_SHIFT
-        "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n"
-#endif
-#if PT_VOTE_TRI_SHIFT
-        "s_lshl_b32 s72, s72, " PT_STR(PT_VOTE_TRI_SHIFT) "\n"
-#endif
-        "s_cmp_ge_u32 s71, s72\n"
-        "s_cbranch_scc0 TP_TRI_%=\n"
-        // ---- one node ----
-        "s_mov_b64 exec, s[62:63]\n"
-        "ds_read_b128 v[24:27], v12\n"
-        "ds_read_b128 v[28:31], v12 offset:16\n"
-        "s_waitcnt lgkmcnt(1)\n"
-        "v_sub_f32_e32 v33, v24, v0\n"
-        "v_sub_f32_e32 v34, v27, v0\n"
-        "v_sub_f32_e32 v35, v25, v1\n"
-        "v_sub_f32_e32 v37, v26, v2\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_sub_f32_e32 v36, v28, v1\n"
-        "v_sub_f32_e32 v38, v29, v2\n"
-        "v_mul_f32_e32 v33, v8, v33\n"
-        "v_mul_f32_e32 v34, v8, v34\n"
-        "v_mul_f32_e32 v35, v9, v35\n"
-        "v_mul_f32_e32 v36, v9, v36\n"
-        "v_mul_f32_e32 v37, v10, v37\n"
-        "v_mul_f32_e32 v38, v10, v38\n"
-        "v_min_f32_e32 v39, v33, v34\n"
-        "v_min_f32_e32 v40, v35, v36\n"
-        "v_min_f32_e32 v41, v37, v38\n"
-        "v_max_f32_e32 v33, v33, v34\n"
-        "v_max_f32_e32 v35, v35, v36\n"
-        "v_max_f32_e32 v37, v37, v38\n"
-        "v_min3_f32 v33, v33, v35, v37\n"               // t far
-        "v_max3_f32 v39, v39, v40, v41\n"               // t near
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v33\n"         // !(tf <= 1e-5)
-        "v_min_f32_e32 v33, v33, v21\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v33, v39\n"          // !(tn > tf) && !(tn > tmax)
-        "s_and_b64 s[66:67], s[66:67], vcc\n"               // box
-        "v_cmp_lt_i32_e32 vcc, -1, v31\n"                  // leaf
-        "v_add_u32_e32 v33, 32, v12\n"
-        "s_or_b64 s[68:69], vcc, s[66:67]\n"
-        "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v30, v33, s[68:69]\n"     // (box || leaf) ? next node : escape link
-        "v_cndmask_b32_e32 v14, v14, v31, vcc\n"           // box && leaf: its triangles
-        "v_cndmask_b32_e32 v13, v13, v30, vcc\n"
-        "s_mov_b64 exec, -1\n"
-        "s_branch TP_LOOP_%=\n"
-        // ---- one triangle ----
-        "TP_TRI_%=:\n"
-        "s_mov_b64 exec, s[60:61]\n"
-        "ds_read_b128 v[28:31], v13 offset:16\n"
-        "ds_read_b32 v32, v13 offset:32\n"
-        "ds_read_b128 v[24:27], v13\n"
-        "v_add_u32_e32 v13, 48, v13\n"
-        "s_waitcnt lgkmcnt(1)\n"
-        "v_mul_f32_e32 v33, v5, v32\n"                   // s1 = cross(d, e2)
-        "v_mul_f32_e32 v42, v6, v31\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v6, v30\n"
-        "v_mul_f32_e32 v42, v4, v32\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v4, v31\n"
-        "v_mul_f32_e32 v42, v5, v30\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_mul_f32_e32 v36, v33, v27\n"                  // divisor = dot(s1, e1)
-        "v_mul_f32_e32 v42, v34, v28\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_mul_f32_e32 v42, v35, v29\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        // 1.0f / divisor: one Newton step from v_rcp_f32 IS the IEEE quotient for 2^-100 <= |x| <= 2^100
-        // (all 2^32 inputs checked on gfx950, tools/micro/rcp_exact.hip).  Larger, infinite or NaN divisors
-        // take the IEEE sequence; smaller ones are rejected by the 1e-8 test below whatever the quotient is.
-        "v_rcp_f32_e32 v38, v36\n"
-        "v_sub_f32_e32 v24, v0, v24\n"                   // s = o - v1
-        "v_sub_f32_e32 v25, v1, v25\n"
-        "v_sub_f32_e32 v26, v2, v26\n"
-        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
-        "v_fma_f32 v41, -v36, v38, 1.0\n"
-        "v_fma_f32 v37, v41, v38, v38\n"                // invDivisor
-        "s_cmp_lg_u64 s[66:67], 0\n"
-        "s_cbranch_scc1 TP_DIV_IEEE_%=\n"
-        "TP_DIV_DONE_%=:\n"
-        "v_mul_f32_e32 v43, v24, v33\n"                  // dot(s, s1)
-        "v_mul_f32_e32 v42, v25, v34\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v42, v26, v35\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v33, v25, v29\n"                  // s2 = cross(s, e1)
-        "v_mul_f32_e32 v42, v26, v28\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v26, v27\n"
-        "v_mul_f32_e32 v42, v24, v29\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v24, v28\n"
-        "v_mul_f32_e32 v42, v25, v27\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v43, v43, v37\n"                  // b1
-        "v_mul_f32_e32 v38, v4, v33\n"                    // dot(d, s2)
-        "v_mul_f32_e32 v42, v5, v34\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v42, v6, v35\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v38, v38, v37\n"                    // b2
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"      // !(|divisor| < 1e-8)
-        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"                  // !(b1 < 0)
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"                // !(b1 > 1)
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"                   // !(b2 < 0)
-        "v_add_f32_e32 v42, v43, v38\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"                 // !(b1 + b2 > 1)
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TP_TRI_END_%=\n"
-        "v_mul_f32_e32 v39, v30, v33\n"                   // dot(e2, s2)
-        "v_mul_f32_e32 v42, v31, v34\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v42, v32, v35\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v39, v39, v37\n"                    // t
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"              // !(t < tmin)
-        "v_cmp_ngt_f32_e64 s[66:67], v39, v21\n"           // !(t > tmax)
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TP_TRI_END_%=\n"
-        // accepted: new closest hit (any-hit rays stop here)
-        "v_and_b32_e32 v42, 0x100, v11\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v42\n"
-        "v_mov_b32_e32 v24, %[end]\n"
-        "v_mov_b32_e32 v21, v39\n"
-        "v_subrev_u32_e32 v20, 48, v13\n"
-        "v_mov_b32_e32 v22, v43\n"
-        "v_mov_b32_e32 v23, v38\n"
-        "v_cndmask_b32_e32 v12, v12, v24, vcc\n"
-        "v_cndmask_b32_e64 v14, v14, -1, vcc\n"
-        "TP_TRI_END_%=:\n"
-        "s_mov_b64 exec, -1\n"
-        "s_branch TP_LOOP_%=\n"
-        "TP_DIV_IEEE_%=:\n"
-        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
-        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
-        "v_rcp_f32_e32 v38, v37\n"
-        "s_nop 0\n"
-        "v_fma_f32 v41, -v37, v38, 1.0\n"
-        "v_fmac_f32_e32 v38, v41, v38\n"
-        "v_mul_f32_e32 v40, v39, v38\n"
-        "v_fma_f32 v41, -v37, v40, v39\n"
-        "v_fmac_f32_e32 v40, v41, v38\n"
-        "v_fma_f32 v37, -v37, v40, v39\n"
-        "v_div_fmas_f32 v37, v37, v38, v40\n"
-        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
-        "s_branch TP_DIV_DONE_%=\n"
-        // ---- some rays finished: store results; the idle count only changes here, so does the refill test ----
-        "TP_FIN_%=:\n"
-        "s_mov_b64 exec, s[68:69]\n"
-        "s_mov_b32 s72, 0xaaaaaaab\n"
-        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
-        "v_subrev_u32_e32 v33, %[bias], v20\n"
-        "v_mul_hi_u32 v33, v33, s72\n"
-        "v_lshrrev_b32_e32 v33, 5, v33\n"                 // (cursor - bias) / 48
-        "v_cndmask_b32_e64 v20, v33, -1, vcc\n"
-        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"        // m_busy
-        "ds_write_b128 v15, v[20:23] offset:16\n"
-        "v_mov_b32_e32 v15, -1\n"
-        "s_mov_b64 exec, -1\n"
-        "TP_FILL_%=:\n"
-        "s_cmp_ge_i32 s70, %[rays]\n"
-        "s_cbranch_scc1 TP_EMPTY_%=\n"
-        "s_bcnt1_i32_b64 s71, s[64:65]\n"
-        "s_cmp_gt_u32 s71, %[maxbusy]\n"
-        "s_cbranch_scc1 TP_VOTE_%=\n"
-        // refill: idle lanes take the next slots in lane order
-        "s_not_b64 s[66:67], s[64:65]\n"
-        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
-        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
-        "v_add_u32_e32 v33, s70, v33\n"
-        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
-        "s_and_b64 s[66:67], vcc, s[66:67]\n"
-        "s_sub_i32 s71, 64, s71\n"
-        "s_add_i32 s70, s70, s71\n"
-        "s_mov_b64 exec, s[66:67]\n"
-        "v_lshl_add_u32 v15, v33, 5, %[pool]\n"
-        "ds_read_b128 v[4:7], v15\n"
-        "ds_read_b128 v[8:11], v15 offset:16\n"
-        "v_mov_b32_e32 v12, %[first]\n"
-        "v_mov_b32_e32 v13, 0\n"
-        "v_mov_b32_e32 v14, -1\n"
-        "v_mov_b32_e32 v20, -1\n"
-        "v_mov_b32_e32 v22, 0\n"
-        "v_mov_b32_e32 v23, 0\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_and_b32_e32 v33, 0xff, v11\n"
-        "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
-        "ds_read_b96 v[0:2], v33 offset:%[org]\n"
-        "v_mov_b32_e32 v21, v7\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, -1\n"
-        "s_branch TP_LOOP_%=\n"
-        "TP_EMPTY_%=:\n"                                     // nothing left to fetch
-        "s_cmp_lg_u64 s[64:65], 0\n"
-        "s_cbranch_scc1 TP_VOTE_%=\n"
-        "TP_DONE_%=:\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, -1\n"
-        :
-        : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias),
-          [eps] "s"(s_eps), [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16)
-        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-          "s72", "s76", "s77", "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14",
-          "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32",
-          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
+    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n",
+                 "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
+                 "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", [unused] "n"(0))
+}
+
+// Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
+// 32-bit VGPR-offset form.  (vmcnt also counts this wave's earlier sample stores; they are long gone.)
+__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps)
+{
+    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
+    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
+    const int s_end = __builtin_amdgcn_readfirstlane(mem.end);
+    const int s_first = 0, s_bias = 0;
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
+    const unsigned long long nodes = (unsigned long long)mem.nodes, tris = (unsigned long long)mem.tris;
+    const unsigned long long s_nodes = uniform64(nodes), s_tris = uniform64(tris);
+    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
+                 "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
+                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", [nodes] "s"(s_nodes), [tris] "s"(s_tris))
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -1690,7 +1702,10 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 mem.first = 0;
                 mem.end = 32 * P.n_nodes;
                 mem.tri_bias = 0;
-                trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
+                if (COUNT && !PT_ASM_IN_COUNT)
+                    trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
+                else
+                    trace_pool_global_asm(lds_address(pool), L.n_rays, mem, P.eps);
             }
             if (COUNT) {
                 cyc_mark = __builtin_readcyclecounter();

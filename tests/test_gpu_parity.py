@@ -335,6 +335,25 @@ def test_emitter_pretest_is_exact_with_many_lights_and_env(gpt):
     assert_bit_exact(ag, ao, "3 emitter triangles")
 
 
+@pytest.mark.parametrize("scale,W,H,spp", [(0.3, 160, 120, 4), (1.0, 128, 96, 2)])
+def test_large_scene_in_global_memory(gpt, scale, W, H, spp):
+    """Config-5 stand-in (22k / 253k triangles, 16 bounces): the scene does not fit LDS, traversal reads HBM/L2
+    through 32-bit cursors (device pointers with bit 31 set included); plain and counting build."""
+    scene, meta = scenes.stress_scene(scale, max_depth=16)
+    cam = ol.cornell_camera(meta, W, H)
+    ref, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
+    co = ol.counters("soft")
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"stress scene x{scale}")
+        r.enable_counters(True)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"stress scene x{scale}, counting build")
+        cg = r.read_counters()
+    assert cg["samples"] == co["samples"] and cg["bounce_iters"] == co["bounce_iters"]
+    assert 0 < cg["node_visits"] <= co["node_visits"]
+
+
 # ---- BASELINE.json full size: size-independent properties -------------------------------------
 
 def test_full_hd_properties(gpt):
