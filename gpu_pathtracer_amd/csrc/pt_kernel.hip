@@ -1391,26 +1391,15 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
 #endif
 
     const uint32_t n_items = n_owned * P.n_chunks;
-    for (;;) {
-        // ---- persistent scheduler: one atomic per wave per work item -------------------------
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= n_items) break;
-        const uint32_t chunk = t / n_owned;
-        const uint32_t tile_local = t - chunk * n_owned;
-        const uint32_t tile = P.rank + tile_local * P.n_ranks;
-        const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-        const uint32_t chunk_first = P.iter_first + chunk * P.chunk_iters;
-        const uint32_t chunk_count = (chunk + 1u == P.n_chunks) ? P.iter_count - chunk * P.chunk_iters : P.chunk_iters;
-        // The item's samples (64 pixels x chunk_count iterations, all independent: each goes to its own slot of
-        // its iteration's plane) are handed out dynamically: a lane whose path ends takes the next sample of the
-        // tile, whichever pixel it belongs to, so cheap pixels do not leave their lanes idle.
-        // sample s -> pixel s % 64 of the tile, iteration chunk_first + s / 64.
-        const uint32_t n_item_samples = 64u * chunk_count;
-        uint32_t next_sample = 0;                       // wave-uniform
-        uint32_t x = 0, y = 0, pixel = 0, iter = chunk_first;
-
+    // ---- persistent scheduler: one atomic per wave per work item.  The item's samples (64 pixels x chunk_count
+    // iterations, all independent: each goes to its own slot of its iteration's plane) are handed out dynamically:
+    // a lane whose path ends takes the next sample of the tile, whichever pixel it belongs to, and when the item
+    // runs out the wave fetches its next item in the same round - it never drains between items, only once, at
+    // the end of the launch.  sample s -> pixel s % 64 of the tile, iteration chunk_first + s / 64.
+    uint32_t tx = 0, ty = 0, chunk_first = 0, n_item_samples = 0, next_sample = 0;     // wave-uniform
+    bool more_items = true;
+    uint32_t x = 0, y = 0, pixel = 0, iter = 0;
+    {
         // ---- per-path state ---------------------------------------------------------
         Rng rng;
         rng.x = 1;
@@ -1634,6 +1623,24 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             }
             // ---- regenerate: pathtracer.cu:881-903 ---------------------------------------
             bool start = false;
+            if (next_sample >= n_item_samples && more_items && !__all(alive)) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= n_items) {
+                    more_items = false;
+                } else {
+                    const uint32_t chunk = t / n_owned;
+                    const uint32_t tile_local = t - chunk * n_owned;
+                    const uint32_t tile = P.rank + tile_local * P.n_ranks;
+                    tx = tile % P.tiles_x;
+                    ty = tile / P.tiles_x;
+                    chunk_first = P.iter_first + chunk * P.chunk_iters;
+                    const uint32_t chunk_count = (chunk + 1u == P.n_chunks) ? P.iter_count - chunk * P.chunk_iters : P.chunk_iters;
+                    n_item_samples = 64u * chunk_count;
+                    next_sample = 0;
+                }
+            }
             if (next_sample < n_item_samples) {
                 const unsigned long long m_idle = ballot(!alive);
                 const uint32_t s = next_sample + (uint32_t)lane_rank(m_idle);
@@ -1668,7 +1675,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             }
             PT_SUBPHASE(cyc_regen)
             if (!__any(alive)) {
-                if (next_sample >= n_item_samples) break;
+                if (next_sample >= n_item_samples && !more_items) break;
                 continue;                              // only samples of pixels outside the frame were drawn
             }
 

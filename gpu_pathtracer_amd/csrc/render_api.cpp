@@ -420,14 +420,17 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         P.iter_count = iter_count - done < batch_cap ? iter_count - done : batch_cap;
         P.reset = (reset && done == 0) ? 1 : 0;
         P.out = (done + P.iter_count == iter_count) ? out_tonemapped_dev : nullptr;
-        // Work items = (iteration chunk, tile), all independent.  The batch is cut into chunks until there
-        // are about kItemsPerWave (24) items per resident wave (small frames and multi-GPU shards would otherwise
-        // wait for their slowest tile); a chunk is never shorter than kMinChunk iterations because lanes idle
-        // while a wave drains at the end of each item.
-        const long kItemsPerWave = 24, kMinChunk = 8;
-        long n_chunks = (kItemsPerWave * resident_waves + n_owned - 1) / n_owned;
-        const long max_chunks = P.iter_count / kMinChunk > 0 ? P.iter_count / kMinChunk : 1;
-        if (n_chunks > max_chunks) n_chunks = max_chunks;
+        // Work items = (iteration chunk, tile), all independent; a wave streams from one item into the next
+        // without draining.  Two costs pull in opposite directions: every item costs a queue round trip and a
+        // partly filled hand-out (~5 us of a wave's time), and at the end of the launch waves wait for the last
+        // items (~half an item).  With I items per wave the sum is I*o/T + 1/(2I), minimal at I = sqrt(T/(2o));
+        // T is estimated from the sample count at ~1 sample/us/wave.  1080p x 64 iterations: full frame -> chunks
+        // of 8-9 iterations, a 1/8 shard -> 3-4 (measured optimum: tools/gpu_chunks.py, profiles/r01/kernel_variants.log).
+        const double owned_samples = (double)n_owned * 64.0 * (double)P.iter_count;
+        double items_per_wave = std::sqrt(owned_samples / (10.0 * (double)resident_waves));
+        if (items_per_wave < 4.0) items_per_wave = 4.0;
+        long n_chunks = (long)(items_per_wave * (double)resident_waves / (double)n_owned + 0.5);
+        if (n_chunks > (long)P.iter_count) n_chunks = (long)P.iter_count;
         if (n_chunks < 1) n_chunks = 1;
         uint32_t chunk_iters = (uint32_t)((P.iter_count + n_chunks - 1) / n_chunks);
         if (ctx->chunk_override) chunk_iters = ctx->chunk_override < P.iter_count ? ctx->chunk_override : P.iter_count;
