@@ -753,6 +753,9 @@ __device__ __forceinline__ V3 get_texel(const DevParams &P, const gpt_material &
 {
     if (m.textureIdx == -1)
         return V3{m.diffuse.x, m.diffuse.y, m.diffuse.z};
+#ifdef PT_ANALYSIS_LAMBERT
+    return V3{0.f, 0.f, 0.f};
+#endif
     const DevTexture t = P.textures[m.textureIdx];
     int w = t.width, h = t.height;
     float xx = w * uv.x;
@@ -873,6 +876,12 @@ __device__ __forceinline__ float power_heuristic(int nf, float fPdf, int ng, flo
 }
 __device__ __forceinline__ float luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)); }
 __device__ __forceinline__ bool same_hemisphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }
+// PT_ANALYSIS_LAMBERT (never shipped): compile only the lambertian / area-light path, to read its ISA
+#ifdef PT_ANALYSIS_LAMBERT
+#define PT_MATERIAL_TYPE(m) GPT_MT_LAMBERTIAN
+#else
+#define PT_MATERIAL_TYPE(m) (m).type
+#endif
 __device__ __forceinline__ bool is_delta(int type) { return type == GPT_MT_MIRROR || type == GPT_MT_DIELECTRIC; }
 __device__ __forceinline__ float max_(float a, float b) { return a > b ? a : b; }                     // common.h:98-101
 
@@ -881,7 +890,7 @@ __device__ __forceinline__ void sample_bsdf(const DevParams &P, const gpt_materi
                                             V3 dpdu, V3 u, V3 &out, V3 &fr, float &pdf)
 {
     const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
-    switch (material.type) {
+    switch (PT_MATERIAL_TYPE(material)) {
     case GPT_MT_LAMBERTIAN: {
         V3 n = nor;
         if (dot(nor, in) < 0)
@@ -1054,7 +1063,7 @@ __device__ __forceinline__ void eval_bsdf(const DevParams &P, const gpt_material
                                           V2 uv, V3 dpdu, V3 &fr, float &pdf)
 {
     const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
-    switch (material.type) {
+    switch (PT_MATERIAL_TYPE(material)) {
     case GPT_MT_LAMBERTIAN:
         if (!same_hemisphere(in, out, nor)) {
             fr = v3(0.f, 0.f, 0.f);
@@ -1386,6 +1395,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         probe[1 + (i)] += now_ - probe[0];                                                   \
         probe[0] = now_;                                                                     \
     }
+#elif defined(PT_ISA_MARKS)        // analysis builds: comments in the .s that delimit the shading sub-phases
+#define PT_MARK(i) asm volatile("; ISA_MARK " #i);
 #else
 #define PT_MARK(i)
 #endif
@@ -1496,7 +1507,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                             q.org = pos;
                             // direct light with multiple importance sampling: everything that
                             // does not depend on visibility is evaluated now
-                            if (!is_delta(material.type)) {
+                            if (!is_delta(PT_MATERIAL_TYPE(material))) {
                                 float u = rng_uniform(rng);
                                 float choicePdf;
                                 int idx = lookup_light_distribution(P, u, choicePdf);
@@ -1581,7 +1592,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 sample_bsdf(P, material, wo, nor, uv, dpdu, v3(ux, uy, uz), out, fr, pdf);
                                 if (!is_black(fr)) {
                                     beta *= fr * fabs_(dot(nor, out)) / pdf;
-                                    specular = is_delta(material.type);
+                                    specular = is_delta(PT_MATERIAL_TYPE(material));
                                     bool kill = false;
                                     if (bounces > 3) {
                                         float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
@@ -1612,6 +1623,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             }
 
             PT_SUBPHASE(cyc_hit)
+            PT_MARK(8)
             if (finish) {
                 // The sample goes to its iteration's plane as is; the finite-guard of pathtracer.cu:1019-1020
                 // and the accumulation run in iteration order in pt_output_kernel.
@@ -1674,6 +1686,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 if (COUNT) cnt.samples++;
             }
             PT_SUBPHASE(cyc_regen)
+            PT_MARK(5)
             if (!__any(alive)) {
                 if (next_sample >= n_item_samples && !more_items) break;
                 continue;                              // only samples of pixels outside the frame were drawn
@@ -1687,6 +1700,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             // ---- deposit this bounce's rays, drain the pool, pick up the results -----------------
             if (!alive) q.has_p = q.has_m = q.has_s = false;
             const PoolLayout L = pool_deposit(pool, q, lane);
+            PT_MARK(6)
             wave_lds_fence();
             unsigned long long c0 = 0;
             if (COUNT) {
