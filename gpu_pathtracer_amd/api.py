@@ -44,6 +44,7 @@ def load():
     sig = {
         "gpt_begin": [vp, u32, u32, f32, C.c_int, C.POINTER(vp)],
         "gpt_set_tile_owner": [vp, C.c_int, C.c_int],
+        "gpt_set_integrator": [vp, i32, i32, C.c_float],
         "gpt_render": [vp, vp, u32, u32, C.c_int, vp],
         "gpt_tonemap": [vp, u32, C.c_int, vp],
         "gpt_synchronize": [vp],
@@ -188,6 +189,15 @@ class Renderer:
 
     def set_tile_owner(self, rank, n_ranks):
         check(self.lib.gpt_set_tile_owner(self.ctx, rank, n_ranks))
+
+    def set_integrator(self, kind, value):
+        """"pt": value = maxDepth; "ao": value = maxDist (the reference reads both from the scene on every Render call)"""
+        if kind == "pt":
+            check(self.lib.gpt_set_integrator(self.ctx, st.IT_PT, int(value), 0.0))
+        elif kind == "ao":
+            check(self.lib.gpt_set_integrator(self.ctx, st.IT_AO, 0, float(value)))
+        else:
+            raise ValueError(f"integrator {kind!r} is not supported (pt, ao)")
 
     def render(self, camera, iter_first, iter_count, reset=False, out_dev=None):
         check(self.lib.gpt_render(self.ctx, C.byref(camera), int(iter_first), int(iter_count), int(bool(reset)), out_dev))

@@ -36,8 +36,13 @@ void BeginRender(Scene &scene, unsigned width, unsigned height, float ep)
 
 void Render(Scene &scene, unsigned width, unsigned height, Camera *camera, unsigned iter, bool reset, float3_t *output)
 {
-    (void)scene; (void)width; (void)height;   // fixed at BeginRender, as in the reference
+    (void)width; (void)height;                // fixed at BeginRender, as in the reference
     if (!g_ctx) { std::fprintf(stderr, "Render: BeginRender has not succeeded\n"); return; }
+    // the integrator is read from the scene on every call (pathtracer.cu:2711-2715)
+    if (gpt_set_integrator(g_ctx, (int32_t)scene.integrator.type, scene.integrator.maxDepth, scene.integrator.maxDist) != GPT_OK) {
+        report("Render");
+        return;
+    }
     if (gpt_render(g_ctx, camera, iter, 1, reset ? 1 : 0, reinterpret_cast<float *>(output)) != GPT_OK) report("Render");
 }
 

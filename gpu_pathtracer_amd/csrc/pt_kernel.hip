@@ -1332,7 +1332,9 @@ struct RayResults {    // this lane's own rays, read back from the pool
 // the vector-memory pipe.
 constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray pools exactly 4 workgroups per CU
 
-template <bool COUNT, bool SMALL>
+// INTEG: GPT_IT_PT = Path (pathtracer.cu:880-1021), GPT_IT_AO = Ao (:830-876: one cosine-weighted occlusion ray
+// of length maxDist per primary hit; the same pools, drain and sample planes)
+template <bool COUNT, bool SMALL, int INTEG>
 __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
     __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
@@ -1483,9 +1485,9 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 // ---- the path ray came back: pathtracer.cu:905-1016 ----------------------
                 if (!finish && q.has_p) {
                     if (res.prim_p < 0) {
-                        if ((bounces == 0 || specular) && P.inf.isvalid)
+                        if (INTEG == GPT_IT_PT && (bounces == 0 || specular) && P.inf.isvalid)
                             Li += beta * inf_le(P.inf, q.dir_p);
-                        finish = true;
+                        finish = true;          // Ao: the sample is 0 (pathtracer.cu:852-855)
                     } else {
                         Ray r;
                         r.o = q.org;
@@ -1500,7 +1502,36 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                         q.has_s = q.has_m = q.has_p = false;
                         PT_MARK(1)
 
-                        if ((bounces == 0 || specular) && isect.lightIdx != -1) {
+                        if (INTEG == GPT_IT_AO) {
+                            // pathtracer.cu:857-872
+                            V3 n = nor;
+                            if (dot(wo, nor) < 0.f)
+                                n = -n;
+                            float u1 = rng_uniform(rng);
+                            float u2 = rng_uniform(rng);
+                            float pdf;
+                            V3 dir = cosine_hemisphere(u1, u2, pdf);
+                            V3 uu = dpdu, ww;
+                            ww = cross(uu, n);
+                            dir = to_world(dir, uu, n, ww);
+                            float cosine = dot(dir, n);
+                            float v = cosine * ONE_OVER_PI / pdf;
+                            cand = v3(v, v, v);                 // L += v if the occlusion ray escapes
+                            beta_ld = v3(1.f, 1.f, 1.f);
+                            q.org = pos;
+                            if (!is_black(cand)) {               // a zero term adds nothing either way (NaN is traced)
+                                q.dir_s = dir;
+                                q.tmax_s = P.ao_max_dist;
+                                q.has_s = true;
+                            }
+                            direct = true;
+                            ending = true;
+                            if (!q.has_s) {
+                                Li += beta_ld * v3(0.f, 0.f, 0.f);
+                                direct = false;
+                                finish = true;
+                            }
+                        } else if ((bounces == 0 || specular) && isect.lightIdx != -1) {
                             Li += beta * area_le(P.lights[isect.lightIdx], nor, wo);
                             finish = true;
                         } else {
@@ -1809,7 +1840,8 @@ __global__ void __launch_bounds__(256) pt_output_kernel(const DevParams P)
     for (uint32_t k = 0; k < P.iter_count; ++k, s += P.plane) {
         const float4 sv = *s;
         const V3 Li = V3{sv.x, sv.y, sv.z};
-        if (!is_inf(Li) && !is_nan(Li)) col = Li;
+        // Path stores a finite sample (pathtracer.cu:1019), Ao any sample that is not NaN (:874)
+        if (P.integrator == GPT_IT_AO ? !is_nan(Li) : (!is_inf(Li) && !is_nan(Li))) col = Li;
         acc += col;
     }
     P.acc[3 * pixel] = acc.x;
@@ -1879,8 +1911,8 @@ namespace pt {
 int render_kernel_blocks_per_cu(bool count)
 {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true>, 256, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true>, 256, 0);
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true, GPT_IT_PT>, 256, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true, GPT_IT_PT>, 256, 0);
     if (e != hipSuccess || n < 1) n = 2;
     if (n > 8) n = 8;
     return n;
@@ -1890,10 +1922,20 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream
 {
     const bool small = 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4 &&
                        !getenv("GPT_NO_LDS_SCENE");
-    if (count && small) hipLaunchKernelGGL((pt_render_kernel<true, true>), dim3(n_blocks), dim3(256), 0, stream, P);
-    else if (count) hipLaunchKernelGGL((pt_render_kernel<true, false>), dim3(n_blocks), dim3(256), 0, stream, P);
-    else if (small) hipLaunchKernelGGL((pt_render_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL((pt_render_kernel<false, false>), dim3(n_blocks), dim3(256), 0, stream, P);
+    const bool ao = P.integrator == GPT_IT_AO;
+#define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
+    if (!ao) {
+        if (count && small) PT_LAUNCH(true, true, GPT_IT_PT);
+        else if (count) PT_LAUNCH(true, false, GPT_IT_PT);
+        else if (small) PT_LAUNCH(false, true, GPT_IT_PT);
+        else PT_LAUNCH(false, false, GPT_IT_PT);
+    } else {
+        if (count && small) PT_LAUNCH(true, true, GPT_IT_AO);
+        else if (count) PT_LAUNCH(true, false, GPT_IT_AO);
+        else if (small) PT_LAUNCH(false, true, GPT_IT_AO);
+        else PT_LAUNCH(false, false, GPT_IT_AO);
+    }
+#undef PT_LAUNCH
     return hipGetLastError();
 }
 

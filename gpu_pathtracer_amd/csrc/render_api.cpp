@@ -190,8 +190,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         return GPT_ERR_INVALID_ARG;
     }
     *out = nullptr;
-    if (scene->integrator_type != GPT_IT_PT) {
-        gpt_set_error("gpt_begin: integrator type %d is not supported (only \"pt\")", scene->integrator_type);
+    if (scene->integrator_type != GPT_IT_PT && scene->integrator_type != GPT_IT_AO) {
+        gpt_set_error("gpt_begin: integrator type %d is not supported (\"pt\" and \"ao\" are)", scene->integrator_type);
         return GPT_ERR_UNSUPPORTED;
     }
     if (scene->n_prims < 0 || scene->n_nodes < 0 || scene->n_materials <= 0 || scene->n_light_distribution < 1) {
@@ -325,7 +325,9 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.n_materials = scene->n_materials;
     P.n_lights = scene->n_lights;
     P.n_cdf = scene->n_light_distribution;
-    P.max_depth = scene->max_depth;
+    P.integrator = scene->integrator_type;
+    P.max_depth = scene->integrator_type == GPT_IT_PT ? scene->max_depth : 0;
+    P.ao_max_dist = scene->integrator_type == GPT_IT_AO ? scene->max_dist : 0.f;
     P.eps = epsilon;
 
     // ---- film: reference launch geometry (pathtracer.cu:2707-2709, 881-883)
@@ -372,6 +374,19 @@ int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks)
     }
     ctx->P.rank = (uint32_t)rank;
     ctx->P.n_ranks = (uint32_t)n_ranks;
+    return GPT_OK;
+}
+
+int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth, float max_dist)
+{
+    if (!ctx) { gpt_set_error("gpt_set_integrator: null context"); return GPT_ERR_INVALID_ARG; }
+    if (integrator_type != GPT_IT_PT && integrator_type != GPT_IT_AO) {
+        gpt_set_error("gpt_set_integrator: integrator type %d is not supported (\"pt\" and \"ao\" are)", integrator_type);
+        return GPT_ERR_UNSUPPORTED;
+    }
+    ctx->P.integrator = integrator_type;
+    if (integrator_type == GPT_IT_PT) ctx->P.max_depth = max_depth;
+    else ctx->P.ao_max_dist = max_dist;
     return GPT_OK;
 }
 

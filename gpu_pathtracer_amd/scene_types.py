@@ -54,6 +54,7 @@ AREA = np.dtype({
 })
 
 MT_LAMBERTIAN, MT_MIRROR, MT_DIELECTRIC, MT_ROUGHDIELECTRIC, MT_ROUGHCONDUCTOR, MT_SUBSTRATE = range(6)
+IT_AO = 0
 IT_PT = 1
 
 
@@ -99,8 +100,19 @@ class SceneDesc(C.Structure):
         ("light_distribution", C.c_void_p), ("n_light_distribution", C.c_int32),
         ("infinite", C.c_void_p),
         ("textures", C.c_void_p), ("n_textures", C.c_int32),
-        ("integrator_type", C.c_int32), ("max_depth", C.c_int32),
+        ("integrator_type", C.c_int32), ("max_depth", C.c_int32),     # max_depth shares storage with max_dist (ao)
     ]
+
+    def set_integrator(self, kind, value):
+        """kind "pt": value = maxDepth (int); kind "ao": value = maxDist (float) - the reference's union."""
+        import struct
+        if kind == "pt":
+            self.integrator_type, self.max_depth = IT_PT, int(value)
+        elif kind == "ao":
+            self.integrator_type = IT_AO
+            self.max_depth = struct.unpack("<i", struct.pack("<f", float(value)))[0]
+        else:
+            raise ValueError(f"integrator {kind!r} is not supported (pt, ao)")
 
 
 assert C.sizeof(Infinite) == 72 and Infinite.center.offset == 16 and Infinite.isvalid.offset == 68

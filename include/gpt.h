@@ -34,7 +34,7 @@ extern "C" {
 
 #define GPT_OK                 0
 #define GPT_ERR_INVALID_ARG   -1
-#define GPT_ERR_UNSUPPORTED   -2   /* integrator other than "pt", non-triangle primitive */
+#define GPT_ERR_UNSUPPORTED   -2   /* integrator other than "pt" / "ao", non-triangle primitive */
 #define GPT_ERR_HIP           -3   /* a HIP runtime call failed (message has file:line) */
 #define GPT_ERR_NO_DEVICE     -4
 #define GPT_ERR_IO            -5
@@ -60,6 +60,11 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
  * (zero), so a sum-reduce of the accumulators over ranks equals the 1-GPU image
  * bit for bit.  Default rank 0 of 1. */
 int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks);
+
+/* The reference reads scene.integrator.{type, maxDepth | maxDist} on the host at every Render() call
+ * (src/pathtracer.cu:2711-2715); gpt_begin takes them from the scene description and this call changes them
+ * afterwards.  GPT_IT_PT uses max_depth, GPT_IT_AO uses max_dist; other integrators: GPT_ERR_UNSUPPORTED. */
+int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth, float max_dist);
 
 /* Render (src/pathtracer.cu:2705-2750), batched: for iter = iter_first ..
  * iter_first+iter_count-1 add one sample per pixel, seeded by (pixel, iter),

@@ -156,8 +156,11 @@ typedef struct gpt_scene_desc {
     const gpt_infinite *infinite;    /* &scene.infinite (may be NULL = invalid) */
     const gpt_texture *textures;     /* scene.textures */
     int32_t n_textures;
-    int32_t integrator_type;         /* scene.integrator.type, must be GPT_IT_PT */
-    int32_t max_depth;               /* scene.integrator.maxDepth */
+    int32_t integrator_type;         /* scene.integrator.type: GPT_IT_PT or GPT_IT_AO */
+    union {                          /* the reference's anonymous union (src/scene.h:38-46) */
+        int32_t max_depth;           /* scene.integrator.maxDepth (pt) */
+        float max_dist;              /* scene.integrator.maxDist  (ao) */
+    };
 } gpt_scene_desc;
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@
  *   BSDFs          pathtracer.cu:51-169,491-826 (all six material types)
  *   textures       pathtracer.cu:324-359
  *   lights         area.h:14-41, infinite.h:17-94, pathtracer.cu:172-185
- *   integrator     pathtracer.cu:880-1021       (Path)
+ *   integrator     pathtracer.cu:880-1021       (Path), :830-876 (Ao)
  *   film           pathtracer.cu:187-204,2516-2531 (Output: accumulate + tonemap)
  *   BVH build      bvh.cpp:38-173               (binned SAH, preorder flatten)
  *   scene init     scene.h:50-83                (light power CDF, env bounding sphere)
@@ -1052,6 +1052,55 @@ static int path_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uin
     return 0;
 }
 
+/* ---- Ao: pathtracer.cu:830-876 ---------------------------------------------------------------------- */
+/* returns 1 and writes *L_out when the reference stores the sample (always on a miss, `!IsNan(L)` on a hit -
+ * an infinite value IS stored, unlike Path's guard) */
+static int ao_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint32_t y, uint32_t pixel,
+                     uint32_t iter, float maxDist, f3 *L_out)
+{
+    rng_t rng;
+    rng_seed(&rng, wang_hash(pixel) + wang_hash(iter));
+
+    float offsetx = rng_uniform(&rng) - 0.5f;
+    float offsety = rng_uniform(&rng) - 0.5f;
+    float du1 = rng_uniform(&rng);
+    float du2 = rng_uniform(&rng);
+    f2 aperture = uniform_disk(du1, du2);
+    ray_t ray = generate_primary_ray(cam, x + offsetx, y + offsety, aperture);
+    ray.tmin = sc->eps;
+
+    f3 L = mk3(0.f, 0.f, 0.f);
+    isect_t isect;
+    t_cnt.samples++;
+    if (!intersect_closest(sc, &ray, &isect)) {
+        *L_out = mk3(0.f, 0.f, 0.f);
+        return 1;
+    }
+    t_cnt.bounce_iters++;
+    f3 pos = isect.pos;
+    f3 nor = isect.nor;
+    float pdf = 0.f;
+    if (dot3(neg3(ray.d), nor) < 0.f)
+        nor = neg3(nor);
+    float u1 = rng_uniform(&rng);
+    float u2 = rng_uniform(&rng);
+    f3 dir = cosine_hemisphere(u1, u2, &pdf);
+    f3 uu = isect.dpdu, ww;
+    ww = cross3(uu, nor);
+    dir = to_world(dir, uu, nor, ww);
+    float cosine = dot3(dir, nor);
+    ray_t r = mk_ray(pos, dir, sc->eps, maxDist);
+    if (!intersect_any(sc, &r)) {
+        float v = cosine * ONE_OVER_PI / pdf;
+        L = add3(L, mk3(v, v, v));
+    }
+    if (!is_nan3(L)) {
+        *L_out = L;
+        return 1;
+    }
+    return 0;
+}
+
 /* ---- Output: pathtracer.cu:187-204, 2516-2531 ---------------------------------------------------------- */
 static inline f3 tonemap(f3 color, int filmic)
 {
@@ -1087,7 +1136,8 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
                       float eps, uint32_t iter_first, uint32_t iter_count, int reset,
                       float *acc, float *color, float *out, int rank, int n_ranks, int n_threads)
 {
-    if (desc->integrator_type != GPT_IT_PT) return -1;
+    if (desc->integrator_type != GPT_IT_PT && desc->integrator_type != GPT_IT_AO) return -1;
+    const int ao = desc->integrator_type == GPT_IT_AO;
     scene_t sc;
     sc.d = desc;
     sc.eps = eps;
@@ -1114,7 +1164,8 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
                 if (reset) a = mk3(0, 0, 0);
                 for (uint32_t it = iter_first; it < iter_first + iter_count; ++it) {
                     f3 Li;
-                    if (path_sample(&sc, cam, x, y, pixel, it, maxDepth, &Li))
+                    if (ao ? ao_sample(&sc, cam, x, y, pixel, it, desc->max_dist, &Li)
+                           : path_sample(&sc, cam, x, y, pixel, it, maxDepth, &Li))
                         c = Li;
                     a = add3(a, c);
                 }

@@ -384,3 +384,43 @@ def test_full_hd_properties(gpt):
     assert pg.tobytes() == po.tobytes()
     mask = po != 0
     assert (full[mask] == po[mask]).all()
+
+
+# ---- Ao integrator (pathtracer.cu:830-876) -------------------------------------------------------
+
+@pytest.mark.parametrize("what", ["cornell", "zoo_global", "thin_lens"])
+def test_ambient_occlusion_bit_exact(gpt, what):
+    """One cosine-weighted occlusion ray of length maxDist per primary hit; misses write 0; only NaN is discarded."""
+    if what == "cornell":
+        scene, meta = ol.load_cornell(4)
+        W, H, max_dist = 200, 136, 0.5
+        cam = ol.cornell_camera(meta, W, H)
+    elif what == "zoo_global":
+        extra = scenes.concat([scenes.uv_sphere((-0.35, 1.3, 0.2), 0.3, 7), scenes.random_soup(1200, 5, mats=(2, 0, 1))])
+        scene, meta = scenes.zoo_scene(max_depth=4, extra=extra, assign={})
+        W, H, max_dist = 160, 128, 0.25
+        cam = ol.cornell_camera(meta, W, H)
+    else:
+        scene, meta = ol.load_cornell(4)
+        W, H, max_dist = 128, 96, 3.0
+        cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, aperture=0.15, focal=6.0)
+    scene.desc.set_integrator("ao", max_dist)
+    ao_o, col_o, out_o = ol.render(scene, cam, W, H, 0.001, 1, 8, kind="soft", want_out=True)
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        r.render(cam, 1, 8, reset=True)
+        assert_bit_exact(r.read_accum(), ao_o, f"ao {what}")
+        assert_bit_exact(r.read_color(), col_o, f"ao {what} last sample")
+        # the integrator is read at every Render call: switch to Path and back on the same context
+        r.set_integrator("pt", 4)
+        r.render(cam, 1, 2, reset=True)
+        scene.desc.set_integrator("pt", 4)
+        pt_o, _ = ol.render(scene, cam, W, H, 0.001, 1, 2, kind="soft")
+        assert_bit_exact(r.read_accum(), pt_o, f"pt after ao {what}")
+        r.set_integrator("ao", max_dist)
+        r.render(cam, 1, 8, reset=True)
+        assert_bit_exact(r.read_accum(), ao_o, f"ao again {what}")
+        r.enable_counters(True)
+        r.render(cam, 1, 8, reset=True)
+        assert_bit_exact(r.read_accum(), ao_o, f"ao {what}, counting build")
+    mean = ao_o.reshape(-1, 3).mean(0) / 8
+    assert 0.05 < mean[0] < 1.0 and mean[0] == mean[1] == mean[2]

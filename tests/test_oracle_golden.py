@@ -148,3 +148,32 @@ def test_tile_ownership_partitions_the_frame():
     # supports are disjoint
     nz = [(p.reshape(-1, 3) != 0).any(1) for p in parts]
     assert not (nz[0] & nz[1]).any() and not (nz[0] & nz[2]).any() and not (nz[1] & nz[2]).any()
+
+
+def test_ambient_occlusion_oracle_properties():
+    """Ao (pathtracer.cu:830-876) has no golden values in the reference (parity unpinned): check what the
+    algorithm implies.  An unoccluded sample is cos*(1/pi)/(cos/pi) = 1 up to rounding; with a tiny maxDist
+    everything the camera sees is open; a long one darkens the box; misses are 0; thread count does not matter."""
+    scene, meta = ol.load_cornell(4)
+    W, H = 96, 64
+    cam = ol.cornell_camera(meta, W, H)
+    scene.desc.set_integrator("ao", 1e-3)
+    a, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft")
+    img = a.reshape(H, W, 3) / np.float32(4)
+    hit = img[..., 0] > 0
+    assert hit.any() and (~hit).any()                         # 96x64 framing: the box in the middle, nothing beside it
+    per_sample = a.reshape(H, W, 3)[..., 0]                    # every sample is 0 (miss) or 1 (open), so sums are ~integers
+    assert np.abs(per_sample - np.round(per_sample)).max() < 4e-6
+    assert (np.round(per_sample) == 4).sum() > 0.5 * hit.sum()
+    scene.desc.set_integrator("ao", 10.0)
+    b1, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft", threads=1)
+    b8, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft", threads=8)
+    assert b1.tobytes() == b8.tobytes()
+    hit = np.round(per_sample) == 4
+    inside = (b1.reshape(H, W, 3) / np.float32(4))[hit]
+    assert inside.mean() < 0.25                                  # a closed box: almost every 10-unit ray is blocked
+    scene.desc.set_integrator("ao", 0.5)
+    c_soft, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft")
+    c_libm, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="libm")
+    assert np.abs(c_soft - c_libm).max() <= 1.0 + 1e-6 and np.mean(c_soft != c_libm) < 1e-3
+    assert 0.25 < (c_soft.reshape(H, W, 3) / np.float32(4))[hit].mean() < 1.0

@@ -303,6 +303,22 @@ def test_shipped_vpt_scene_settings_are_refused_at_begin(scene_dir):
     assert ls.desc.integrator_type == st.IT_PT and ls.desc.max_depth == 8
 
 
+def test_ao_scene_settings(scene_dir):
+    """"integrator": "ao" + "maxDist" (parsescene.cpp:186-188; default 0.5) land in the union the renderer reads."""
+    import struct
+    js = json.load(open(scene_dir / "scene.json"))
+    js["integrator"] = "ao"
+    js.pop("maxDepth", None)
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    ls = api.LoadedScene(str(scene_dir / "scene.json"))
+    assert ls.desc.integrator_type == st.IT_AO
+    assert struct.unpack("<f", struct.pack("<i", ls.desc.max_depth))[0] == 0.5
+    js["maxDist"] = 0.75
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    ls = api.LoadedScene(str(scene_dir / "scene.json"))
+    assert struct.unpack("<f", struct.pack("<i", ls.desc.max_depth))[0] == 0.75
+
+
 def test_png_writer_follows_savepng(tmp_path):
     """flip Y, clamp, truncate (reference src/imageio.cpp:61-78)"""
     from PIL import Image
