@@ -386,6 +386,72 @@ def test_full_hd_properties(gpt):
     assert (full[mask] == po[mask]).all()
 
 
+def full_size_properties(gpt, scene, cam, W, H, eps, spp, n_crop, crop_rank):
+    """Size-independent properties at a BASELINE.json frame size: batching invariance, tile-partition invariance
+    (the multi-GPU rule: shards sum to the frame), all finite, and an oracle-checked crop (1/n_crop of the tiles,
+    spread over the frame, rendered by the oracle through the same tile-ownership rule)."""
+    # a fresh context per check: `reset` clears the accumulator but not kernel_color (as in the reference), and a
+    # pixel whose first sample is not finite re-adds whatever kernel_color held before
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.render(cam, 1, spp, reset=True)
+        full = r.read_accum()
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.render(cam, 1, 1, reset=True)
+        if spp > 1:
+            r.render(cam, 2, spp - 1, reset=False)
+        assert full.tobytes() == r.read_accum().tobytes(), "batching"
+    total = np.zeros_like(full)
+    for k in range(4):                                       # 4 shards, as 4 ranks would render them
+        with gpt.Renderer(scene.desc, W, H, eps) as r:
+            r.set_tile_owner(k, 4)
+            r.render(cam, 1, spp, reset=True)
+            total += r.read_accum()
+    assert total.tobytes() == full.tobytes(), "tile partition"
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.set_tile_owner(crop_rank, n_crop)
+        r.render(cam, 1, spp, reset=True)
+        crop_g = r.read_accum()
+    assert np.isfinite(full).all()
+    crop_o, _ = ol.render(scene, cam, W, H, eps, 1, spp, rank=crop_rank, n_ranks=n_crop)
+    assert crop_g.tobytes() == crop_o.tobytes(), "oracle crop"
+    mask = crop_o != 0
+    assert mask.any() and (full[mask] == crop_o[mask]).all()
+    return full
+
+
+def test_config3_material_scene_full_hd(gpt):
+    """BASELINE config 3 stand-in (the shaderball meshes are not shipped): anisotropic rough conductor,
+    glass, substrate and mirror on smooth-shaded spheres, checker texture, 1920x1080, depth 10, eps 0.0005."""
+    extra = scenes.concat([scenes.uv_sphere((-0.45, 0.45, 0.3), 0.4, 8, nu=24, nv=16), scenes.uv_sphere((0.4, 0.35, 0.45), 0.33, 7, nu=24, nv=16),
+                           scenes.uv_sphere((0.05, 1.25, -0.3), 0.35, 10, nu=24, nv=16)])
+    scene, meta = scenes.zoo_scene(max_depth=10, extra=extra, assign={"short": 5, "tall": 13, "floor": 12, "back": 9})
+    W, H = 1920, 1080
+    cam = ol.cornell_camera(meta, W, H)
+    full_size_properties(gpt, scene, cam, W, H, 0.0005, 2, 128, 37)
+
+
+def test_config4_environment_light_full_hd(gpt):
+    """BASELINE config 4 stand-in: no area light, a lat-long environment map with rotation lights 22k triangles;
+    depth 7; the frame is the sum of its tile shards (what the RCCL reduce adds up)."""
+    prims, _, meta = scenes.cornell_raw()
+    allp = scenes.concat([prims[0:2], scenes.stress_parts(0.3)])          # floor + three dense blobs, open to the sky
+    c, s_ = np.float32(np.cos(np.pi / 6)), np.float32(np.sin(np.pi / 6))
+    scene = ol.make_scene(allp, scenes.material_table(), light_radiance=meta["light_radiance"], max_depth=7, env=scenes.sky_env(256, 128),
+                          env_rotate_uvw=((c, 0.0, -s_), (0.0, 1.0, 0.0), (s_, 0.0, c)), textures=[scenes.checker_texture()])
+    W, H = 1920, 1080
+    cam = ol.make_camera((0.3, 1.4, 5.5), (0, 0.8, 0), (0, 1, 0), (W, H), 35.0)
+    full = full_size_properties(gpt, scene, cam, W, H, 0.001, 2, 128, 90)
+    assert (full.reshape(H, W, 3).sum(-1) > 0).mean() > 0.95             # the sky is visible behind everything
+
+
+def test_config5_stress_scene_4k(gpt):
+    """BASELINE config 5 stand-in: 253 300 triangles, 16 bounces, 3840x2160."""
+    scene, meta = scenes.stress_scene(1.0, max_depth=16)
+    W, H = 3840, 2160
+    cam = ol.cornell_camera(meta, W, H)
+    full_size_properties(gpt, scene, cam, W, H, 0.001, 1, 1024, 411)
+
+
 # ---- Ao integrator (pathtracer.cu:830-876) -------------------------------------------------------
 
 @pytest.mark.parametrize("what", ["cornell", "zoo_global", "thin_lens"])
