@@ -158,6 +158,20 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the compute-side picture next to the (logical) HBM figure: wave-level VALU instructions issued per second
+        # against what 1024 SIMDs can issue (one fp32 wave64 instruction per ~2.43 cycles, measured with
+        # tools/micro/issue_rate.hip); instruction counts come from the committed SQ counter pass
+        valu = None
+        sq = os.path.join(ROOT, "profiles", "pmc_sq.json")
+        if os.path.exists(sq) and world == 1:
+            try:
+                n_valu = json.load(open(sq)).get("valu_insts_per_launch")
+                peak_issue = 1024 * 2.4e9 / 2.43
+                valu = {"insts_per_launch": n_valu, "achieved_per_s": n_valu / (avg_ms * 1e-3), "peak_per_s": peak_issue,
+                        "frac": n_valu / (avg_ms * 1e-3) / peak_issue,
+                        "active_lanes_of_64": json.load(open(sq)).get("active_lanes_per_valu_inst")}
+            except Exception:
+                valu = None
         line = {
             "metric": "Msamples/s at 1920x1080, 8-bounce PT",
             "value": samples / dt_max / 1e6,
@@ -174,8 +188,8 @@ def main():
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pt::pt_render_kernel<false, true> (counting off, BVH staged in LDS)", "avg_launch_ms": avg_ms, "launches": launches,
-                         "algorithmic_bytes_per_sample": b_alg,
+                         "kernel": "pt::pt_render_kernel<false, true, 1> (counting off, scene staged in LDS, Path integrator)", "avg_launch_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_sample": b_alg, "valu_issue": valu,
                          "note": "algorithmic = reference-layout bytes (SURVEY.md 8d); the 7.4 KB scene is "
                                  "cache-resident, so this logical figure can exceed the HBM peak"},
         }

@@ -20,3 +20,5 @@ python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summa
 # keep the merge small: drop the big traces, keep stats + summaries
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 du -sh $OUT
+# instruction counts of the path kernel (SQ counters, own passes) -> pmc_sq.json for bench.py's valu_issue figure
+bash tools/pmc_sq.sh $TAG/sq > /dev/null 2>&1; cat $OUT/sq/sq_summary.txt 2>/dev/null | tail -8

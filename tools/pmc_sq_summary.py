@@ -17,3 +17,12 @@ if g("SQ_WAVE_CYCLES"):
         if g(k): print(f"{k}/SQ_WAVE_CYCLES = {g(k)/g('SQ_WAVE_CYCLES'):.3f}")
 if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
     print("SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.3f" % (g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CYCLES")))
+
+# machine-readable copy for bench.py (profiles/pmc_sq.json): instruction counts per launch of the path kernel
+import json
+if g("SQ_INSTS_VALU"):
+    json.dump({"valu_insts_per_launch": g("SQ_INSTS_VALU"), "salu_insts_per_launch": g("SQ_INSTS_SALU"),
+               "lds_insts_per_launch": g("SQ_INSTS_LDS"),
+               "active_lanes_per_valu_inst": (g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")) if g("SQ_ACTIVE_INST_VALU") else None,
+               "note": "rocprofv3 --pmc SQ_INSTS_* (own passes), mean over pt_render_kernel launches of bench.py"},
+              open(os.path.join(out, "pmc_sq.json"), "w"))
