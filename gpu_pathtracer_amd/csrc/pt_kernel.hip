@@ -137,6 +137,13 @@ constexpr int kWaveLdsFloat4 = 2 * kPoolSlots + 64;   // slots (2 x float4) + on
 #ifndef PT_VOTE_NODE_SHIFT
 #define PT_VOTE_NODE_SHIFT 1      // a node trip costs half a triangle trip: 2 * node-waiters >= triangle-waiters
 #endif
+// scenes in global memory: a node trip waits on L2/HBM and most of a long ray's steps are node steps, so triangle
+// trips are taken earlier: node trip iff node-waiters >= 2 * triangle-waiters (253k-triangle stand-in at 4K:
+// node-biased 534, plain majority 604, this rule 656, 4x 650, 8x 604 Msamples/s)
+#ifndef PT_GLOBAL_VOTE_WEIGHT
+#define PT_GLOBAL_VOTE_WEIGHT "s_lshl_b32 s72, s72, 1\n"
+#define PT_GLOBAL_VOTE_TRI_SHIFT 1
+#endif
 #ifndef PT_VOTE_TRI_SHIFT
 #define PT_VOTE_TRI_SHIFT 0
 #endif
@@ -213,12 +220,14 @@ struct GlobalScene {
     const char *nodes, *tris;
     int first, end;                        // cursor of node 0, cursor one past the last node
     int tri_bias;                          // cursor of triangle 0
+    static constexpr int vote_node_shift = 0, vote_tri_shift = PT_GLOBAL_VOTE_TRI_SHIFT;
     __device__ __forceinline__ float4 node4(int c) const { return *reinterpret_cast<const float4 *>(nodes + (unsigned)c); }
     __device__ __forceinline__ float4 tri4(int c) const { return *reinterpret_cast<const float4 *>(tris + (unsigned)c); }
     __device__ __forceinline__ float tri1(int c) const { return *reinterpret_cast<const float *>(tris + (unsigned)c); }
 };
 struct LdsScene {
     int first, end, tri_bias;
+    static constexpr int vote_node_shift = PT_VOTE_NODE_SHIFT, vote_tri_shift = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float native4 __attribute__((ext_vector_type(4)));
     __device__ __forceinline__ float4 node4(int c) const
@@ -308,7 +317,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         if (COUNT && first_active_lane()) { cnt.w_trip++; cnt.l_trip += (uint32_t)popc(m_busy); }
 
         const unsigned long long m_node = m_more & ~m_tri;
-        const bool node_trip = (popc(m_node) << PT_VOTE_NODE_SHIFT) >= (popc(m_tri) << PT_VOTE_TRI_SHIFT);
+        const bool node_trip = (popc(m_node) << Mem::vote_node_shift) >= (popc(m_tri) << Mem::vote_tri_shift);
         {
             if (node_trip && more_nodes && !want_tri) {
                 // ---- one node --------------------------------------------------------------
@@ -400,7 +409,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 #define PT_STR(x) PT_STR2(x)
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
-#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, ...) \
+#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ...) \
     asm volatile( \
         "s_mov_b32 s70, 0\n" \
         "s_mov_b32 s76, 0x322bcc77\n" \
@@ -422,7 +431,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n" \
         "s_bcnt1_i32_b64 s71, s[62:63]\n" \
         "s_bcnt1_i32_b64 s72, s[60:61]\n" \
-        "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n" \
+        VOTE_WEIGHT \
         "s_cmp_ge_u32 s71, s72\n" \
         "s_cbranch_scc0 TP_TRI_%=\n" \
         "s_mov_b64 exec, s[62:63]\n" \
@@ -630,7 +639,8 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
     PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n",
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
-                 "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", [unused] "n"(0))
+                 "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
+                 "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n", [unused] "n"(0))
 }
 
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
@@ -646,7 +656,7 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     const unsigned long long s_nodes = uniform64(nodes), s_tris = uniform64(tris);
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
-                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", [nodes] "s"(s_nodes), [tris] "s"(s_tris))
+                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT, [nodes] "s"(s_nodes), [tris] "s"(s_tris))
 }
 
 // mesh.h:68-95 evaluated once for the final hit
