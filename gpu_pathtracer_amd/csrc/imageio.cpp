@@ -11,8 +11,8 @@
 // output), a PNG reader (8-bit grey / grey+alpha / RGB / RGBA / palette,
 // non-interlaced) on a small inflate, and PFM (little- or big-endian float32)
 // for linear radiance and environment maps, an OpenEXR scanline reader (NONE / RLE / ZIPS / ZIP,
-// half / float) for the reference's environment maps, and a baseline JPEG reader for textures.
-// Progressive JPEG and EXR PIZ are not implemented (DESIGN.md "Next").
+// half / float) for the reference's environment maps, and a baseline + progressive JPEG reader for textures.
+// EXR PIZ is not implemented (DESIGN.md "Next").
 #include "imageio.h"
 
 #include <cmath>
@@ -321,11 +321,11 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
     return true;
 }
 
-// ---- baseline JPEG (sequential DCT, Huffman, 8-bit, 1 or 3 components, any h/v sampling, restart
-// intervals).  Chroma is up-sampled by replication and the inverse DCT is evaluated in float; stb_image, which
+// ---- JPEG: baseline and progressive DCT (Huffman, 8-bit, 1 or 3 components, any h/v sampling, restart
+// intervals; spectral selection and successive approximation for SOF2 files).  Chroma is up-sampled by replication and the inverse DCT is evaluated in float; stb_image, which
 // the reference uses, has its own fixed-point IDCT and smooth chroma filter, so texel values can differ from
-// the reference's by a few 8-bit steps (parity of JPEG textures is unpinned — DESIGN.md).  Progressive and
-// arithmetic-coded files are refused.
+// the reference's by a few 8-bit steps (parity of JPEG textures is unpinned — DESIGN.md).  Arithmetic-coded,
+// lossless and hierarchical files are refused.
 namespace {
 struct JpegHuff {
     unsigned char bits[17] = {0};
@@ -420,8 +420,12 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
     if (!read_file(path, d) || d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return false;
     float qt[4][64] = {{0}};
     JpegHuff hdc[4], hac[4];
-    struct Comp { int id, h, v, tq, td, ta, pred; std::vector<unsigned char> plane; int pw, ph; } comp[3];
+    // coefficients of every 8x8 block (natural order, not yet dequantised): a progressive file fills them in over
+    // several scans (spectral selection Ss..Se, successive approximation Ah/Al), a baseline file in one
+    struct Comp { int id, h, v, tq, td, ta, pred; std::vector<short> coef; int bw, bh, pw, ph; } comp[3];
     int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
+    bool progressive = false, have_scan = false;
+    int mcux = 0, mcuy = 0;
     width = height = 0;
     size_t pos = 2;
     while (pos + 4 <= d.size()) {
@@ -457,8 +461,9 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
                 q += (size_t)total;
                 h.build();
             }
-        } else if (marker == 0xc0 || marker == 0xc1) {
-            if (seglen < 6 || seg[0] != 8) return false;
+        } else if (marker == 0xc0 || marker == 0xc1 || marker == 0xc2) {
+            if (width || seglen < 6 || seg[0] != 8) return false;
+            progressive = marker == 0xc2;
             height = seg[1] << 8 | seg[2];
             width = seg[3] << 8 | seg[4];
             ncomp = seg[5];
@@ -468,76 +473,201 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
                 comp[i].h = seg[7 + 3 * i] >> 4;
                 comp[i].v = seg[7 + 3 * i] & 15;
                 comp[i].tq = seg[8 + 3 * i];
-                if (comp[i].h < 1 || comp[i].v < 1 || comp[i].tq > 3) return false;
+                if (comp[i].h < 1 || comp[i].v < 1 || comp[i].h > 4 || comp[i].v > 4 || comp[i].tq > 3) return false;
                 if (comp[i].h > hmax) hmax = comp[i].h;
                 if (comp[i].v > vmax) vmax = comp[i].v;
             }
-        } else if (marker == 0xc2 || (marker >= 0xc5 && marker <= 0xcf && marker != 0xc8 && marker != 0xcc)) {
-            return false;    // progressive / lossless / arithmetic
+            mcux = (width + 8 * hmax - 1) / (8 * hmax);
+            mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (int i = 0; i < ncomp; ++i) {
+                comp[i].bw = mcux * comp[i].h;            // blocks per row / column, padded to whole MCUs
+                comp[i].bh = mcuy * comp[i].v;
+                comp[i].pw = comp[i].bw * 8;
+                comp[i].ph = comp[i].bh * 8;
+                comp[i].coef.assign((size_t)comp[i].bw * comp[i].bh * 64, 0);
+                comp[i].pred = 0;
+                comp[i].td = comp[i].ta = 0;
+            }
+        } else if (marker >= 0xc5 && marker <= 0xcf && marker != 0xc8 && marker != 0xcc) {
+            return false;    // lossless / hierarchical / arithmetic coding
         } else if (marker == 0xdd) {
             if (seglen < 2) return false;
             restart = seg[0] << 8 | seg[1];
         } else if (marker == 0xda) {
-            if (!width || seglen < 1 || seg[0] != ncomp) return false;
-            for (int i = 0; i < ncomp; ++i) {
+            if (!width || seglen < 1) return false;
+            const int ns = seg[0];
+            if (ns < 1 || ns > ncomp || seglen < 1 + 2 * (size_t)ns + 3) return false;
+            int order[3];
+            for (int i = 0; i < ns; ++i) {
                 const int cid = seg[1 + 2 * i];
-                for (int k = 0; k < ncomp; ++k)
-                    if (comp[k].id == cid) { comp[k].td = seg[2 + 2 * i] >> 4; comp[k].ta = seg[2 + 2 * i] & 15; }
+                int k = 0;
+                while (k < ncomp && comp[k].id != cid) ++k;
+                if (k == ncomp) return false;
+                comp[k].td = seg[2 + 2 * i] >> 4;
+                comp[k].ta = seg[2 + 2 * i] & 15;
+                if (comp[k].td > 3 || comp[k].ta > 3) return false;
+                order[i] = k;
             }
-            const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
-            for (int i = 0; i < ncomp; ++i) {
-                comp[i].pw = mcux * comp[i].h * 8;
-                comp[i].ph = mcuy * comp[i].v * 8;
-                comp[i].plane.assign((size_t)comp[i].pw * comp[i].ph, 0);
-                comp[i].pred = 0;
-                if (comp[i].td > 3 || comp[i].ta > 3) return false;
-            }
+            int ss = seg[1 + 2 * ns], se = seg[2 + 2 * ns];
+            const int ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if (!progressive) { ss = 0; se = 63; if (ah || al) return false; }
+            else if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || ah > 13 || al > 13) return false;
             JpegBits br{d.data(), d.size(), pos + len};
-            int count = 0;
-            for (int my = 0; my < mcuy; ++my)
-                for (int mx = 0; mx < mcux; ++mx) {
-                    if (restart && count && count % restart == 0) {
-                        br.reset();
-                        while (br.pos + 1 < br.n && !(br.p[br.pos] == 0xff && br.p[br.pos + 1] >= 0xd0 && br.p[br.pos + 1] <= 0xd7)) ++br.pos;
-                        br.pos += 2;
-                        for (int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+            for (int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+            int eobrun = 0;
+
+            // one 8x8 block of component c in this scan
+            auto decode_block = [&](Comp &c, short *blk) -> bool {
+                if (!progressive) {
+                    const int t = br.decode(hdc[c.td]);
+                    if (t < 0 || t > 16) return false;
+                    c.pred += jpeg_extend(br.receive(t), t);
+                    blk[0] = (short)c.pred;
+                    for (int k = 1; k < 64;) {
+                        const int rs = br.decode(hac[c.ta]);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r != 15) break;
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if (k > 63) return false;
+                        blk[zigzag[k]] = (short)jpeg_extend(br.receive(sz), sz);
+                        ++k;
                     }
-                    ++count;
-                    for (int i = 0; i < ncomp; ++i)
-                        for (int by = 0; by < comp[i].v; ++by)
-                            for (int bx = 0; bx < comp[i].h; ++bx) {
-                                float blk[64] = {0};
-                                int t = br.decode(hdc[comp[i].td]);
-                                if (t < 0 || t > 16) return false;
-                                comp[i].pred += jpeg_extend(br.receive(t), t);
-                                blk[0] = comp[i].pred * qt[comp[i].tq][0];
-                                for (int k = 1; k < 64;) {
-                                    const int rs = br.decode(hac[comp[i].ta]);
-                                    if (rs < 0) return false;
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (r != 15) break;
-                                        k += 16;
-                                        continue;
-                                    }
-                                    k += r;
-                                    if (k > 63) return false;
-                                    blk[zigzag[k]] = jpeg_extend(br.receive(sz), sz) * qt[comp[i].tq][zigzag[k]];
-                                    ++k;
-                                }
-                                jpeg_idct(blk, &comp[i].plane[(size_t)((my * comp[i].v + by) * 8) * comp[i].pw + (size_t)(mx * comp[i].h + bx) * 8], comp[i].pw);
-                            }
+                    return true;
                 }
-            break;
+                if (ss == 0) {                                   // DC scan
+                    if (ah == 0) {
+                        const int t = br.decode(hdc[c.td]);
+                        if (t < 0 || t > 16) return false;
+                        c.pred += jpeg_extend(br.receive(t), t);
+                        blk[0] = (short)(c.pred * (1 << al));
+                    } else if (br.bit()) {
+                        blk[0] = (short)(blk[0] + (1 << al));
+                    }
+                    return true;
+                }
+                if (ah == 0) {                                   // AC, first pass of this band
+                    if (eobrun) { --eobrun; return true; }
+                    for (int k = ss; k <= se;) {
+                        const int rs = br.decode(hac[c.ta]);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r < 15) {
+                                eobrun = (1 << r) - 1;
+                                if (r) eobrun += br.receive(r);
+                                break;
+                            }
+                            k += 16;
+                        } else {
+                            k += r;
+                            if (k > se) return false;
+                            blk[zigzag[k]] = (short)(jpeg_extend(br.receive(sz), sz) * (1 << al));
+                            ++k;
+                        }
+                    }
+                    return true;
+                }
+                // AC refinement (ITU T.81 G.1.2.3): one more bit for every coefficient already non-zero, new
+                // coefficients of magnitude 1 << al interleaved with them
+                const short bit = (short)(1 << al);
+                auto refine = [&](short &p) {
+                    if (br.bit() && (p & bit) == 0) p = (short)(p > 0 ? p + bit : p - bit);
+                };
+                if (eobrun) {
+                    --eobrun;
+                    for (int k = ss; k <= se; ++k)
+                        if (blk[zigzag[k]] != 0) refine(blk[zigzag[k]]);
+                    return true;
+                }
+                int k = ss;
+                do {
+                    const int rs = br.decode(hac[c.ta]);
+                    if (rs < 0) return false;
+                    int r = rs >> 4, sv = rs & 15;
+                    if (sv == 0) {
+                        if (r < 15) {
+                            eobrun = (1 << r) - 1;
+                            if (r) eobrun += br.receive(r);
+                            r = 64;                              // the rest of this block only gets refinement bits
+                        }
+                    } else {
+                        if (sv != 1) return false;
+                        sv = br.bit() ? bit : -bit;
+                    }
+                    while (k <= se) {
+                        short &p = blk[zigzag[k++]];
+                        if (p != 0) refine(p);
+                        else {
+                            if (r == 0) { p = (short)sv; break; }
+                            --r;
+                        }
+                    }
+                } while (k <= se);
+                return true;
+            };
+            auto at_restart = [&]() {
+                br.reset();
+                while (br.pos + 1 < br.n && !(br.p[br.pos] == 0xff && br.p[br.pos + 1] >= 0xd0 && br.p[br.pos + 1] <= 0xd7)) ++br.pos;
+                br.pos += 2;
+                for (int i = 0; i < ncomp; ++i) comp[i].pred = 0;
+                eobrun = 0;
+            };
+            int count = 0;
+            if (ns == 1) {
+                // a scan of one component covers only the blocks that hold image data, row by row (A.2.3)
+                Comp &c = comp[order[0]];
+                const int w = ((width * c.h + hmax - 1) / hmax + 7) / 8, h = ((height * c.v + vmax - 1) / vmax + 7) / 8;
+                for (int by = 0; by < h; ++by)
+                    for (int bx = 0; bx < w; ++bx) {
+                        if (restart && count && count % restart == 0) at_restart();
+                        ++count;
+                        if (!decode_block(c, &c.coef[((size_t)by * c.bw + bx) * 64])) return false;
+                    }
+            } else {
+                for (int my = 0; my < mcuy; ++my)
+                    for (int mx = 0; mx < mcux; ++mx) {
+                        if (restart && count && count % restart == 0) at_restart();
+                        ++count;
+                        for (int i = 0; i < ns; ++i) {
+                            Comp &c = comp[order[i]];
+                            for (int by = 0; by < c.v; ++by)
+                                for (int bx = 0; bx < c.h; ++bx)
+                                    if (!decode_block(c, &c.coef[((size_t)(my * c.v + by) * c.bw + (size_t)(mx * c.h + bx)) * 64])) return false;
+                        }
+                    }
+            }
+            have_scan = true;
+            // the next marker: first 0xff followed by something that is neither a stuffed zero nor RSTn
+            pos = br.pos;
+            while (pos + 1 < d.size() && !(d[pos] == 0xff && d[pos + 1] != 0 && d[pos + 1] != 0xff && !(d[pos + 1] >= 0xd0 && d[pos + 1] <= 0xd7))) ++pos;
+            if (!progressive) break;                              // a baseline file is complete after its scan(s) of all components
+            continue;
         }
         pos += len;
     }
-    if (!width || comp[0].plane.empty()) return false;
+    if (!width || !have_scan) return false;
+    // dequantise + inverse DCT into 8-bit planes
+    std::vector<unsigned char> plane[3];
+    for (int i = 0; i < ncomp; ++i) {
+        plane[i].assign((size_t)comp[i].pw * comp[i].ph, 0);
+        for (int by = 0; by < comp[i].bh; ++by)
+            for (int bx = 0; bx < comp[i].bw; ++bx) {
+                const short *cf = &comp[i].coef[((size_t)by * comp[i].bw + bx) * 64];
+                float blk[64];
+                for (int k = 0; k < 64; ++k) blk[k] = cf[k] * qt[comp[i].tq][k];
+                jpeg_idct(blk, &plane[i][(size_t)(by * 8) * comp[i].pw + (size_t)bx * 8], comp[i].pw);
+            }
+    }
     components = ncomp;
     rgba.resize((size_t)width * height * 4);
     for (int y = 0; y < height; ++y)
         for (int x = 0; x < width; ++x) {
-            auto at = [&](int i) { return (float)comp[i].plane[(size_t)(y * comp[i].v / vmax) * comp[i].pw + (size_t)(x * comp[i].h / hmax)]; };
+            auto at = [&](int i) { return (float)plane[i][(size_t)(y * comp[i].v / vmax) * comp[i].pw + (size_t)(x * comp[i].h / hmax)]; };
             unsigned char *o = &rgba[((size_t)y * width + x) * 4];
             if (ncomp == 1) { o[0] = o[1] = o[2] = (unsigned char)at(0); }
             else {

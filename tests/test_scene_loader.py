@@ -196,28 +196,71 @@ def test_exr_environment_map(scene_dir, compression, pixel_type):
     assert (inf.u.x, inf.v.y, inf.w.z) == (1.0, 1.0, 1.0)      # no "rotate": identity axes (documented deviation)
 
 
-@pytest.mark.parametrize("subsampling,quality", [(0, 95), (1, 90), (2, 85)])
-def test_jpeg_texture(scene_dir, subsampling, quality):
-    """Baseline JPEG textures (the reference's sponza uses .jpg): decoded within a few 8-bit steps of an
-    independent decoder (PIL); exact agreement with stb_image's fixed-point IDCT is not claimed."""
+@pytest.mark.parametrize("subsampling,quality,progressive", [(0, 95, False), (1, 90, False), (2, 85, False),
+                                                              (0, 95, True), (1, 90, True), (2, 60, True)])
+def test_jpeg_texture(scene_dir, subsampling, quality, progressive):
+    """JPEG textures (the reference's sponza uses .jpg), baseline and progressive (libjpeg's default scan script:
+    interleaved DC, spectral bands, successive-approximation refinements): decoded within a few 8-bit steps of an
+    independent decoder (PIL); exact agreement with stb_image's fixed-point IDCT is not claimed.  The progressive
+    file must decode to exactly what the baseline file of the same coefficients decodes to."""
     import ctypes as C
     from PIL import Image
     yy, xx = np.mgrid[0:37, 0:50]
     img = np.stack([(xx * 5) % 256, (yy * 7) % 256, ((xx + yy) * 3) % 256], -1).astype(np.uint8)
     img = (img // 2 + 60).astype(np.uint8)
-    Image.fromarray(img).save(scene_dir / "tex.jpg", quality=quality, subsampling=subsampling)
+    Image.fromarray(img).save(scene_dir / "tex.jpg", quality=quality, subsampling=subsampling, progressive=progressive)
+    if progressive:
+        assert b"\xff\xc2" in (scene_dir / "tex.jpg").read_bytes()          # really an SOF2 file
+        Image.fromarray(img).save(scene_dir / "tex_b.jpg", quality=quality, subsampling=subsampling, progressive=False)
     ref = np.asarray(Image.open(scene_dir / "tex.jpg").convert("RGB")).astype(np.float32)
     js = json.load(open(scene_dir / "scene.json"))
     js["material"].append({"name": "jpg", "bsdf": "lambertian", "diffuse": "tex.jpg"})
+    if progressive:
+        js["material"].append({"name": "jpg_b", "bsdf": "lambertian", "diffuse": "tex_b.jpg"})
     json.dump(js, open(scene_dir / "scene.json", "w"))
     ls = api.LoadedScene(str(scene_dir / "scene.json"))
     trec = C.cast(ls.desc.textures, C.POINTER(st.Texture))[0]
     assert (trec.width, trec.height) == (50, 37)
     got = np.ctypeslib.as_array(C.cast(trec.data, C.POINTER(C.c_uint8)), shape=(37, 50, 4))[..., :3].astype(np.float32)
+    if progressive:                                                       # same coefficients, scan order only differs
+        tb = C.cast(ls.desc.textures, C.POINTER(st.Texture))[1]
+        base = np.ctypeslib.as_array(C.cast(tb.data, C.POINTER(C.c_uint8)), shape=(37, 50, 4))[..., :3]
+        assert (base == got).all()
     want = np.floor(np.power(ref[::-1] / 255.0, 2.2) * 255.0)       # flip + sRGB->linear + truncate, as LoadTexture
     tol = 6 if subsampling == 0 else 40                               # chroma replication vs PIL's smooth upsampling
     assert np.abs(got - want).mean() < (1.0 if subsampling == 0 else 3.0)
     assert np.abs(got - want).max() <= tol
+
+
+def test_jpeg_progressive_with_restart_markers_and_grayscale(scene_dir):
+    """Progressive scans with restart intervals (EOB runs and DC predictors reset at every RSTn) and one-component
+    files: the progressive file decodes to exactly the texels of the baseline file with the same coefficients."""
+    import ctypes as C
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:131, 0:203]
+    img = np.stack([(xx * 3 + yy) % 256, (yy * 2) % 256, (xx ^ yy) % 256], -1).astype(np.uint8)
+    img = (img * 0.6 + rng.integers(0, 60, img.shape)).astype(np.uint8)
+    cases = [("p_rst.jpg", dict(quality=80, subsampling=2, progressive=True, restart_marker_blocks=3)),
+             ("b_rst.jpg", dict(quality=80, subsampling=2, progressive=False, restart_marker_blocks=3)),
+             ("p_gray.jpg", dict(quality=70, progressive=True)), ("b_gray.jpg", dict(quality=70, progressive=False))]
+    js = json.load(open(scene_dir / "scene.json"))
+    for name, kw in cases:
+        Image.fromarray(img if "gray" not in name else img[..., 0]).save(scene_dir / name, **kw)
+        js["material"].append({"name": name, "bsdf": "lambertian", "diffuse": name})
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    assert (scene_dir / "p_rst.jpg").read_bytes().count(b"\xff\xd0") > 20
+    ls = api.LoadedScene(str(scene_dir / "scene.json"))
+    tex = []
+    for i, (name, _) in enumerate(cases):
+        t = C.cast(ls.desc.textures, C.POINTER(st.Texture))[i]
+        assert (t.width, t.height) == (203, 131)
+        a = np.ctypeslib.as_array(C.cast(t.data, C.POINTER(C.c_uint8)), shape=(131, 203, 4))[..., :3].copy()
+        ref = np.asarray(Image.open(scene_dir / name).convert("RGB")).astype(np.float32)
+        want = np.floor(np.power(ref[::-1] / 255.0, 2.2) * 255.0)
+        assert np.abs(a - want).mean() < (0.1 if "gray" in name else 3.0)
+        tex.append(a)
+    assert (tex[0] == tex[1]).all() and (tex[2] == tex[3]).all()
 
 
 def test_exr_writer_roundtrip_through_the_reader(scene_dir):
