@@ -125,6 +125,16 @@ __device__ __forceinline__ V3 rcp3(V3 d) { return V3{1.f / d.x, 1.f / d.y, 1.f /
 // bbox.h:77-96 and mesh.h:45-67.
 constexpr int kPoolSlots = 192;                    // 3 rays x 64 lanes
 constexpr int kWaveLdsFloat4 = 2 * kPoolSlots + 64;   // slots (2 x float4) + one origin per lane
+// Scenes in global memory ("carry" layout): rays keep FIXED slots (kind * 64 + owner lane) so that results and
+// unfinished rays survive a shading round, a compacted fetch-order list says which slots are new this round, one
+// pending mask per lane says which of its rays are still out, and every lane has a record for a suspended ray.
+constexpr int kOrderOff = kWaveLdsFloat4;             // 192 x u16 slot indices
+constexpr int kPendOff = kOrderOff + 24;              // 64 x u32: bit k = ray of kind k not finished yet
+constexpr int kSuspOff = kPendOff + 16;               // 64 x {cursor, tri, tri_last, slot | result-in-progress}
+constexpr int kWaveCarryFloat4 = kSuspOff + 128;
+#ifndef PT_STOP_T
+#define PT_STOP_T 24                                  // a dry pool with <= this many rays in flight ends the drain
+#endif
 #ifndef PT_FETCH_T
 #define PT_FETCH_T 12
 #endif
@@ -201,6 +211,24 @@ __device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &r
     return L;
 }
 
+// carry layout: the rays of the lanes in `depositing` go to their fixed slots; returns how many are new
+__device__ __forceinline__ int pool_deposit_fixed(float4 *pool, const RaySet &rs, unsigned lane, bool depositing)
+{
+    const bool dp = depositing && rs.has_p, dm = depositing && rs.has_m, ds = depositing && rs.has_s;
+    const unsigned long long m_p = ballot(dp), m_m = ballot(dm), m_s = ballot(ds);
+    const int n_p = popc(m_p), n_m = popc(m_m);
+    unsigned short *order = reinterpret_cast<unsigned short *>(pool + kOrderOff);
+    unsigned *pend = reinterpret_cast<unsigned *>(pool + kPendOff);
+    if (depositing) {
+        pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
+        pend[lane] = (dp ? 1u : 0u) | (dm ? 2u : 0u) | (ds ? 4u : 0u);
+    }
+    if (dp) { pool_put(pool, (int)lane, rs.dir_p, __builtin_inff(), lane, false); order[lane_rank(m_p)] = (unsigned short)lane; }
+    if (dm) { pool_put(pool, 64 + (int)lane, rs.dir_m, __builtin_inff(), lane, rs.mis_any); order[n_p + lane_rank(m_m)] = (unsigned short)(64u + lane); }
+    if (ds) { pool_put(pool, 128 + (int)lane, rs.dir_s, rs.tmax_s, lane, true); order[n_p + n_m + lane_rank(m_s)] = (unsigned short)(128u + lane); }
+    return n_p + n_m + popc(m_s);
+}
+
 __device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
 {
     const float4 r = pool[2 * slot + 1];
@@ -254,7 +282,7 @@ __device__ __forceinline__ unsigned lds_address(const void *p)      // LDS byte 
     return (unsigned)(unsigned long long)p;                          // low half of the flat (shared aperture) address
 }
 
-template <bool COUNT, class Mem>
+template <bool COUNT, bool FIXED, class Mem>
 __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, const Mem mem)
 {
     const int end = mem.end;
@@ -286,6 +314,8 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
                 // ray finished: the result overwrites the second half of its slot (the direction stays)
                 const int prim = hprim < 0 ? -1 : (int)((unsigned)(hprim - tri_bias) / 48u);
                 pool[2 * slot + 1] = make_float4(__int_as_float(prim), tmax, hb1, hb2);
+                if (FIXED)      // carry layout: tell the owner (lane slot % 64) that its ray of kind slot / 64 is back
+                    atomicAnd(reinterpret_cast<unsigned *>(pool + kPendOff) + (slot & 63), ~(1u << (slot >> 6)));
                 slot = -1;
             }
         }
@@ -293,8 +323,9 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         const int n_idle = 64 - popc(m_busy);
         if (next < n_rays && n_idle >= kFetchThreshold) {       // (an empty wave has 64 idle lanes)
             // ---- refill: idle lanes take the next slots, in lane order ------------------
-            const int mine = next + lane_rank(~m_busy);
-            if (slot < 0 && mine < n_rays) {
+            const int nth = next + lane_rank(~m_busy);
+            if (slot < 0 && nth < n_rays) {
+                const int mine = FIXED ? (int)reinterpret_cast<const unsigned short *>(pool + kOrderOff)[nth] : nth;
                 const float4 r0 = pool[2 * mine];
                 const float4 r1 = pool[2 * mine + 1];
                 const int tag = __float_as_int(r1.w);
@@ -407,18 +438,45 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 // (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
+// Hooks of the loop macro.
+//  classic (LDS scenes): every lane starts idle, slot i of the compacted pool is ray i, a dry pool is drained to the end.
+#define PT_ENTRY_IDLE \
+        "v_mov_b32_e32 v12, %[end]\n" "v_mov_b32_e32 v13, 0\n" "v_mov_b32_e32 v14, -1\n" "v_mov_b32_e32 v15, -1\n"
+#define PT_FETCH_COMPACT "v_lshl_add_u32 v15, v33, 5, %[pool]\n"
+#define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n"
+//  carry (scenes in global memory): a lane resumes the ray it was tracing when the last drain stopped (its cursors and
+//  partial result come back from its suspend record, direction and origin from the ray's slot); the i-th new ray is
+//  slot order[i]; a finished ray clears its bit in the owner's pending mask; a dry pool with few rays left in flight
+//  ends the drain (if this round had new rays: otherwise nothing would ever get ready) and every lane parks its state.
+#define PT_ENTRY_RESUME \
+        "v_mbcnt_lo_u32_b32 v33, -1, 0\n" "v_mbcnt_hi_u32_b32 v33, -1, v33\n" "v_lshl_add_u32 v34, v33, 5, %[susp]\n" \
+        "ds_read_b128 v[12:15], v34\n" "ds_read_b128 v[20:23], v34 offset:16\n" "s_waitcnt lgkmcnt(0)\n" \
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n" "s_mov_b64 exec, s[64:65]\n" \
+        "ds_read_b128 v[4:7], v15\n" "ds_read_b128 v[8:11], v15 offset:16\n" "s_waitcnt lgkmcnt(0)\n" \
+        "v_and_b32_e32 v33, 0xff, v11\n" "v_lshl_add_u32 v33, v33, 4, %[pool]\n" "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
+        "s_waitcnt lgkmcnt(0)\n" "s_mov_b64 exec, -1\n"
+#define PT_FETCH_ORDERED \
+        "v_lshl_add_u32 v34, v33, 1, %[order]\n" "ds_read_u16 v34, v34\n" "s_waitcnt lgkmcnt(0)\n" "v_lshl_add_u32 v15, v34, 5, %[pool]\n"
+#define PT_FINISH_PENDING \
+        "v_subrev_u32_e32 v34, %[pool], v15\n" "v_lshrrev_b32_e32 v35, 11, v34\n" "v_bfe_u32 v34, v34, 5, 6\n" \
+        "v_lshlrev_b32_e64 v35, v35, 1\n" "v_not_b32_e32 v35, v35\n" "v_lshl_add_u32 v34, v34, 2, %[pend]\n" "ds_and_b32 v34, v35\n"
+#define PT_DRY_MAY_STOP \
+        "s_cmp_eq_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_DONE_%=\n" \
+        "s_cmp_eq_u32 %[allow], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n" \
+        "s_bcnt1_i32_b64 s71, s[64:65]\n" "s_cmp_gt_u32 s71, %[tstop]\n" "s_cbranch_scc1 TP_VOTE_%=\n"
+#define PT_EXIT_SUSPEND \
+        "v_mbcnt_lo_u32_b32 v33, -1, 0\n" "v_mbcnt_hi_u32_b32 v33, -1, v33\n" "v_lshl_add_u32 v34, v33, 5, %[susp]\n" \
+        "ds_write_b128 v34, v[12:15]\n" "ds_write_b128 v34, v[20:23] offset:16\n"
+
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
-#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ...) \
+#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, ...) \
     asm volatile( \
         "s_mov_b32 s70, 0\n" \
         "s_mov_b32 s76, 0x322bcc77\n" \
         "s_mov_b32 s77, 0x71800000\n" \
         "s_mov_b64 s[64:65], 0\n" \
-        "v_mov_b32_e32 v12, %[end]\n" \
-        "v_mov_b32_e32 v13, 0\n" \
-        "v_mov_b32_e32 v14, -1\n" \
-        "v_mov_b32_e32 v15, -1\n" \
+        ENTRY_STATE \
         "s_branch TP_FILL_%=\n" \
         "TP_LOOP_%=:\n" \
         "v_cmp_le_i32_e64 s[60:61], v13, v14\n" \
@@ -581,6 +639,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_cndmask_b32_e64 v20, v33, -1, vcc\n" \
         "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n" \
         "ds_write_b128 v15, v[20:23] offset:16\n" \
+        FINISH_EXTRA \
         "v_mov_b32_e32 v15, -1\n" \
         "s_mov_b64 exec, -1\n" \
         "TP_FILL_%=:\n" \
@@ -598,7 +657,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "s_sub_i32 s71, 64, s71\n" \
         "s_add_i32 s70, s70, s71\n" \
         "s_mov_b64 exec, s[66:67]\n" \
-        "v_lshl_add_u32 v15, v33, 5, %[pool]\n" \
+        FETCH_SLOT \
         "ds_read_b128 v[4:7], v15\n" \
         "ds_read_b128 v[8:11], v15 offset:16\n" \
         "v_mov_b32_e32 v12, %[first]\n" \
@@ -616,9 +675,9 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "s_mov_b64 exec, -1\n" \
         "s_branch TP_LOOP_%=\n" \
         "TP_EMPTY_%=:\n" \
-        "s_cmp_lg_u64 s[64:65], 0\n" \
-        "s_cbranch_scc1 TP_VOTE_%=\n" \
+        DRY_POOL \
         "TP_DONE_%=:\n" \
+        EXIT_EXTRA \
         "s_waitcnt lgkmcnt(0)\n" \
         "s_mov_b64 exec, -1\n" \
         : \
@@ -640,23 +699,28 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n",
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
-                 "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n", [unused] "n"(0))
+                 "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
+                 PT_ENTRY_IDLE, PT_FETCH_COMPACT, "", PT_DRY_DRAIN, "", [unused] "n"(0))
 }
 
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
 // 32-bit VGPR-offset form.  (vmcnt also counts this wave's earlier sample stores; they are long gone.)
-__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps)
+__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
     const int s_end = __builtin_amdgcn_readfirstlane(mem.end);
     const int s_first = 0, s_bias = 0;
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    const unsigned long long nodes = (unsigned long long)mem.nodes, tris = (unsigned long long)mem.tris;
-    const unsigned long long s_nodes = uniform64(nodes), s_tris = uniform64(tris);
+    const unsigned long long s_nodes = uniform64((unsigned long long)mem.nodes), s_tris = uniform64((unsigned long long)mem.tris);
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
-                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT, [nodes] "s"(s_nodes), [tris] "s"(s_tris))
+                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
+                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
+                 [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
+                 [allow] "s"(s_allow), [tstop] "n"(PT_STOP_T))
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -1382,9 +1446,17 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         P.lights = reinterpret_cast<const DevLight *>(lds_scene + o_light);
         P.materials = reinterpret_cast<const gpt_material *>(lds_scene + o_mat);
     }
-    __shared__ float4 lds_pool[4 * kWaveLdsFloat4];     // one private ray pool per wavefront
-    float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveLdsFloat4;
+    constexpr bool CARRY = !SMALL;                      // scenes in global memory: fixed slots, drains may stop early
+    constexpr int kWaveFloat4 = CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4;
+    __shared__ float4 lds_pool[4 * kWaveFloat4];        // one private ray pool per wavefront
+    float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
     const unsigned lane = threadIdx.x & 63u;
+    if (CARRY) {                                        // nothing pending, no suspended ray (an idle lane's cursors)
+        reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;
+        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
+        pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+    }
+    bool waiting = false;                               // carry: some of this path's rays are still being traced
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
@@ -1452,7 +1524,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             bool finish = false;
             if (COUNT) cyc_sub = __builtin_readcyclecounter();
             PT_MARK(0)
-            if (alive) {
+            if (alive && !waiting) {
                 // ---- resolve the direct light of the previous bounce ------------------
                 if (direct) {
                     V3 Ld = v3(0.f, 0.f, 0.f);
@@ -1740,7 +1812,15 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             }
             // ---- deposit this bounce's rays, drain the pool, pick up the results -----------------
             if (!alive) q.has_p = q.has_m = q.has_s = false;
-            const PoolLayout L = pool_deposit(pool, q, lane);
+            PoolLayout L;
+            int n_new = 0;
+            if (CARRY) {
+                n_new = pool_deposit_fixed(pool, q, lane, alive && !waiting);
+                L.m_p = L.m_m = L.m_s = 0ull;
+                L.n_p = L.n_m = L.n_rays = 0;
+            } else {
+                L = pool_deposit(pool, q, lane);
+            }
             PT_MARK(6)
             wave_lds_fence();
             unsigned long long c0 = 0;
@@ -1754,7 +1834,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 mem.end = mem.first + 32 * P.n_nodes;
                 mem.tri_bias = mem.end;
                 if (COUNT && !PT_ASM_IN_COUNT)      // the counting build runs the C++ twin (it has the counters)
-                    trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
+                    trace_pool<COUNT, false>(P, pool, L.n_rays, cnt, mem);
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
             } else {
@@ -1764,10 +1844,10 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 mem.first = 0;
                 mem.end = 32 * P.n_nodes;
                 mem.tri_bias = 0;
-                if (COUNT && !PT_ASM_IN_COUNT)
-                    trace_pool<COUNT>(P, pool, L.n_rays, cnt, mem);
+                if (COUNT && !PT_ASM_IN_COUNT)      // (the twin always drains to the end: nothing is ever suspended)
+                    trace_pool<COUNT, true>(P, pool, n_new, cnt, mem);
                 else
-                    trace_pool_global_asm(lds_address(pool), L.n_rays, mem, P.eps);
+                    trace_pool_global_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0);
             }
             if (COUNT) {
                 cyc_mark = __builtin_readcyclecounter();
@@ -1780,21 +1860,22 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 const float4 ro = pool[2 * kPoolSlots + lane];
                 q.org = V3{ro.x, ro.y, ro.z};
             }
-            if (q.has_p) {
-                const int sl = lane_rank(L.m_p);
+            if (CARRY) waiting = alive && reinterpret_cast<const volatile unsigned *>(pool + kPendOff)[lane] != 0u;
+            if (q.has_p && !waiting) {
+                const int sl = CARRY ? (int)lane : lane_rank(L.m_p);
                 const RayResult rr = pool_result(pool, sl);
                 const float4 rd = pool[2 * sl];
                 q.dir_p = V3{rd.x, rd.y, rd.z};
                 res.prim_p = rr.prim; res.t_p = rr.t; res.b1_p = rr.b1; res.b2_p = rr.b2;
             }
-            if (q.has_m) {
-                const int sl = L.n_p + lane_rank(L.m_m);
+            if (q.has_m && !waiting) {
+                const int sl = CARRY ? 64 + (int)lane : L.n_p + lane_rank(L.m_m);
                 const RayResult rr = pool_result(pool, sl);
                 const float4 rd = pool[2 * sl];
                 q.dir_m = V3{rd.x, rd.y, rd.z};
                 res.prim_m = rr.prim; res.t_m = rr.t; res.b1_m = rr.b1; res.b2_m = rr.b2;
             }
-            if (q.has_s) res.occluded = pool_result(pool, L.n_p + L.n_m + lane_rank(L.m_s)).prim >= 0;
+            if (q.has_s && !waiting) res.occluded = pool_result(pool, CARRY ? 128 + (int)lane : L.n_p + L.n_m + lane_rank(L.m_s)).prim >= 0;
             wave_lds_fence();
         }
     }
