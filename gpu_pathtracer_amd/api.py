@@ -45,6 +45,7 @@ def load():
         "gpt_begin": [vp, u32, u32, f32, C.c_int, C.POINTER(vp)],
         "gpt_set_tile_owner": [vp, C.c_int, C.c_int],
         "gpt_set_integrator": [vp, i32, i32, C.c_float],
+        "gpt_set_traversal_order": [vp, i32],
         "gpt_render": [vp, vp, u32, u32, C.c_int, vp],
         "gpt_tonemap": [vp, u32, C.c_int, vp],
         "gpt_synchronize": [vp],
@@ -189,6 +190,10 @@ class Renderer:
 
     def set_tile_owner(self, rank, n_ranks):
         check(self.lib.gpt_set_tile_owner(self.ctx, rank, n_ranks))
+
+    def set_traversal_order(self, near_first):
+        """False: the reference's order (default); True: nearer child first (include/gpt_traversal.h)"""
+        check(self.lib.gpt_set_traversal_order(self.ctx, 1 if near_first else 0))
 
     def set_integrator(self, kind, value):
         """"pt": value = maxDepth; "ao": value = maxDist (the reference reads both from the scene on every Render call)"""

@@ -246,8 +246,14 @@ __device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
 //   LdsScene     the scene was staged into LDS with every link rebased to an absolute LDS address
 struct GlobalScene {
     const char *nodes, *tris;
-    int first, end;                        // cursor of node 0, cursor one past the last node
+    int first, end;                        // cursor of node 0, cursor one past the last node (of variant 0)
     int tri_bias;                          // cursor of triangle 0
+    int near_stride;                       // near-first traversal: bytes per node-array variant (0 = reference order)
+    __device__ __forceinline__ int first_of(V3 d) const   // the ray's variant: 0, or 1 + octant of its direction
+    {
+        const int oct = (int)((__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2));
+        return near_stride ? (1 + oct) * near_stride : 0;
+    }
     static constexpr int vote_node_shift = 0, vote_tri_shift = PT_GLOBAL_VOTE_TRI_SHIFT;
     __device__ __forceinline__ float4 node4(int c) const { return *reinterpret_cast<const float4 *>(nodes + (unsigned)c); }
     __device__ __forceinline__ float4 tri4(int c) const { return *reinterpret_cast<const float4 *>(tris + (unsigned)c); }
@@ -255,6 +261,7 @@ struct GlobalScene {
 };
 struct LdsScene {
     int first, end, tri_bias;
+    __device__ __forceinline__ int first_of(V3) const { return first; }
     static constexpr int vote_node_shift = PT_VOTE_NODE_SHIFT, vote_tri_shift = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float native4 __attribute__((ext_vector_type(4)));
@@ -285,7 +292,7 @@ __device__ __forceinline__ unsigned lds_address(const void *p)      // LDS byte 
 template <bool COUNT, bool FIXED, class Mem>
 __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, const Mem mem)
 {
-    const int end = mem.end;
+    const int n_bytes = mem.end - mem.first;      // one node array (every ray walks exactly one variant)
     const int tri_bias = mem.tri_bias;
     const float tmin_ray = P.eps;          // every ray of the integrator starts at epsilon
 
@@ -298,6 +305,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
     int any_hit = 0;
     V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
     float tmax = 0.f;
+    int end = 0;                                   // per ray: one past the last node of its variant
     int idx = end, tri = 0, tri_last = -1;
     int hprim = -1;
     float hb1 = 0.f, hb2 = 0.f;
@@ -336,7 +344,8 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
                 d = V3{r0.x, r0.y, r0.z};
                 inv = V3{r1.x, r1.y, r1.z};
                 tmax = r0.w;
-                idx = mem.first;
+                idx = mem.first_of(d);
+                end = idx + n_bytes;
                 tri = 0;
                 tri_last = -1;
                 hprim = -1;
@@ -443,6 +452,14 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 #define PT_ENTRY_IDLE \
         "v_mov_b32_e32 v12, %[end]\n" "v_mov_b32_e32 v13, 0\n" "v_mov_b32_e32 v14, -1\n" "v_mov_b32_e32 v15, -1\n"
 #define PT_FETCH_COMPACT "v_lshl_add_u32 v15, v33, 5, %[pool]\n"
+#define PT_CURSOR_FIRST "v_mov_b32_e32 v12, %[first]\n"
+//  per-ray node array (global scenes): variant = 0, or 1 + octant of the direction in near-first mode
+//  ([vstride] = bytes per variant or 0, [first] = cursor of the variant octant 0 maps to); v3 = one past its last node
+#define PT_CURSOR_VARIANT \
+        "v_mov_b32_e32 v34, 0\n" "s_cmp_eq_u32 %[vstride], 0\n" "s_cbranch_scc1 TP_CV1_%=\n" \
+        "v_lshrrev_b32_e32 v34, 31, v4\n" "v_lshrrev_b32_e32 v35, 31, v5\n" "v_lshrrev_b32_e32 v36, 31, v6\n" \
+        "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
+        "TP_CV1_%=:\n" "v_add_u32_e32 v12, %[first], v34\n" "v_add_u32_e32 v3, %[end], v12\n"
 #define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n"
 //  carry (scenes in global memory): a lane resumes the ray it was tracing when the last drain stopped (its cursors and
 //  partial result come back from its suspend record, direction and origin from the ray's slot); the i-th new ray is
@@ -451,8 +468,12 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 #define PT_ENTRY_RESUME \
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n" "v_mbcnt_hi_u32_b32 v33, -1, v33\n" "v_lshl_add_u32 v34, v33, 5, %[susp]\n" \
         "ds_read_b128 v[12:15], v34\n" "ds_read_b128 v[20:23], v34 offset:16\n" "s_waitcnt lgkmcnt(0)\n" \
-        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n" "s_mov_b64 exec, s[64:65]\n" \
+        "v_mov_b32_e32 v3, 0\n" "v_cmp_lt_i32_e64 s[64:65], -1, v15\n" "s_mov_b64 exec, s[64:65]\n" \
         "ds_read_b128 v[4:7], v15\n" "ds_read_b128 v[8:11], v15 offset:16\n" "s_waitcnt lgkmcnt(0)\n" \
+        "v_mov_b32_e32 v34, 0\n" "s_cmp_eq_u32 %[vstride], 0\n" "s_cbranch_scc1 TP_CV2_%=\n" \
+        "v_lshrrev_b32_e32 v34, 31, v4\n" "v_lshrrev_b32_e32 v35, 31, v5\n" "v_lshrrev_b32_e32 v36, 31, v6\n" \
+        "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
+        "TP_CV2_%=:\n" "v_add_u32_e32 v34, %[first], v34\n" "v_add_u32_e32 v3, %[end], v34\n" \
         "v_and_b32_e32 v33, 0xff, v11\n" "v_lshl_add_u32 v33, v33, 4, %[pool]\n" "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
         "s_waitcnt lgkmcnt(0)\n" "s_mov_b64 exec, -1\n"
 #define PT_FETCH_ORDERED \
@@ -470,7 +491,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
-#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, ...) \
+#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, FETCH_CURSOR, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, ...) \
     asm volatile( \
         "s_mov_b32 s70, 0\n" \
         "s_mov_b32 s76, 0x322bcc77\n" \
@@ -480,7 +501,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "s_branch TP_FILL_%=\n" \
         "TP_LOOP_%=:\n" \
         "v_cmp_le_i32_e64 s[60:61], v13, v14\n" \
-        "v_cmp_gt_i32_e64 s[62:63], %[end], v12\n" \
+        "v_cmp_gt_i32_e64 s[62:63], " RAY_END ", v12\n" \
         "v_cmp_lt_i32_e64 s[64:65], -1, v15\n" \
         "s_or_b64 s[66:67], s[60:61], s[62:63]\n" \
         "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n" \
@@ -605,7 +626,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "s_cbranch_scc0 TP_TRI_END_%=\n" \
         "v_and_b32_e32 v42, 0x100, v11\n" \
         "v_cmp_ne_u32_e32 vcc, 0, v42\n" \
-        "v_mov_b32_e32 v24, %[end]\n" \
+        "v_mov_b32_e32 v24, " RAY_END "\n" \
         "v_mov_b32_e32 v21, v39\n" \
         "v_subrev_u32_e32 v20, 48, v13\n" \
         "v_mov_b32_e32 v22, v43\n" \
@@ -660,13 +681,13 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         FETCH_SLOT \
         "ds_read_b128 v[4:7], v15\n" \
         "ds_read_b128 v[8:11], v15 offset:16\n" \
-        "v_mov_b32_e32 v12, %[first]\n" \
         "v_mov_b32_e32 v13, 0\n" \
         "v_mov_b32_e32 v14, -1\n" \
         "v_mov_b32_e32 v20, -1\n" \
         "v_mov_b32_e32 v22, 0\n" \
         "v_mov_b32_e32 v23, 0\n" \
         "s_waitcnt lgkmcnt(0)\n" \
+        FETCH_CURSOR \
         "v_and_b32_e32 v33, 0xff, v11\n" \
         "v_lshl_add_u32 v33, v33, 4, %[pool]\n" \
         "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
@@ -684,7 +705,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias), \
           [eps] "s"(s_eps), __VA_ARGS__, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", \
-          "s72", "s76", "s77", "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
+          "s72", "s76", "s77", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
           "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
           "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
 
@@ -700,7 +721,7 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
                  "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
-                 PT_ENTRY_IDLE, PT_FETCH_COMPACT, "", PT_DRY_DRAIN, "", [unused] "n"(0))
+                 PT_ENTRY_IDLE, PT_FETCH_COMPACT, PT_CURSOR_FIRST, "%[end]", "", PT_DRY_DRAIN, "", [unused] "n"(0))
 }
 
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
@@ -709,8 +730,9 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
-    const int s_end = __builtin_amdgcn_readfirstlane(mem.end);
-    const int s_first = 0, s_bias = 0;
+    const int s_end = __builtin_amdgcn_readfirstlane(mem.end - mem.first);      // bytes of one node array
+    const int s_vstride = __builtin_amdgcn_readfirstlane(mem.near_stride);
+    const int s_first = s_vstride, s_bias = 0;                                   // variant 0, or variant 1 + octant
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
     const unsigned long long s_nodes = uniform64((unsigned long long)mem.nodes), s_tris = uniform64((unsigned long long)mem.tris);
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
@@ -718,9 +740,9 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
                  "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
-                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
+                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
-                 [allow] "s"(s_allow), [tstop] "n"(PT_STOP_T))
+                 [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "n"(PT_STOP_T))
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -1844,6 +1866,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 mem.first = 0;
                 mem.end = 32 * P.n_nodes;
                 mem.tri_bias = 0;
+                mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
                 if (COUNT && !PT_ASM_IN_COUNT)      // (the twin always drains to the end: nothing is ever suspended)
                     trace_pool<COUNT, true>(P, pool, n_new, cnt, mem);
                 else
@@ -2011,7 +2034,7 @@ int render_kernel_blocks_per_cu(bool count)
 
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream)
 {
-    const bool small = 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4 &&
+    const bool small = P.traversal == 0 && 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4 &&
                        !getenv("GPT_NO_LDS_SCENE");
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)

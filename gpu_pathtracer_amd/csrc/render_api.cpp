@@ -24,6 +24,8 @@
 #include "../../include/gpt.h"
 #include "host_util.h"
 #include "pt_layout.h"
+#include "../../include/gpt_traversal.h"
+#include "../../include/gpt_traversal.h"
 
 namespace pt {
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream);
@@ -149,32 +151,66 @@ void pack_triangle(const gpt_triangle &t, DevTri &dt, DevShade &ds)
     ds.lightIdx = t.lightIdx;
 }
 
-// Threaded links: escape(i) = first preorder index after subtree(i).
-void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
+// Threaded traversal: the nodes are laid out in the order they are visited; an inner node continues at the next node
+// when its box is hit and at its "escape" (the first node after its subtree in that order) when it is missed.
+// Variant 0 is the reference's order (left child first, pathtracer.cu:221-252); variants 1..8 are the near-first orders
+// of the eight ray-direction octants (include/gpt_traversal.h): the same tree, children swapped where the octant says so.
+// Every variant is a complete array of n nodes; a ray uses exactly one of them.
+void thread_nodes_ordered(const gpt_bvh_node *nodes, int n, int octant /* -1 = reference order */, int variant_base, DevNode *out)
 {
-    out.resize((size_t)n);
-    std::vector<int> escape((size_t)n, n);
-    // preorder: children of i are i+1 (left) and second_child_offset (right)
-    for (int i = 0; i < n; ++i) {
-        const gpt_bvh_node &nd = nodes[i];
-        if (!nd.is_leaf && nd.second_child_offset > 0) {
-            if (i + 1 < n) escape[(size_t)i + 1] = nd.second_child_offset;
-            if (nd.second_child_offset < n) escape[(size_t)nd.second_child_offset] = escape[(size_t)i];
+    if (n <= 0) return;
+    std::vector<int> order;                 // visiting order: order[k] = original node index
+    order.reserve((size_t)n);
+    std::vector<int> subtree_end((size_t)n, 0);      // position (in the new order) one past the node's subtree
+    std::vector<int> pos((size_t)n, 0);
+    // iterative preorder with the octant's child order; post-visit fixes subtree_end
+    struct Frame { int node; int stage; };
+    std::vector<Frame> stack;
+    stack.push_back({0, 0});
+    while (!stack.empty()) {
+        Frame &f = stack.back();
+        const gpt_bvh_node &nd = nodes[f.node];
+        if (f.stage == 0) {
+            pos[(size_t)f.node] = (int)order.size();
+            order.push_back(f.node);
+            f.stage = 1;
+            if (!nd.is_leaf && nd.second_child_offset > 0) {
+                const bool right_first = octant >= 0 && gpt_right_child_first(gpt_node_order_code(nodes, f.node), octant);
+                const int first = right_first ? nd.second_child_offset : f.node + 1;
+                const int second = right_first ? f.node + 1 : nd.second_child_offset;
+                const int me = f.node;
+                (void)me;
+                stack.push_back({second, 0});     // popped after the first child's whole subtree
+                stack.push_back({first, 0});
+            }
+        } else {
+            subtree_end[(size_t)f.node] = (int)order.size();
+            stack.pop_back();
         }
     }
-    for (int i = 0; i < n; ++i) {
+    // NB: the loop above pushes both children at once, so a node's post-visit runs after BOTH subtrees: exactly what
+    // subtree_end needs.
+    for (int k = 0; k < n; ++k) {
+        const int i = order[(size_t)k];
         const gpt_bvh_node &nd = nodes[i];
-        DevNode &d = out[(size_t)i];
+        DevNode &d = out[(size_t)k];
         d.bmin[0] = nd.fmin.x; d.bmin[1] = nd.fmin.y; d.bmin[2] = nd.fmin.z;
         d.bmax[0] = nd.fmax.x; d.bmax[1] = nd.fmax.y; d.bmax[2] = nd.fmax.z;
         if (nd.is_leaf) {
             d.link = nd.start * (int32_t)sizeof(DevTri);
             d.last = nd.end * (int32_t)sizeof(DevTri);
         } else {
-            d.link = escape[(size_t)i] * (int32_t)sizeof(DevNode);
+            d.link = (variant_base + subtree_end[(size_t)i]) * (int32_t)sizeof(DevNode);
             d.last = -1;
         }
     }
+}
+
+// all nine variants, variant v at [v * n, (v + 1) * n)
+void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
+{
+    out.resize((size_t)n * 9);
+    for (int v = 0; v < 9; ++v) thread_nodes_ordered(nodes, n, v - 1, v * n, out.data() + (size_t)v * n);
 }
 
 }  // namespace
@@ -199,8 +235,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         return GPT_ERR_INVALID_ARG;
     }
     // traversal cursors are 32-bit byte offsets into the packed node / triangle arrays (pt_layout.h)
-    if ((int64_t)scene->n_nodes * (int64_t)sizeof(DevNode) > INT32_MAX || (int64_t)scene->n_prims * (int64_t)sizeof(DevTri) > INT32_MAX) {
-        gpt_set_error("gpt_begin: scene too large (%d nodes, %d primitives; limits 67108863 / 44739242)", scene->n_nodes, scene->n_prims);
+    if ((int64_t)scene->n_nodes * 9 * (int64_t)sizeof(DevNode) > INT32_MAX || (int64_t)scene->n_prims * (int64_t)sizeof(DevTri) > INT32_MAX) {
+        gpt_set_error("gpt_begin: scene too large (%d nodes, %d primitives; limits 7456540 / 44739242)", scene->n_nodes, scene->n_prims);
         return GPT_ERR_UNSUPPORTED;
     }
     for (int i = 0; i < scene->n_prims; ++i) {
@@ -387,6 +423,16 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
     ctx->P.integrator = integrator_type;
     if (integrator_type == GPT_IT_PT) ctx->P.max_depth = max_depth;
     else ctx->P.ao_max_dist = max_dist;
+    return GPT_OK;
+}
+
+int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
+{
+    if (!ctx || (order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_NEAR_FIRST)) {
+        gpt_set_error("gpt_set_traversal_order: invalid argument");
+        return GPT_ERR_INVALID_ARG;
+    }
+    ctx->P.traversal = order;
     return GPT_OK;
 }
 

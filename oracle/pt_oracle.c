@@ -54,6 +54,7 @@
 
 #include "../include/gpt_types.h"
 #include "../include/gpt_softmath.h"
+#include "../include/gpt_traversal.h"
 
 #ifdef ORACLE_SOFTMATH
 #define M_SIN(x)   gpt_sinf(x)
@@ -265,6 +266,7 @@ typedef struct {
     const gpt_scene_desc *d;
     gpt_infinite inf;     /* copy; isvalid = 0 when desc->infinite is NULL */
     float eps;
+    const unsigned char *order;   /* near-first traversal: one gpt_node_order_code per node; NULL = reference order */
 } scene_t;
 
 /* ---- AABB slab test: bbox.h:77-96 ------------------------------------------ */
@@ -334,12 +336,27 @@ static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isec
 }
 
 /* ---- traversal: pathtracer.cu:214-296 ------------------------------------------ */
+/* Traversal order (include/gpt_traversal.h): the reference pushes the right child, then the left one.  In
+ * near-first mode the child that lies first along the ray is popped first; `order` holds one code per node. */
+static int g_traversal = GPT_TRAVERSAL_REFERENCE;
+static inline void push_children(const scene_t *sc, const gpt_bvh_node *node, int node_idx, int oct, int *stack, int *top)
+{
+    if (sc->order && gpt_right_child_first(sc->order[node_idx], oct)) {
+        stack[(*top)++] = node_idx + 1;
+        stack[(*top)++] = node->second_child_offset;
+    } else {
+        stack[(*top)++] = node->second_child_offset;
+        stack[(*top)++] = node_idx + 1;
+    }
+}
+
 static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
 {
     int stack[64];
     int top = 0;
     int ret = 0;
     int node_idx = 0;
+    const int oct = gpt_direction_octant(ray->d.x, ray->d.y, ray->d.z);
     t_cnt.closest_rays++;
     if (sc->d->n_nodes <= 0) return 0;
     for (;;) {
@@ -347,8 +364,7 @@ static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
         t_cnt.node_visits++;
         if (bbox_intersect(node, ray)) {
             if (!node->is_leaf) {
-                stack[top++] = node->second_child_offset;
-                stack[top++] = node_idx + 1;
+                push_children(sc, node, node_idx, oct, stack, &top);
             } else {
                 for (int i = node->start; i <= node->end; ++i) {
                     const gpt_primitive *prim = &sc->d->prims[i];
@@ -372,6 +388,7 @@ static int intersect_any(const scene_t *sc, ray_t *ray)
     int stack[64];
     int top = 0;
     int node_idx = 0;
+    const int oct = gpt_direction_octant(ray->d.x, ray->d.y, ray->d.z);
     t_cnt.shadow_rays++;
     if (sc->d->n_nodes <= 0) return 0;
     for (;;) {
@@ -379,8 +396,7 @@ static int intersect_any(const scene_t *sc, ray_t *ray)
         t_cnt.node_visits++;
         if (bbox_intersect(node, ray)) {
             if (!node->is_leaf) {
-                stack[top++] = node->second_child_offset;
-                stack[top++] = node_idx + 1;
+                push_children(sc, node, node_idx, oct, stack, &top);
             } else {
                 for (int i = node->start; i <= node->end; ++i) {
                     const gpt_primitive *prim = &sc->d->prims[i];
@@ -1149,6 +1165,13 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     int filmic = cam->filmic;
     if (n_threads < 1) n_threads = 1;
     memset(&g_cnt, 0, sizeof(g_cnt));
+    unsigned char *order = NULL;
+    if (g_traversal == GPT_TRAVERSAL_NEAR_FIRST && desc->n_nodes > 0) {
+        order = (unsigned char *)calloc((size_t)desc->n_nodes, 1);
+        for (int i = 0; i < desc->n_nodes; ++i)
+            if (!desc->nodes[i].is_leaf) order[i] = (unsigned char)gpt_node_order_code(desc->nodes, i);
+    }
+    sc.order = order;
 
 #pragma omp parallel num_threads(n_threads)
     {
@@ -1188,6 +1211,15 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
             g_cnt.samples += t_cnt.samples;
         }
     }
+    free(order);
+    return 0;
+}
+
+/* GPT_TRAVERSAL_REFERENCE (default) or GPT_TRAVERSAL_NEAR_FIRST for the following oracle_render calls */
+API int oracle_set_traversal(int mode)
+{
+    if (mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_NEAR_FIRST) return -1;
+    g_traversal = mode;
     return 0;
 }
 

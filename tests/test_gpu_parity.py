@@ -452,6 +452,50 @@ def test_config5_stress_scene_4k(gpt):
     full_size_properties(gpt, scene, cam, W, H, 0.001, 1, 1024, 411)
 
 
+# ---- near-first traversal order (include/gpt_traversal.h) --------------------------------------------
+
+@pytest.mark.parametrize("what", ["cornell", "stress", "zoo_env"])
+def test_near_first_traversal_matches_the_oracle_in_the_same_mode(gpt, what):
+    """Same tree, nearer child first: GPU == oracle(near-first) bit for bit; against the reference order the bar is
+    north_star's 1e-4 relative RMS (in practice the films are identical: only exact ties could differ)."""
+    if what == "cornell":
+        scene, meta = ol.load_cornell(8)
+        W, H, spp, eps = 192, 128, 8, 0.001
+        cam = ol.cornell_camera(meta, W, H)
+    elif what == "stress":
+        scene, meta = scenes.stress_scene(0.4, max_depth=16)
+        W, H, spp, eps = 160, 120, 4, 0.001
+        cam = ol.cornell_camera(meta, W, H)
+    else:
+        scene, meta = scenes.zoo_scene(max_depth=7, with_env=True, assign={"short": 7, "tall": 13, "back": 2, "ceil": 2},
+                                       extra=scenes.uv_sphere((0.0, 1.2, 0.0), 0.4, 8, nu=20, nv=14))
+        W, H, spp, eps = 160, 128, 6, 0.001
+        cam = ol.make_camera((0.3, 1.2, 7.5), (0, 1, 0), (0, 1, 0), (W, H), 40.0)
+    lib = ol.load("soft")
+    ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
+    visits_ref = ol.counters("soft")["node_visits"]
+    try:
+        assert lib.oracle_set_traversal(1) == 0
+        near, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
+        visits_near = ol.counters("soft")["node_visits"]
+    finally:
+        lib.oracle_set_traversal(0)
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.set_traversal_order(True)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), near, f"near-first {what}")
+        r.enable_counters(True)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), near, f"near-first {what}, counting build")
+        r.enable_counters(False)
+        r.set_traversal_order(False)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"reference order again {what}")
+    assert (rel_rms(near, ref) <= RMS_TOL).all()
+    if what == "stress":                      # (no guarantee in general: an any-hit ray may meet its occluder later)
+        assert visits_near < 0.95 * visits_ref
+
+
 # ---- Ao integrator (pathtracer.cu:830-876) -------------------------------------------------------
 
 @pytest.mark.parametrize("what", ["cornell", "zoo_global", "thin_lens"])

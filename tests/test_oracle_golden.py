@@ -177,3 +177,26 @@ def test_ambient_occlusion_oracle_properties():
     c_libm, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="libm")
     assert np.abs(c_soft - c_libm).max() <= 1.0 + 1e-6 and np.mean(c_soft != c_libm) < 1e-3
     assert 0.25 < (c_soft.reshape(H, W, 3) / np.float32(4))[hit].mean() < 1.0
+
+
+def test_near_first_traversal_agrees_with_the_reference_order():
+    """include/gpt_traversal.h: visiting the nearer child first changes the work, not the picture (bar: 1e-4 relative
+    RMS; only exact ties and rounding coincidences between box and triangle tests could differ)."""
+    import scenes
+    lib = ol.load("soft")
+    for scene, meta, W, H, spp in ((ol.load_cornell(8) + (96, 96, 8)), (scenes.stress_scene(0.25, max_depth=12) + (96, 72, 4))):
+        cam = ol.cornell_camera(meta, W, H)
+        ref, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
+        c_ref = ol.counters("soft")
+        try:
+            assert lib.oracle_set_traversal(1) == 0
+            near, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
+            c_near = ol.counters("soft")
+        finally:
+            lib.oracle_set_traversal(0)
+        a, b = near.reshape(-1, 3).astype(np.float64), ref.reshape(-1, 3).astype(np.float64)
+        rms = np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))
+        assert (rms <= 1e-4).all()
+        assert c_near["samples"] == c_ref["samples"] and c_near["closest_rays"] == c_ref["closest_rays"]
+        assert c_near["node_visits"] <= c_ref["node_visits"] and c_near["prim_tests"] <= c_ref["prim_tests"]
+    assert lib.oracle_set_traversal(7) == -1
