@@ -452,6 +452,46 @@ def test_config5_stress_scene_4k(gpt):
     full_size_properties(gpt, scene, cam, W, H, 0.001, 1, 1024, 411)
 
 
+# ---- edge cases -----------------------------------------------------------------------------------------
+
+def test_edge_cases_empty_scene_tiny_frames_single_triangle(gpt):
+    """No geometry at all (environment light only), a frame narrower than one 32-pixel launch column (the
+    reference's grid is width/32 x height/4: nothing is rendered), a single triangle, one-iteration batches."""
+    mats = scenes.material_table()
+    # (1) empty scene under a sky: every primary ray escapes
+    empty = ol.make_scene(np.zeros(0, dtype=st.PRIMITIVE), mats, light_radiance=[1, 1, 1], max_depth=4, env=scenes.sky_env(32, 16),
+                          env_rotate_uvw=((1, 0, 0), (0, 1, 0), (0, 0, 1)), textures=[scenes.checker_texture()])
+    cam = ol.make_camera((0, 1, 5), (0, 1, 0), (0, 1, 0), (64, 36), 40.0)
+    ag, cg, ao, co = render_both(gpt, empty, cam, 64, 36, 0.001, 1, 3)
+    assert_bit_exact(ag, ao, "empty scene")
+    assert np.count_nonzero(ag) > 0
+    # (2) a 31 x 7 frame: stride = 32 * (31 / 32) = 0, rows = 4 * (7 / 4) = 4 -> no pixel is ever written
+    scene, meta = ol.load_cornell(4)
+    cam = ol.cornell_camera(meta, 31, 7)
+    with gpt.Renderer(scene.desc, 31, 7, 0.001) as r:
+        r.render(cam, 1, 2, reset=True)
+        assert not r.read_accum().any()
+    # (3) 40 x 6: one launch column, one launch row
+    cam = ol.cornell_camera(meta, 40, 6)
+    ag, cg, ao, co = render_both(gpt, scene, cam, 40, 6, 0.001, 1, 5)
+    assert_bit_exact(ag, ao, "40x6")
+    # (4) a single emissive triangle seen head-on (1 node, LDS path) and the same scene forced through global memory
+    tri = scenes.make_tri((-1, 0, 0), (1, 0, 0), (0, 1.5, 0), (0, 0, 1), (0, 0, 1), (0, 0, 1), mat=4, light=0)
+    one = np.zeros(1, dtype=st.PRIMITIVE)
+    one[0] = tri
+    s1 = ol.make_scene(one, mats, light_radiance=[3, 2, 1], max_depth=3, textures=[scenes.checker_texture()])
+    cam = ol.make_camera((0, 0.6, 4), (0, 0.6, 0), (0, 1, 0), (96, 64), 35.0)
+    ref, _ = ol.render(s1, cam, 96, 64, 0.001, 1, 4, kind="soft")
+    with gpt.Renderer(s1.desc, 96, 64, 0.001) as r:
+        for it in range(1, 5):                       # the reference's call pattern: one iteration per Render
+            r.render(cam, it, 1, reset=(it == 1))
+        assert_bit_exact(r.read_accum(), ref, "single triangle, 1-iteration calls")
+        r.set_traversal_order(True)                  # (near-first always traverses from global memory)
+        r.render(cam, 1, 4, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "single triangle through the global-memory path")
+    assert np.count_nonzero(ref) > 0
+
+
 # ---- near-first traversal order (include/gpt_traversal.h) --------------------------------------------
 
 @pytest.mark.parametrize("what", ["cornell", "stress", "zoo_env"])
