@@ -158,6 +158,7 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #define PT_VOTE_TRI_SHIFT 0
 #endif
 constexpr int kFetchThreshold = PT_FETCH_T;        // idle lanes that trigger a refill
+static_assert(PT_STOP_T < 64 - PT_FETCH_T, "a resumed drain must start with a refill (the loop header runs after it)");
 
 struct RaySet {        // what one lane deposits
     V3 org;
@@ -460,7 +461,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_lshrrev_b32_e32 v34, 31, v4\n" "v_lshrrev_b32_e32 v35, 31, v5\n" "v_lshrrev_b32_e32 v36, 31, v6\n" \
         "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
         "TP_CV1_%=:\n" "v_add_u32_e32 v12, %[first], v34\n" "v_add_u32_e32 v3, %[end], v12\n"
-#define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n"
+#define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_LOOP_%=\n"
 //  carry (scenes in global memory): a lane resumes the ray it was tracing when the last drain stopped (its cursors and
 //  partial result come back from its suspend record, direction and origin from the ray's slot); the i-th new ray is
 //  slot order[i]; a finished ray clears its bit in the owner's pending mask; a dry pool with few rays left in flight
@@ -483,8 +484,8 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_lshlrev_b32_e64 v35, v35, 1\n" "v_not_b32_e32 v35, v35\n" "v_lshl_add_u32 v34, v34, 2, %[pend]\n" "ds_and_b32 v34, v35\n"
 #define PT_DRY_MAY_STOP \
         "s_cmp_eq_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_DONE_%=\n" \
-        "s_cmp_eq_u32 %[allow], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n" \
-        "s_bcnt1_i32_b64 s71, s[64:65]\n" "s_cmp_gt_u32 s71, %[tstop]\n" "s_cbranch_scc1 TP_VOTE_%=\n"
+        "s_cmp_eq_u32 %[allow], 0\n" "s_cbranch_scc1 TP_LOOP_%=\n" \
+        "s_bcnt1_i32_b64 s71, s[64:65]\n" "s_cmp_gt_u32 s71, %[tstop]\n" "s_cbranch_scc1 TP_LOOP_%=\n"
 #define PT_EXIT_SUSPEND \
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n" "v_mbcnt_hi_u32_b32 v33, -1, v33\n" "v_lshl_add_u32 v34, v33, 5, %[susp]\n" \
         "ds_write_b128 v34, v[12:15]\n" "ds_write_b128 v34, v[20:23] offset:16\n"
