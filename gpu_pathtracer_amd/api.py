@@ -76,7 +76,13 @@ def load():
         "gpt_save_exr": [C.c_char_p, i32, i32, vp],
     }
     for name, args in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # kernel A/B runs load older builds through GPT_LIB_PATH; the product library must export everything
+            if os.environ.get("GPT_LIB_PATH") and os.environ.get("GPT_ALLOW_OLD_LIB"):
+                continue
+            raise
         fn.argtypes = args
         fn.restype = C.c_int
     for name in ("gpt_accum_device_ptr", "gpt_color_device_ptr"):

@@ -446,6 +446,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 // restored to all ones.
 // gfx950 hazards honoured by hand: >= 2 wait states between a VALU write of VCC/SGPR and a VALU read of it
 // (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
+#define PT_COMMA ,
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
 // Hooks of the loop macro.
@@ -461,7 +462,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_lshrrev_b32_e32 v34, 31, v4\n" "v_lshrrev_b32_e32 v35, 31, v5\n" "v_lshrrev_b32_e32 v36, 31, v6\n" \
         "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
         "TP_CV1_%=:\n" "v_add_u32_e32 v12, %[first], v34\n" "v_add_u32_e32 v3, %[end], v12\n"
-#define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_LOOP_%=\n"
+#define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n"
 //  carry (scenes in global memory): a lane resumes the ray it was tracing when the last drain stopped (its cursors and
 //  partial result come back from its suspend record, direction and origin from the ray's slot); the i-th new ray is
 //  slot order[i]; a finished ray clears its bit in the owner's pending mask; a dry pool with few rays left in flight
@@ -476,7 +477,8 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
         "TP_CV2_%=:\n" "v_add_u32_e32 v34, %[first], v34\n" "v_add_u32_e32 v3, %[end], v34\n" \
         "v_and_b32_e32 v33, 0xff, v11\n" "v_lshl_add_u32 v33, v33, 4, %[pool]\n" "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
-        "s_waitcnt lgkmcnt(0)\n" "s_mov_b64 exec, -1\n"
+        "s_waitcnt lgkmcnt(0)\n" "s_mov_b64 exec, -1\n" \
+        "v_cmp_le_i32_e64 s[60:61], v13, v14\n" "v_cmp_gt_i32_e64 s[62:63], v3, v12\n"   /* the vote masks of the loop header: a drain that starts with resumed rays and nothing to fetch goes from the dry-pool test straight to the vote */
 #define PT_FETCH_ORDERED \
         "v_lshl_add_u32 v34, v33, 1, %[order]\n" "ds_read_u16 v34, v34\n" "s_waitcnt lgkmcnt(0)\n" "v_lshl_add_u32 v15, v34, 5, %[pool]\n"
 #define PT_FINISH_PENDING \
@@ -484,15 +486,15 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_lshlrev_b32_e64 v35, v35, 1\n" "v_not_b32_e32 v35, v35\n" "v_lshl_add_u32 v34, v34, 2, %[pend]\n" "ds_and_b32 v34, v35\n"
 #define PT_DRY_MAY_STOP \
         "s_cmp_eq_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_DONE_%=\n" \
-        "s_cmp_eq_u32 %[allow], 0\n" "s_cbranch_scc1 TP_LOOP_%=\n" \
-        "s_bcnt1_i32_b64 s71, s[64:65]\n" "s_cmp_gt_u32 s71, %[tstop]\n" "s_cbranch_scc1 TP_LOOP_%=\n"
+        "s_cmp_eq_u32 %[allow], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n" \
+        "s_bcnt1_i32_b64 s71, s[64:65]\n" "s_cmp_gt_u32 s71, %[tstop]\n" "s_cbranch_scc1 TP_VOTE_%=\n"
 #define PT_EXIT_SUSPEND \
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n" "v_mbcnt_hi_u32_b32 v33, -1, v33\n" "v_lshl_add_u32 v34, v33, 5, %[susp]\n" \
         "ds_write_b128 v34, v[12:15]\n" "ds_write_b128 v34, v[20:23] offset:16\n"
 
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
-#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, FETCH_CURSOR, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, ...) \
+#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
     asm volatile( \
         "s_mov_b32 s70, 0\n" \
         "s_mov_b32 s76, 0x322bcc77\n" \
@@ -682,13 +684,14 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         FETCH_SLOT \
         "ds_read_b128 v[4:7], v15\n" \
         "ds_read_b128 v[8:11], v15 offset:16\n" \
+        CURSOR_EARLY \
         "v_mov_b32_e32 v13, 0\n" \
         "v_mov_b32_e32 v14, -1\n" \
         "v_mov_b32_e32 v20, -1\n" \
         "v_mov_b32_e32 v22, 0\n" \
         "v_mov_b32_e32 v23, 0\n" \
         "s_waitcnt lgkmcnt(0)\n" \
-        FETCH_CURSOR \
+        CURSOR_LATE \
         "v_and_b32_e32 v33, 0xff, v11\n" \
         "v_lshl_add_u32 v33, v33, 4, %[pool]\n" \
         "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
@@ -706,7 +709,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias), \
           [eps] "s"(s_eps), __VA_ARGS__, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", \
-          "s72", "s76", "s77", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
+          "s72", "s76", "s77", MORE_CLOBBERS "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
           "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
           "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
 
@@ -722,7 +725,7 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
                  "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
-                 PT_ENTRY_IDLE, PT_FETCH_COMPACT, PT_CURSOR_FIRST, "%[end]", "", PT_DRY_DRAIN, "", [unused] "n"(0))
+                 PT_ENTRY_IDLE, PT_FETCH_COMPACT, PT_CURSOR_FIRST, "", "%[end]", "", PT_DRY_DRAIN, "", , [unused] "n"(0))
 }
 
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
@@ -741,7 +744,7 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
                  "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
-                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
+                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
                  [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "n"(PT_STOP_T))
 }

@@ -95,7 +95,6 @@ struct DevParams {
     int32_t n_lights;
     int32_t n_cdf;
     int32_t max_depth;
-    int32_t traversal;          // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_NEAR_FIRST (nodes holds 9 threaded variants)
     int32_t integrator;         // GPT_IT_PT or GPT_IT_AO
     float ao_max_dist;          // scene.integrator.maxDist (ao)
     float eps;
@@ -118,6 +117,7 @@ struct DevParams {
     uint32_t n_chunks;           // ceil(iter_count / chunk_iters)
     uint32_t *tile_counter;      // work queue head (zeroed before every launch)
     unsigned long long *counters;  // work counters (counting build only)
+    int32_t traversal;           // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_NEAR_FIRST (nodes holds 9 threaded variants)
 };
 
 }  // namespace pt

@@ -21,7 +21,7 @@ print(json.dumps({"hash8spp": h, "ms64": best, "msamples": W*H*64/best/1e3}))
 ''' % (ROOT, ROOT)
 ref = None
 for name in sys.argv[1:]:
-    env = dict(os.environ, GPT_LIB_PATH=os.path.join(ROOT, "build", "variants", f"libgpt_{name}.so"))
+    env = dict(os.environ, GPT_LIB_PATH=os.path.join(ROOT, "build", "variants", f"libgpt_{name}.so"), GPT_ALLOW_OLD_LIB="1")
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]
     try:
