@@ -132,8 +132,14 @@ constexpr int kOrderOff = kWaveLdsFloat4;             // 192 x u16 slot indices
 constexpr int kPendOff = kOrderOff + 24;              // 64 x u32: bit k = ray of kind k not finished yet
 constexpr int kSuspOff = kPendOff + 16;               // 64 x {cursor, tri, tri_last, slot | result-in-progress}
 constexpr int kWaveCarryFloat4 = kSuspOff + 128;
+// A dry pool with <= T rays in flight ends the drain.  T trades emptier shading rounds against shorter tails: long
+// rays and cheap materials want it high, expensive BSDFs low.  Measured optimum (tools/gpu_configs.py): 8-16 on the
+// 2k-triangle material scene and the env-lit 22k-triangle scene, 24 on the 253k-triangle stand-in.
 #ifndef PT_STOP_T
-#define PT_STOP_T 24                                  // a dry pool with <= this many rays in flight ends the drain
+#define PT_STOP_T 24                                  // deep trees (>= 64k nodes)
+#endif
+#ifndef PT_STOP_T_SMALL
+#define PT_STOP_T_SMALL 12                            // everything else in global memory
 #endif
 #ifndef PT_FETCH_T
 #define PT_FETCH_T 12
@@ -158,7 +164,7 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #define PT_VOTE_TRI_SHIFT 0
 #endif
 constexpr int kFetchThreshold = PT_FETCH_T;        // idle lanes that trigger a refill
-static_assert(PT_STOP_T < 64 - PT_FETCH_T, "a resumed drain must start with a refill (the loop header runs after it)");
+static_assert(PT_STOP_T < 64 - PT_FETCH_T && PT_STOP_T_SMALL < 64 - PT_FETCH_T, "a resumed drain must start with a refill (the loop header runs after it)");
 
 struct RaySet {        // what one lane deposits
     V3 org;
@@ -741,12 +747,13 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     const unsigned long long s_nodes = uniform64((unsigned long long)mem.nodes), s_tris = uniform64((unsigned long long)mem.tris);
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
+    const int s_tstop = __builtin_amdgcn_readfirstlane(mem.end - mem.first >= 65536 * 32 ? PT_STOP_T : PT_STOP_T_SMALL);
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
                  "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
                  PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
-                 [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "n"(PT_STOP_T))
+                 [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
 }
 
 // mesh.h:68-95 evaluated once for the final hit
