@@ -63,7 +63,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)       # 4 x 64 iterations = one full-size launch
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,8 +111,9 @@ def main():
             dist.barrier()
 
     def job(steps):
-        for k in range(steps):
-            r.render(cam, 1 + k * SPP_PER_STEP, SPP_PER_STEP, reset=(k == 0))
+        # K steps of SPP_PER_STEP iterations each, handed to the renderer in one call: it cuts them into launches of
+        # up to 256 iterations (a launch has a fixed cost; the reference's one-iteration-per-Render is the other extreme)
+        r.render(cam, 1, steps * SPP_PER_STEP, reset=True)
         r.synchronize()
         if dist is not None:
             dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)     # the one collective: float3 framebuffer over xGMI
@@ -148,14 +149,15 @@ def main():
             cpu = cpu_baseline()
             b_alg = cpu_baseline.b_alg      # algorithmic bytes of the reference algorithm on this workload
         # this rank's launches cover its own tiles: samples per launch on this rank
-        samples_per_launch = WIDTH * HEIGHT * SPP_PER_STEP / world
+        samples_per_launch = samples / world / max(1, launches)
         avg_ms = kernel_ms / max(1, launches)
         achieved = b_alg * samples_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))          # counters were taken on 256-iteration launches: scale to this run's
+                traffic = rec.get("hbm_bytes_per_launch") * (samples / world / max(1, launches)) / (WIDTH * HEIGHT * rec.get("iterations_per_launch", 256))
             except Exception:
                 traffic = None
         # the compute-side picture next to the (logical) HBM figure: wave-level VALU instructions issued per second
@@ -165,7 +167,8 @@ def main():
         sq = os.path.join(ROOT, "profiles", "pmc_sq.json")
         if os.path.exists(sq) and world == 1:
             try:
-                n_valu = json.load(open(sq)).get("valu_insts_per_launch")
+                rec = json.load(open(sq))
+                n_valu = rec.get("valu_insts_per_launch") * samples_per_launch / (WIDTH * HEIGHT * rec.get("iterations_per_launch", 256))
                 peak_issue = 1024 * 2.4e9 / 2.43
                 valu = {"insts_per_launch": n_valu, "achieved_per_s": n_valu / (avg_ms * 1e-3), "peak_per_s": peak_issue,
                         "frac": n_valu / (avg_ms * 1e-3) / peak_issue,
@@ -189,6 +192,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pt::pt_render_kernel<false, true, 1> (counting off, scene staged in LDS, Path integrator)", "avg_launch_ms": avg_ms, "launches": launches,
+                         "iterations_per_launch": args.steps * SPP_PER_STEP / max(1, launches),
                          "algorithmic_bytes_per_sample": b_alg, "valu_issue": valu,
                          "note": "algorithmic = reference-layout bytes (SURVEY.md 8d); the 7.4 KB scene is "
                                  "cache-resident, so this logical figure can exceed the HBM peak"},

@@ -60,7 +60,7 @@ struct gpt_ctx {
     uint32_t chunk_override = 0;          // GPT_CHUNK_ITERS (experiments)
     float *samples = nullptr;             // per-iteration sample planes, grown on demand
     uint32_t sample_planes = 0;           // planes allocated
-    uint32_t max_batch = 64;              // iterations per path-kernel launch (GPT_MAX_BATCH)
+    uint32_t max_batch = 256;             // iterations per path-kernel launch (GPT_MAX_BATCH); also capped by kMaxPlaneBytes
     bool count_next = false;
     int n_cus = 256;
     int blocks_per_cu[2] = {4, 4};
@@ -455,8 +455,15 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         HIP_TRY(hipMemsetAsync(ctx->acc, 0, (size_t)ctx->width * ctx->height * 3 * sizeof(float), ctx->stream));
     if (n_owned == 0 || iter_count == 0) return GPT_OK;
 
-    // sample planes for one launch (grown on demand, never shrunk)
-    const uint32_t batch_cap = iter_count < ctx->max_batch ? iter_count : ctx->max_batch;
+    // sample planes for one launch (grown on demand, never shrunk).  A launch has a fixed cost of 0.2-0.6 ms (start-up
+    // and the wait for the last work items), so launches are long: up to 256 iterations, 8.5 GB of planes at 1080p,
+    // and never more than 16 GiB of the 288 (tools/gpu_batch.py: 64 -> 256 iterations per launch is +1.5 % on the full
+    // frame and 7.0x -> 7.5x for a 1/8 shard).
+    const size_t kMaxPlaneBytes = (size_t)16 << 30;
+    uint32_t by_memory = (uint32_t)(kMaxPlaneBytes / ((size_t)ctx->P.plane * 4 * sizeof(float)));
+    if (by_memory < 1) by_memory = 1;
+    const uint32_t max_batch = ctx->max_batch < by_memory ? ctx->max_batch : by_memory;
+    const uint32_t batch_cap = iter_count < max_batch ? iter_count : max_batch;
     if (ctx->sample_planes < batch_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->samples) {

@@ -12,8 +12,8 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OU
 # per-kernel time of the same command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python bench.py --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/prof_stats.err
 # HBM traffic counters, each in its own pass (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o fetch -- python bench.py --no-cpu-baseline --steps 4 --warmup 1 > /dev/null 2> $OUT/prof_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -o write -- python bench.py --no-cpu-baseline --steps 4 --warmup 1 > /dev/null 2> $OUT/prof_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o fetch -- python bench.py --no-cpu-baseline --steps 8 --warmup 4 > /dev/null 2> $OUT/prof_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -o write -- python bench.py --no-cpu-baseline --steps 8 --warmup 4 > /dev/null 2> $OUT/prof_write.err
 find $OUT -name "*.csv" | head -20
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
 python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt

@@ -22,7 +22,7 @@ if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
 import json
 if g("SQ_INSTS_VALU"):
     json.dump({"valu_insts_per_launch": g("SQ_INSTS_VALU"), "salu_insts_per_launch": g("SQ_INSTS_SALU"),
-               "lds_insts_per_launch": g("SQ_INSTS_LDS"),
+               "lds_insts_per_launch": g("SQ_INSTS_LDS"), "iterations_per_launch": 256,
                "active_lanes_per_valu_inst": (g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")) if g("SQ_ACTIVE_INST_VALU") else None,
                "note": "rocprofv3 --pmc SQ_INSTS_* (own passes), mean over pt_render_kernel launches of bench.py"},
               open(os.path.join(out, "pmc_sq.json"), "w"))

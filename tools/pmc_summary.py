@@ -27,6 +27,6 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     w = res["WRITE_SIZE"]["mean_KiB_per_launch"] * 1024
     print(f"per launch: fetch raw {f/1e6:.2f} MB (x2 gfx950 correction {2*f/1e6:.2f} MB), write {w/1e6:.2f} MB, "
           f"total raw {(f+w)/1e6:.2f} MB, corrected {(2*f+w)/1e6:.2f} MB")
-    json.dump({"hbm_bytes_per_launch": 2 * f + w, "fetch_raw_bytes": f, "write_bytes": w,
+    json.dump({"hbm_bytes_per_launch": 2 * f + w, "fetch_raw_bytes": f, "write_bytes": w, "iterations_per_launch": 256,
                "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, mean over pt_render_kernel launches"},
               open(os.path.join(out, "pmc_traffic.json"), "w"))
