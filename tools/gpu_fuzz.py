@@ -1,0 +1,71 @@
+"""Randomised GPU-vs-oracle soak: random triangle soups + Cornell parts, random materials, cameras, frame sizes,
+iteration batching, integrator (pt / ao), traversal order and memory path; every film must match the oracle bit for bit.
+usage: python tools/gpu_fuzz.py <seconds> [seed]      (run under `timeout`; each case is small)"""
+import os, sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import scenes, oracle_lib as ol
+from gpu_pathtracer_amd import api, scene_types as st
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+lib = ol.load("soft")
+t_end = time.time() + budget
+n_cases = n_bad = 0
+while time.time() < t_end:
+    n_cases += 1
+    n_soup = int(rng.choice([0, 3, 40, 400, 3000]))
+    mats = tuple(int(m) for m in rng.choice([0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13], size=4))
+    parts = []
+    if n_soup:
+        parts.append(scenes.random_soup(n_soup, int(rng.integers(1 << 30)), mats=mats, size=float(rng.choice([0.05, 0.15, 0.4]))))
+    if rng.random() < 0.5:
+        parts.append(scenes.uv_sphere((float(rng.uniform(-.5, .5)), float(rng.uniform(.3, 1.6)), float(rng.uniform(-.5, .5))),
+                                      float(rng.uniform(.15, .45)), int(rng.choice(mats)), nu=int(rng.choice([6, 12, 20])), nv=int(rng.choice([4, 8, 14]))))
+    extra = scenes.concat(parts) if parts else None
+    with_env = bool(rng.random() < 0.35)
+    with_area = bool(rng.random() < 0.8) or not with_env
+    depth = int(rng.choice([1, 2, 4, 7, 12, 20]))
+    assign = {k: int(rng.choice(mats)) for k in ("short", "tall", "floor", "back", "left", "right", "ceil") if rng.random() < 0.5}
+    scene, meta = scenes.zoo_scene(max_depth=depth, with_env=with_env, with_area_light=with_area, assign=assign, extra=extra)
+    W, H = int(rng.choice([32, 40, 64, 97, 128, 200])), int(rng.choice([4, 9, 36, 64, 100, 131]))
+    spp = int(rng.choice([1, 2, 3, 5, 9]))
+    kind = rng.choice(["pinhole", "lens", "outside"])
+    if kind == "pinhole":
+        cam = ol.cornell_camera(meta, W, H)
+    elif kind == "lens":
+        cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, aperture=float(rng.uniform(0.02, 0.3)), focal=float(rng.uniform(4, 8)))
+    else:
+        cam = ol.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.2, 2.5)), float(rng.uniform(3, 8))), (0, 1, 0), (0, 1, 0), (W, H), float(rng.uniform(15, 70)))
+    ao = bool(rng.random() < 0.2)
+    near = bool(rng.random() < 0.3)
+    force_global = bool(rng.random() < 0.4)
+    eps = float(rng.choice([0.001, 0.0005, 0.01]))
+    if ao:
+        scene.desc.set_integrator("ao", float(rng.choice([0.05, 0.5, 3.0])))
+    lib.oracle_set_traversal(1 if near else 0)
+    try:
+        ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
+    finally:
+        lib.oracle_set_traversal(0)
+    if force_global: os.environ["GPT_NO_LDS_SCENE"] = "1"
+    else: os.environ.pop("GPT_NO_LDS_SCENE", None)
+    with api.Renderer(scene.desc, W, H, eps) as r:
+        r.set_traversal_order(near)
+        if rng.random() < 0.5:
+            r.render(cam, 1, spp, reset=True)
+        else:                                   # split the iterations into two calls
+            k = int(rng.integers(1, spp + 1))
+            r.render(cam, 1, k, reset=True)
+            if k < spp: r.render(cam, k + 1, spp - k, reset=False)
+        got = r.read_accum()
+    bad = int(np.count_nonzero(got.view(np.uint32) != ref.view(np.uint32)))
+    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} near {near} global {force_global}"
+    if bad:
+        n_bad += 1
+        print("MISMATCH", bad, tag, flush=True)
+    elif n_cases % 20 == 0:
+        print("ok", tag, flush=True)
+print(f"{n_cases} cases, {n_bad} mismatches, seed {seed}", flush=True)
+sys.exit(1 if n_bad else 0)
