@@ -226,6 +226,11 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         return GPT_ERR_INVALID_ARG;
     }
     *out = nullptr;
+    if (scene->integrator_type == GPT_IT_VPT) {
+        // the oracle restates Volpath for homogeneous media (oracle/pt_oracle.c vpt_sample); the kernel does not yet
+        gpt_set_error("gpt_begin: the \"vpt\" integrator is not built on the GPU yet (%d media in the scene; \"pt\" and \"ao\" are supported)", scene->n_mediums);
+        return GPT_ERR_UNSUPPORTED;
+    }
     if (scene->integrator_type != GPT_IT_PT && scene->integrator_type != GPT_IT_AO) {
         gpt_set_error("gpt_begin: integrator type %d is not supported (\"pt\" and \"ao\" are)", scene->integrator_type);
         return GPT_ERR_UNSUPPORTED;

@@ -578,6 +578,8 @@ void Scene::Describe(gpt_scene_desc &d, std::vector<gpt_texture> &tex) const
     d.n_textures = (int32_t)tex.size();
     d.integrator_type = (int32_t)integrator.type;
     d.max_depth = integrator.maxDepth;
+    d.mediums = mediums.empty() ? nullptr : mediums.data();
+    d.n_mediums = (int32_t)mediums.size();
 }
 
 // ================================================================= LoadScene ==============
@@ -603,11 +605,37 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
     }
     const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
 
-    // media are out of scope for the "pt" path; their names only matter because a mesh that names an
-    // inside/outside medium and no material is legal in the reference (parsescene.cpp:359-380)
+    // ---- media (parsescene.cpp:72-137).  Homogeneous media are stored as the reference stores them (sigmaA, sigmaS
+    // scaled, sigmaT their sum, g); a heterogeneous medium keeps its coefficients and grid size but its density file
+    // is not read: the "pt" and "ao" integrators never look at media, and "vpt" refuses heterogeneous ones.
     std::vector<std::string> mediumName;
+    scene.mediums.clear();
     if (doc.has("medium") && doc.at("medium").kind == Json::Arr)
-        for (auto &m : doc.at("medium").arr) mediumName.push_back(gets(m, "name", ""));
+        for (auto &m : doc.at("medium").arr) {
+            mediumName.push_back(gets(m, "name", ""));
+            float a[3], sc3[3];
+            get3(m, "sigmaA", one3, a);
+            get3(m, "sigmaS", one3, sc3);
+            const float scale = getf(m, "scale", 1.f);
+            gpt_medium md;
+            std::memset(&md, 0, sizeof(md));
+            md.g = getf(m, "g", 0.f);
+            const bool hom = gets(m, "type", "homogeneous") == "homogeneous";
+            md.type = hom ? GPT_MEDIUM_HOMOGENEOUS : GPT_MEDIUM_HETEROGENEOUS;
+            gpt_float3 sa = {a[0] * scale, a[1] * scale, a[2] * scale}, ss = {sc3[0] * scale, sc3[1] * scale, sc3[2] * scale};
+            gpt_float3 st = {sa.x + ss.x, sa.y + ss.y, sa.z + ss.z};
+            md.homogeneous.sigmaA = sa;            // (same offsets in both views of the union)
+            md.homogeneous.sigmaS = ss;
+            md.homogeneous.sigmaT = st;
+            if (!hom) {
+                md.heterogeneous.nx = m.has("nx") ? (int)m.at("nx").num : 0;
+                md.heterogeneous.ny = m.has("ny") ? (int)m.at("ny").num : 0;
+                md.heterogeneous.nz = m.has("nz") ? (int)m.at("nz").num : 0;
+                md.heterogeneous.iterMax = m.has("iterMax") ? (int)m.at("iterMax").num : 1000;
+                md.heterogeneous.evalTransmittanceType = m.has("evalTransmittanceType") ? (int)m.at("evalTransmittanceType").num : 1;
+            }
+            scene.mediums.push_back(md);
+        }
     auto getMedium = [&](const std::string &m) {
         for (size_t i = 0; i < mediumName.size(); ++i) if (mediumName[i] == m) return (int)i;
         return -1;

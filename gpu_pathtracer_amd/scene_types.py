@@ -56,6 +56,7 @@ AREA = np.dtype({
 MT_LAMBERTIAN, MT_MIRROR, MT_DIELECTRIC, MT_ROUGHDIELECTRIC, MT_ROUGHCONDUCTOR, MT_SUBSTRATE = range(6)
 IT_AO = 0
 IT_PT = 1
+IT_VPT = 2
 
 
 class Float3(C.Structure):
@@ -64,6 +65,22 @@ class Float3(C.Structure):
 
 class Float2(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+# gpt_medium (104 bytes): type, g, then the homogeneous coefficients at offset 8 (the heterogeneous view of the union is
+# not used from Python)
+MEDIUM = np.dtype({"names": ["type", "g", "sigmaA", "sigmaS", "sigmaT"], "formats": [np.int32, np.float32, F3, F3, F3],
+                   "offsets": [0, 4, 8, 20, 32], "itemsize": 104})
+
+
+def make_medium(sigma_a, sigma_s, g=0.0, scale=1.0):
+    """homogeneous medium as parsescene.cpp:86-98 builds it: sigmaA, sigmaS scaled, sigmaT = their sum"""
+    m = np.zeros((), dtype=MEDIUM)
+    a = (np.asarray(sigma_a, np.float32) * np.float32(scale)).astype(np.float32)
+    s_ = (np.asarray(sigma_s, np.float32) * np.float32(scale)).astype(np.float32)
+    m["type"], m["g"] = 0, np.float32(g)
+    m["sigmaA"], m["sigmaS"], m["sigmaT"] = f3(a), f3(s_), f3((a + s_).astype(np.float32))
+    return m
 
 
 class Infinite(C.Structure):
@@ -101,6 +118,7 @@ class SceneDesc(C.Structure):
         ("infinite", C.c_void_p),
         ("textures", C.c_void_p), ("n_textures", C.c_int32),
         ("integrator_type", C.c_int32), ("max_depth", C.c_int32),     # max_depth shares storage with max_dist (ao)
+        ("mediums", C.c_void_p), ("n_mediums", C.c_int32),
     ]
 
     def set_integrator(self, kind, value):
@@ -108,11 +126,13 @@ class SceneDesc(C.Structure):
         import struct
         if kind == "pt":
             self.integrator_type, self.max_depth = IT_PT, int(value)
+        elif kind == "vpt":
+            self.integrator_type, self.max_depth = IT_VPT, int(value)
         elif kind == "ao":
             self.integrator_type = IT_AO
             self.max_depth = struct.unpack("<i", struct.pack("<f", float(value)))[0]
         else:
-            raise ValueError(f"integrator {kind!r} is not supported (pt, ao)")
+            raise ValueError(f"integrator {kind!r} is not supported (pt, vpt, ao)")
 
 
 assert C.sizeof(Infinite) == 72 and Infinite.center.offset == 16 and Infinite.isvalid.offset == 68

@@ -206,4 +206,22 @@ GPT_HD GPT_INL float gpt_powf(float x, float y)
     return (float)gpt_exp_d((double)y * gpt_log_d((double)x));
 }
 
+/* expf / logf for the participating-media code (src/medium.h:15,41-43, src/common.h:81-86, src/wrap.h:158-160).
+ * expf: underflows to 0 below -104 (0x1p-150 rounds to 0), overflows to +inf above 88.73; NaN stays NaN.
+ * logf: log(0) = -inf, log(x < 0) = NaN, log(+inf) = +inf; denormal floats are exact in double. */
+GPT_HD GPT_INL float gpt_expf(float x)
+{
+    if (gpt_isnanf(x)) return x;
+    if (x > 88.8f) return gpt_u2f(0x7f800000u);
+    if (x < -104.f) return 0.f;
+    return (float)gpt_exp_d((double)x);
+}
+GPT_HD GPT_INL float gpt_logf(float x)
+{
+    if (gpt_isnanf(x) || x < 0.f) return gpt_u2f(0x7fc00000u);
+    if (x == 0.f) return gpt_u2f(0xff800000u);
+    if (gpt_isinff(x)) return x;
+    return (float)gpt_log_d((double)x);
+}
+
 #endif /* GPT_SOFTMATH_H */

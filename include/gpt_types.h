@@ -136,6 +136,25 @@ typedef struct gpt_camera {          /* src/camera.h:8-26 */
     float area;                      /* @100 */
 } gpt_camera;
 
+typedef struct gpt_medium {          /* src/medium.h:9-13,53-62,186-193 */
+    int32_t type;                    /* @0  GPT_MEDIUM_HOMOGENEOUS / GPT_MEDIUM_HETEROGENEOUS */
+    float g;                         /* @4  Henyey-Greenstein asymmetry (0 = isotropic) */
+    union {                          /* @8 */
+        struct { gpt_float3 sigmaA, sigmaS, sigmaT; } homogeneous;
+        struct {
+            gpt_float3 sigmaA, sigmaS, sigmaT;
+            int32_t nx, ny, nz;
+            const float *density;
+            float invMaxDensity;
+            gpt_float3 p0, p1;
+            int32_t iterMax;
+            int32_t evalTransmittanceType;
+        } heterogeneous;             /* layout only: heterogeneous media are not rendered (GPT_ERR_UNSUPPORTED) */
+    };
+} gpt_medium;
+#define GPT_MEDIUM_HOMOGENEOUS   0
+#define GPT_MEDIUM_HETEROGENEOUS 1
+
 typedef struct gpt_texture {         /* src/texture.h:9-28 (vector<uchar4> + size) */
     const gpt_uchar4 *data;          /* width*height texels, row 0 = bottom */
     int32_t width, height;
@@ -158,9 +177,11 @@ typedef struct gpt_scene_desc {
     int32_t n_textures;
     int32_t integrator_type;         /* scene.integrator.type: GPT_IT_PT or GPT_IT_AO */
     union {                          /* the reference's anonymous union (src/scene.h:38-46) */
-        int32_t max_depth;           /* scene.integrator.maxDepth (pt) */
+        int32_t max_depth;           /* scene.integrator.maxDepth (pt, vpt) */
         float max_dist;              /* scene.integrator.maxDist  (ao) */
     };
+    const gpt_medium *mediums;       /* scene.mediums (vpt; triangles and the camera refer to them by index) */
+    int32_t n_mediums;
 } gpt_scene_desc;
 
 #ifdef __cplusplus
@@ -185,6 +206,7 @@ GPT_STATIC_ASSERT(sizeof(gpt_area) == 192 && offsetof(gpt_area, triangle) == 16,
 GPT_STATIC_ASSERT(offsetof(gpt_area, medium) == 184, "Area layout");
 GPT_STATIC_ASSERT(sizeof(gpt_infinite) == 72 && offsetof(gpt_infinite, center) == 16, "Infinite layout");
 GPT_STATIC_ASSERT(offsetof(gpt_infinite, u) == 32 && offsetof(gpt_infinite, isvalid) == 68, "Infinite layout");
+GPT_STATIC_ASSERT(sizeof(gpt_medium) == 104 && offsetof(gpt_medium, heterogeneous.density) == 56, "Medium layout");
 GPT_STATIC_ASSERT(sizeof(gpt_camera) == 104 && offsetof(gpt_camera, resolution) == 48, "Camera layout");
 GPT_STATIC_ASSERT(offsetof(gpt_camera, filmic) == 72 && offsetof(gpt_camera, medium) == 76, "Camera layout");
 GPT_STATIC_ASSERT(offsetof(gpt_camera, pixel2screen) == 88 && offsetof(gpt_camera, area) == 100, "Camera layout");

@@ -63,6 +63,8 @@
 #define M_ATAN(x)  gpt_atanf(x)
 #define M_ACOS(x)  gpt_acosf(x)
 #define M_POW(x,y) gpt_powf(x, y)
+#define M_EXP(x)   gpt_expf(x)
+#define M_LOG(x)   gpt_logf(x)
 #else
 #define M_SIN(x)   sinf(x)
 #define M_COS(x)   cosf(x)
@@ -70,6 +72,8 @@
 #define M_ATAN(x)  atanf(x)
 #define M_ACOS(x)  acosf(x)
 #define M_POW(x,y) powf(x, y)
+#define M_EXP(x)   expf(x)
+#define M_LOG(x)   logf(x)
 #endif
 
 #define API __attribute__((visibility("default")))
@@ -145,7 +149,7 @@ static inline float rng_uniform(rng_t *r)
 
 /* ---- Ray / Intersection ------------------------------------------------- */
 typedef struct { f3 o, d; float tmin, tmax; } ray_t;                  /* ray.h:7-12 (medium unused in PT) */
-typedef struct { f3 pos, nor; f2 uv; f3 dpdu; int matIdx, lightIdx; } isect_t; /* intersection.h:6-19 */
+typedef struct { f3 pos, nor; f2 uv; f3 dpdu; int matIdx, lightIdx, mediumInside, mediumOutside; } isect_t; /* intersection.h:6-19 */
 
 static inline ray_t mk_ray(f3 o, f3 d, float tmin, float tmax) { ray_t r; r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax; return r; }
 static inline f3 ray_at(const ray_t *r, float t) { return add3(r->o, scl3(r->d, t)); }
@@ -330,6 +334,8 @@ static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isec
         isect->uv = add2(add2(scl2(t->v1.uv, b0), scl2(t->v2.uv, b1)), scl2(t->v3.uv, b2));
         isect->matIdx = t->matIdx;
         isect->lightIdx = t->lightIdx;
+        isect->mediumInside = t->mediumInside;      /* mesh.h:93-94 */
+        isect->mediumOutside = t->mediumOutside;
         isect->dpdu = normalize3(cross3(isect->nor, normalize3(dpdv)));
     }
     return 1;
@@ -1068,6 +1074,261 @@ static int path_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uin
     return 0;
 }
 
+/* ---- Volpath: pathtracer.cu:298-322, 1025-1242; homogeneous media: medium.h:9-51, phase: medium.h:196-233 ------------
+ * A medium is referred to by index (-1 = vacuum).  Heterogeneous media are refused before rendering starts. */
+static inline f3 exp3(f3 c) { return mk3(M_EXP(c.x), M_EXP(c.y), M_EXP(c.z)); }                    /* common.h:81-86 */
+static inline f3 hom_tr(const gpt_medium *m, float tmax) { return exp3(scl3(m->homogeneous.sigmaT, -tmax)); }   /* medium.h:14-17 */
+static inline f3 hom_sample(const gpt_medium *m, float ray_tmax, float u, float *t, int *sampled)       /* medium.h:19-50 */
+{
+    f3 sigmaT = m->homogeneous.sigmaT, sigmaS = m->homogeneous.sigmaS;
+    float sigma = dot3(sigmaT, mk3(0.212671f, 0.715160f, 0.072169f));
+    float dist = -M_LOG(u) / sigma;                                 /* wrap.h:158-160 */
+    f3 Tr = exp3(scl3(sigmaT, -dist));
+    float pdf = sigma * M_EXP(sigma * -dist);
+    int sampledMedium = dist < ray_tmax;
+    *sampled = sampledMedium;
+    *t = dist;
+    return sampledMedium ? dvs3(mul3(Tr, sigmaS), pdf) : dvs3(mul3(sigmaT, Tr), pdf);
+}
+static inline void medium_phase(const gpt_medium *m, f3 in, f3 out, float *phase)                    /* medium.h:222-233 */
+{
+    float g = m->g;
+    if (g == 0) { *phase = ONE_OVER_FOUR_PI; return; }
+    float costheta = dot3(in, out);
+    float cubicTerm = (1.f + g * g - 2.f * g * costheta);
+    *phase = ONE_OVER_FOUR_PI * (1.f - g * g) / sqrtf(cubicTerm * cubicTerm * cubicTerm);
+}
+static inline void medium_sample_phase(const gpt_medium *m, float ux, float uy, f3 *dir, float *phase, float *pdf)   /* medium.h:196-220 */
+{
+    float g = m->g;
+    if (g == 0) {
+        *phase = ONE_OVER_FOUR_PI;
+        *dir = uniform_sphere(ux, uy, pdf);
+        return;
+    }
+    float costheta;
+    if (fabsf(g) < 1e-3f)
+        costheta = 1.f - 2.f * ux;
+    else {
+        float sqrtTerm = (1.f - g * g) / (1.f - g + 2.f * g * ux);
+        costheta = (1.f + g * g - sqrtTerm * sqrtTerm) / (2.f * g);
+    }
+    float sintheta = sqrtf(1.f - costheta * costheta);
+    float phi = TWOPI * uy;
+    float sinphi = M_SIN(phi), cosphi = M_COS(phi);
+    *dir = mk3(sintheta * cosphi, costheta, sintheta * sinphi);
+    float cubicTerm = (1.f + g * g - 2.f * g * costheta);
+    *phase = ONE_OVER_FOUR_PI * (1.f - g * g) / sqrtf(cubicTerm * cubicTerm * cubicTerm);
+    *pdf = *phase;
+}
+static inline int medium_of_side(const isect_t *isect, float side)      /* outside when `side` > 0 */
+{
+    return side > 0 ? isect->mediumOutside : isect->mediumInside;
+}
+/* Tr (pathtracer.cu:298-322): walk along the shadow ray through the surfaces without a material */
+static f3 vpt_tr(const scene_t *sc, ray_t ray, int medium)
+{
+    f3 tr = mk3(1, 1, 1);
+    float tmax = ray.tmax;
+    for (;;) {
+        isect_t isect;
+        int hit = intersect_closest(sc, &ray, &isect);
+        if (hit && isect.matIdx != -1)
+            return mk3(0, 0, 0);
+        if (medium >= 0)
+            tr = mul3(tr, hom_tr(&sc->d->mediums[medium], ray.tmax));
+        if (!hit) break;
+        medium = medium_of_side(&isect, dot3(ray.d, isect.nor));
+        tmax -= ray.tmax;
+        ray = mk_ray(ray_at(&ray, ray.tmax), ray.d, sc->eps, tmax);
+    }
+    return tr;
+}
+
+static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint32_t y, uint32_t pixel,
+                      uint32_t iter, int maxDepth, f3 *Li_out)
+{
+    rng_t rng;
+    rng_seed(&rng, wang_hash(pixel) + wang_hash(iter));
+    float offsetx = rng_uniform(&rng) - 0.5f;
+    float offsety = rng_uniform(&rng) - 0.5f;
+    float du1 = rng_uniform(&rng);
+    float du2 = rng_uniform(&rng);
+    f2 aperture = uniform_disk(du1, du2);
+    ray_t r = generate_primary_ray(cam, x + offsetx, y + offsety, aperture);
+    r.tmin = sc->eps;
+    int medium = cam->medium;                      /* -1 = none (pathtracer.cu:1043) */
+
+    f3 Li = mk3(0.f, 0.f, 0.f);
+    f3 beta = mk3(1.f, 1.f, 1.f);
+    isect_t isect;
+    isect.lightIdx = -1;
+    int specular = 0;
+    t_cnt.samples++;
+    for (int bounces = 0; bounces < maxDepth; ++bounces) {
+        t_cnt.bounce_iters++;
+        if (!intersect_closest(sc, &r, &isect)) {
+            if ((bounces == 0 || specular) && sc->inf.isvalid)
+                Li = add3(Li, mul3(beta, inf_lookup(&sc->inf, r.d)));
+            break;
+        }
+        f3 pos = isect.pos;
+        f3 nor = isect.nor;
+        f2 uv = isect.uv;
+        f3 dpdu = isect.dpdu;
+
+        float sampledDist = 0.f;
+        int sampledMedium = 0;
+        if (medium >= 0) {
+            float u = rng_uniform(&rng);
+            beta = mul3(beta, hom_sample(&sc->d->mediums[medium], r.tmax, u, &sampledDist, &sampledMedium));
+        }
+        if (is_black(beta)) break;
+        if (sampledMedium) {
+            const gpt_medium *m = &sc->d->mediums[medium];
+            int inf = 0;
+            float u = rng_uniform(&rng);
+            float choicePdf;
+            int idx = lookup_light_distribution(sc, u, &choicePdf);
+            if (idx == sc->d->n_lights) inf = 1;
+            f3 samplePos = ray_at(&r, sampledDist);
+            float u1x = rng_uniform(&rng);
+            float u1y = rng_uniform(&rng);
+            f2 u1 = mk2(u1x, u1y);
+            f3 radiance = mk3(0, 0, 0), lightNor;
+            ray_t shadowRay = mk_ray(samplePos, mk3(0, 0, 0), sc->eps, 0.f);
+            float lightPdf = 0.f;
+            if (idx >= 0) {
+                if (!inf)
+                    area_sample_light(&sc->d->lights[idx], samplePos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
+                else
+                    inf_sample_light(&sc->inf, samplePos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
+            }
+            f3 tr = vpt_tr(sc, shadowRay, medium);
+            float phase;
+            medium_phase(m, neg3(r.d), shadowRay.d, &phase);
+            if (!is_black(radiance))
+                Li = add3(Li, dvs3(mul3(scl3(mul3(tr, beta), phase), radiance), lightPdf * choicePdf));
+            float pdf;
+            float pux = rng_uniform(&rng);
+            float puy = rng_uniform(&rng);
+            f3 dir;
+            medium_sample_phase(m, pux, puy, &dir, &phase, &pdf);
+            r = mk_ray(samplePos, dir, sc->eps, INFINITY);
+            specular = 0;
+        } else {
+            if (bounces == 0 || specular) {
+                if (isect.lightIdx != -1) {
+                    f3 tr = mk3(1.f, 1.f, 1.f);
+                    if (medium >= 0) tr = hom_tr(&sc->d->mediums[medium], r.tmax);
+                    Li = add3(Li, mul3(mul3(tr, beta), area_le(&sc->d->lights[isect.lightIdx], nor, neg3(r.d))));
+                    break;
+                }
+            }
+            if (isect.matIdx == -1) {
+                bounces--;
+                medium = medium_of_side(&isect, dot3(r.d, isect.nor));
+                r = mk_ray(pos, r.d, sc->eps, INFINITY);
+                continue;
+            }
+            gpt_material material = sc->d->materials[isect.matIdx];
+            if (!is_delta(material.type)) {
+                f3 Ld = mk3(0.f, 0.f, 0.f);
+                int inf = 0;
+                float u = rng_uniform(&rng);
+                float choicePdf;
+                int idx = lookup_light_distribution(sc, u, &choicePdf);
+                if (idx == sc->d->n_lights) inf = 1;
+                float u1x = rng_uniform(&rng);
+                float u1y = rng_uniform(&rng);
+                f2 u1 = mk2(u1x, u1y);
+                f3 radiance = mk3(0, 0, 0), lightNor;
+                ray_t shadowRay = mk_ray(pos, mk3(0, 0, 0), sc->eps, 0.f);
+                float lightPdf = 0.f;
+                if (idx >= 0) {
+                    if (!inf)
+                        area_sample_light(&sc->d->lights[idx], pos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
+                    else
+                        inf_sample_light(&sc->inf, pos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
+                }
+                if (!is_black(radiance)) {
+                    f3 fr;
+                    float samplePdf;
+                    eval_bsdf(sc, &material, neg3(r.d), shadowRay.d, nor, uv, dpdu, &fr, &samplePdf);
+                    f3 tr = vpt_tr(sc, shadowRay, medium);
+                    float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                    Ld = add3(Ld, dvs3(scl3(mul3(mul3(scl3(tr, weight), fr), radiance), fabsf(dot3(nor, shadowRay.d))),
+                                       lightPdf * choicePdf));
+                }
+                float usx = rng_uniform(&rng);
+                float usy = rng_uniform(&rng);
+                float usz = rng_uniform(&rng);
+                f3 out, fr;
+                float pdf;
+                sample_bsdf(sc, &material, neg3(r.d), nor, uv, dpdu, mk3(usx, usy, usz), &out, &fr, &pdf);
+                if (!(is_black(fr) || pdf == 0)) {
+                    isect_t lightIsect;
+                    lightIsect.lightIdx = -1;
+                    ray_t lightRay = mk_ray(pos, out, sc->eps, INFINITY);
+                    if (intersect_closest(sc, &lightRay, &lightIsect)) {
+                        f3 p = lightIsect.pos;
+                        f3 n = lightIsect.nor;
+                        f3 radiance2 = mk3(0.f, 0.f, 0.f);
+                        if (lightIsect.lightIdx != -1)
+                            radiance2 = area_le(&sc->d->lights[lightIsect.lightIdx], n, neg3(lightRay.d));
+                        if (!is_black(radiance2)) {
+                            float pdfA = 1.f / tri_surface_area(&sc->d->lights[lightIsect.lightIdx].triangle);
+                            float choicePdf2 = pdf_from_light_distribution(sc, lightIsect.lightIdx);
+                            f3 pp = sub3(p, pos);
+                            float lenSquare = dot3(pp, pp);
+                            float costheta = fabsf(dot3(n, lightRay.d));
+                            float lPdf = pdfA * lenSquare / (costheta);
+                            float weight = power_heuristic(1, pdf, 1, lPdf * choicePdf2);
+                            f3 tr = mk3(1.f, 1.f, 1.f);
+                            if (medium >= 0) tr = hom_tr(&sc->d->mediums[medium], lightRay.tmax);
+                            Ld = add3(Ld, dvs3(scl3(mul3(mul3(scl3(tr, weight), fr), radiance2), fabsf(dot3(out, nor))), pdf));
+                        }
+                    } else if (sc->inf.isvalid) {
+                        f3 radiance2 = inf_lookup(&sc->inf, lightRay.d);
+                        float choicePdf2 = pdf_from_light_distribution(sc, sc->d->n_lights);
+                        float lightPdf2 = ONE_OVER_FOUR_PI;
+                        float weight = power_heuristic(1, pdf, 1, lightPdf2 * choicePdf2);
+                        f3 tr = mk3(1.f, 1.f, 1.f);
+                        if (medium >= 0) tr = hom_tr(&sc->d->mediums[medium], lightRay.tmax);
+                        Ld = add3(Ld, dvs3(scl3(mul3(mul3(scl3(tr, weight), fr), radiance2), fabsf(dot3(out, nor))), pdf));
+                    }
+                }
+                Li = add3(Li, mul3(beta, Ld));
+            }
+            float ux = rng_uniform(&rng);
+            float uy = rng_uniform(&rng);
+            float uz = rng_uniform(&rng);
+            f3 out, fr;
+            float pdf;
+            sample_bsdf(sc, &material, neg3(r.d), nor, uv, dpdu, mk3(ux, uy, uz), &out, &fr, &pdf);
+            if (is_black(fr))
+                break;
+            beta = mul3(beta, dvs3(scl3(fr, fabsf(dot3(nor, out))), pdf));
+            specular = is_delta(material.type);
+            int m2 = medium_of_side(&isect, dot3(out, nor));
+            m2 = dot3(neg3(r.d), nor) * dot3(out, nor) > 0 ? medium : m2;       /* a reflection stays in its medium */
+            medium = m2;
+            r = mk_ray(pos, out, sc->eps, INFINITY);
+        }
+        if (bounces > 3) {
+            float illumate = clampf(1.f - luminance(beta), 0.f, 1.f);
+            if (rng_uniform(&rng) < illumate)
+                break;
+            beta = dvs3(beta, 1 - illumate);
+        }
+    }
+    if (!is_inf3(Li) && !is_nan3(Li)) {
+        *Li_out = Li;
+        return 1;
+    }
+    return 0;
+}
+
 /* ---- Ao: pathtracer.cu:830-876 ---------------------------------------------------------------------- */
 /* returns 1 and writes *L_out when the reference stores the sample (always on a miss, `!IsNan(L)` on a hit -
  * an infinite value IS stored, unlike Path's guard) */
@@ -1152,8 +1413,11 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
                       float eps, uint32_t iter_first, uint32_t iter_count, int reset,
                       float *acc, float *color, float *out, int rank, int n_ranks, int n_threads)
 {
-    if (desc->integrator_type != GPT_IT_PT && desc->integrator_type != GPT_IT_AO) return -1;
-    const int ao = desc->integrator_type == GPT_IT_AO;
+    if (desc->integrator_type != GPT_IT_PT && desc->integrator_type != GPT_IT_AO && desc->integrator_type != GPT_IT_VPT) return -1;
+    const int ao = desc->integrator_type == GPT_IT_AO, vpt = desc->integrator_type == GPT_IT_VPT;
+    if (vpt)
+        for (int i = 0; i < desc->n_mediums; ++i)
+            if (desc->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS) return -2;      /* heterogeneous media: not restated */
     scene_t sc;
     sc.d = desc;
     sc.eps = eps;
@@ -1188,7 +1452,8 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
                 for (uint32_t it = iter_first; it < iter_first + iter_count; ++it) {
                     f3 Li;
                     if (ao ? ao_sample(&sc, cam, x, y, pixel, it, desc->max_dist, &Li)
-                           : path_sample(&sc, cam, x, y, pixel, it, maxDepth, &Li))
+                           : vpt ? vpt_sample(&sc, cam, x, y, pixel, it, maxDepth, &Li)
+                                 : path_sample(&sc, cam, x, y, pixel, it, maxDepth, &Li))
                         c = Li;
                     a = add3(a, c);
                 }
@@ -1483,6 +1748,8 @@ API void oracle_math_batch(int fn, const float *x, const float *y, float *out, i
         case 6: out[i] = x[i] / y[i]; break;
         case 7: out[i] = sqrtf(x[i]); break;
         case 8: out[i] = 1.0f / sqrtf(x[i]); break;
+        case 9: out[i] = M_EXP(x[i]); break;
+        case 10: out[i] = M_LOG(x[i]); break;
         default: out[i] = 0.f; break;
         }
     }

@@ -78,6 +78,14 @@ class Scene:
     def set_max_depth(self, d):
         self.desc.max_depth = d
 
+    def set_mediums(self, mediums):
+        """list of st.make_medium(...) records; triangles / the camera refer to them by index"""
+        self.mediums = np.zeros(max(1, len(mediums)), dtype=st.MEDIUM)
+        for i, m in enumerate(mediums):
+            self.mediums[i] = m
+        self.desc.mediums = st.ptr(self.mediums) if len(mediums) else None
+        self.desc.n_mediums = len(mediums)
+
 
 def bvh_build(prims, lib=None):
     lib = lib or load("soft")

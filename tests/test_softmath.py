@@ -20,6 +20,8 @@ CASES = [
     (2, "tan", np.tan, lambda r, n: r.random(n) * 8.5 - 0.5),
     (3, "atan", np.arctan, lambda r, n: r.standard_normal(n) * np.exp(r.standard_normal(n) * 4)),
     (4, "acos", np.arccos, lambda r, n: r.random(n) * 2 - 1),
+    (9, "exp", np.exp, lambda r, n: r.standard_normal(n) * 20),
+    (10, "log", np.log, lambda r, n: np.exp(r.standard_normal(n) * 12)),
 ]
 
 
@@ -49,6 +51,16 @@ def test_soft_edge_cases():
     assert batch("soft", 0, np.zeros(1, np.float32))[0] == 0 and batch("soft", 1, np.zeros(1, np.float32))[0] == 1
     big = np.array([np.inf, -np.inf, 1e30, -1e30], np.float32)
     assert np.allclose(batch("soft", 3, big), [np.pi / 2, -np.pi / 2, np.pi / 2, -np.pi / 2])
+
+
+def test_soft_exp_log_edge_cases():
+    x = np.array([0.0, -0.0, 1.0, np.inf, -1.0, 1e-45, 88.9, -105.0, -np.inf], np.float32)
+    with np.errstate(all="ignore"):
+        lg = batch("soft", 10, x)
+        ex = batch("soft", 9, x)
+    assert lg[0] == -np.inf and lg[1] == -np.inf and lg[2] == 0 and lg[3] == np.inf and np.isnan(lg[4])
+    assert lg[5] == np.float32(np.log(np.float64(np.float32(1e-45))))
+    assert ex[0] == 1 and ex[2] == np.float32(np.e) and ex[3] == np.inf and ex[6] == np.inf and ex[7] == 0 and ex[8] == 0
 
 
 def test_ieee_ops_match_numpy():
