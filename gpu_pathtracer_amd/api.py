@@ -205,10 +205,12 @@ class Renderer:
         """"pt": value = maxDepth; "ao": value = maxDist (the reference reads both from the scene on every Render call)"""
         if kind == "pt":
             check(self.lib.gpt_set_integrator(self.ctx, st.IT_PT, int(value), 0.0))
+        elif kind == "vpt":
+            check(self.lib.gpt_set_integrator(self.ctx, st.IT_VPT, int(value), 0.0))
         elif kind == "ao":
             check(self.lib.gpt_set_integrator(self.ctx, st.IT_AO, 0, float(value)))
         else:
-            raise ValueError(f"integrator {kind!r} is not supported (pt, ao)")
+            raise ValueError(f"integrator {kind!r} is not supported (pt, vpt, ao)")
 
     def render(self, camera, iter_first, iter_count, reset=False, out_dev=None):
         check(self.lib.gpt_render(self.ctx, C.byref(camera), int(iter_first), int(iter_count), int(bool(reset)), out_dev))

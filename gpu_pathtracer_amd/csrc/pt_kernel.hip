@@ -1410,6 +1410,52 @@ __device__ __forceinline__ V3 tonemap(V3 in, bool filmic)   // pathtracer.cu:187
     return in;
 }
 
+// ------------------------------------------------ participating media -----
+// Homogeneous media and the Henyey-Greenstein phase function (src/medium.h:9-51,196-233), as oracle/pt_oracle.c
+// restates them (hom_tr, hom_sample, medium_phase, medium_sample_phase).
+__device__ __forceinline__ V3 exp3(V3 c) { return V3{gpt_expf(c.x), gpt_expf(c.y), gpt_expf(c.z)}; }       // common.h:81-86
+__device__ __forceinline__ V3 hom_tr(const DevMedium &m, float tmax)                                          // medium.h:14-17
+{
+    return exp3(V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]} * (-tmax));
+}
+__device__ __forceinline__ V3 hom_sample(const DevMedium &m, float ray_tmax, float u, float &t, bool &sampled)  // medium.h:19-50
+{
+    const V3 sigmaT = V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]}, sigmaS = V3{m.sigmaS[0], m.sigmaS[1], m.sigmaS[2]};
+    float sigma = dot(sigmaT, v3(0.212671f, 0.715160f, 0.072169f));
+    float dist = -gpt_logf(u) / sigma;                                  // wrap.h:158-160
+    V3 Tr = exp3(sigmaT * (-dist));
+    float pdf = sigma * gpt_expf(sigma * -dist);
+    bool sampledMedium = dist < ray_tmax;
+    sampled = sampledMedium;
+    t = dist;
+    return sampledMedium ? (Tr * sigmaS) / pdf : (sigmaT * Tr) / pdf;
+}
+__device__ __forceinline__ float medium_phase(const DevMedium &m, V3 in, V3 out)                               // medium.h:222-233
+{
+    float g = m.g;
+    if (g == 0) return ONE_OVER_FOUR_PI;
+    float costheta = dot(in, out);
+    float cubicTerm = (1.f + g * g - 2.f * g * costheta);
+    return ONE_OVER_FOUR_PI * (1.f - g * g) / sqrt_rn(cubicTerm * cubicTerm * cubicTerm);
+}
+__device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, float uy)                      // medium.h:196-220
+{
+    float g = m.g;
+    float unused;
+    if (g == 0) return uniform_sphere(ux, uy, unused);
+    float costheta;
+    if (fabs_(g) < 1e-3f)
+        costheta = 1.f - 2.f * ux;
+    else {
+        float sqrtTerm = (1.f - g * g) / (1.f - g + 2.f * g * ux);
+        costheta = (1.f + g * g - sqrtTerm * sqrtTerm) / (2.f * g);
+    }
+    float sintheta = sqrt_rn(1.f - costheta * costheta);
+    float phi = TWOPI * uy;
+    float sinphi = gpt_sinf(phi), cosphi = gpt_cosf(phi);
+    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+}
+
 // ----------------------------------------------------- the render kernel -----
 // normal + light index of a hit, for the MIS light ray (mesh.h:87-90): the
 // other Intersection fields are not read at pathtracer.cu:960-976
@@ -1440,7 +1486,9 @@ struct RayResults {    // this lane's own rays, read back from the pool
 constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray pools exactly 4 workgroups per CU
 
 // INTEG: GPT_IT_PT = Path (pathtracer.cu:880-1021), GPT_IT_AO = Ao (:830-876: one cosine-weighted occlusion ray
-// of length maxDist per primary hit; the same pools, drain and sample planes)
+// of length maxDist per primary hit; the same pools, drain and sample planes), GPT_IT_VPT = Volpath (:1025-1242) for
+// homogeneous media in scenes without material-less interface surfaces: a shadow ray is then still one any-hit ray,
+// and every transmittance factor is known at shading time or from the hit distance of the BSDF-sampled light ray
 template <bool COUNT, bool SMALL, int INTEG>
 __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
@@ -1490,6 +1538,10 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
     bool waiting = false;                               // carry: some of this path's rays are still being traced
+    // Volpath: the medium the path ray travels in (-1 = none), the one the pending direct-light rays travel in, and
+    // whether an occluded light sample poisons the sample (Tr = 0 times a non-finite factor is NaN, pathtracer.cu:1092,1150)
+    int medium = -1, medium_ld = -1;
+    bool poison_occluded = false;
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
@@ -1562,6 +1614,11 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 if (direct) {
                     V3 Ld = v3(0.f, 0.f, 0.f);
                     if (q.has_s && !res.occluded) Ld += cand;
+                    if (INTEG == GPT_IT_VPT && q.has_s && res.occluded && poison_occluded)
+                        Ld += v3(__builtin_nanf(""));           // Tr = 0 times a non-finite factor (pathtracer.cu:298-322)
+                    V3 tr_m = v3(1.f, 1.f, 1.f);                 // Volpath: transmittance along the BSDF-sampled light ray
+                    if (INTEG == GPT_IT_VPT && q.has_m && medium_ld >= 0)
+                        tr_m = hom_tr(P.mediums[medium_ld], res.prim_m >= 0 ? res.t_m : __builtin_inff());
                     if (q.has_m) {
                         if (res.prim_m >= 0) {
                           if (!q.mis_any) {
@@ -1578,7 +1635,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 float costheta = fabs_(dot(n, q.dir_m));
                                 float lPdf = pdfA * lenSquare / (costheta);
                                 float weight = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
-                                Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
+                                if (INTEG == GPT_IT_VPT) Ld += weight * tr_m * mis_fr * radiance * mis_cos / mis_pdf;
+                                else Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
                             }
                           }
                         } else if (P.inf.isvalid) {
@@ -1586,7 +1644,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                             float choicePdf = pdf_from_light_distribution(P, P.n_lights);
                             float lightPdf = ONE_OVER_FOUR_PI;                             // infinite.h:38-41
                             float weight = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
-                            Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
+                            if (INTEG == GPT_IT_VPT) Ld += weight * tr_m * mis_fr * radiance * mis_cos / mis_pdf;
+                            else Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
                         }
                     }
                     // executed even when both rays were skipped: beta * 0 is NaN for a non-finite
@@ -1600,7 +1659,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 // ---- the path ray came back: pathtracer.cu:905-1016 ----------------------
                 if (!finish && q.has_p) {
                     if (res.prim_p < 0) {
-                        if (INTEG == GPT_IT_PT && (bounces == 0 || specular) && P.inf.isvalid)
+                        if (INTEG != GPT_IT_AO && (bounces == 0 || specular) && P.inf.isvalid)
                             Li += beta * inf_le(P.inf, q.dir_p);
                         finish = true;          // Ao: the sample is 0 (pathtracer.cu:852-855)
                     } else {
@@ -1617,7 +1676,81 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                         q.has_s = q.has_m = q.has_p = false;
                         PT_MARK(1)
 
-                        if (INTEG == GPT_IT_AO) {
+                        // Volpath (pathtracer.cu:1062-1070): the medium decides whether the ray gets as far as the surface
+                        bool scattered = false;
+                        float scatter_t = 0.f;
+                        if (INTEG == GPT_IT_VPT && medium >= 0) {
+                            float u = rng_uniform(rng);
+                            beta *= hom_sample(P.mediums[medium], res.t_p, u, scatter_t, scattered);
+                        }
+                        if (INTEG == GPT_IT_VPT && is_black(beta)) {
+                            finish = true;
+                        } else if (INTEG == GPT_IT_VPT && scattered) {
+                            // ---- a scattering event inside the medium (pathtracer.cu:1071-1101) ----
+                            const DevMedium M = P.mediums[medium];
+                            float u = rng_uniform(rng);
+                            float choicePdf;
+                            int idx = lookup_light_distribution(P, u, choicePdf);
+                            bool inf = idx == P.n_lights;
+                            V3 samplePos = q.org + q.dir_p * scatter_t;
+                            float u1x = rng_uniform(rng);
+                            float u1y = rng_uniform(rng);
+                            V3 radiance = v3(0.f), lightNor;
+                            Ray shadowRay;
+                            shadowRay.o = samplePos;
+                            shadowRay.d = v3(0.f);
+                            shadowRay.tmin = P.eps;
+                            shadowRay.tmax = 0.f;
+                            float lightPdf = 0.f;
+                            if (idx >= 0) {
+                                if (!inf)
+                                    area_sample_light(P.lights[idx], samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                else
+                                    inf_sample_light(P.inf, samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                            }
+                            float phase = medium_phase(M, wo, shadowRay.d);
+                            poison_occluded = false;
+                            if (!is_black(radiance)) {
+                                // Li += tr * beta * phase * radiance / (lightPdf * choicePdf), tr = 0 when the light is hidden
+                                const V3 tr1 = hom_tr(M, shadowRay.tmax);
+                                cand = tr1 * beta * phase * radiance / (lightPdf * choicePdf);
+                                poison_occluded = is_nan(v3(0.f) * beta * phase * radiance / (lightPdf * choicePdf));
+                                if (!is_black(cand) || poison_occluded) {
+                                    q.dir_s = shadowRay.d;
+                                    q.tmax_s = shadowRay.tmax;
+                                    q.has_s = true;
+                                }
+                            }
+                            beta_ld = v3(1.f, 1.f, 1.f);
+                            direct = true;
+                            float pux = rng_uniform(rng);
+                            float puy = rng_uniform(rng);
+                            const V3 dir = medium_sample_phase(M, pux, puy);
+                            q.org = samplePos;
+                            specular = false;
+                            ending = true;
+                            if (bounces + 1 < P.max_depth) {
+                                bool kill = false;
+                                if (bounces > 3) {
+                                    float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                    if (rng_uniform(rng) < illumate)
+                                        kill = true;
+                                    else
+                                        beta /= (1 - illumate);
+                                }
+                                if (!kill) {
+                                    q.dir_p = dir;
+                                    q.has_p = true;
+                                    ending = false;
+                                    bounces++;
+                                }
+                            }
+                            if (ending && !q.has_s) {
+                                Li += beta_ld * v3(0.f, 0.f, 0.f);
+                                direct = false;
+                                finish = true;
+                            }
+                        } else if (INTEG == GPT_IT_AO) {
                             // pathtracer.cu:857-872
                             V3 n = nor;
                             if (dot(wo, nor) < 0.f)
@@ -1647,13 +1780,20 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 finish = true;
                             }
                         } else if ((bounces == 0 || specular) && isect.lightIdx != -1) {
-                            Li += beta * area_le(P.lights[isect.lightIdx], nor, wo);
+                            if (INTEG == GPT_IT_VPT) {
+                                V3 tr = v3(1.f, 1.f, 1.f);
+                                if (medium >= 0) tr = hom_tr(P.mediums[medium], res.t_p);
+                                Li += tr * beta * area_le(P.lights[isect.lightIdx], nor, wo);        // pathtracer.cu:1103-1115
+                            } else {
+                                Li += beta * area_le(P.lights[isect.lightIdx], nor, wo);
+                            }
                             finish = true;
                         } else {
                             q.org = pos;
                             // direct light with multiple importance sampling: everything that
                             // does not depend on visibility is evaluated now
                             if (!is_delta(PT_MATERIAL_TYPE(material))) {
+                                poison_occluded = false;
                                 float u = rng_uniform(rng);
                                 float choicePdf;
                                 int idx = lookup_light_distribution(P, u, choicePdf);
@@ -1679,10 +1819,19 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                     float samplePdf;
                                     eval_bsdf(P, material, wo, shadowRay.d, nor, uv, dpdu, fr, samplePdf);
                                     float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
-                                    cand = weight * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
+                                    if (INTEG == GPT_IT_VPT) {
+                                        // Ld += weight * tr * fr * radiance * |cos| / pdf with tr = Tr(shadowRay): the medium's
+                                        // transmittance if the light is visible, 0 if not (pathtracer.cu:1146-1151)
+                                        V3 tr1 = v3(1.f, 1.f, 1.f);
+                                        if (medium >= 0) tr1 = hom_tr(P.mediums[medium], shadowRay.tmax);
+                                        cand = weight * tr1 * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
+                                        poison_occluded = is_nan(weight * v3(0.f) * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf));
+                                    } else {
+                                        cand = weight * fr * radiance * fabs_(dot(nor, shadowRay.d)) / (lightPdf * choicePdf);
+                                    }
                                     // an exactly-zero term (e.g. the light is below the horizon of a lambertian
                                     // surface: Fr returns 0) adds nothing whether or not the light is visible
-                                    if (!is_black(cand)) {
+                                    if (!is_black(cand) || (INTEG == GPT_IT_VPT && poison_occluded)) {
                                         q.dir_s = shadowRay.d;
                                         q.tmax_s = shadowRay.tmax;
                                         q.has_s = true;
@@ -1723,6 +1872,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                     }
                                 }
                                 beta_ld = beta;
+                                medium_ld = medium;
                                 direct = true;
                                 PT_MARK(3)
                             }
@@ -1739,6 +1889,14 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 if (!is_black(fr)) {
                                     beta *= fr * fabs_(dot(nor, out)) / pdf;
                                     specular = is_delta(PT_MATERIAL_TYPE(material));
+                                    if (INTEG == GPT_IT_VPT) {
+                                        // the medium on the side the new ray leaves on; a reflection stays where it was
+                                        // (pathtracer.cu:1223-1227)
+                                        const int m_in = P.prim_media[2 * res.prim_p], m_out = P.prim_media[2 * res.prim_p + 1];
+                                        int m2 = dot(out, nor) > 0 ? m_out : m_in;
+                                        m2 = dot(wo, nor) * dot(out, nor) > 0 ? medium : m2;
+                                        medium = m2;
+                                    }
                                     bool kill = false;
                                     if (bounces > 3) {
                                         float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
@@ -1828,6 +1986,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 bounces = 0;
                 ending = false;
                 direct = false;
+                medium = INTEG == GPT_IT_VPT ? P.cam.medium : -1;      // pathtracer.cu:1043
                 alive = true;
                 if (COUNT) cnt.samples++;
             }
@@ -2049,7 +2208,12 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream
                        !getenv("GPT_NO_LDS_SCENE");
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
-    if (!ao) {
+    if (P.integrator == GPT_IT_VPT) {
+        if (count && small) PT_LAUNCH(true, true, GPT_IT_VPT);
+        else if (count) PT_LAUNCH(true, false, GPT_IT_VPT);
+        else if (small) PT_LAUNCH(false, true, GPT_IT_VPT);
+        else PT_LAUNCH(false, false, GPT_IT_VPT);
+    } else if (!ao) {
         if (count && small) PT_LAUNCH(true, true, GPT_IT_PT);
         else if (count) PT_LAUNCH(true, false, GPT_IT_PT);
         else if (small) PT_LAUNCH(false, true, GPT_IT_PT);

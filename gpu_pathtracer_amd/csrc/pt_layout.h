@@ -80,6 +80,14 @@ struct DevInfinite {
 };
 
 // kernel arguments (by value in the kernarg segment)
+struct alignas(16) DevMedium {       // a homogeneous medium (src/medium.h:9-51,186-233)
+    float sigmaS[3];
+    float g;
+    float sigmaT[3];
+    float _pad;
+};
+static_assert(sizeof(DevMedium) == 32, "DevMedium");
+
 struct DevParams {
     const DevNode *nodes;
     const DevTri *tris;
@@ -118,6 +126,9 @@ struct DevParams {
     uint32_t *tile_counter;      // work queue head (zeroed before every launch)
     unsigned long long *counters;  // work counters (counting build only)
     int32_t traversal;           // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_NEAR_FIRST (nodes holds 9 threaded variants)
+    // Volpath only (new fields go at the END: the kernarg layout steers the register allocation of the headline kernel)
+    const struct DevMedium *mediums;   // homogeneous media
+    const int32_t *prim_media;         // per primitive (BVH order): mediumInside, mediumOutside
 };
 
 }  // namespace pt

@@ -58,6 +58,8 @@ struct gpt_ctx {
     uint32_t *tile_counter = nullptr;
     unsigned long long *counters = nullptr;
     uint32_t chunk_override = 0;          // GPT_CHUNK_ITERS (experiments)
+    bool media_ok = true;                 // every medium is homogeneous and every index valid ("vpt" can run)
+    int n_mediums = 0;
     float *samples = nullptr;             // per-iteration sample planes, grown on demand
     uint32_t sample_planes = 0;           // planes allocated
     uint32_t max_batch = 256;             // iterations per path-kernel launch (GPT_MAX_BATCH); also capped by kMaxPlaneBytes
@@ -226,13 +228,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         return GPT_ERR_INVALID_ARG;
     }
     *out = nullptr;
-    if (scene->integrator_type == GPT_IT_VPT) {
-        // the oracle restates Volpath for homogeneous media (oracle/pt_oracle.c vpt_sample); the kernel does not yet
-        gpt_set_error("gpt_begin: the \"vpt\" integrator is not built on the GPU yet (%d media in the scene; \"pt\" and \"ao\" are supported)", scene->n_mediums);
-        return GPT_ERR_UNSUPPORTED;
-    }
-    if (scene->integrator_type != GPT_IT_PT && scene->integrator_type != GPT_IT_AO) {
-        gpt_set_error("gpt_begin: integrator type %d is not supported (\"pt\" and \"ao\" are)", scene->integrator_type);
+    if (scene->integrator_type != GPT_IT_PT && scene->integrator_type != GPT_IT_AO && scene->integrator_type != GPT_IT_VPT) {
+        gpt_set_error("gpt_begin: integrator type %d is not supported (\"pt\", \"vpt\" and \"ao\" are)", scene->integrator_type);
         return GPT_ERR_UNSUPPORTED;
     }
     if (scene->n_prims < 0 || scene->n_nodes < 0 || scene->n_materials <= 0 || scene->n_light_distribution < 1) {
@@ -258,6 +255,16 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         if (l < -1 || l >= scene->n_lights) {
             gpt_set_error("gpt_begin: primitive %d has light index %d outside [-1,%d)", i, l, scene->n_lights);
             return GPT_ERR_INVALID_ARG;
+        }
+    }
+    if (scene->integrator_type == GPT_IT_VPT) {
+        // Volpath here renders homogeneous media only (density grids are out of scope: DESIGN.md); refused before any
+        // device work so that the answer is the same with and without a GPU
+        for (int i = 0; i < scene->n_mediums; ++i) {
+            if (!scene->mediums || scene->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS) {
+                gpt_set_error("gpt_begin: \"vpt\" renders homogeneous media only (medium %d is not)", i);
+                return GPT_ERR_UNSUPPORTED;
+            }
         }
     }
     int n_dev = 0;
@@ -315,6 +322,36 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     if ((rc = dev_upload(ctx, lights.data(), lights.size(), &P.lights)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, scene->light_distribution, (size_t)scene->n_light_distribution, &P.light_cdf)) != GPT_OK)
         return fail(rc);
+    // ---- participating media (Volpath).  Only homogeneous media are rendered; they are uploaded whenever the scene has
+    // them, so that gpt_set_integrator can switch to "vpt" later.
+    ctx->media_ok = scene->n_mediums == 0 || scene->mediums != nullptr;
+    for (int i = 0; i < scene->n_mediums && ctx->media_ok; ++i)
+        if (scene->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS) ctx->media_ok = false;
+    ctx->n_mediums = scene->n_mediums;
+    if (ctx->media_ok) {
+        std::vector<DevMedium> media((size_t)scene->n_mediums);
+        for (int i = 0; i < scene->n_mediums; ++i) {
+            const gpt_medium &m = scene->mediums[i];
+            DevMedium &d = media[(size_t)i];
+            std::memset(&d, 0, sizeof(d));
+            d.sigmaS[0] = m.homogeneous.sigmaS.x; d.sigmaS[1] = m.homogeneous.sigmaS.y; d.sigmaS[2] = m.homogeneous.sigmaS.z;
+            d.sigmaT[0] = m.homogeneous.sigmaT.x; d.sigmaT[1] = m.homogeneous.sigmaT.y; d.sigmaT[2] = m.homogeneous.sigmaT.z;
+            d.g = m.g;
+        }
+        std::vector<int32_t> prim_media((size_t)scene->n_prims * 2);
+        for (int i = 0; i < scene->n_prims; ++i) {
+            const int mi = scene->prims[i].triangle.mediumInside, mo = scene->prims[i].triangle.mediumOutside;
+            if (mi < -1 || mi >= scene->n_mediums || mo < -1 || mo >= scene->n_mediums) ctx->media_ok = false;
+            prim_media[2 * (size_t)i] = mi;
+            prim_media[2 * (size_t)i + 1] = mo;
+        }
+        if ((rc = dev_upload(ctx, media.data(), media.size(), &P.mediums)) != GPT_OK) return fail(rc);
+        if ((rc = dev_upload(ctx, prim_media.data(), prim_media.size(), &P.prim_media)) != GPT_OK) return fail(rc);
+    }
+    if (scene->integrator_type == GPT_IT_VPT && !ctx->media_ok) {
+        gpt_set_error("gpt_begin: \"vpt\" renders homogeneous media only (and medium indices must be -1 or < %d)", scene->n_mediums);
+        return fail(GPT_ERR_UNSUPPORTED);
+    }
 
     // ---- textures
     std::vector<DevTexture> texs((size_t)scene->n_textures);
@@ -367,7 +404,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.n_lights = scene->n_lights;
     P.n_cdf = scene->n_light_distribution;
     P.integrator = scene->integrator_type;
-    P.max_depth = scene->integrator_type == GPT_IT_PT ? scene->max_depth : 0;
+    P.max_depth = scene->integrator_type != GPT_IT_AO ? scene->max_depth : 0;
     P.ao_max_dist = scene->integrator_type == GPT_IT_AO ? scene->max_dist : 0.f;
     P.eps = epsilon;
 
@@ -421,12 +458,16 @@ int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks)
 int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth, float max_dist)
 {
     if (!ctx) { gpt_set_error("gpt_set_integrator: null context"); return GPT_ERR_INVALID_ARG; }
-    if (integrator_type != GPT_IT_PT && integrator_type != GPT_IT_AO) {
-        gpt_set_error("gpt_set_integrator: integrator type %d is not supported (\"pt\" and \"ao\" are)", integrator_type);
+    if (integrator_type != GPT_IT_PT && integrator_type != GPT_IT_AO && integrator_type != GPT_IT_VPT) {
+        gpt_set_error("gpt_set_integrator: integrator type %d is not supported (\"pt\", \"vpt\" and \"ao\" are)", integrator_type);
+        return GPT_ERR_UNSUPPORTED;
+    }
+    if (integrator_type == GPT_IT_VPT && !ctx->media_ok) {
+        gpt_set_error("gpt_set_integrator: \"vpt\" renders homogeneous media only");
         return GPT_ERR_UNSUPPORTED;
     }
     ctx->P.integrator = integrator_type;
-    if (integrator_type == GPT_IT_PT) ctx->P.max_depth = max_depth;
+    if (integrator_type == GPT_IT_PT || integrator_type == GPT_IT_VPT) ctx->P.max_depth = max_depth;
     else ctx->P.ao_max_dist = max_dist;
     return GPT_OK;
 }
@@ -446,6 +487,10 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
 {
     if (!ctx || !camera) {
         gpt_set_error("gpt_render: null context or camera");
+        return GPT_ERR_INVALID_ARG;
+    }
+    if (ctx->P.integrator == GPT_IT_VPT && (camera->medium < -1 || camera->medium >= ctx->n_mediums)) {
+        gpt_set_error("gpt_render: camera medium %d outside [-1,%d)", camera->medium, ctx->n_mediums);
         return GPT_ERR_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));

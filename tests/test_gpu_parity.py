@@ -547,6 +547,74 @@ def test_near_first_traversal_matches_the_oracle_in_the_same_mode(gpt, what):
         assert visits_near < 0.95 * visits_ref
 
 
+# ---- Volpath, homogeneous media (pathtracer.cu:1025-1242) ---------------------------------------------
+
+@pytest.mark.parametrize("what", ["fog_cornell", "murky_glass", "fog_env_hg", "fog_large_scene"])
+def test_volpath_homogeneous_bit_exact(gpt, what):
+    """Distance sampling in the ray's medium, in-scattering with the phase function, transmittance on light samples,
+    BSDF-sampled light rays and directly seen emitters, medium changes at refracting surfaces."""
+    fog = st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.3)
+    hg = st.make_medium((0.02, 0.02, 0.02), (0.35, 0.3, 0.25), 0.7, 1.0)
+    back = st.make_medium((0.3, 0.05, 0.02), (0.2, 0.4, 0.6), -0.4, 2.0)
+    cam_medium = 0
+    if what == "fog_cornell":
+        scene, meta = ol.load_cornell(8)
+        W, H, spp, eps = 160, 128, 8, 0.001
+        cam = ol.cornell_camera(meta, W, H)
+    elif what == "murky_glass":
+        # a glass sphere (material 7) filled with a coloured medium, seen through clear air: the medium changes at refraction
+        sphere = scenes.uv_sphere((0.1, 0.75, 0.2), 0.55, 7, nu=20, nv=14)
+        sphere["triangle"]["mediumInside"] = 2
+        scene, meta = scenes.zoo_scene(max_depth=10, extra=sphere, assign={"short": 2, "tall": 5})
+        W, H, spp, eps = 160, 160, 8, 0.001
+        cam = ol.cornell_camera(meta, W, H)
+        cam_medium = -1
+    elif what == "fog_env_hg":
+        scene, meta = scenes.zoo_scene(max_depth=7, with_env=True, assign={"short": 7, "tall": 13, "back": 2, "ceil": 2})
+        W, H, spp, eps = 160, 128, 6, 0.001
+        cam = ol.make_camera((0.3, 1.2, 7.5), (0, 1, 0), (0, 1, 0), (W, H), 40.0)
+        cam_medium = 1
+    else:
+        scene, meta = scenes.stress_scene(0.3, max_depth=12)
+        W, H, spp, eps = 128, 96, 4, 0.001
+        cam = ol.cornell_camera(meta, W, H)
+        cam_medium = 1
+    scene.set_mediums([fog, hg, back])
+    scene.desc.set_integrator("vpt", scene.desc.max_depth)
+    cam.medium = cam_medium
+    ref, col_o = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
+    assert np.isfinite(ref).all() and ref.mean() > 0
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"vpt {what}")
+        assert_bit_exact(r.read_color(), col_o, f"vpt {what} last sample")
+        r.enable_counters(True)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"vpt {what}, counting build")
+        r.enable_counters(False)
+        # the integrator is read at every Render call: Path on the same context ignores the media
+        r.set_integrator("pt", scene.desc.max_depth)
+        r.render(cam, 1, 2, reset=True)
+        scene.desc.set_integrator("pt", scene.desc.max_depth)
+        pt_o, _ = ol.render(scene, cam, W, H, eps, 1, 2, kind="soft")
+        assert_bit_exact(r.read_accum(), pt_o, f"pt after vpt {what}")
+
+
+def test_volpath_refuses_heterogeneous_media(gpt):
+    scene, meta = ol.load_cornell(4)
+    het = st.make_medium((1, 1, 1), (1, 1, 1))
+    het["type"] = 1
+    scene.set_mediums([het])
+    scene.desc.set_integrator("vpt", 4)
+    with pytest.raises(gpt.GptError) as e:
+        gpt.Renderer(scene.desc, 64, 64, 0.001)
+    assert "homogeneous" in str(e.value)
+    scene.desc.set_integrator("pt", 4)
+    with gpt.Renderer(scene.desc, 64, 64, 0.001) as r:          # Path does not care
+        with pytest.raises(gpt.GptError):
+            r.set_integrator("vpt", 4)
+
+
 # ---- Ao integrator (pathtracer.cu:830-876) -------------------------------------------------------
 
 @pytest.mark.parametrize("what", ["cornell", "zoo_global", "thin_lens"])

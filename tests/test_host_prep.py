@@ -120,7 +120,7 @@ def test_begin_without_gpu_fails_loudly():
 
 def test_unsupported_integrator_is_refused():
     scene, _ = ol.load_cornell(4)
-    scene.desc.integrator_type = 2      # "vpt": out of scope for this library
+    scene.desc.integrator_type = 3      # "lt" (light tracing): out of scope for this library
     ctx = C.c_void_p()
     rc = api.load().gpt_begin(C.byref(scene.desc), 64, 64, C.c_float(0.001), 0, C.byref(ctx))
     assert rc == -2 and b"integrator" in api.load().gpt_last_error()

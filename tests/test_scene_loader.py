@@ -355,9 +355,9 @@ def test_shipped_vpt_scene_settings_are_refused_at_begin(scene_dir):
     assert med[0]["type"] == 0 and med[1]["type"] == 1 and med[0]["g"] == 0
     assert np.allclose([med[0]["sigmaS"]["x"], med[0]["sigmaS"]["y"], med[0]["sigmaS"]["z"]], np.float32([0.70, 1.22, 1.90]) * np.float32(25))
     assert med[0]["sigmaT"]["z"] == np.float32(np.float32(0.0142) * np.float32(25)) + np.float32(np.float32(1.90) * np.float32(25))
-    with pytest.raises(api.GptError) as e:             # the renderer: Volpath is not built on the GPU yet
+    with pytest.raises(api.GptError) as e:             # the renderer: homogeneous media only ("hhh" is a density grid)
         api.Renderer(ls.desc, 64, 64, 0.001)
-    assert "vpt" in str(e.value)
+    assert "homogeneous" in str(e.value)
     ls.set_integrator(st.IT_PT, 8)
     assert ls.desc.integrator_type == st.IT_PT and ls.desc.max_depth == 8
 
