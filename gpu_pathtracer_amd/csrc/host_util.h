@@ -11,3 +11,8 @@
 
 // stores a printf-formatted message retrievable through gpt_last_error()
 void gpt_set_error(const char *fmt, ...) GPT_PRINTF_LIKE;
+
+#include <cstdio>
+// fopen(path, "rb"); if that fails, the same with the file name matched case-insensitively inside its directory: the
+// reference's scenes were written on a case-insensitive file system ("geometry/Right.obj" names right.obj)
+FILE *gpt_fopen_read(const char *path);

@@ -200,7 +200,7 @@ bool inflate_raw(const unsigned char *src, size_t n, std::vector<unsigned char> 
 
 bool read_file(const char *path, std::vector<unsigned char> &data)
 {
-    FILE *f = std::fopen(path, "rb");
+    FILE *f = gpt_fopen_read(path);
     if (!f) return false;
     std::fseek(f, 0, SEEK_END);
     long n = std::ftell(f);

@@ -68,7 +68,8 @@ public:
     std::vector<Material> materials;
     std::vector<Area> lights;
     std::vector<Texture> textures;
-    std::vector<gpt_medium> mediums;         // parsescene.cpp:72-137 (homogeneous coefficients; heterogeneous grids are not loaded)
+    std::vector<gpt_medium> mediums;         // parsescene.cpp:72-137
+    std::vector<std::vector<float>> density_grids;   // own the heterogeneous media's density arrays
     std::vector<float> lightDistribution;
     std::vector<float3_t> infinite_data;     // owns infinite.data
     Camera *camera = nullptr;

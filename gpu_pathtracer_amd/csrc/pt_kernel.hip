@@ -202,6 +202,8 @@ __device__ __forceinline__ void pool_put(float4 *pool, int slot, V3 dir, float t
     pool[2 * slot + 1] = make_float4(1.f / dir.x, 1.f / dir.y, 1.f / dir.z, __int_as_float((int)(owner | (any_hit ? 256u : 0u))));
 }
 
+// P_TMAX: the path ray's interval ends at rs.tmax_s (the one-ray-at-a-time Volpath walks bounded segments with it)
+template <bool P_TMAX = false>
 __device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &rs, unsigned lane)
 {
     PoolLayout L;
@@ -212,13 +214,14 @@ __device__ __forceinline__ PoolLayout pool_deposit(float4 *pool, const RaySet &r
     L.n_m = popc(L.m_m);
     L.n_rays = L.n_p + L.n_m + popc(L.m_s);
     pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
-    if (rs.has_p) pool_put(pool, lane_rank(L.m_p), rs.dir_p, __builtin_inff(), lane, false);
+    if (rs.has_p) pool_put(pool, lane_rank(L.m_p), rs.dir_p, P_TMAX ? rs.tmax_s : __builtin_inff(), lane, false);
     if (rs.has_m) pool_put(pool, L.n_p + lane_rank(L.m_m), rs.dir_m, __builtin_inff(), lane, rs.mis_any);
     if (rs.has_s) pool_put(pool, L.n_p + L.n_m + lane_rank(L.m_s), rs.dir_s, rs.tmax_s, lane, true);
     return L;
 }
 
 // carry layout: the rays of the lanes in `depositing` go to their fixed slots; returns how many are new
+template <bool P_TMAX = false>
 __device__ __forceinline__ int pool_deposit_fixed(float4 *pool, const RaySet &rs, unsigned lane, bool depositing)
 {
     const bool dp = depositing && rs.has_p, dm = depositing && rs.has_m, ds = depositing && rs.has_s;
@@ -230,7 +233,7 @@ __device__ __forceinline__ int pool_deposit_fixed(float4 *pool, const RaySet &rs
         pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
         pend[lane] = (dp ? 1u : 0u) | (dm ? 2u : 0u) | (ds ? 4u : 0u);
     }
-    if (dp) { pool_put(pool, (int)lane, rs.dir_p, __builtin_inff(), lane, false); order[lane_rank(m_p)] = (unsigned short)lane; }
+    if (dp) { pool_put(pool, (int)lane, rs.dir_p, P_TMAX ? rs.tmax_s : __builtin_inff(), lane, false); order[lane_rank(m_p)] = (unsigned short)lane; }
     if (dm) { pool_put(pool, 64 + (int)lane, rs.dir_m, __builtin_inff(), lane, rs.mis_any); order[n_p + lane_rank(m_m)] = (unsigned short)(64u + lane); }
     if (ds) { pool_put(pool, 128 + (int)lane, rs.dir_s, rs.tmax_s, lane, true); order[n_p + n_m + lane_rank(m_s)] = (unsigned short)(128u + lane); }
     return n_p + n_m + popc(m_s);
@@ -1456,6 +1459,124 @@ __device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, 
     return v3(sintheta * cosphi, costheta, sintheta * sinphi);
 }
 
+// Heterogeneous media (src/medium.h:53-182), as oracle/pt_oracle.c restates them (het_d, het_density, het_tr,
+// het_sample): a density grid in the box p0..p1, sampled by delta tracking; transmittance by delta (0), ratio (1) or
+// residual ratio (2) tracking.  Every loop draws from the path's generator and ends after iterMax steps at the latest.
+__device__ __forceinline__ int f2i_sat(float f)        // float -> int as v_cvt_i32_f32 defines it (truncate, saturate, NaN -> 0)
+{
+    if (f != f) return 0;
+    if (f <= -2147483648.f) return (int)0x80000000;
+    if (f >= 2147483648.f) return 0x7fffffff;
+    return (int)f;
+}
+__device__ __forceinline__ float het_d(const DevMedium &m, float px, float py, float pz)                     // medium.h:176-181
+{
+    const int x = f2i_sat(px), y = f2i_sat(py), z = f2i_sat(pz);
+    if (x < 0 || x > m.nx - 1 || y < 0 || y > m.ny - 1 || z < 0 || z > m.nz - 1) return 0.f;
+    return m.density[(size_t)z * (size_t)m.ny * (size_t)m.nx + (size_t)y * (size_t)m.nx + (size_t)x];
+}
+__device__ __forceinline__ float lerp_(float a, float b, float t) { return a + t * (b - a); }               // cutil_math.h:1008-1011
+__device__ __forceinline__ float het_density(const DevMedium &m, V3 p)                                       // medium.h:160-174
+{
+    const V3 ps = v3(p.x * m.nx, p.y * m.ny, p.z * m.nz);
+    const V3 psi = v3(__builtin_floorf(ps.x), __builtin_floorf(ps.y), __builtin_floorf(ps.z));
+    const V3 delta = ps - psi;
+    float d00 = lerp_(het_d(m, psi.x, psi.y, psi.z), het_d(m, psi.x + 1, psi.y, psi.z), delta.x);
+    float d10 = lerp_(het_d(m, psi.x, psi.y + 1, psi.z), het_d(m, psi.x + 1, psi.y + 1, psi.z), delta.x);
+    float d01 = lerp_(het_d(m, psi.x, psi.y, psi.z + 1), het_d(m, psi.x + 1, psi.y, psi.z + 1), delta.x);
+    float d11 = lerp_(het_d(m, psi.x, psi.y + 1, psi.z + 1), het_d(m, psi.x + 1, psi.y + 1, psi.z + 1), delta.x);
+    float d0 = lerp_(d00, d10, delta.y);
+    float d1 = lerp_(d01, d11, delta.y);
+    return lerp_(d0, d1, delta.z);
+}
+__device__ __forceinline__ V3 het_local(const DevMedium &m, V3 o, V3 d, float dist)      // (r(dist) - p0) / (p1 - p0)
+{
+    const V3 p0 = V3{m.p0[0], m.p0[1], m.p0[2]}, ext = V3{m.p1[0], m.p1[1], m.p1[2]} - p0;
+    const V3 p = (o + d * dist) - p0;
+    return v3(p.x / ext.x, p.y / ext.y, p.z / ext.z);
+}
+__device__ __noinline__ float het_tr(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng)                 // medium.h:64-132
+{
+    const float invMax = m.invMaxDensity;
+    const float sigma = dot(V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]}, v3(0.212671f, 0.715160f, 0.072169f));
+    float tr = 1.f, dist = 0.f;
+    int iter = m.iterMax;
+    if (m.trType == 0) {
+        for (;;) {
+            dist += -gpt_logf(rng_uniform(rng)) * invMax / sigma;
+            if (dist >= tmax) break;
+            const float dens = het_density(m, het_local(m, o, d, dist));
+            if (dens * invMax > rng_uniform(rng)) { tr = 0; break; }
+            if (--iter == 0) { tr = 0; break; }
+        }
+    } else if (m.trType == 1) {
+        for (;;) {
+            dist += -gpt_logf(rng_uniform(rng)) * invMax / sigma;
+            if (dist >= tmax) break;
+            tr *= 1.f - het_density(m, het_local(m, o, d, dist)) * invMax;
+            if (tr < 0.1f) {
+                const float q = 1.f - tr;
+                if (rng_uniform(rng) < q) return 0.f;
+                tr = 1;
+            }
+            if (--iter == 0) break;
+        }
+    } else {
+        const float maxDensity = 1 / invMax;
+        const float ce = 0.5f * maxDensity;
+        const float tc = gpt_expf(-tmax * ce * sigma);
+        for (;;) {
+            dist += -gpt_logf(rng_uniform(rng)) * (1 / (maxDensity - ce) / sigma);
+            if (dist >= tmax) break;
+            tr *= 1.f - (het_density(m, het_local(m, o, d, dist)) - ce) / (maxDensity - ce);
+            if (tr < 0.1f) {
+                const float q = 1.f - tr;
+                if (rng_uniform(rng) < q) return 0.f;
+                tr /= (1.f - q);
+            }
+            if (--iter == 0) break;
+        }
+        tr *= tc;
+    }
+    return tr;
+}
+__device__ __noinline__ V3 het_sample(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng, float &t, bool &sampled)   // medium.h:134-157
+{
+    const float invMax = m.invMaxDensity;
+    const float sigma = dot(V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]}, v3(0.212671f, 0.715160f, 0.072169f));
+    float dist = 0.f;
+    int iter = m.iterMax;
+    for (;;) {
+        dist += -gpt_logf(rng_uniform(rng)) * invMax / sigma;
+        if (dist >= tmax) break;
+        const float dens = het_density(m, het_local(m, o, d, dist));
+        if (dens * invMax > rng_uniform(rng)) {
+            t = dist;
+            sampled = true;
+            return v3(m.sigmaS[0] / m.sigmaT[0], m.sigmaS[1] / m.sigmaT[1], m.sigmaS[2] / m.sigmaT[2]);
+        }
+        if (--iter == 0) break;
+    }
+    t = dist;
+    sampled = false;
+    return v3(1.f, 1.f, 1.f);
+}
+// the type switch of every call site (pathtracer.cu:307-312,1064-1069,1106-1111,1172-1177,1193-1198)
+__device__ __forceinline__ V3 med_tr(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng)
+{
+    if (m.type == GPT_MEDIUM_HOMOGENEOUS) return hom_tr(m, tmax);
+    const float tr = het_tr(m, o, d, tmax, rng);
+    return v3(tr, tr, tr);
+}
+__device__ __forceinline__ V3 med_sample(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng, float &t, bool &sampled)
+{
+    if (m.type == GPT_MEDIUM_HOMOGENEOUS) {
+        const float u = rng_uniform(rng);
+        return hom_sample(m, tmax, u, t, sampled);
+    }
+    return het_sample(m, o, d, tmax, rng, t, sampled);
+}
+
 // ----------------------------------------------------- the render kernel -----
 // normal + light index of a hit, for the MIS light ray (mesh.h:87-90): the
 // other Intersection fields are not read at pathtracer.cu:960-976
@@ -1489,6 +1610,10 @@ constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray p
 // of length maxDist per primary hit; the same pools, drain and sample planes), GPT_IT_VPT = Volpath (:1025-1242) for
 // homogeneous media in scenes without material-less interface surfaces: a shadow ray is then still one any-hit ray,
 // and every transmittance factor is known at shading time or from the hit distance of the BSDF-sampled light ray
+// Volpath with density grids or material-less surfaces: an internal fourth value of INTEG (not an integrator type of the
+// ABI; launch_render picks it when DevParams.vpt_walk is set) and the stages of its per-path state machine
+#define PT_IT_VPT_WALK 8
+constexpr int kStPath = 0, kStShadow = 1, kStMisStart = 2, kStMis = 3, kStContinue = 4;
 template <bool COUNT, bool SMALL, int INTEG>
 __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
@@ -1594,6 +1719,19 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         bool direct = false;       // a non-delta bounce is waiting for `Li += beta*Ld` (pathtracer.cu:994)
         bool ending = false;       // the path has no continuation; the sample ends once Ld is resolved
         bool alive = false;
+        // ---- the one-ray-at-a-time Volpath (PT_IT_VPT_WALK) only: where the path's state machine stands, the surface
+        // hit (or scatter point) it is working on, the shadow walk and the pieces of the pending light-sample term
+        int stage = 0;
+        V3 ctx_o = v3(0.f), ctx_d = v3(0.f);
+        float ctx_t = 0.f, ctx_b1 = 0.f, ctx_b2 = 0.f;
+        int ctx_prim = -1;
+        bool ctx_scatter = false;
+        V3 walk_tr = v3(1.f);
+        int walk_medium = -1;
+        float walk_left = 0.f;
+        float sav_w = 0.f, sav_abs = 0.f, sav_den = 1.f;
+        V3 sav_fr = v3(0.f), sav_rad = v3(0.f), Ld_acc = v3(0.f);
+        bool sav_has = false;
 
         RaySet q;
         q.org = q.dir_s = q.dir_m = q.dir_p = v3(0.f);
@@ -1609,7 +1747,306 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             bool finish = false;
             if (COUNT) cyc_sub = __builtin_readcyclecounter();
             PT_MARK(0)
-            if (alive && !waiting) {
+            if (INTEG == PT_IT_VPT_WALK && alive && !waiting) {
+                // ---- Volpath, general form (pathtracer.cu:298-322,1025-1242): one ray in flight per path.  Density
+                // grids draw random numbers per traced segment and material-less surfaces split a shadow ray into
+                // segments, so nothing can be sampled ahead of the ray it depends on: the loop body of the reference
+                // is cut at its Intersect() calls into stages, and a lane steps through them until it has a ray to
+                // trace or the sample ends.  The ray is (q.org, q.dir_p, q.tmax_s); its closest hit arrives in res.*_p.
+                bool hit = res.prim_p >= 0;
+                q.has_p = false;
+                for (;;) {
+                    if (stage == kStPath) {
+                        // ---- the path ray came back (pathtracer.cu:1049-1129)
+                        if (!hit) {
+                            if ((bounces == 0 || specular) && P.inf.isvalid)
+                                Li += beta * inf_le(P.inf, q.dir_p);
+                            finish = true;
+                            break;
+                        }
+                        Ray r;
+                        r.o = q.org;
+                        r.d = q.dir_p;
+                        const Hit isect = make_hit(P, r, res.t_p, res.prim_p, res.b1_p, res.b2_p);
+                        const V3 wo = -q.dir_p;
+                        bool scattered = false;
+                        float scatter_t = 0.f;
+                        if (medium >= 0)
+                            beta *= med_sample(P.mediums[medium], q.org, q.dir_p, res.t_p, rng, scatter_t, scattered);
+                        if (is_black(beta)) {
+                            finish = true;
+                            break;
+                        }
+                        if (scattered) {
+                            // a scattering event inside the medium (:1071-1101): light sample, then its shadow walk
+                            const DevMedium &M = P.mediums[medium];
+                            float u = rng_uniform(rng);
+                            float choicePdf;
+                            int idx = lookup_light_distribution(P, u, choicePdf);
+                            bool inf = idx == P.n_lights;
+                            V3 samplePos = q.org + q.dir_p * scatter_t;
+                            float u1x = rng_uniform(rng);
+                            float u1y = rng_uniform(rng);
+                            V3 radiance = v3(0.f), lightNor;
+                            Ray shadowRay;
+                            shadowRay.o = samplePos;
+                            shadowRay.d = v3(0.f);
+                            shadowRay.tmin = P.eps;
+                            shadowRay.tmax = 0.f;
+                            float lightPdf = 0.f;
+                            if (idx >= 0) {
+                                if (!inf)
+                                    area_sample_light(P.lights[idx], samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                else
+                                    inf_sample_light(P.inf, samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                            }
+                            sav_w = medium_phase(M, wo, shadowRay.d);
+                            sav_rad = radiance;
+                            sav_den = lightPdf * choicePdf;
+                            sav_has = !is_black(radiance);
+                            ctx_scatter = true;
+                            ctx_o = samplePos;
+                            walk_tr = v3(1.f, 1.f, 1.f);       // Tr() is walked whatever the radiance is (:1092)
+                            walk_medium = medium;
+                            walk_left = shadowRay.tmax;
+                            q.org = shadowRay.o;
+                            q.dir_p = shadowRay.d;
+                            q.tmax_s = shadowRay.tmax;
+                            q.has_p = true;
+                            stage = kStShadow;
+                            break;
+                        }
+                        if ((bounces == 0 || specular) && isect.lightIdx != -1) {
+                            V3 tr = v3(1.f, 1.f, 1.f);
+                            if (medium >= 0) tr = med_tr(P.mediums[medium], q.org, q.dir_p, res.t_p, rng);
+                            Li += tr * beta * area_le(P.lights[isect.lightIdx], isect.nor, wo);      // :1103-1115
+                            finish = true;
+                            break;
+                        }
+                        if (isect.matIdx == -1) {
+                            // a surface without a material only separates two media (:1117-1124): not a bounce
+                            medium = dot(q.dir_p, isect.nor) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
+                            q.org = isect.pos;
+                            q.tmax_s = __builtin_inff();
+                            q.has_p = true;
+                            break;
+                        }
+                        ctx_scatter = false;
+                        ctx_o = q.org;
+                        ctx_d = q.dir_p;
+                        ctx_t = res.t_p;
+                        ctx_prim = res.prim_p;
+                        ctx_b1 = res.b1_p;
+                        ctx_b2 = res.b2_p;
+                        const gpt_material material = P.materials[isect.matIdx];
+                        if (is_delta(PT_MATERIAL_TYPE(material))) {
+                            stage = kStContinue;
+                            continue;
+                        }
+                        // direct light (:1128-1151): the light sample; its shadow ray is walked before anything else is drawn
+                        Ld_acc = v3(0.f, 0.f, 0.f);
+                        float u = rng_uniform(rng);
+                        float choicePdf;
+                        int idx = lookup_light_distribution(P, u, choicePdf);
+                        bool inf = idx == P.n_lights;
+                        float u1x = rng_uniform(rng);
+                        float u1y = rng_uniform(rng);
+                        V3 radiance = v3(0.f), lightNor;
+                        Ray shadowRay;
+                        shadowRay.o = isect.pos;
+                        shadowRay.d = v3(0.f);
+                        shadowRay.tmin = P.eps;
+                        shadowRay.tmax = 0.f;
+                        float lightPdf = 0.f;
+                        if (idx >= 0) {
+                            if (!inf)
+                                area_sample_light(P.lights[idx], isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                            else
+                                inf_sample_light(P.inf, isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                        }
+                        if (is_black(radiance)) {
+                            stage = kStMisStart;
+                            continue;
+                        }
+                        V3 fr;
+                        float samplePdf;
+                        eval_bsdf(P, material, wo, shadowRay.d, isect.nor, isect.uv, isect.dpdu, fr, samplePdf);
+                        sav_w = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                        sav_fr = fr;
+                        sav_rad = radiance;
+                        sav_abs = fabs_(dot(isect.nor, shadowRay.d));
+                        sav_den = lightPdf * choicePdf;
+                        walk_tr = v3(1.f, 1.f, 1.f);
+                        walk_medium = medium;
+                        walk_left = shadowRay.tmax;
+                        q.org = shadowRay.o;
+                        q.dir_p = shadowRay.d;
+                        q.tmax_s = shadowRay.tmax;
+                        q.has_p = true;
+                        stage = kStShadow;
+                        break;
+                    } else if (stage == kStShadow) {
+                        // ---- one segment of Tr() (:298-322) came back
+                        bool walked = false;
+                        if (hit) {
+                            V3 n;
+                            int lightIdx;
+                            make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                            const int hit_mat = __float_as_int(reinterpret_cast<const float *>(reinterpret_cast<const float4 *>(P.shade) + 5 * res.prim_p + 4)[2]);
+                            if (hit_mat != -1) {
+                                walk_tr = v3(0.f, 0.f, 0.f);
+                                walked = true;
+                            } else {
+                                if (walk_medium >= 0) walk_tr = walk_tr * med_tr(P.mediums[walk_medium], q.org, q.dir_p, res.t_p, rng);
+                                walk_medium = dot(q.dir_p, n) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
+                                walk_left -= res.t_p;
+                                q.org = q.org + q.dir_p * res.t_p;
+                                q.tmax_s = walk_left;
+                                q.has_p = true;
+                                break;
+                            }
+                        } else {
+                            if (walk_medium >= 0) walk_tr = walk_tr * med_tr(P.mediums[walk_medium], q.org, q.dir_p, q.tmax_s, rng);
+                            walked = true;
+                        }
+                        if (walked && ctx_scatter) {
+                            if (sav_has) Li += walk_tr * beta * sav_w * sav_rad / sav_den;             // :1096-1097
+                            float pux = rng_uniform(rng);
+                            float puy = rng_uniform(rng);
+                            const V3 dir = medium_sample_phase(P.mediums[medium], pux, puy);
+                            specular = false;
+                            finish = true;
+                            if (bounces + 1 < P.max_depth) {
+                                bool kill = false;
+                                if (bounces > 3) {
+                                    float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                    if (rng_uniform(rng) < illumate)
+                                        kill = true;
+                                    else
+                                        beta /= (1 - illumate);
+                                }
+                                if (!kill) {
+                                    q.org = ctx_o;
+                                    q.dir_p = dir;
+                                    q.tmax_s = __builtin_inff();
+                                    q.has_p = true;
+                                    finish = false;
+                                    bounces++;
+                                    stage = kStPath;
+                                }
+                            }
+                            break;
+                        }
+                        Ld_acc += sav_w * walk_tr * sav_fr * sav_rad * sav_abs / sav_den;              // :1150
+                        stage = kStMisStart;
+                        continue;
+                    } else if (stage == kStMisStart) {
+                        // ---- the BSDF-sampled light ray (:1153-1160)
+                        Ray r;
+                        r.o = ctx_o;
+                        r.d = ctx_d;
+                        const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                        const gpt_material material = P.materials[isect.matIdx];
+                        float usx = rng_uniform(rng);
+                        float usy = rng_uniform(rng);
+                        float usz = rng_uniform(rng);
+                        V3 out, fr;
+                        float pdf;
+                        sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
+                        if (!(is_black(fr) || pdf == 0)) {
+                            mis_fr = fr;
+                            mis_cos = fabs_(dot(out, isect.nor));
+                            mis_pdf = pdf;
+                            q.org = isect.pos;
+                            q.dir_p = out;
+                            q.tmax_s = __builtin_inff();
+                            q.has_p = true;
+                            stage = kStMis;
+                            break;
+                        }
+                        Li += beta * Ld_acc;
+                        stage = kStContinue;
+                        continue;
+                    } else if (stage == kStMis) {
+                        // ---- ... came back (:1161-1205)
+                        if (hit) {
+                            V3 n;
+                            int lightIdx;
+                            make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                            V3 radiance = v3(0.f, 0.f, 0.f);
+                            if (lightIdx != -1) radiance = area_le(P.lights[lightIdx], n, -q.dir_p);
+                            if (!is_black(radiance)) {
+                                V3 pp = q.org + res.t_p * q.dir_p;
+                                float pdfA = 1.f / P.lights[lightIdx].area;
+                                float choicePdf = pdf_from_light_distribution(P, lightIdx);
+                                float lenSquare = dot(pp - q.org, pp - q.org);
+                                float costheta = fabs_(dot(n, q.dir_p));
+                                float lPdf = pdfA * lenSquare / (costheta);
+                                float weight = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
+                                V3 tr = v3(1.f, 1.f, 1.f);
+                                if (medium >= 0) tr = med_tr(P.mediums[medium], q.org, q.dir_p, res.t_p, rng);
+                                Ld_acc += weight * tr * mis_fr * radiance * mis_cos / mis_pdf;
+                            }
+                        } else if (P.inf.isvalid) {
+                            V3 radiance = inf_le(P.inf, q.dir_p);
+                            float choicePdf = pdf_from_light_distribution(P, P.n_lights);
+                            float lightPdf = ONE_OVER_FOUR_PI;
+                            float weight = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
+                            V3 tr = v3(1.f, 1.f, 1.f);
+                            if (medium >= 0) tr = med_tr(P.mediums[medium], q.org, q.dir_p, __builtin_inff(), rng);
+                            Ld_acc += weight * tr * mis_fr * radiance * mis_cos / mis_pdf;
+                        }
+                        Li += beta * Ld_acc;
+                        stage = kStContinue;
+                        continue;
+                    } else {
+                        // ---- kStContinue: the continuation (:1210-1229) and the roulette (:1232-1238).  On the last bounce
+                        // nothing of it reaches Li, so it is skipped.
+                        finish = true;
+                        if (bounces + 1 < P.max_depth) {
+                            Ray r;
+                            r.o = ctx_o;
+                            r.d = ctx_d;
+                            const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                            const gpt_material material = P.materials[isect.matIdx];
+                            const V3 wo = -ctx_d;
+                            float ux = rng_uniform(rng);
+                            float uy = rng_uniform(rng);
+                            float uz = rng_uniform(rng);
+                            V3 out, fr;
+                            float pdf;
+                            sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
+                            if (!is_black(fr)) {
+                                beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
+                                specular = is_delta(PT_MATERIAL_TYPE(material));
+                                const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
+                                int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
+                                m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
+                                medium = m2;
+                                bool kill = false;
+                                if (bounces > 3) {
+                                    float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                    if (rng_uniform(rng) < illumate)
+                                        kill = true;
+                                    else
+                                        beta /= (1 - illumate);
+                                }
+                                if (!kill) {
+                                    q.org = isect.pos;
+                                    q.dir_p = out;
+                                    q.tmax_s = __builtin_inff();
+                                    q.has_p = true;
+                                    finish = false;
+                                    bounces++;
+                                    stage = kStPath;
+                                }
+                            }
+                        }
+                        break;
+                    }
+                }
+            }
+            if (INTEG != PT_IT_VPT_WALK && alive && !waiting) {
                 // ---- resolve the direct light of the previous bounce ------------------
                 if (direct) {
                     V3 Ld = v3(0.f, 0.f, 0.f);
@@ -1986,7 +2423,11 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 bounces = 0;
                 ending = false;
                 direct = false;
-                medium = INTEG == GPT_IT_VPT ? P.cam.medium : -1;      // pathtracer.cu:1043
+                medium = (INTEG == GPT_IT_VPT || INTEG == PT_IT_VPT_WALK) ? P.cam.medium : -1;      // pathtracer.cu:1043
+                if (INTEG == PT_IT_VPT_WALK) {
+                    stage = kStPath;
+                    q.tmax_s = __builtin_inff();
+                }
                 alive = true;
                 if (COUNT) cnt.samples++;
             }
@@ -2007,11 +2448,11 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             PoolLayout L;
             int n_new = 0;
             if (CARRY) {
-                n_new = pool_deposit_fixed(pool, q, lane, alive && !waiting);
+                n_new = pool_deposit_fixed<INTEG == PT_IT_VPT_WALK>(pool, q, lane, alive && !waiting);
                 L.m_p = L.m_m = L.m_s = 0ull;
                 L.n_p = L.n_m = L.n_rays = 0;
             } else {
-                L = pool_deposit(pool, q, lane);
+                L = pool_deposit<INTEG == PT_IT_VPT_WALK>(pool, q, lane);
             }
             PT_MARK(6)
             wave_lds_fence();
@@ -2208,7 +2649,12 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream
                        !getenv("GPT_NO_LDS_SCENE");
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
-    if (P.integrator == GPT_IT_VPT) {
+    if (P.integrator == GPT_IT_VPT && (P.vpt_walk || getenv("GPT_VPT_WALK"))) {     // (the env forces the general kernel: tests)
+        if (count && small) PT_LAUNCH(true, true, PT_IT_VPT_WALK);
+        else if (count) PT_LAUNCH(true, false, PT_IT_VPT_WALK);
+        else if (small) PT_LAUNCH(false, true, PT_IT_VPT_WALK);
+        else PT_LAUNCH(false, false, PT_IT_VPT_WALK);
+    } else if (P.integrator == GPT_IT_VPT) {
         if (count && small) PT_LAUNCH(true, true, GPT_IT_VPT);
         else if (count) PT_LAUNCH(true, false, GPT_IT_VPT);
         else if (small) PT_LAUNCH(false, true, GPT_IT_VPT);

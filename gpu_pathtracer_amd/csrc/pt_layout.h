@@ -80,13 +80,19 @@ struct DevInfinite {
 };
 
 // kernel arguments (by value in the kernarg segment)
-struct alignas(16) DevMedium {       // a homogeneous medium (src/medium.h:9-51,186-233)
+struct alignas(16) DevMedium {       // a medium (src/medium.h:9-62,186-233)
     float sigmaS[3];
     float g;
     float sigmaT[3];
-    float _pad;
+    int32_t type;                    // GPT_MEDIUM_HOMOGENEOUS / GPT_MEDIUM_HETEROGENEOUS; the rest is the density grid
+    const float *density;            // nx*ny*nz floats in HBM, x fastest
+    int32_t nx, ny;
+    int32_t nz, iterMax, trType;     // trType: 0 delta, 1 ratio, 2 residual ratio tracking (medium.h:60)
+    float invMaxDensity;
+    float p0[3], _pad0;
+    float p1[3], _pad1;
 };
-static_assert(sizeof(DevMedium) == 32, "DevMedium");
+static_assert(sizeof(DevMedium) == 96, "DevMedium");
 
 struct DevParams {
     const DevNode *nodes;
@@ -127,8 +133,9 @@ struct DevParams {
     unsigned long long *counters;  // work counters (counting build only)
     int32_t traversal;           // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_NEAR_FIRST (nodes holds 9 threaded variants)
     // Volpath only (new fields go at the END: the kernarg layout steers the register allocation of the headline kernel)
-    const struct DevMedium *mediums;   // homogeneous media
+    const struct DevMedium *mediums;
     const int32_t *prim_media;         // per primitive (BVH order): mediumInside, mediumOutside
+    int32_t vpt_walk;                  // Volpath: density grids or material-less surfaces -> the one-ray-at-a-time kernel
 };
 
 }  // namespace pt

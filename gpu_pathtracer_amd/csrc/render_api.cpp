@@ -58,7 +58,8 @@ struct gpt_ctx {
     uint32_t *tile_counter = nullptr;
     unsigned long long *counters = nullptr;
     uint32_t chunk_override = 0;          // GPT_CHUNK_ITERS (experiments)
-    bool media_ok = true;                 // every medium is homogeneous and every index valid ("vpt" can run)
+    bool media_ok = true;                 // every medium record and medium index is valid ("vpt" can run)
+    bool has_interface = false;           // some primitive has no material (matIdx -1): only "vpt" renders such scenes
     int n_mediums = 0;
     float *samples = nullptr;             // per-iteration sample planes, grown on demand
     uint32_t sample_planes = 0;           // planes allocated
@@ -247,8 +248,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
             return GPT_ERR_UNSUPPORTED;
         }
         const int m = scene->prims[i].triangle.matIdx;
-        if (m < 0 || m >= scene->n_materials) {
-            gpt_set_error("gpt_begin: primitive %d has material index %d outside [0,%d)", i, m, scene->n_materials);
+        if (m < -1 || m >= scene->n_materials) {      // -1: a material-less surface between two media (parsescene.cpp:357)
+            gpt_set_error("gpt_begin: primitive %d has material index %d outside [-1,%d)", i, m, scene->n_materials);
             return GPT_ERR_INVALID_ARG;
         }
         const int l = scene->prims[i].triangle.lightIdx;
@@ -257,15 +258,30 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
             return GPT_ERR_INVALID_ARG;
         }
     }
-    if (scene->integrator_type == GPT_IT_VPT) {
-        // Volpath here renders homogeneous media only (density grids are out of scope: DESIGN.md); refused before any
-        // device work so that the answer is the same with and without a GPU
-        for (int i = 0; i < scene->n_mediums; ++i) {
-            if (!scene->mediums || scene->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS) {
-                gpt_set_error("gpt_begin: \"vpt\" renders homogeneous media only (medium %d is not)", i);
-                return GPT_ERR_UNSUPPORTED;
-            }
-        }
+    // ---- media and material-less surfaces, checked before any device work (same answer with and without a GPU)
+    bool has_interface = false, media_ok = scene->n_mediums == 0 || scene->mediums != nullptr;
+    for (int i = 0; i < scene->n_prims; ++i) {
+        const gpt_triangle &t = scene->prims[i].triangle;
+        if (t.matIdx == -1) has_interface = true;
+        if (t.mediumInside < -1 || t.mediumInside >= scene->n_mediums || t.mediumOutside < -1 || t.mediumOutside >= scene->n_mediums)
+            media_ok = false;
+    }
+    for (int i = 0; i < scene->n_mediums && media_ok; ++i) {
+        const gpt_medium &m = scene->mediums[i];
+        if (m.type == GPT_MEDIUM_HOMOGENEOUS) continue;
+        const auto &h = m.heterogeneous;
+        // the tracking loops end after iterMax steps at the latest (medium.h:70,138): it has to be positive
+        if (m.type != GPT_MEDIUM_HETEROGENEOUS || h.nx <= 0 || h.ny <= 0 || h.nz <= 0 || (int64_t)h.nx * h.ny * h.nz > ((int64_t)1 << 30) ||
+            !h.density || h.iterMax < 1 || h.iterMax > (1 << 20) || h.evalTransmittanceType < 0 || h.evalTransmittanceType > 2)
+            media_ok = false;
+    }
+    if (scene->integrator_type == GPT_IT_VPT && !media_ok) {
+        gpt_set_error("gpt_begin: \"vpt\": a medium record or a medium index of the scene is invalid (%d media)", scene->n_mediums);
+        return GPT_ERR_INVALID_ARG;
+    }
+    if (scene->integrator_type != GPT_IT_VPT && has_interface) {
+        gpt_set_error("gpt_begin: the scene has surfaces without a material (media interfaces); only \"vpt\" renders them");
+        return GPT_ERR_UNSUPPORTED;
     }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -322,13 +338,13 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     if ((rc = dev_upload(ctx, lights.data(), lights.size(), &P.lights)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, scene->light_distribution, (size_t)scene->n_light_distribution, &P.light_cdf)) != GPT_OK)
         return fail(rc);
-    // ---- participating media (Volpath).  Only homogeneous media are rendered; they are uploaded whenever the scene has
-    // them, so that gpt_set_integrator can switch to "vpt" later.
-    ctx->media_ok = scene->n_mediums == 0 || scene->mediums != nullptr;
-    for (int i = 0; i < scene->n_mediums && ctx->media_ok; ++i)
-        if (scene->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS) ctx->media_ok = false;
+    // ---- participating media (Volpath): uploaded whenever the scene has them, so that gpt_set_integrator can switch to
+    // "vpt" later.  Density grids go to HBM as they are (x fastest).
+    ctx->media_ok = media_ok;
+    ctx->has_interface = has_interface;
     ctx->n_mediums = scene->n_mediums;
-    if (ctx->media_ok) {
+    bool walk = has_interface;
+    if (media_ok) {
         std::vector<DevMedium> media((size_t)scene->n_mediums);
         for (int i = 0; i < scene->n_mediums; ++i) {
             const gpt_medium &m = scene->mediums[i];
@@ -337,21 +353,31 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
             d.sigmaS[0] = m.homogeneous.sigmaS.x; d.sigmaS[1] = m.homogeneous.sigmaS.y; d.sigmaS[2] = m.homogeneous.sigmaS.z;
             d.sigmaT[0] = m.homogeneous.sigmaT.x; d.sigmaT[1] = m.homogeneous.sigmaT.y; d.sigmaT[2] = m.homogeneous.sigmaT.z;
             d.g = m.g;
+            d.type = m.type;
+            if (m.type == GPT_MEDIUM_HETEROGENEOUS) {
+                const auto &h = m.heterogeneous;
+                walk = true;
+                d.nx = h.nx; d.ny = h.ny; d.nz = h.nz;
+                d.iterMax = h.iterMax;
+                d.trType = h.evalTransmittanceType;
+                d.invMaxDensity = h.invMaxDensity;
+                d.p0[0] = h.p0.x; d.p0[1] = h.p0.y; d.p0[2] = h.p0.z;
+                d.p1[0] = h.p1.x; d.p1[1] = h.p1.y; d.p1[2] = h.p1.z;
+                if ((rc = dev_upload(ctx, h.density, (size_t)h.nx * h.ny * h.nz, &d.density)) != GPT_OK) return fail(rc);
+            }
         }
         std::vector<int32_t> prim_media((size_t)scene->n_prims * 2);
         for (int i = 0; i < scene->n_prims; ++i) {
-            const int mi = scene->prims[i].triangle.mediumInside, mo = scene->prims[i].triangle.mediumOutside;
-            if (mi < -1 || mi >= scene->n_mediums || mo < -1 || mo >= scene->n_mediums) ctx->media_ok = false;
-            prim_media[2 * (size_t)i] = mi;
-            prim_media[2 * (size_t)i + 1] = mo;
+            prim_media[2 * (size_t)i] = scene->prims[i].triangle.mediumInside;
+            prim_media[2 * (size_t)i + 1] = scene->prims[i].triangle.mediumOutside;
         }
         if ((rc = dev_upload(ctx, media.data(), media.size(), &P.mediums)) != GPT_OK) return fail(rc);
         if ((rc = dev_upload(ctx, prim_media.data(), prim_media.size(), &P.prim_media)) != GPT_OK) return fail(rc);
     }
-    if (scene->integrator_type == GPT_IT_VPT && !ctx->media_ok) {
-        gpt_set_error("gpt_begin: \"vpt\" renders homogeneous media only (and medium indices must be -1 or < %d)", scene->n_mediums);
-        return fail(GPT_ERR_UNSUPPORTED);
-    }
+    // Two Volpath kernels (pt_kernel.hip): with homogeneous media and no material-less surfaces every transmittance is
+    // known from a segment length, and a bounce keeps its three rays in flight; otherwise (density grids draw random
+    // numbers per segment, interfaces split shadow rays into segments) the path is a one-ray-at-a-time state machine.
+    P.vpt_walk = walk ? 1 : 0;
 
     // ---- textures
     std::vector<DevTexture> texs((size_t)scene->n_textures);
@@ -463,7 +489,11 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
         return GPT_ERR_UNSUPPORTED;
     }
     if (integrator_type == GPT_IT_VPT && !ctx->media_ok) {
-        gpt_set_error("gpt_set_integrator: \"vpt\" renders homogeneous media only");
+        gpt_set_error("gpt_set_integrator: \"vpt\": a medium record or a medium index of the scene is invalid");
+        return GPT_ERR_INVALID_ARG;
+    }
+    if (integrator_type != GPT_IT_VPT && ctx->has_interface) {
+        gpt_set_error("gpt_set_integrator: the scene has surfaces without a material (media interfaces); only \"vpt\" renders them");
         return GPT_ERR_UNSUPPORTED;
     }
     ctx->P.integrator = integrator_type;

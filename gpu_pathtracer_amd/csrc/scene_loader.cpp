@@ -252,7 +252,7 @@ struct ObjMesh {
 
 bool read_obj(const std::string &path, ObjMesh &m)
 {
-    FILE *f = std::fopen(path.c_str(), "rb");
+    FILE *f = gpt_fopen_read(path.c_str());
     if (!f) return false;
     char line[4096];
     std::vector<ObjMesh::Corner> face;
@@ -605,11 +605,12 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
     }
     const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
 
-    // ---- media (parsescene.cpp:72-137).  Homogeneous media are stored as the reference stores them (sigmaA, sigmaS
-    // scaled, sigmaT their sum, g); a heterogeneous medium keeps its coefficients and grid size but its density file
-    // is not read: the "pt" and "ao" integrators never look at media, and "vpt" refuses heterogeneous ones.
+    // ---- media (parsescene.cpp:72-137).  Stored as the reference stores them: sigmaA, sigmaS scaled, sigmaT their
+    // sum, g; a heterogeneous medium also gets its density grid (a text file of nx*ny*nz floats, x fastest:
+    // medium.h:235-244), the box p0..p1 it fills, 1 / its largest density, iterMax and the tracking variant.
     std::vector<std::string> mediumName;
     scene.mediums.clear();
+    scene.density_grids.clear();
     if (doc.has("medium") && doc.at("medium").kind == Json::Arr)
         for (auto &m : doc.at("medium").arr) {
             mediumName.push_back(gets(m, "name", ""));
@@ -628,14 +629,64 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
             md.homogeneous.sigmaS = ss;
             md.homogeneous.sigmaT = st;
             if (!hom) {
-                md.heterogeneous.nx = m.has("nx") ? (int)m.at("nx").num : 0;
-                md.heterogeneous.ny = m.has("ny") ? (int)m.at("ny").num : 0;
-                md.heterogeneous.nz = m.has("nz") ? (int)m.at("nz").num : 0;
+                if (st.x != st.y || st.x != st.z) {            // parsescene.cpp:101-104 (the reference exits)
+                    gpt_set_error("sigmaA and sigmaS requires uniform attenuation coefficient");
+                    return false;
+                }
+                if (!m.has("nx") || !m.has("ny") || !m.has("nz") || !m.has("p0") || !m.has("p1") || !m.has("density")) {
+                    gpt_set_error("heterogeneous medium \"%s\": nx, ny, nz, p0, p1 and density are required", mediumName.back().c_str());
+                    return false;
+                }
+                const int nx = (int)m.at("nx").num, ny = (int)m.at("ny").num, nz = (int)m.at("nz").num;
+                if (nx <= 0 || ny <= 0 || nz <= 0 || (int64_t)nx * ny * nz > (int64_t)1 << 30) {
+                    gpt_set_error("heterogeneous medium \"%s\": bad grid size %d x %d x %d", mediumName.back().c_str(), nx, ny, nz);
+                    return false;
+                }
+                md.heterogeneous.nx = nx;
+                md.heterogeneous.ny = ny;
+                md.heterogeneous.nz = nz;
+                float p[3];
+                get3(m, "p0", zero3, p);
+                md.heterogeneous.p0 = {p[0], p[1], p[2]};
+                get3(m, "p1", zero3, p);
+                md.heterogeneous.p1 = {p[0], p[1], p[2]};
                 md.heterogeneous.iterMax = m.has("iterMax") ? (int)m.at("iterMax").num : 1000;
                 md.heterogeneous.evalTransmittanceType = m.has("evalTransmittanceType") ? (int)m.at("evalTransmittanceType").num : 1;
+                // the density file: whitespace-separated decimal floats (the reference reads them with fscanf "%f")
+                const std::string dfile = base + m.at("density").str;
+                FILE *df = gpt_fopen_read(dfile.c_str());
+                if (!df) {
+                    gpt_set_error("density file [\"%s\"] is not good", dfile.c_str());
+                    return false;
+                }
+                std::string dtext;
+                char dbuf[65536];
+                size_t dgot;
+                while ((dgot = std::fread(dbuf, 1, sizeof(dbuf), df)) > 0) dtext.append(dbuf, dgot);
+                std::fclose(df);
+                const size_t n = (size_t)nx * ny * nz;
+                scene.density_grids.emplace_back(n);
+                std::vector<float> &grid = scene.density_grids.back();
+                const char *cp = dtext.c_str();
+                float mx = 0.f;
+                for (size_t i = 0; i < n; ++i) {
+                    char *endp = nullptr;
+                    const float v = std::strtof(cp, &endp);
+                    if (endp == cp) {
+                        gpt_set_error("density file [\"%s\"] holds %zu values, %zu are needed", dfile.c_str(), i, n);
+                        return false;
+                    }
+                    cp = endp;
+                    grid[i] = v;
+                    if (v > mx) mx = v;
+                }
+                md.heterogeneous.invMaxDensity = 1.f / mx;      // parsescene.cpp:126-131
             }
             scene.mediums.push_back(md);
         }
+    // the grids are complete (no reallocation from here on): point the records at them
+    for (size_t i = 0, g = 0; i < scene.mediums.size(); ++i)
+        if (scene.mediums[i].type == GPT_MEDIUM_HETEROGENEOUS) scene.mediums[i].heterogeneous.density = scene.density_grids[g++].data();
     auto getMedium = [&](const std::string &m) {
         for (size_t i = 0; i < mediumName.size(); ++i) if (mediumName[i] == m) return (int)i;
         return -1;

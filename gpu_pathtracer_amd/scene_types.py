@@ -67,10 +67,13 @@ class Float2(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float)]
 
 
-# gpt_medium (104 bytes): type, g, then the homogeneous coefficients at offset 8 (the heterogeneous view of the union is
-# not used from Python)
-MEDIUM = np.dtype({"names": ["type", "g", "sigmaA", "sigmaS", "sigmaT"], "formats": [np.int32, np.float32, F3, F3, F3],
-                   "offsets": [0, 4, 8, 20, 32], "itemsize": 104})
+# gpt_medium (104 bytes): type, g, then the union at offset 8 - the coefficients sit at the same offsets in both views,
+# the density grid (src/medium.h:53-62) follows them
+MEDIUM = np.dtype({"names": ["type", "g", "sigmaA", "sigmaS", "sigmaT", "nx", "ny", "nz", "density", "invMaxDensity",
+                             "p0", "p1", "iterMax", "evalTransmittanceType"],
+                   "formats": [np.int32, np.float32, F3, F3, F3, np.int32, np.int32, np.int32, np.uint64, np.float32,
+                               F3, F3, np.int32, np.int32],
+                   "offsets": [0, 4, 8, 20, 32, 44, 48, 52, 56, 64, 68, 80, 92, 96], "itemsize": 104})
 
 
 def make_medium(sigma_a, sigma_s, g=0.0, scale=1.0):
@@ -80,6 +83,20 @@ def make_medium(sigma_a, sigma_s, g=0.0, scale=1.0):
     s_ = (np.asarray(sigma_s, np.float32) * np.float32(scale)).astype(np.float32)
     m["type"], m["g"] = 0, np.float32(g)
     m["sigmaA"], m["sigmaS"], m["sigmaT"] = f3(a), f3(s_), f3((a + s_).astype(np.float32))
+    return m
+
+
+def make_het_medium(sigma_a, sigma_s, grid, p0, p1, iter_max=1000, tr_type=1, g=0.0, scale=1.0):
+    """heterogeneous medium as parsescene.cpp:99-132 builds it.  `grid` is a C-contiguous float32 array of shape
+    (nz, ny, nx) (x fastest, medium.h:176-181) that the CALLER keeps alive; sigmaA + sigmaS must be grey."""
+    assert grid.dtype == np.float32 and grid.ndim == 3 and grid.flags["C_CONTIGUOUS"]
+    m = make_medium(sigma_a, sigma_s, g, scale)
+    m["type"] = 1
+    m["nz"], m["ny"], m["nx"] = grid.shape
+    m["density"] = grid.ctypes.data
+    m["invMaxDensity"] = np.float32(1.0) / np.float32(max(np.float32(0), grid.max()))
+    m["p0"], m["p1"] = f3(np.asarray(p0, np.float32)), f3(np.asarray(p1, np.float32))
+    m["iterMax"], m["evalTransmittanceType"] = iter_max, tr_type
     return m
 
 

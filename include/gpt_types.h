@@ -175,7 +175,7 @@ typedef struct gpt_scene_desc {
     const gpt_infinite *infinite;    /* &scene.infinite (may be NULL = invalid) */
     const gpt_texture *textures;     /* scene.textures */
     int32_t n_textures;
-    int32_t integrator_type;         /* scene.integrator.type: GPT_IT_PT or GPT_IT_AO */
+    int32_t integrator_type;         /* scene.integrator.type: GPT_IT_PT, GPT_IT_VPT or GPT_IT_AO */
     union {                          /* the reference's anonymous union (src/scene.h:38-46) */
         int32_t max_depth;           /* scene.integrator.maxDepth (pt, vpt) */
         float max_dist;              /* scene.integrator.maxDist  (ao) */

@@ -1075,7 +1075,7 @@ static int path_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uin
 }
 
 /* ---- Volpath: pathtracer.cu:298-322, 1025-1242; homogeneous media: medium.h:9-51, phase: medium.h:196-233 ------------
- * A medium is referred to by index (-1 = vacuum).  Heterogeneous media are refused before rendering starts. */
+ * A medium is referred to by index (-1 = vacuum). */
 static inline f3 exp3(f3 c) { return mk3(M_EXP(c.x), M_EXP(c.y), M_EXP(c.z)); }                    /* common.h:81-86 */
 static inline f3 hom_tr(const gpt_medium *m, float tmax) { return exp3(scl3(m->homogeneous.sigmaT, -tmax)); }   /* medium.h:14-17 */
 static inline f3 hom_sample(const gpt_medium *m, float ray_tmax, float u, float *t, int *sampled)       /* medium.h:19-50 */
@@ -1089,6 +1089,126 @@ static inline f3 hom_sample(const gpt_medium *m, float ray_tmax, float u, float 
     *sampled = sampledMedium;
     *t = dist;
     return sampledMedium ? dvs3(mul3(Tr, sigmaS), pdf) : dvs3(mul3(sigmaT, Tr), pdf);
+}
+/* float -> int as the GPU converts it (cvt.rzi.s32.f32 / v_cvt_i32_f32: truncate, saturate, NaN -> 0); C leaves the
+ * out-of-range cases undefined */
+static inline int f2i_sat(float f)
+{
+    if (f != f) return 0;
+    if (f <= -2147483648.f) return INT32_MIN;
+    if (f >= 2147483648.f) return INT32_MAX;
+    return (int)f;
+}
+static inline float het_d(const gpt_medium *m, float px, float py, float pz)                         /* medium.h:176-181 */
+{
+    const int nx = m->heterogeneous.nx, ny = m->heterogeneous.ny, nz = m->heterogeneous.nz;
+    int x = f2i_sat(px), y = f2i_sat(py), z = f2i_sat(pz);
+    if (x < 0 || x > nx - 1 || y < 0 || y > ny - 1 || z < 0 || z > nz - 1) return 0.f;
+    return m->heterogeneous.density[(size_t)z * ny * nx + (size_t)y * nx + x];
+}
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }                     /* cutil_math.h:1008-1011 */
+static inline float het_density(const gpt_medium *m, f3 p)                                           /* medium.h:160-174 */
+{
+    f3 ps = mk3(p.x * m->heterogeneous.nx, p.y * m->heterogeneous.ny, p.z * m->heterogeneous.nz);
+    f3 psi = mk3(floorf(ps.x), floorf(ps.y), floorf(ps.z));
+    f3 delta = sub3(ps, psi);
+    float d00 = lerpf(het_d(m, psi.x, psi.y, psi.z), het_d(m, psi.x + 1, psi.y, psi.z), delta.x);
+    float d10 = lerpf(het_d(m, psi.x, psi.y + 1, psi.z), het_d(m, psi.x + 1, psi.y + 1, psi.z), delta.x);
+    float d01 = lerpf(het_d(m, psi.x, psi.y, psi.z + 1), het_d(m, psi.x + 1, psi.y, psi.z + 1), delta.x);
+    float d11 = lerpf(het_d(m, psi.x, psi.y + 1, psi.z + 1), het_d(m, psi.x + 1, psi.y + 1, psi.z + 1), delta.x);
+    float d0 = lerpf(d00, d10, delta.y);
+    float d1 = lerpf(d01, d11, delta.y);
+    return lerpf(d0, d1, delta.z);
+}
+static inline f3 het_local(const gpt_medium *m, const ray_t *r, float dist)      /* (r(dist) - p0) / (p1 - p0) */
+{
+    f3 d = sub3(m->heterogeneous.p1, m->heterogeneous.p0);
+    f3 p = sub3(ray_at(r, dist), m->heterogeneous.p0);
+    return mk3(p.x / d.x, p.y / d.y, p.z / d.z);
+}
+/* Heterogeneous::Tr (medium.h:64-132): delta (0), ratio (1) or residual ratio (2) tracking along [0, ray.tmax) */
+static f3 het_tr(const gpt_medium *m, const ray_t *ray, rng_t *rng)
+{
+    const float invMax = m->heterogeneous.invMaxDensity;
+    float sigma = dot3(m->heterogeneous.sigmaT, mk3(0.212671f, 0.715160f, 0.072169f));
+    float tr = 1.f, dist = 0.f;
+    int iter = m->heterogeneous.iterMax;
+    if (m->heterogeneous.evalTransmittanceType == 0) {
+        for (;;) {
+            dist += -M_LOG(rng_uniform(rng)) * invMax / sigma;
+            if (dist >= ray->tmax) break;
+            float dens = het_density(m, het_local(m, ray, dist));
+            if (dens * invMax > rng_uniform(rng)) { tr = 0; break; }
+            if (--iter == 0) { tr = 0; break; }
+        }
+    } else if (m->heterogeneous.evalTransmittanceType == 1) {
+        for (;;) {
+            dist += -M_LOG(rng_uniform(rng)) * invMax / sigma;
+            if (dist >= ray->tmax) break;
+            tr *= 1.f - het_density(m, het_local(m, ray, dist)) * invMax;
+            if (tr < 0.1f) {
+                float q = 1.f - tr;
+                if (rng_uniform(rng) < q) return mk3(0.f, 0.f, 0.f);
+                tr = 1;
+            }
+            if (--iter == 0) break;
+        }
+    } else {
+        float maxDensity = 1 / invMax;
+        float ce = (float)(0.5 * maxDensity);
+        float tc = M_EXP(-ray->tmax * ce * sigma);
+        for (;;) {
+            dist += -M_LOG(rng_uniform(rng)) * (1 / (maxDensity - ce) / sigma);
+            if (dist >= ray->tmax) break;
+            tr *= 1.f - (het_density(m, het_local(m, ray, dist)) - ce) / (maxDensity - ce);
+            if (tr < 0.1f) {
+                float q = 1.f - tr;
+                if (rng_uniform(rng) < q) return mk3(0.f, 0.f, 0.f);
+                tr /= (1.f - q);
+            }
+            if (--iter == 0) break;
+        }
+        tr *= tc;
+    }
+    return mk3(tr, tr, tr);
+}
+/* Heterogeneous::Sample (medium.h:134-157): delta tracking to the next real collision before ray.tmax */
+static f3 het_sample(const gpt_medium *m, const ray_t *ray, rng_t *rng, float *t, int *sampled)
+{
+    const float invMax = m->heterogeneous.invMaxDensity;
+    float sigma = dot3(m->heterogeneous.sigmaT, mk3(0.212671f, 0.715160f, 0.072169f));
+    float dist = 0.f;
+    int iter = m->heterogeneous.iterMax;
+    for (;;) {
+        dist += -M_LOG(rng_uniform(rng)) * invMax / sigma;
+        if (dist >= ray->tmax) break;
+        float dens = het_density(m, het_local(m, ray, dist));
+        if (dens * invMax > rng_uniform(rng)) {
+            *t = dist;
+            *sampled = 1;
+            f3 ss = m->heterogeneous.sigmaS, st = m->heterogeneous.sigmaT;
+            return mk3(ss.x / st.x, ss.y / st.y, ss.z / st.z);
+        }
+        if (--iter == 0) break;
+    }
+    *t = dist;
+    *sampled = 0;
+    return mk3(1.f, 1.f, 1.f);
+}
+/* the type switch at every call site of the reference (pathtracer.cu:307-312,1064-1069,1106-1111,1172-1177,1193-1198) */
+static inline f3 med_tr(const scene_t *sc, int medium, const ray_t *ray, rng_t *rng)
+{
+    const gpt_medium *m = &sc->d->mediums[medium];
+    return m->type == GPT_MEDIUM_HOMOGENEOUS ? hom_tr(m, ray->tmax) : het_tr(m, ray, rng);
+}
+static inline f3 med_sample(const scene_t *sc, int medium, const ray_t *ray, rng_t *rng, float *t, int *sampled)
+{
+    const gpt_medium *m = &sc->d->mediums[medium];
+    if (m->type == GPT_MEDIUM_HOMOGENEOUS) {
+        float u = rng_uniform(rng);
+        return hom_sample(m, ray->tmax, u, t, sampled);
+    }
+    return het_sample(m, ray, rng, t, sampled);
 }
 static inline void medium_phase(const gpt_medium *m, f3 in, f3 out, float *phase)                    /* medium.h:222-233 */
 {
@@ -1126,7 +1246,7 @@ static inline int medium_of_side(const isect_t *isect, float side)      /* outsi
     return side > 0 ? isect->mediumOutside : isect->mediumInside;
 }
 /* Tr (pathtracer.cu:298-322): walk along the shadow ray through the surfaces without a material */
-static f3 vpt_tr(const scene_t *sc, ray_t ray, int medium)
+static f3 vpt_tr(const scene_t *sc, ray_t ray, int medium, rng_t *rng)
 {
     f3 tr = mk3(1, 1, 1);
     float tmax = ray.tmax;
@@ -1136,7 +1256,7 @@ static f3 vpt_tr(const scene_t *sc, ray_t ray, int medium)
         if (hit && isect.matIdx != -1)
             return mk3(0, 0, 0);
         if (medium >= 0)
-            tr = mul3(tr, hom_tr(&sc->d->mediums[medium], ray.tmax));
+            tr = mul3(tr, med_tr(sc, medium, &ray, rng));
         if (!hit) break;
         medium = medium_of_side(&isect, dot3(ray.d, isect.nor));
         tmax -= ray.tmax;
@@ -1180,8 +1300,7 @@ static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint
         float sampledDist = 0.f;
         int sampledMedium = 0;
         if (medium >= 0) {
-            float u = rng_uniform(&rng);
-            beta = mul3(beta, hom_sample(&sc->d->mediums[medium], r.tmax, u, &sampledDist, &sampledMedium));
+            beta = mul3(beta, med_sample(sc, medium, &r, &rng, &sampledDist, &sampledMedium));
         }
         if (is_black(beta)) break;
         if (sampledMedium) {
@@ -1204,7 +1323,7 @@ static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint
                 else
                     inf_sample_light(&sc->inf, samplePos, u1, &radiance, &shadowRay, &lightNor, &lightPdf, sc->eps);
             }
-            f3 tr = vpt_tr(sc, shadowRay, medium);
+            f3 tr = vpt_tr(sc, shadowRay, medium, &rng);
             float phase;
             medium_phase(m, neg3(r.d), shadowRay.d, &phase);
             if (!is_black(radiance))
@@ -1220,7 +1339,7 @@ static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint
             if (bounces == 0 || specular) {
                 if (isect.lightIdx != -1) {
                     f3 tr = mk3(1.f, 1.f, 1.f);
-                    if (medium >= 0) tr = hom_tr(&sc->d->mediums[medium], r.tmax);
+                    if (medium >= 0) tr = med_tr(sc, medium, &r, &rng);
                     Li = add3(Li, mul3(mul3(tr, beta), area_le(&sc->d->lights[isect.lightIdx], nor, neg3(r.d))));
                     break;
                 }
@@ -1255,7 +1374,7 @@ static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint
                     f3 fr;
                     float samplePdf;
                     eval_bsdf(sc, &material, neg3(r.d), shadowRay.d, nor, uv, dpdu, &fr, &samplePdf);
-                    f3 tr = vpt_tr(sc, shadowRay, medium);
+                    f3 tr = vpt_tr(sc, shadowRay, medium, &rng);
                     float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
                     Ld = add3(Ld, dvs3(scl3(mul3(mul3(scl3(tr, weight), fr), radiance), fabsf(dot3(nor, shadowRay.d))),
                                        lightPdf * choicePdf));
@@ -1285,7 +1404,7 @@ static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint
                             float lPdf = pdfA * lenSquare / (costheta);
                             float weight = power_heuristic(1, pdf, 1, lPdf * choicePdf2);
                             f3 tr = mk3(1.f, 1.f, 1.f);
-                            if (medium >= 0) tr = hom_tr(&sc->d->mediums[medium], lightRay.tmax);
+                            if (medium >= 0) tr = med_tr(sc, medium, &lightRay, &rng);
                             Ld = add3(Ld, dvs3(scl3(mul3(mul3(scl3(tr, weight), fr), radiance2), fabsf(dot3(out, nor))), pdf));
                         }
                     } else if (sc->inf.isvalid) {
@@ -1294,7 +1413,7 @@ static int vpt_sample(const scene_t *sc, const gpt_camera *cam, uint32_t x, uint
                         float lightPdf2 = ONE_OVER_FOUR_PI;
                         float weight = power_heuristic(1, pdf, 1, lightPdf2 * choicePdf2);
                         f3 tr = mk3(1.f, 1.f, 1.f);
-                        if (medium >= 0) tr = hom_tr(&sc->d->mediums[medium], lightRay.tmax);
+                        if (medium >= 0) tr = med_tr(sc, medium, &lightRay, &rng);
                         Ld = add3(Ld, dvs3(scl3(mul3(mul3(scl3(tr, weight), fr), radiance2), fabsf(dot3(out, nor))), pdf));
                     }
                 }
@@ -1416,8 +1535,9 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     if (desc->integrator_type != GPT_IT_PT && desc->integrator_type != GPT_IT_AO && desc->integrator_type != GPT_IT_VPT) return -1;
     const int ao = desc->integrator_type == GPT_IT_AO, vpt = desc->integrator_type == GPT_IT_VPT;
     if (vpt)
-        for (int i = 0; i < desc->n_mediums; ++i)
-            if (desc->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS) return -2;      /* heterogeneous media: not restated */
+        for (int i = 0; i < desc->n_mediums; ++i)      /* a tracking loop ends after iterMax steps at the latest: it must be positive */
+            if (desc->mediums[i].type != GPT_MEDIUM_HOMOGENEOUS &&
+                (desc->mediums[i].heterogeneous.iterMax < 1 || !desc->mediums[i].heterogeneous.density)) return -2;
     scene_t sc;
     sc.d = desc;
     sc.eps = eps;

@@ -78,11 +78,13 @@ class Scene:
     def set_max_depth(self, d):
         self.desc.max_depth = d
 
-    def set_mediums(self, mediums):
-        """list of st.make_medium(...) records; triangles / the camera refer to them by index"""
+    def set_mediums(self, mediums, keep=()):
+        """list of st.make_medium / st.make_het_medium records; triangles / the camera refer to them by index.
+        `keep`: the density grids the records point at (held here so that they outlive the records)"""
         self.mediums = np.zeros(max(1, len(mediums)), dtype=st.MEDIUM)
         for i, m in enumerate(mediums):
             self.mediums[i] = m
+        self.medium_grids = list(keep)
         self.desc.mediums = st.ptr(self.mediums) if len(mediums) else None
         self.desc.n_mediums = len(mediums)
 

@@ -72,6 +72,44 @@ def uv_sphere(center, radius, mat, nu=12, nv=8):
     return out
 
 
+def box_mesh(lo, hi, mat, inside=-1, outside=-1):
+    """axis-aligned box, 12 triangles, face normals pointing outwards; mat = -1 makes it a material-less surface that
+    only separates the media `inside` / `outside` (parsescene.cpp:345-357)"""
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+
+    def corner(ix, iy, iz):
+        return np.array([hi[0] if ix else lo[0], hi[1] if iy else lo[1], hi[2] if iz else lo[2]], np.float32)
+
+    faces = [  # (normal, four corners counter-clockwise seen from outside)
+        ((-1, 0, 0), [(0, 0, 0), (0, 0, 1), (0, 1, 1), (0, 1, 0)]), ((1, 0, 0), [(1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 0, 1)]),
+        ((0, -1, 0), [(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1)]), ((0, 1, 0), [(0, 1, 0), (0, 1, 1), (1, 1, 1), (1, 1, 0)]),
+        ((0, 0, -1), [(0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 0)]), ((0, 0, 1), [(0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]),
+    ]
+    out = np.zeros(12, dtype=st.PRIMITIVE)
+    k = 0
+    for n, cs in faces:
+        a, b, c, d = (corner(*ix) for ix in cs)
+        out[k] = make_tri(a, b, c, n, n, n, (0, 0), (1, 0), (1, 1), mat)
+        out[k + 1] = make_tri(a, c, d, n, n, n, (0, 0), (1, 1), (0, 1), mat)
+        k += 2
+    out["triangle"]["mediumInside"] = inside
+    out["triangle"]["mediumOutside"] = outside
+    return out
+
+
+def smoke_grid(nx=24, ny=20, nz=16, seed=3):
+    """a lumpy density field (float32, shape (nz, ny, nx)) with empty regions and a few dense blobs"""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(np.linspace(0, 1, nz), np.linspace(0, 1, ny), np.linspace(0, 1, nx), indexing="ij")
+    g = np.zeros((nz, ny, nx), np.float64)
+    for _ in range(5):
+        c = rng.uniform(0.15, 0.85, 3)
+        r = rng.uniform(0.12, 0.3)
+        g += rng.uniform(0.4, 1.5) * np.exp(-(((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (r * r)))
+    g[g < 0.08] = 0.0
+    return np.ascontiguousarray(g.astype(np.float32))
+
+
 def random_soup(n, seed, lo=(-0.9, 0.05, -0.9), hi=(0.9, 1.9, 0.9), size=0.12, mats=(2,)):
     rng = np.random.default_rng(seed)
     out = np.zeros(n, dtype=st.PRIMITIVE)
@@ -193,11 +231,11 @@ def stress_parts(scale=1.0):
     ])
 
 
-def stress_scene(scale=1.0, max_depth=16):
+def stress_scene(scale=1.0, max_depth=16, extra=None):
     prims, _, meta = cornell_raw()
     keep = concat([prims[0:10], prims[34:36]])      # walls + light, no boxes
     keep["triangle"]["lightIdx"][10:] = [0, 1]
-    allp = concat([keep, stress_parts(scale)])
+    allp = concat([keep, stress_parts(scale)] + ([extra] if extra is not None else []))
     scene = ol.make_scene(allp, material_table(), light_radiance=meta["light_radiance"], max_depth=max_depth,
                           textures=[checker_texture()])
     return scene, meta

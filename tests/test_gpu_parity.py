@@ -600,19 +600,119 @@ def test_volpath_homogeneous_bit_exact(gpt, what):
         assert_bit_exact(r.read_accum(), pt_o, f"pt after vpt {what}")
 
 
-def test_volpath_refuses_heterogeneous_media(gpt):
+# ---- Volpath, general form: density grids and material-less surfaces (medium.h:53-182, pathtracer.cu:298-322) ----
+
+def walk_case(what):
+    fog = st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.05)
+    murk = st.make_medium((0.3, 0.05, 0.02), (0.8, 1.4, 2.0), 0.5, 2.0)
+    grid = scenes.smoke_grid()
+    lo, hi = (-0.5, 0.3, -0.4), (0.5, 1.5, 0.4)
+    keep = [grid]
+    cam_medium = -1
+    if what == "interface_fog_box":
+        # a homogeneous medium inside a material-less box, thin fog outside it (the camera's medium)
+        box = scenes.box_mesh(lo, hi, -1, inside=1, outside=0)
+        scene, meta = scenes.zoo_scene(max_depth=9, extra=box, assign={"short": 7, "tall": 5})
+        media = [fog, murk]
+        W, H, spp, cam_medium = 128, 128, 6, 0
+        cam = ol.cornell_camera(meta, W, H)
+    elif what in ("smoke_delta", "smoke_ratio", "smoke_residual"):
+        tr_type = {"smoke_delta": 0, "smoke_ratio": 1, "smoke_residual": 2}[what]
+        box = scenes.box_mesh(lo, hi, -1, inside=1, outside=-1)
+        scene, meta = scenes.zoo_scene(max_depth=9, extra=box, assign={"short": 2, "tall": 5})
+        media = [fog, st.make_het_medium((1, 1, 1), (9, 9, 9), grid, lo, hi, 200, tr_type, 0.3, 1.0)]
+        W, H, spp = 128, 128, 6
+        cam = ol.cornell_camera(meta, W, H)
+    elif what == "camera_in_smoke":
+        # no interface: the grid fills the room and beyond, the camera sits in it, an environment light makes escaping
+        # rays run their tracking loop to iterMax
+        scene, meta = scenes.zoo_scene(max_depth=6, with_env=True, assign={"short": 7, "tall": 13, "back": 2, "ceil": 2})
+        media = [st.make_het_medium((0.3, 0.3, 0.3), (1.5, 1.5, 1.5), grid, (-1.5, -0.5, -1.5), (1.5, 2.5, 8.0), 48, 1, -0.3, 1.0)]
+        W, H, spp, cam_medium = 96, 96, 4, 0
+        cam = ol.make_camera((0.3, 1.2, 7.5), (0, 1, 0), (0, 1, 0), (W, H), 40.0)
+    elif what == "smoke_large_scene":
+        box = scenes.box_mesh((-0.6, 0.2, -0.5), (0.6, 1.6, 0.5), -1, inside=0, outside=-1)
+        scene, meta = scenes.stress_scene(0.3, max_depth=10, extra=box)
+        media = [st.make_het_medium((2, 2, 2), (6, 6, 6), grid, (-0.6, 0.2, -0.5), (0.6, 1.6, 0.5), 100, 1, 0.0, 1.0)]
+        W, H, spp = 96, 96, 3
+        cam = ol.cornell_camera(meta, W, H)
+    else:
+        raise KeyError(what)
+    scene.set_mediums(media, keep=keep)
+    scene.desc.set_integrator("vpt", scene.desc.max_depth)
+    cam.medium = cam_medium
+    return scene, cam, W, H, spp
+
+
+@pytest.mark.parametrize("what", ["interface_fog_box", "smoke_delta", "smoke_ratio", "smoke_residual", "camera_in_smoke",
+                                  "smoke_large_scene"])
+def test_volpath_walk_bit_exact(gpt, what):
+    """Density grids (delta-tracked collisions; delta / ratio / residual-ratio transmittance, all drawing from the
+    path's generator) and surfaces without a material (shadow rays walked segment by segment, path rays passing
+    through without a bounce): the one-ray-at-a-time Volpath kernel against the oracle."""
+    scene, cam, W, H, spp = walk_case(what)
+    eps = 0.001
+    ref, col_o = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
+    assert np.isfinite(ref).all() and ref.mean() > 0
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"vpt walk {what}")
+        assert_bit_exact(r.read_color(), col_o, f"vpt walk {what} last sample")
+        r.enable_counters(True)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, f"vpt walk {what}, counting build")
+        r.enable_counters(False)
+        # batches of iterations continue the same film
+        r.render(cam, 1, 2, reset=True)
+        r.render(cam, 3, spp - 2, reset=False)
+        assert_bit_exact(r.read_accum(), ref, f"vpt walk {what}, two calls")
+
+
+def test_volpath_two_kernels_agree(gpt, monkeypatch):
+    """A scene with homogeneous media only runs on the three-rays-per-bounce kernel; forced through the general
+    one-ray-at-a-time kernel it has to produce the same film (and both equal the oracle's)."""
+    fog = st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.3)
+    scene, meta = scenes.zoo_scene(max_depth=8, with_env=True, assign={"short": 7, "tall": 13})
+    scene.set_mediums([fog])
+    scene.desc.set_integrator("vpt", 8)
+    W, H, spp, eps = 128, 96, 5, 0.001
+    cam = ol.cornell_camera(meta, W, H)
+    cam.medium = 0
+    ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "three-ray kernel")
+        monkeypatch.setenv("GPT_VPT_WALK", "1")
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "one-ray kernel")
+
+
+def test_volpath_scene_checks(gpt):
+    """What cannot be rendered is refused with a message: bad medium records, material-less surfaces under Path / Ao."""
     scene, meta = ol.load_cornell(4)
-    het = st.make_medium((1, 1, 1), (1, 1, 1))
-    het["type"] = 1
-    scene.set_mediums([het])
+    bad = st.make_medium((1, 1, 1), (1, 1, 1))
+    bad["type"] = 1                                  # heterogeneous without a grid
+    scene.set_mediums([bad])
     scene.desc.set_integrator("vpt", 4)
     with pytest.raises(gpt.GptError) as e:
         gpt.Renderer(scene.desc, 64, 64, 0.001)
-    assert "homogeneous" in str(e.value)
+    assert "medium" in str(e.value)
     scene.desc.set_integrator("pt", 4)
     with gpt.Renderer(scene.desc, 64, 64, 0.001) as r:          # Path does not care
         with pytest.raises(gpt.GptError):
             r.set_integrator("vpt", 4)
+    box = scenes.box_mesh((-0.3, 0.3, -0.3), (0.3, 0.9, 0.3), -1, inside=0, outside=-1)
+    scene, meta = scenes.zoo_scene(max_depth=4, extra=box)
+    scene.set_mediums([st.make_medium((1, 1, 1), (1, 1, 1))])
+    with pytest.raises(gpt.GptError) as e:           # "pt" would index materials[-1] (pathtracer.cu:936)
+        gpt.Renderer(scene.desc, 64, 64, 0.001)
+    assert "material" in str(e.value)
+    scene.desc.set_integrator("vpt", 4)
+    with gpt.Renderer(scene.desc, 64, 64, 0.001) as r:
+        with pytest.raises(gpt.GptError):
+            r.set_integrator("pt", 4)
+        with pytest.raises(gpt.GptError):
+            r.set_integrator("ao", 0.5)
 
 
 # ---- Ao integrator (pathtracer.cu:830-876) -------------------------------------------------------

@@ -336,30 +336,72 @@ def test_loader_errors(tmp_path, scene_dir):
     assert "sphere" in str(e.value)
 
 
-def test_shipped_vpt_scene_settings_are_refused_at_begin(scene_dir):
-    """The reference's own cornell json is a "vpt" scene; the loader accepts the key, the renderer refuses it."""
+def test_shipped_vpt_scene_settings(scene_dir):
+    """The reference's own cornell json is a "vpt" scene with a homogeneous medium, a density grid and a material-less
+    mesh around it (scenes/cornell_box/scene.json): all of it is loaded the way parsescene.cpp:72-137,340-392 does."""
     js = json.load(open(scene_dir / "scene.json"))
     js["integrator"] = "vpt"
     js["maxDepth"] = 17
-    json.dump(js, open(scene_dir / "scene.json", "w"))
+    nx, ny, nz = 4, 3, 2
+    vals = (np.arange(nx * ny * nz, dtype=np.float32) * np.float32(0.37) % np.float32(2.5)).astype(np.float32)
+    with open(scene_dir / "geometry" / "density.d", "w") as f:
+        for v in vals:
+            f.write(f"{v:.6f}\n")                                    # one value per line, like the shipped file
     js["medium"] = [{"type": "homogeneous", "sigmaA": [0.0014, 0.0025, 0.0142], "sigmaS": [0.70, 1.22, 1.90], "scale": 25.0, "name": "vol"},
-                    {"type": "heterogeneous", "sigmaA": [10, 10, 10], "sigmaS": [90, 90, 90], "nx": 100, "ny": 100, "nz": 40,
+                    {"type": "heterogeneous", "sigmaA": [10, 10, 10], "sigmaS": [90, 90, 90], "nx": nx, "ny": ny, "nz": nz,
                      "p0": [-0.63, 0.27, -0.2415], "p1": [0.693, 1.593, 0.2415], "density": "geometry/density.d", "iterMax": 2000, "name": "hhh"}]
     js["camera"]["medium"] = "vol"
+    first_mesh = js["scene"][0]["mesh"]
+    js["scene"].append({"mesh": first_mesh, "inside": "hhh", "outside": "", "translate": [0, 0.5, 0]})
     json.dump(js, open(scene_dir / "scene.json", "w"))
     ls = api.LoadedScene(str(scene_dir / "scene.json"))
     assert ls.desc.integrator_type == 2 and ls.desc.max_depth == 17
-    # the media of the shipped cornell json (parsescene.cpp:72-137): coefficients scaled, sigmaT = sigmaA + sigmaS
     assert ls.desc.n_mediums == 2 and ls.camera.medium == 0
     med = np.ctypeslib.as_array(C.cast(ls.desc.mediums, C.POINTER(C.c_uint8)), shape=(2 * 104,)).view(st.MEDIUM)
     assert med[0]["type"] == 0 and med[1]["type"] == 1 and med[0]["g"] == 0
     assert np.allclose([med[0]["sigmaS"]["x"], med[0]["sigmaS"]["y"], med[0]["sigmaS"]["z"]], np.float32([0.70, 1.22, 1.90]) * np.float32(25))
     assert med[0]["sigmaT"]["z"] == np.float32(np.float32(0.0142) * np.float32(25)) + np.float32(np.float32(1.90) * np.float32(25))
-    with pytest.raises(api.GptError) as e:             # the renderer: homogeneous media only ("hhh" is a density grid)
-        api.Renderer(ls.desc, 64, 64, 0.001)
-    assert "homogeneous" in str(e.value)
+    h = med[1]
+    assert (h["nx"], h["ny"], h["nz"], h["iterMax"], h["evalTransmittanceType"]) == (nx, ny, nz, 2000, 1)
+    assert h["p0"]["x"] == np.float32(-0.63) and h["p1"]["y"] == np.float32(1.593) and h["sigmaT"]["x"] == np.float32(100)
+    grid = np.ctypeslib.as_array(C.cast(int(h["density"]), C.POINTER(C.c_float)), shape=(nx * ny * nz,))
+    want = np.float32([float(f"{v:.6f}") for v in vals])
+    assert (grid == want).all()
+    assert h["invMaxDensity"] == np.float32(1) / want.max()
+    # the mesh without a material: matIdx -1, the grid inside, nothing outside
+    prims = ls.array("prims", "n_prims", st.PRIMITIVE)["triangle"]
+    iface = prims[prims["matIdx"] == -1]
+    assert len(iface) > 0 and (iface["mediumInside"] == 1).all() and (iface["mediumOutside"] == -1).all()
+    assert (prims[prims["matIdx"] != -1]["mediumInside"] == -1).all()
+    # "pt" cannot render material-less surfaces and says so before it looks for a device
     ls.set_integrator(st.IT_PT, 8)
     assert ls.desc.integrator_type == st.IT_PT and ls.desc.max_depth == 8
+    with pytest.raises(api.GptError) as e:
+        api.Renderer(ls.desc, 64, 64, 0.001)
+    assert "material" in str(e.value)
+    # a grid whose file is short, and a coloured attenuation (the reference exits), are load errors
+    with open(scene_dir / "geometry" / "density.d", "w") as f:
+        f.write("0.5 0.25\n")
+    with pytest.raises(api.GptError) as e:
+        api.LoadedScene(str(scene_dir / "scene.json"))
+    assert "holds 2 values" in str(e.value)
+    js["medium"][1]["sigmaS"] = [90, 80, 90]
+    json.dump(js, open(scene_dir / "scene.json", "w"))
+    with pytest.raises(api.GptError) as e:
+        api.LoadedScene(str(scene_dir / "scene.json"))
+    assert "uniform attenuation" in str(e.value)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scenes/cornell_box/scene.json"), reason="the reference tree is not here")
+def test_reference_cornell_box_loads_unmodified():
+    """scenes/cornell_box/scene.json of the reference, as shipped (vpt, 100x100x40 density grid, material-less mesh)."""
+    ls = api.LoadedScene("/root/reference/scenes/cornell_box/scene.json")
+    assert ls.desc.integrator_type == st.IT_VPT and ls.desc.max_depth == 17 and ls.desc.n_mediums == 2
+    med = np.ctypeslib.as_array(C.cast(ls.desc.mediums, C.POINTER(C.c_uint8)), shape=(2 * 104,)).view(st.MEDIUM)
+    h = med[1]
+    assert (h["nx"], h["ny"], h["nz"]) == (100, 100, 40) and h["density"] != 0 and h["invMaxDensity"] > 0
+    prims = ls.array("prims", "n_prims", st.PRIMITIVE)["triangle"]
+    assert (prims["matIdx"] == -1).sum() == 12 and ls.desc.n_lights == 2
 
 
 def test_ao_scene_settings(scene_dir):
