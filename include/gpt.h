@@ -64,8 +64,8 @@ int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks);
 /* The reference reads scene.integrator.{type, maxDepth | maxDist} on the host at every Render() call
  * (src/pathtracer.cu:2711-2715); gpt_begin takes them from the scene description and this call changes them
  * afterwards.  GPT_IT_PT and GPT_IT_VPT use max_depth, GPT_IT_AO uses max_dist.  GPT_IT_VPT (Volpath, :1025-1242)
- * renders homogeneous media only: a scene with a density-grid medium gets GPT_ERR_UNSUPPORTED, as do the other
- * integrator types. */
+ * renders homogeneous and density-grid media and material-less surfaces (matIdx -1) between them; Path and Ao refuse
+ * a scene with such surfaces (GPT_ERR_UNSUPPORTED), as every call refuses the other integrator types. */
 int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth, float max_dist);
 
 /* Traversal order of the BVH (include/gpt_traversal.h): GPT_TRAVERSAL_REFERENCE (0, default: the reference's order,

@@ -149,7 +149,7 @@ typedef struct gpt_medium {          /* src/medium.h:9-13,53-62,186-193 */
             gpt_float3 p0, p1;
             int32_t iterMax;
             int32_t evalTransmittanceType;
-        } heterogeneous;             /* layout only: heterogeneous media are not rendered (GPT_ERR_UNSUPPORTED) */
+        } heterogeneous;             /* density: nx*ny*nz floats, x fastest; 1 <= iterMax <= 2^20 */
     };
 } gpt_medium;
 #define GPT_MEDIUM_HOMOGENEOUS   0

@@ -636,6 +636,22 @@ def walk_case(what):
         media = [st.make_het_medium((2, 2, 2), (6, 6, 6), grid, (-0.6, 0.2, -0.5), (0.6, 1.6, 0.5), 100, 1, 0.0, 1.0)]
         W, H, spp = 96, 96, 3
         cam = ol.cornell_camera(meta, W, H)
+    elif what == "shipped_like":
+        # the shape of the reference's scenes/cornell_box/scene.json: bare Cornell walls, a 100 x 100 x 40 grid with
+        # sigmaT = 100 in a material-less box, ratio tracking with iterMax 2000, 17 bounces, the camera in vacuum
+        grid = scenes.smoke_grid(100, 100, 40, seed=11)
+        keep = [grid]
+        lo, hi = (-0.63, 0.27, -0.2415), (0.693, 1.593, 0.2415)
+        box = scenes.box_mesh(lo, hi, -1, inside=1, outside=-1)
+        prims, _, meta = scenes.cornell_raw()
+        walls = scenes.concat([prims[0:10], prims[34:36], box])
+        walls["triangle"]["lightIdx"][10:12] = [0, 1]
+        scene = ol.make_scene(walls, scenes.material_table(), light_radiance=meta["light_radiance"], max_depth=17,
+                              textures=[scenes.checker_texture()])
+        media = [st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 25.0),
+                 st.make_het_medium((10, 10, 10), (90, 90, 90), grid, lo, hi, 2000, 1, 0.0, 1.0)]
+        W, H, spp = 256, 256, 4
+        cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)
     else:
         raise KeyError(what)
     scene.set_mediums(media, keep=keep)
@@ -645,7 +661,7 @@ def walk_case(what):
 
 
 @pytest.mark.parametrize("what", ["interface_fog_box", "smoke_delta", "smoke_ratio", "smoke_residual", "camera_in_smoke",
-                                  "smoke_large_scene"])
+                                  "smoke_large_scene", "shipped_like"])
 def test_volpath_walk_bit_exact(gpt, what):
     """Density grids (delta-tracked collisions; delta / ratio / residual-ratio transmittance, all drawing from the
     path's generator) and surfaces without a material (shadow rays walked segment by segment, path rays passing
