@@ -1459,9 +1459,10 @@ __device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, 
     return v3(sintheta * cosphi, costheta, sintheta * sinphi);
 }
 
-// Heterogeneous media (src/medium.h:53-182), as oracle/pt_oracle.c restates them (het_d, het_density, het_tr,
-// het_sample): a density grid in the box p0..p1, sampled by delta tracking; transmittance by delta (0), ratio (1) or
-// residual ratio (2) tracking.  Every loop draws from the path's generator and ends after iterMax steps at the latest.
+// Heterogeneous media (src/medium.h:53-182), as oracle/pt_oracle.c restates them (het_d, het_density; het_tr and
+// het_sample are the shared tracking loop of the PT_IT_VPT_WALK kernel): a density grid in the box p0..p1, sampled by
+// delta tracking; transmittance by delta (0), ratio (1) or residual ratio (2) tracking.  Every loop draws from the
+// path's generator and ends after iterMax steps at the latest.
 __device__ __forceinline__ int f2i_sat(float f)        // float -> int as v_cvt_i32_f32 defines it (truncate, saturate, NaN -> 0)
 {
     if (f != f) return 0;
@@ -1494,87 +1495,6 @@ __device__ __forceinline__ V3 het_local(const DevMedium &m, V3 o, V3 d, float di
     const V3 p0 = V3{m.p0[0], m.p0[1], m.p0[2]}, ext = V3{m.p1[0], m.p1[1], m.p1[2]} - p0;
     const V3 p = (o + d * dist) - p0;
     return v3(p.x / ext.x, p.y / ext.y, p.z / ext.z);
-}
-__device__ __noinline__ float het_tr(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng)                 // medium.h:64-132
-{
-    const float invMax = m.invMaxDensity;
-    const float sigma = dot(V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]}, v3(0.212671f, 0.715160f, 0.072169f));
-    float tr = 1.f, dist = 0.f;
-    int iter = m.iterMax;
-    if (m.trType == 0) {
-        for (;;) {
-            dist += -gpt_logf(rng_uniform(rng)) * invMax / sigma;
-            if (dist >= tmax) break;
-            const float dens = het_density(m, het_local(m, o, d, dist));
-            if (dens * invMax > rng_uniform(rng)) { tr = 0; break; }
-            if (--iter == 0) { tr = 0; break; }
-        }
-    } else if (m.trType == 1) {
-        for (;;) {
-            dist += -gpt_logf(rng_uniform(rng)) * invMax / sigma;
-            if (dist >= tmax) break;
-            tr *= 1.f - het_density(m, het_local(m, o, d, dist)) * invMax;
-            if (tr < 0.1f) {
-                const float q = 1.f - tr;
-                if (rng_uniform(rng) < q) return 0.f;
-                tr = 1;
-            }
-            if (--iter == 0) break;
-        }
-    } else {
-        const float maxDensity = 1 / invMax;
-        const float ce = 0.5f * maxDensity;
-        const float tc = gpt_expf(-tmax * ce * sigma);
-        for (;;) {
-            dist += -gpt_logf(rng_uniform(rng)) * (1 / (maxDensity - ce) / sigma);
-            if (dist >= tmax) break;
-            tr *= 1.f - (het_density(m, het_local(m, o, d, dist)) - ce) / (maxDensity - ce);
-            if (tr < 0.1f) {
-                const float q = 1.f - tr;
-                if (rng_uniform(rng) < q) return 0.f;
-                tr /= (1.f - q);
-            }
-            if (--iter == 0) break;
-        }
-        tr *= tc;
-    }
-    return tr;
-}
-__device__ __noinline__ V3 het_sample(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng, float &t, bool &sampled)   // medium.h:134-157
-{
-    const float invMax = m.invMaxDensity;
-    const float sigma = dot(V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]}, v3(0.212671f, 0.715160f, 0.072169f));
-    float dist = 0.f;
-    int iter = m.iterMax;
-    for (;;) {
-        dist += -gpt_logf(rng_uniform(rng)) * invMax / sigma;
-        if (dist >= tmax) break;
-        const float dens = het_density(m, het_local(m, o, d, dist));
-        if (dens * invMax > rng_uniform(rng)) {
-            t = dist;
-            sampled = true;
-            return v3(m.sigmaS[0] / m.sigmaT[0], m.sigmaS[1] / m.sigmaT[1], m.sigmaS[2] / m.sigmaT[2]);
-        }
-        if (--iter == 0) break;
-    }
-    t = dist;
-    sampled = false;
-    return v3(1.f, 1.f, 1.f);
-}
-// the type switch of every call site (pathtracer.cu:307-312,1064-1069,1106-1111,1172-1177,1193-1198)
-__device__ __forceinline__ V3 med_tr(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng)
-{
-    if (m.type == GPT_MEDIUM_HOMOGENEOUS) return hom_tr(m, tmax);
-    const float tr = het_tr(m, o, d, tmax, rng);
-    return v3(tr, tr, tr);
-}
-__device__ __forceinline__ V3 med_sample(const DevMedium &m, V3 o, V3 d, float tmax, Rng &rng, float &t, bool &sampled)
-{
-    if (m.type == GPT_MEDIUM_HOMOGENEOUS) {
-        const float u = rng_uniform(rng);
-        return hom_sample(m, tmax, u, t, sampled);
-    }
-    return het_sample(m, o, d, tmax, rng, t, sampled);
 }
 
 // ----------------------------------------------------- the render kernel -----
@@ -1613,7 +1533,9 @@ constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray p
 // Volpath with density grids or material-less surfaces: an internal fourth value of INTEG (not an integrator type of the
 // ABI; launch_render picks it when DevParams.vpt_walk is set) and the stages of its per-path state machine
 #define PT_IT_VPT_WALK 8
-constexpr int kStPath = 0, kStShadow = 1, kStMisStart = 2, kStMis = 3, kStContinue = 4;
+constexpr int kStPath = 0, kStShadow = 1, kStMisStart = 2, kStMis = 3, kStContinue = 4, kStPathB = 5, kStEmit = 6, kStShadowB = 7,
+              kStShadowDone = 8, kStMisB = 9;
+constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 template <bool COUNT, bool SMALL, int INTEG>
 __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
@@ -1747,302 +1669,440 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
             bool finish = false;
             if (COUNT) cyc_sub = __builtin_readcyclecounter();
             PT_MARK(0)
-            if (INTEG == PT_IT_VPT_WALK && alive && !waiting) {
+            if (INTEG == PT_IT_VPT_WALK) {
                 // ---- Volpath, general form (pathtracer.cu:298-322,1025-1242): one ray in flight per path.  Density
                 // grids draw random numbers per traced segment and material-less surfaces split a shadow ray into
                 // segments, so nothing can be sampled ahead of the ray it depends on: the loop body of the reference
-                // is cut at its Intersect() calls into stages, and a lane steps through them until it has a ray to
-                // trace or the sample ends.  The ray is (q.org, q.dir_p, q.tmax_s); its closest hit arrives in res.*_p.
-                bool hit = res.prim_p >= 0;
-                q.has_p = false;
+                // is cut at its Intersect() calls and at its medium Sample() / Tr() calls into stages.  A lane steps
+                // through them until it has a ray to trace or the sample ends; whenever it needs a medium walked it
+                // posts a tracking job, and the jobs of all lanes - whatever their stage - run in ONE shared loop.
+                // The ray is (q.org, q.dir_p, q.tmax_s); its closest hit arrives in res.*_p.
+                const bool hit = res.prim_p >= 0;
+                bool busy = alive && !waiting;
+                if (busy) q.has_p = false;
+                int job = kJobNone, job_medium = -1;
+                float job_tmax = 0.f, job_t = 0.f;
+                bool job_sampled = false;
+                V3 job_v = v3(1.f, 1.f, 1.f);          // the job's answer: Sample()'s weight or Tr()
                 for (;;) {
-                    if (stage == kStPath) {
-                        // ---- the path ray came back (pathtracer.cu:1049-1129)
-                        if (!hit) {
-                            if ((bounces == 0 || specular) && P.inf.isvalid)
-                                Li += beta * inf_le(P.inf, q.dir_p);
-                            finish = true;
-                            break;
-                        }
-                        Ray r;
-                        r.o = q.org;
-                        r.d = q.dir_p;
-                        const Hit isect = make_hit(P, r, res.t_p, res.prim_p, res.b1_p, res.b2_p);
-                        const V3 wo = -q.dir_p;
-                        bool scattered = false;
-                        float scatter_t = 0.f;
-                        if (medium >= 0)
-                            beta *= med_sample(P.mediums[medium], q.org, q.dir_p, res.t_p, rng, scatter_t, scattered);
-                        if (is_black(beta)) {
-                            finish = true;
-                            break;
-                        }
-                        if (scattered) {
-                            // a scattering event inside the medium (:1071-1101): light sample, then its shadow walk
-                            const DevMedium &M = P.mediums[medium];
-                            float u = rng_uniform(rng);
-                            float choicePdf;
-                            int idx = lookup_light_distribution(P, u, choicePdf);
-                            bool inf = idx == P.n_lights;
-                            V3 samplePos = q.org + q.dir_p * scatter_t;
-                            float u1x = rng_uniform(rng);
-                            float u1y = rng_uniform(rng);
-                            V3 radiance = v3(0.f), lightNor;
-                            Ray shadowRay;
-                            shadowRay.o = samplePos;
-                            shadowRay.d = v3(0.f);
-                            shadowRay.tmin = P.eps;
-                            shadowRay.tmax = 0.f;
-                            float lightPdf = 0.f;
-                            if (idx >= 0) {
-                                if (!inf)
-                                    area_sample_light(P.lights[idx], samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
-                                else
-                                    inf_sample_light(P.inf, samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
-                            }
-                            sav_w = medium_phase(M, wo, shadowRay.d);
-                            sav_rad = radiance;
-                            sav_den = lightPdf * choicePdf;
-                            sav_has = !is_black(radiance);
-                            ctx_scatter = true;
-                            ctx_o = samplePos;
-                            walk_tr = v3(1.f, 1.f, 1.f);       // Tr() is walked whatever the radiance is (:1092)
-                            walk_medium = medium;
-                            walk_left = shadowRay.tmax;
-                            q.org = shadowRay.o;
-                            q.dir_p = shadowRay.d;
-                            q.tmax_s = shadowRay.tmax;
-                            q.has_p = true;
-                            stage = kStShadow;
-                            break;
-                        }
-                        if ((bounces == 0 || specular) && isect.lightIdx != -1) {
-                            V3 tr = v3(1.f, 1.f, 1.f);
-                            if (medium >= 0) tr = med_tr(P.mediums[medium], q.org, q.dir_p, res.t_p, rng);
-                            Li += tr * beta * area_le(P.lights[isect.lightIdx], isect.nor, wo);      // :1103-1115
-                            finish = true;
-                            break;
-                        }
-                        if (isect.matIdx == -1) {
-                            // a surface without a material only separates two media (:1117-1124): not a bounce
-                            medium = dot(q.dir_p, isect.nor) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
-                            q.org = isect.pos;
-                            q.tmax_s = __builtin_inff();
-                            q.has_p = true;
-                            break;
-                        }
-                        ctx_scatter = false;
-                        ctx_o = q.org;
-                        ctx_d = q.dir_p;
-                        ctx_t = res.t_p;
-                        ctx_prim = res.prim_p;
-                        ctx_b1 = res.b1_p;
-                        ctx_b2 = res.b2_p;
-                        const gpt_material material = P.materials[isect.matIdx];
-                        if (is_delta(PT_MATERIAL_TYPE(material))) {
-                            stage = kStContinue;
-                            continue;
-                        }
-                        // direct light (:1128-1151): the light sample; its shadow ray is walked before anything else is drawn
-                        Ld_acc = v3(0.f, 0.f, 0.f);
-                        float u = rng_uniform(rng);
-                        float choicePdf;
-                        int idx = lookup_light_distribution(P, u, choicePdf);
-                        bool inf = idx == P.n_lights;
-                        float u1x = rng_uniform(rng);
-                        float u1y = rng_uniform(rng);
-                        V3 radiance = v3(0.f), lightNor;
-                        Ray shadowRay;
-                        shadowRay.o = isect.pos;
-                        shadowRay.d = v3(0.f);
-                        shadowRay.tmin = P.eps;
-                        shadowRay.tmax = 0.f;
-                        float lightPdf = 0.f;
-                        if (idx >= 0) {
-                            if (!inf)
-                                area_sample_light(P.lights[idx], isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
-                            else
-                                inf_sample_light(P.inf, isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
-                        }
-                        if (is_black(radiance)) {
-                            stage = kStMisStart;
-                            continue;
-                        }
-                        V3 fr;
-                        float samplePdf;
-                        eval_bsdf(P, material, wo, shadowRay.d, isect.nor, isect.uv, isect.dpdu, fr, samplePdf);
-                        sav_w = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
-                        sav_fr = fr;
-                        sav_rad = radiance;
-                        sav_abs = fabs_(dot(isect.nor, shadowRay.d));
-                        sav_den = lightPdf * choicePdf;
-                        walk_tr = v3(1.f, 1.f, 1.f);
-                        walk_medium = medium;
-                        walk_left = shadowRay.tmax;
-                        q.org = shadowRay.o;
-                        q.dir_p = shadowRay.d;
-                        q.tmax_s = shadowRay.tmax;
-                        q.has_p = true;
-                        stage = kStShadow;
-                        break;
-                    } else if (stage == kStShadow) {
-                        // ---- one segment of Tr() (:298-322) came back
-                        bool walked = false;
-                        if (hit) {
-                            V3 n;
-                            int lightIdx;
-                            make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
-                            const int hit_mat = __float_as_int(reinterpret_cast<const float *>(reinterpret_cast<const float4 *>(P.shade) + 5 * res.prim_p + 4)[2]);
-                            if (hit_mat != -1) {
-                                walk_tr = v3(0.f, 0.f, 0.f);
-                                walked = true;
-                            } else {
-                                if (walk_medium >= 0) walk_tr = walk_tr * med_tr(P.mediums[walk_medium], q.org, q.dir_p, res.t_p, rng);
-                                walk_medium = dot(q.dir_p, n) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
-                                walk_left -= res.t_p;
-                                q.org = q.org + q.dir_p * res.t_p;
-                                q.tmax_s = walk_left;
-                                q.has_p = true;
-                                break;
-                            }
-                        } else {
-                            if (walk_medium >= 0) walk_tr = walk_tr * med_tr(P.mediums[walk_medium], q.org, q.dir_p, q.tmax_s, rng);
-                            walked = true;
-                        }
-                        if (walked && ctx_scatter) {
-                            if (sav_has) Li += walk_tr * beta * sav_w * sav_rad / sav_den;             // :1096-1097
-                            float pux = rng_uniform(rng);
-                            float puy = rng_uniform(rng);
-                            const V3 dir = medium_sample_phase(P.mediums[medium], pux, puy);
-                            specular = false;
-                            finish = true;
-                            if (bounces + 1 < P.max_depth) {
-                                bool kill = false;
-                                if (bounces > 3) {
-                                    float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
-                                    if (rng_uniform(rng) < illumate)
-                                        kill = true;
-                                    else
-                                        beta /= (1 - illumate);
+                    if (busy) {
+                        job = kJobNone;
+                        for (;;) {
+                            if (stage == kStPath) {
+                                // ---- the path ray came back (pathtracer.cu:1049-1070)
+                                if (!hit) {
+                                    if ((bounces == 0 || specular) && P.inf.isvalid)
+                                        Li += beta * inf_le(P.inf, q.dir_p);
+                                    finish = true;
+                                    busy = false;
+                                    break;
                                 }
-                                if (!kill) {
-                                    q.org = ctx_o;
-                                    q.dir_p = dir;
+                                stage = kStPathB;
+                                job_sampled = false;
+                                if (medium >= 0) {
+                                    job = kJobSample;
+                                    job_medium = medium;
+                                    job_tmax = res.t_p;
+                                    break;
+                                }
+                                continue;
+                            } else if (stage == kStPathB) {
+                                // ---- ... and its medium has been sampled (:1070-1129)
+                                if (medium >= 0) beta *= job_v;
+                                if (is_black(beta)) {
+                                    finish = true;
+                                    busy = false;
+                                    break;
+                                }
+                                Ray r;
+                                r.o = q.org;
+                                r.d = q.dir_p;
+                                const Hit isect = make_hit(P, r, res.t_p, res.prim_p, res.b1_p, res.b2_p);
+                                const V3 wo = -q.dir_p;
+                                if (job_sampled) {
+                                    // a scattering event inside the medium (:1071-1101): light sample, then its shadow walk
+                                    const DevMedium &M = P.mediums[medium];
+                                    float u = rng_uniform(rng);
+                                    float choicePdf;
+                                    int idx = lookup_light_distribution(P, u, choicePdf);
+                                    bool inf = idx == P.n_lights;
+                                    V3 samplePos = q.org + q.dir_p * job_t;
+                                    float u1x = rng_uniform(rng);
+                                    float u1y = rng_uniform(rng);
+                                    V3 radiance = v3(0.f), lightNor;
+                                    Ray shadowRay;
+                                    shadowRay.o = samplePos;
+                                    shadowRay.d = v3(0.f);
+                                    shadowRay.tmin = P.eps;
+                                    shadowRay.tmax = 0.f;
+                                    float lightPdf = 0.f;
+                                    if (idx >= 0) {
+                                        if (!inf)
+                                            area_sample_light(P.lights[idx], samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                        else
+                                            inf_sample_light(P.inf, samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                    }
+                                    sav_w = medium_phase(M, wo, shadowRay.d);
+                                    sav_rad = radiance;
+                                    sav_den = lightPdf * choicePdf;
+                                    sav_has = !is_black(radiance);
+                                    ctx_scatter = true;
+                                    ctx_o = samplePos;
+                                    walk_tr = v3(1.f, 1.f, 1.f);       // Tr() is walked whatever the radiance is (:1092)
+                                    walk_medium = medium;
+                                    walk_left = shadowRay.tmax;
+                                    q.org = shadowRay.o;
+                                    q.dir_p = shadowRay.d;
+                                    q.tmax_s = shadowRay.tmax;
+                                    q.has_p = true;
+                                    stage = kStShadow;
+                                    busy = false;
+                                    break;
+                                }
+                                if ((bounces == 0 || specular) && isect.lightIdx != -1) {
+                                    stage = kStEmit;                                   // :1103-1115
+                                    job_v = v3(1.f, 1.f, 1.f);
+                                    if (medium >= 0) {
+                                        job = kJobTr;
+                                        job_medium = medium;
+                                        job_tmax = res.t_p;
+                                        break;
+                                    }
+                                    continue;
+                                }
+                                if (isect.matIdx == -1) {
+                                    // a surface without a material only separates two media (:1117-1124): not a bounce
+                                    medium = dot(q.dir_p, isect.nor) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
+                                    q.org = isect.pos;
                                     q.tmax_s = __builtin_inff();
                                     q.has_p = true;
-                                    finish = false;
-                                    bounces++;
                                     stage = kStPath;
+                                    busy = false;
+                                    break;
                                 }
-                            }
-                            break;
-                        }
-                        Ld_acc += sav_w * walk_tr * sav_fr * sav_rad * sav_abs / sav_den;              // :1150
-                        stage = kStMisStart;
-                        continue;
-                    } else if (stage == kStMisStart) {
-                        // ---- the BSDF-sampled light ray (:1153-1160)
-                        Ray r;
-                        r.o = ctx_o;
-                        r.d = ctx_d;
-                        const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
-                        const gpt_material material = P.materials[isect.matIdx];
-                        float usx = rng_uniform(rng);
-                        float usy = rng_uniform(rng);
-                        float usz = rng_uniform(rng);
-                        V3 out, fr;
-                        float pdf;
-                        sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
-                        if (!(is_black(fr) || pdf == 0)) {
-                            mis_fr = fr;
-                            mis_cos = fabs_(dot(out, isect.nor));
-                            mis_pdf = pdf;
-                            q.org = isect.pos;
-                            q.dir_p = out;
-                            q.tmax_s = __builtin_inff();
-                            q.has_p = true;
-                            stage = kStMis;
-                            break;
-                        }
-                        Li += beta * Ld_acc;
-                        stage = kStContinue;
-                        continue;
-                    } else if (stage == kStMis) {
-                        // ---- ... came back (:1161-1205)
-                        if (hit) {
-                            V3 n;
-                            int lightIdx;
-                            make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
-                            V3 radiance = v3(0.f, 0.f, 0.f);
-                            if (lightIdx != -1) radiance = area_le(P.lights[lightIdx], n, -q.dir_p);
-                            if (!is_black(radiance)) {
-                                V3 pp = q.org + res.t_p * q.dir_p;
-                                float pdfA = 1.f / P.lights[lightIdx].area;
-                                float choicePdf = pdf_from_light_distribution(P, lightIdx);
-                                float lenSquare = dot(pp - q.org, pp - q.org);
-                                float costheta = fabs_(dot(n, q.dir_p));
-                                float lPdf = pdfA * lenSquare / (costheta);
-                                float weight = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
-                                V3 tr = v3(1.f, 1.f, 1.f);
-                                if (medium >= 0) tr = med_tr(P.mediums[medium], q.org, q.dir_p, res.t_p, rng);
-                                Ld_acc += weight * tr * mis_fr * radiance * mis_cos / mis_pdf;
-                            }
-                        } else if (P.inf.isvalid) {
-                            V3 radiance = inf_le(P.inf, q.dir_p);
-                            float choicePdf = pdf_from_light_distribution(P, P.n_lights);
-                            float lightPdf = ONE_OVER_FOUR_PI;
-                            float weight = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
-                            V3 tr = v3(1.f, 1.f, 1.f);
-                            if (medium >= 0) tr = med_tr(P.mediums[medium], q.org, q.dir_p, __builtin_inff(), rng);
-                            Ld_acc += weight * tr * mis_fr * radiance * mis_cos / mis_pdf;
-                        }
-                        Li += beta * Ld_acc;
-                        stage = kStContinue;
-                        continue;
-                    } else {
-                        // ---- kStContinue: the continuation (:1210-1229) and the roulette (:1232-1238).  On the last bounce
-                        // nothing of it reaches Li, so it is skipped.
-                        finish = true;
-                        if (bounces + 1 < P.max_depth) {
-                            Ray r;
-                            r.o = ctx_o;
-                            r.d = ctx_d;
-                            const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
-                            const gpt_material material = P.materials[isect.matIdx];
-                            const V3 wo = -ctx_d;
-                            float ux = rng_uniform(rng);
-                            float uy = rng_uniform(rng);
-                            float uz = rng_uniform(rng);
-                            V3 out, fr;
-                            float pdf;
-                            sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
-                            if (!is_black(fr)) {
-                                beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
-                                specular = is_delta(PT_MATERIAL_TYPE(material));
-                                const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
-                                int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
-                                m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
-                                medium = m2;
-                                bool kill = false;
-                                if (bounces > 3) {
-                                    float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
-                                    if (rng_uniform(rng) < illumate)
-                                        kill = true;
+                                ctx_scatter = false;
+                                ctx_o = q.org;
+                                ctx_d = q.dir_p;
+                                ctx_t = res.t_p;
+                                ctx_prim = res.prim_p;
+                                ctx_b1 = res.b1_p;
+                                ctx_b2 = res.b2_p;
+                                const gpt_material material = P.materials[isect.matIdx];
+                                if (is_delta(PT_MATERIAL_TYPE(material))) {
+                                    stage = kStContinue;
+                                    continue;
+                                }
+                                // direct light (:1128-1151): the light sample; its shadow ray is walked before anything else is drawn
+                                Ld_acc = v3(0.f, 0.f, 0.f);
+                                float u = rng_uniform(rng);
+                                float choicePdf;
+                                int idx = lookup_light_distribution(P, u, choicePdf);
+                                bool inf = idx == P.n_lights;
+                                float u1x = rng_uniform(rng);
+                                float u1y = rng_uniform(rng);
+                                V3 radiance = v3(0.f), lightNor;
+                                Ray shadowRay;
+                                shadowRay.o = isect.pos;
+                                shadowRay.d = v3(0.f);
+                                shadowRay.tmin = P.eps;
+                                shadowRay.tmax = 0.f;
+                                float lightPdf = 0.f;
+                                if (idx >= 0) {
+                                    if (!inf)
+                                        area_sample_light(P.lights[idx], isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
                                     else
-                                        beta /= (1 - illumate);
+                                        inf_sample_light(P.inf, isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
                                 }
-                                if (!kill) {
+                                if (is_black(radiance)) {
+                                    stage = kStMisStart;
+                                    continue;
+                                }
+                                V3 fr;
+                                float samplePdf;
+                                eval_bsdf(P, material, wo, shadowRay.d, isect.nor, isect.uv, isect.dpdu, fr, samplePdf);
+                                sav_w = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                                sav_fr = fr;
+                                sav_rad = radiance;
+                                sav_abs = fabs_(dot(isect.nor, shadowRay.d));
+                                sav_den = lightPdf * choicePdf;
+                                walk_tr = v3(1.f, 1.f, 1.f);
+                                walk_medium = medium;
+                                walk_left = shadowRay.tmax;
+                                q.org = shadowRay.o;
+                                q.dir_p = shadowRay.d;
+                                q.tmax_s = shadowRay.tmax;
+                                q.has_p = true;
+                                stage = kStShadow;
+                                busy = false;
+                                break;
+                            } else if (stage == kStEmit) {
+                                // ---- a directly seen emitter, attenuated by the path's medium (:1103-1115)
+                                V3 n;
+                                int lightIdx;
+                                make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                                Li += job_v * beta * area_le(P.lights[lightIdx], n, -q.dir_p);
+                                finish = true;
+                                busy = false;
+                                break;
+                            } else if (stage == kStShadow) {
+                                // ---- one segment of Tr() (:298-322) came back
+                                if (hit) {
+                                    const int hit_mat = __float_as_int(reinterpret_cast<const float *>(reinterpret_cast<const float4 *>(P.shade) + 5 * res.prim_p + 4)[2]);
+                                    if (hit_mat != -1) {
+                                        walk_tr = v3(0.f, 0.f, 0.f);
+                                        stage = kStShadowDone;
+                                        continue;
+                                    }
+                                }
+                                stage = kStShadowB;
+                                if (walk_medium >= 0) {
+                                    job = kJobTr;
+                                    job_medium = walk_medium;
+                                    job_tmax = hit ? res.t_p : q.tmax_s;
+                                    break;
+                                }
+                                continue;
+                            } else if (stage == kStShadowB) {
+                                // ---- ... and the medium of the segment has been walked
+                                if (walk_medium >= 0) walk_tr = walk_tr * job_v;
+                                if (hit) {
+                                    V3 n;
+                                    int lightIdx;
+                                    make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                                    walk_medium = dot(q.dir_p, n) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
+                                    walk_left -= res.t_p;
+                                    q.org = q.org + q.dir_p * res.t_p;
+                                    q.tmax_s = walk_left;
+                                    q.has_p = true;
+                                    stage = kStShadow;
+                                    busy = false;
+                                    break;
+                                }
+                                stage = kStShadowDone;
+                                continue;
+                            } else if (stage == kStShadowDone) {
+                                // ---- Tr() is complete
+                                if (ctx_scatter) {
+                                    if (sav_has) Li += walk_tr * beta * sav_w * sav_rad / sav_den;             // :1096-1097
+                                    float pux = rng_uniform(rng);
+                                    float puy = rng_uniform(rng);
+                                    const V3 dir = medium_sample_phase(P.mediums[medium], pux, puy);
+                                    specular = false;
+                                    finish = true;
+                                    if (bounces + 1 < P.max_depth) {
+                                        bool kill = false;
+                                        if (bounces > 3) {
+                                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                            if (rng_uniform(rng) < illumate)
+                                                kill = true;
+                                            else
+                                                beta /= (1 - illumate);
+                                        }
+                                        if (!kill) {
+                                            q.org = ctx_o;
+                                            q.dir_p = dir;
+                                            q.tmax_s = __builtin_inff();
+                                            q.has_p = true;
+                                            finish = false;
+                                            bounces++;
+                                            stage = kStPath;
+                                        }
+                                    }
+                                    busy = false;
+                                    break;
+                                }
+                                Ld_acc += sav_w * walk_tr * sav_fr * sav_rad * sav_abs / sav_den;              // :1150
+                                stage = kStMisStart;
+                                continue;
+                            } else if (stage == kStMisStart) {
+                                // ---- the BSDF-sampled light ray (:1153-1160)
+                                Ray r;
+                                r.o = ctx_o;
+                                r.d = ctx_d;
+                                const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                                const gpt_material material = P.materials[isect.matIdx];
+                                float usx = rng_uniform(rng);
+                                float usy = rng_uniform(rng);
+                                float usz = rng_uniform(rng);
+                                V3 out, fr;
+                                float pdf;
+                                sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
+                                if (!(is_black(fr) || pdf == 0)) {
+                                    mis_fr = fr;
+                                    mis_cos = fabs_(dot(out, isect.nor));
+                                    mis_pdf = pdf;
                                     q.org = isect.pos;
                                     q.dir_p = out;
                                     q.tmax_s = __builtin_inff();
                                     q.has_p = true;
-                                    finish = false;
-                                    bounces++;
-                                    stage = kStPath;
+                                    stage = kStMis;
+                                    busy = false;
+                                    break;
                                 }
+                                Li += beta * Ld_acc;
+                                stage = kStContinue;
+                                continue;
+                            } else if (stage == kStMis) {
+                                // ---- ... came back (:1161-1205)
+                                bool contributes = false;
+                                if (hit) {
+                                    V3 n;
+                                    int lightIdx;
+                                    make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                                    V3 radiance = v3(0.f, 0.f, 0.f);
+                                    if (lightIdx != -1) radiance = area_le(P.lights[lightIdx], n, -q.dir_p);
+                                    if (!is_black(radiance)) {
+                                        V3 pp = q.org + res.t_p * q.dir_p;
+                                        float pdfA = 1.f / P.lights[lightIdx].area;
+                                        float choicePdf = pdf_from_light_distribution(P, lightIdx);
+                                        float lenSquare = dot(pp - q.org, pp - q.org);
+                                        float costheta = fabs_(dot(n, q.dir_p));
+                                        float lPdf = pdfA * lenSquare / (costheta);
+                                        sav_w = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
+                                        sav_rad = radiance;
+                                        job_tmax = res.t_p;
+                                        contributes = true;
+                                    }
+                                } else if (P.inf.isvalid) {
+                                    sav_rad = inf_le(P.inf, q.dir_p);
+                                    float choicePdf = pdf_from_light_distribution(P, P.n_lights);
+                                    float lightPdf = ONE_OVER_FOUR_PI;
+                                    sav_w = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
+                                    job_tmax = __builtin_inff();
+                                    contributes = true;
+                                }
+                                if (contributes) {
+                                    stage = kStMisB;
+                                    job_v = v3(1.f, 1.f, 1.f);
+                                    if (medium >= 0) {
+                                        job = kJobTr;
+                                        job_medium = medium;
+                                        break;
+                                    }
+                                    continue;
+                                }
+                                Li += beta * Ld_acc;
+                                stage = kStContinue;
+                                continue;
+                            } else if (stage == kStMisB) {
+                                Ld_acc += sav_w * job_v * mis_fr * sav_rad * mis_cos / mis_pdf;
+                                Li += beta * Ld_acc;
+                                stage = kStContinue;
+                                continue;
+                            } else {
+                                // ---- kStContinue: the continuation (:1210-1229) and the roulette (:1232-1238).  On the last bounce
+                                // nothing of it reaches Li, so it is skipped.
+                                finish = true;
+                                if (bounces + 1 < P.max_depth) {
+                                    Ray r;
+                                    r.o = ctx_o;
+                                    r.d = ctx_d;
+                                    const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                                    const gpt_material material = P.materials[isect.matIdx];
+                                    const V3 wo = -ctx_d;
+                                    float ux = rng_uniform(rng);
+                                    float uy = rng_uniform(rng);
+                                    float uz = rng_uniform(rng);
+                                    V3 out, fr;
+                                    float pdf;
+                                    sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
+                                    if (!is_black(fr)) {
+                                        beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
+                                        specular = is_delta(PT_MATERIAL_TYPE(material));
+                                        const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
+                                        int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
+                                        m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
+                                        medium = m2;
+                                        bool kill = false;
+                                        if (bounces > 3) {
+                                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                            if (rng_uniform(rng) < illumate)
+                                                kill = true;
+                                            else
+                                                beta /= (1 - illumate);
+                                        }
+                                        if (!kill) {
+                                            q.org = isect.pos;
+                                            q.dir_p = out;
+                                            q.tmax_s = __builtin_inff();
+                                            q.has_p = true;
+                                            finish = false;
+                                            bounces++;
+                                            stage = kStPath;
+                                        }
+                                    }
+                                }
+                                busy = false;
+                                break;
                             }
                         }
-                        break;
+                    }
+                    if (!__any(busy)) break;
+                    // ---- the tracking jobs of this turn: Sample() / Tr() of the medium `job_medium` along the lane's ray
+                    // over [0, job_tmax) (medium.h:14-50,64-157).  Homogeneous media answer in closed form; the density
+                    // grids of all lanes are walked together, each lane drawing from its own path's generator.
+                    if (busy) {
+                        const DevMedium M = P.mediums[job_medium];
+                        if (M.type == GPT_MEDIUM_HOMOGENEOUS) {
+                            if (job == kJobSample) {
+                                const float u = rng_uniform(rng);
+                                job_v = hom_sample(M, job_tmax, u, job_t, job_sampled);
+                            } else {
+                                job_v = hom_tr(M, job_tmax);
+                            }
+                        } else {
+                            // mode: 0 = Sample (delta tracking to the next real collision), 1..3 = Tr by delta / ratio /
+                            // residual ratio tracking
+                            const int mode = job == kJobSample ? 0 : 1 + M.trType;
+                            const float invMax = M.invMaxDensity;
+                            const float sigma = dot(V3{M.sigmaT[0], M.sigmaT[1], M.sigmaT[2]}, v3(0.212671f, 0.715160f, 0.072169f));
+                            const float maxDensity = 1 / invMax;
+                            const float ce = 0.5f * maxDensity;
+                            const float step3 = 1 / (maxDensity - ce) / sigma;
+                            float tr = 1.f, dist = 0.f;
+                            int iter = M.iterMax;
+                            bool sampled = false, zero = false;
+                            for (;;) {
+                                const float l = -gpt_logf(rng_uniform(rng));
+                                if (mode == 3) dist += l * step3;
+                                else dist += l * invMax / sigma;
+                                if (dist >= job_tmax) break;
+                                const float dens = het_density(M, het_local(M, q.org, q.dir_p, dist));
+                                if (mode <= 1) {
+                                    if (dens * invMax > rng_uniform(rng)) {
+                                        sampled = true;          // Sample: a real collision; Tr (delta): the ray is absorbed
+                                        tr = 0;
+                                        break;
+                                    }
+                                    if (--iter == 0) {
+                                        tr = 0;
+                                        break;
+                                    }
+                                } else {
+                                    if (mode == 2) tr *= 1.f - dens * invMax;
+                                    else tr *= 1.f - (dens - ce) / (maxDensity - ce);
+                                    if (tr < 0.1f) {
+                                        const float qq = 1.f - tr;
+                                        if (rng_uniform(rng) < qq) {
+                                            zero = true;
+                                            break;
+                                        }
+                                        if (mode == 2) tr = 1;
+                                        else tr /= (1.f - qq);
+                                    }
+                                    if (--iter == 0) break;
+                                }
+                            }
+                            if (mode == 0) {
+                                job_t = dist;
+                                job_sampled = sampled;
+                                job_v = sampled ? v3(M.sigmaS[0] / M.sigmaT[0], M.sigmaS[1] / M.sigmaT[1], M.sigmaS[2] / M.sigmaT[2]) : v3(1.f, 1.f, 1.f);
+                            } else {
+                                if (mode == 3 && !zero) tr *= gpt_expf(-job_tmax * ce * sigma);
+                                if (zero) tr = 0.f;
+                                job_v = v3(tr, tr, tr);
+                            }
+                        }
                     }
                 }
             }
