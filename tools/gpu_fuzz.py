@@ -1,5 +1,6 @@
 """Randomised GPU-vs-oracle soak: random triangle soups + Cornell parts, random materials, cameras, frame sizes,
-iteration batching, integrator (pt / ao), traversal order and memory path; every film must match the oracle bit for bit.
+iteration batching, integrator (pt / ao / vpt with random homogeneous and density-grid media, material-less boxes and
+medium-filled meshes), traversal order and memory path; every film must match the oracle bit for bit.
 usage: python tools/gpu_fuzz.py <seconds> [seed]      (run under `timeout`; each case is small)"""
 import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -23,6 +24,33 @@ while time.time() < t_end:
     if rng.random() < 0.5:
         parts.append(scenes.uv_sphere((float(rng.uniform(-.5, .5)), float(rng.uniform(.3, 1.6)), float(rng.uniform(-.5, .5))),
                                       float(rng.uniform(.15, .45)), int(rng.choice(mats)), nu=int(rng.choice([6, 12, 20])), nv=int(rng.choice([4, 8, 14]))))
+    # Volpath: random media; sometimes a material-less box holding one, sometimes a mesh filled with one
+    vpt = bool(rng.random() < 0.35)
+    media, grids, cam_medium = [], [], -1
+    if vpt:
+        for _ in range(int(rng.integers(1, 4))):
+            sa, ss = rng.uniform(0.0, 1.5, 3), rng.uniform(0.05, 3.0, 3)
+            g = float(rng.choice([0.0, 0.0, 0.5, -0.6, 0.0005]))
+            if rng.random() < 0.5:
+                media.append(st.make_medium(tuple(sa), tuple(ss), g, float(rng.choice([0.1, 1.0, 4.0]))))
+            else:
+                grid = scenes.smoke_grid(int(rng.integers(2, 20)), int(rng.integers(2, 20)), int(rng.integers(2, 20)), seed=int(rng.integers(1 << 30)))
+                if grid.max() <= 0: grid[0, 0, 0] = np.float32(1)
+                grids.append(grid)
+                lo = rng.uniform(-1.2, -0.2, 3) + np.array([0, 1, 0])
+                hi = lo + rng.uniform(0.4, 2.4, 3)
+                a, sct = float(rng.uniform(0, 3)), float(rng.uniform(0.1, 12))
+                media.append(st.make_het_medium((a, a, a), (sct, sct, sct), grid, tuple(lo), tuple(hi), int(rng.choice([1, 3, 40, 500])),
+                                                int(rng.integers(0, 3)), g, 1.0))
+        nm = len(media)
+        if rng.random() < 0.6:
+            lo = rng.uniform(-0.8, 0.0, 3) + np.array([0, 0.8, 0])
+            hi = lo + rng.uniform(0.2, 1.0, 3)
+            parts.append(scenes.box_mesh(tuple(lo), tuple(hi), -1, inside=int(rng.integers(-1, nm)), outside=int(rng.integers(-1, nm))))
+        if parts and rng.random() < 0.5:
+            parts[0]["triangle"]["mediumInside"] = int(rng.integers(-1, nm))
+            parts[0]["triangle"]["mediumOutside"] = int(rng.integers(-1, nm))
+        cam_medium = int(rng.integers(-1, nm))
     extra = scenes.concat(parts) if parts else None
     with_env = bool(rng.random() < 0.35)
     with_area = bool(rng.random() < 0.8) or not with_env
@@ -38,12 +66,18 @@ while time.time() < t_end:
         cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, aperture=float(rng.uniform(0.02, 0.3)), focal=float(rng.uniform(4, 8)))
     else:
         cam = ol.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.2, 2.5)), float(rng.uniform(3, 8))), (0, 1, 0), (0, 1, 0), (W, H), float(rng.uniform(15, 70)))
-    ao = bool(rng.random() < 0.2)
+    ao = bool(rng.random() < 0.2) and not vpt
     near = bool(rng.random() < 0.3)
     force_global = bool(rng.random() < 0.4)
     eps = float(rng.choice([0.001, 0.0005, 0.01]))
     if ao:
         scene.desc.set_integrator("ao", float(rng.choice([0.05, 0.5, 3.0])))
+    force_walk = False
+    if vpt:
+        scene.set_mediums(media, keep=grids)
+        scene.desc.set_integrator("vpt", depth)
+        cam.medium = cam_medium
+        force_walk = bool(rng.random() < 0.3)
     lib.oracle_set_traversal(1 if near else 0)
     try:
         ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
@@ -51,6 +85,8 @@ while time.time() < t_end:
         lib.oracle_set_traversal(0)
     if force_global: os.environ["GPT_NO_LDS_SCENE"] = "1"
     else: os.environ.pop("GPT_NO_LDS_SCENE", None)
+    if force_walk: os.environ["GPT_VPT_WALK"] = "1"
+    else: os.environ.pop("GPT_VPT_WALK", None)
     with api.Renderer(scene.desc, W, H, eps) as r:
         r.set_traversal_order(near)
         if rng.random() < 0.5:
@@ -61,7 +97,7 @@ while time.time() < t_end:
             if k < spp: r.render(cam, k + 1, spp - k, reset=False)
         got = r.read_accum()
     bad = int(np.count_nonzero(got.view(np.uint32) != ref.view(np.uint32)))
-    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} near {near} global {force_global}"
+    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} near {near} global {force_global}"
     if bad:
         n_bad += 1
         print("MISMATCH", bad, tag, flush=True)
