@@ -20,7 +20,9 @@
  *   BSDFs          pathtracer.cu:51-169,491-826 (all six material types)
  *   textures       pathtracer.cu:324-359
  *   lights         area.h:14-41, infinite.h:17-94, pathtracer.cu:172-185
- *   integrator     pathtracer.cu:880-1021       (Path), :830-876 (Ao)
+ *   integrator     pathtracer.cu:880-1021       (Path), :830-876 (Ao), :298-322,1025-1242 (Volpath)
+ *   media          medium.h:9-51 (homogeneous), :53-182 (density grids: delta / ratio / residual-ratio tracking),
+ *                  :196-233 (Henyey-Greenstein phase function)
  *   film           pathtracer.cu:187-204,2516-2531 (Output: accumulate + tonemap)
  *   BVH build      bvh.cpp:38-173               (binned SAH, preorder flatten)
  *   scene init     scene.h:50-83                (light power CDF, env bounding sphere)
@@ -38,6 +40,11 @@
  * restatement is pinned against the golden values the survey obtained from the
  * reference's own code (RNG table, Cornell BVH listing,
  * rendered radiance at fixed pixels / means), committed under tests/golden/.
+ * Those values cover Path and everything under it (RNG, BVH, traversal, BSDFs,
+ * lights, film).  PARITY UNPINNED for the Ao and Volpath restatements and for
+ * the media: no output of the reference exists for them; they are held to the
+ * algorithm's invariants (tests/test_oracle_golden.py) and to agreement with
+ * the independently written HIP kernels.
  *
  * Two builds of this one file (oracle/Makefile):
  *   liboracle_libm.so  transcendental functions from glibc libm, as in the

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+import scenes
 from gpu_pathtracer_amd import scene_types as st
 
 GOLD = json.load(open(os.path.join(ol.GOLDEN, "survey_appendix_b.json")))
@@ -203,11 +204,9 @@ def test_near_first_traversal_agrees_with_the_reference_order():
 
 
 def test_volpath_oracle_properties():
-    """Volpath (pathtracer.cu:1025-1242) restated for homogeneous media; the GPU kernel does not run it yet, so this
-    is the specification the next step is tested against.  No reference output exists for it (parity unpinned).
-    Checked here: without media it IS Path (same draws, same arithmetic); an absorbing-only medium around a camera
-    that sees the light directly attenuates exactly by exp(-sigmaT * t); the thread count does not matter;
-    heterogeneous media are refused."""
+    """Volpath (pathtracer.cu:1025-1242) with homogeneous media.  No reference output exists for it (parity unpinned).
+    Checked here: without media it IS Path (same draws, same arithmetic); fog between camera and scene dims the film;
+    the thread count does not matter; a density-grid record without a grid is refused."""
     from gpu_pathtracer_amd import scene_types as st
     scene, meta = ol.load_cornell(6)
     W, H = 64, 64
@@ -240,7 +239,7 @@ def test_volpath_oracle_properties():
     # sigmaS = 0: the distance sample never lands inside (pdf sigma*exp(-sigma d), weight sigmaT*Tr/pdf = Tr*sigmaT/(sigma*exp(-sigma*d)))
     # - the reference's estimator for the un-scattered case, so only the ratio's sign and finiteness are asserted here
     assert np.isfinite(a).all() and (a[lit] >= 0).all()
-    # heterogeneous media are not restated
+    # a heterogeneous record needs its grid and a positive iterMax
     het = st.make_medium((1, 1, 1), (1, 1, 1))
     het["type"] = 1
     scene.set_mediums([het])
@@ -249,3 +248,39 @@ def test_volpath_oracle_properties():
     rc = ol.load("soft").oracle_render(C.byref(scene.desc), C.byref(cam), W, H, C.c_float(0.001), 1, 1, 1,
                                        st.ptr(np.zeros(n, np.float32)), st.ptr(np.zeros(n, np.float32)), None, 0, 1, 1)
     assert rc == -2
+
+
+def test_volpath_oracle_density_grids_and_interfaces():
+    """Density grids (medium.h:53-182) behind a material-less surface (pathtracer.cu:1117-1124).  A camera in vacuum
+    looks straight up at the light through an absorbing grid of constant density rho that starts at a material-less
+    sheet and contains the light: the path ray passes the sheet without a bounce, Sample() survives the stretch L to
+    the light with probability T = exp(-sigma rho L), and the emitter is then attenuated by the Tr() estimate of the
+    same stretch, whose mean is T for all three estimators - so the film's mean is T^2 Le."""
+    from gpu_pathtracer_amd import scene_types as st
+    rho, sigma = np.float32(0.7), 0.8
+    grid = np.full((4, 4, 4), rho, np.float32)
+    sheet = scenes.box_mesh((-0.99, 0.9, -0.99), (0.99, 2.5, 0.99), -1, inside=0, outside=-1)[4:6]     # its bottom face
+    assert np.allclose([sheet["triangle"][v]["v"]["y"] for v in ("v1", "v2", "v3")], 0.9)
+    scene, meta = scenes.zoo_scene(max_depth=1, extra=sheet, assign={})
+    W = H = 32
+    up = ol.make_camera((0.0, 0.5, 0.0), (0.0, 2.0, 0.0), (0, 0, 1), (W, H), 4.0)
+    scene.desc.set_integrator("vpt", 1)
+    tri = scene.prims["triangle"]
+    is_sheet = tri["matIdx"] == -1
+    assert is_sheet.sum() == 2
+    tri["mediumInside"][is_sheet] = -1
+    vac, _ = ol.render(scene, up, W, H, 0.001, 1, 1, kind="soft")            # no media: the sheet alone changes nothing
+    tri["mediumInside"][is_sheet] = 0
+    lit = vac.reshape(-1, 3)[:, 0] > 0
+    assert lit.sum() > 900
+    light_y = float(tri["v1"]["v"]["y"][tri["lightIdx"] >= 0][0])
+    T = np.exp(-sigma * float(rho) * (light_y - 0.9))
+    spp = 24
+    for tr_type in (0, 1, 2):
+        het = st.make_het_medium((sigma, sigma, sigma), (0, 0, 0), grid, (-2, -1, -2), (2, 3, 2), 1000, tr_type)
+        scene.set_mediums([het], keep=[grid])
+        f1, _ = ol.render(scene, up, W, H, 0.001, 1, spp, kind="soft", threads=1)
+        f8, _ = ol.render(scene, up, W, H, 0.001, 1, spp, kind="soft", threads=8)
+        assert f1.tobytes() == f8.tobytes() and np.isfinite(f1).all()
+        ratio = f1.reshape(-1, 3)[lit].mean(axis=0) / (spp * vac.reshape(-1, 3)[lit].mean(axis=0))
+        assert np.allclose(ratio, T * T, rtol=0.04), (tr_type, ratio, T * T)
