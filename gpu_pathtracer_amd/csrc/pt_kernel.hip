@@ -1536,6 +1536,16 @@ constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray p
 constexpr int kStPath = 0, kStShadow = 1, kStMisStart = 2, kStMis = 3, kStContinue = 4, kStPathB = 5, kStEmit = 6, kStShadowB = 7,
               kStShadowDone = 8, kStMisB = 9;
 constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
+#ifndef PT_TRACK_STEPS
+#define PT_TRACK_STEPS 16
+#endif
+#ifndef PT_STEP_BATCH
+#define PT_STEP_BATCH 16
+#endif
+#ifndef PT_TRACE_BATCH
+#define PT_TRACE_BATCH 32
+#endif
+constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH;
 template <bool COUNT, bool SMALL, int INTEG>
 __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
@@ -1654,6 +1664,12 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
         float sav_w = 0.f, sav_abs = 0.f, sav_den = 1.f;
         V3 sav_fr = v3(0.f), sav_rad = v3(0.f), Ld_acc = v3(0.f);
         bool sav_has = false;
+        // ... and its tracking job: a walk through a density grid that did not end within kTrackSteps steps is parked
+        // (job_running) and continues in the next round, while the lanes that are done move on
+        int job = 0, job_medium = -1;
+        float job_tmax = 0.f, trk_dist = 0.f, trk_tr = 1.f;
+        int trk_iter = 0;
+        bool job_running = false;
 
         RaySet q;
         q.org = q.dir_s = q.dir_m = q.dir_p = v3(0.f);
@@ -1678,13 +1694,21 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                 // posts a tracking job, and the jobs of all lanes - whatever their stage - run in ONE shared loop.
                 // The ray is (q.org, q.dir_p, q.tmax_s); its closest hit arrives in res.*_p.
                 const bool hit = res.prim_p >= 0;
-                bool busy = alive && !waiting;
+                bool busy = alive && !waiting && !job_running;
                 if (busy) q.has_p = false;
-                int job = kJobNone, job_medium = -1;
-                float job_tmax = 0.f, job_t = 0.f;
+                float job_t = 0.f;
                 bool job_sampled = false;
                 V3 job_v = v3(1.f, 1.f, 1.f);          // the job's answer: Sample()'s weight or Tr()
                 for (;;) {
+                    // Three things a lane can be waiting for: its stage code (busy: it has a traced ray or a finished
+                    // job to consume), a step of its tracking job (job_running) or the pool drain (q.has_p / finish).
+                    // Each costs the wave the same whether 1 or 64 lanes take part, so the stage code - the longest of
+                    // them, one body per stage present - runs when kStepBatch lanes have gathered or nothing is being
+                    // tracked, and the round goes on to the drain when nobody is left to step and kTraceBatch rays wait
+                    // (or nothing is being tracked); otherwise the wave tracks.
+                    const int n_ready = popc(ballot(busy));
+                    int n_track = popc(ballot(job_running));
+                    if (n_ready > 0 && (n_ready >= kStepBatch || n_track == 0)) {
                     if (busy) {
                         job = kJobNone;
                         for (;;) {
@@ -2036,12 +2060,27 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                 break;
                             }
                         }
+                        if (busy) {          // left the stage code with a job posted: a fresh walk
+                            job_running = true;
+                            trk_tr = 1.f;
+                            trk_dist = 0.f;
+                            trk_iter = -1;
+                            busy = false;
+                        }
                     }
-                    if (!__any(busy)) break;
-                    // ---- the tracking jobs of this turn: Sample() / Tr() of the medium `job_medium` along the lane's ray
-                    // over [0, job_tmax) (medium.h:14-50,64-157).  Homogeneous media answer in closed form; the density
-                    // grids of all lanes are walked together, each lane drawing from its own path's generator.
-                    if (busy) {
+                    n_track = popc(ballot(job_running));
+                    }
+                    {
+                        const bool any_ready = __any(busy);           // (only if the stage code was put off)
+                        if (!any_ready && n_track == 0) break;
+                        if (!any_ready && popc(ballot(alive && (q.has_p || finish))) >= kTraceBatch) break;
+                    }
+                    // ---- the tracking jobs: Sample() / Tr() of the medium `job_medium` along the lane's ray over
+                    // [0, job_tmax) (medium.h:14-50,64-157).  Homogeneous media answer in closed form; the density grids
+                    // of all lanes are walked together, each lane drawing from its own path's generator, for at most
+                    // kTrackSteps steps per turn: a longer walk is parked and goes on next round, so that the lanes
+                    // whose walks were short can fetch new work in between instead of idling until the longest ends.
+                    if (job_running) {
                         const DevMedium M = P.mediums[job_medium];
                         if (M.type == GPT_MEDIUM_HOMOGENEOUS) {
                             if (job == kJobSample) {
@@ -2050,6 +2089,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                             } else {
                                 job_v = hom_tr(M, job_tmax);
                             }
+                            job_running = false;
+                            busy = true;
                         } else {
                             // mode: 0 = Sample (delta tracking to the next real collision), 1..3 = Tr by delta / ratio /
                             // residual ratio tracking
@@ -2059,23 +2100,26 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                             const float maxDensity = 1 / invMax;
                             const float ce = 0.5f * maxDensity;
                             const float step3 = 1 / (maxDensity - ce) / sigma;
-                            float tr = 1.f, dist = 0.f;
-                            int iter = M.iterMax;
-                            bool sampled = false, zero = false;
-                            for (;;) {
+                            float tr = trk_tr, dist = trk_dist;
+                            int iter = trk_iter < 0 ? M.iterMax : trk_iter;
+                            bool sampled = false, zero = false, done = false;
+#pragma unroll 1
+                            for (int step = 0; step < kTrackSteps; ++step) {
                                 const float l = -gpt_logf(rng_uniform(rng));
                                 if (mode == 3) dist += l * step3;
                                 else dist += l * invMax / sigma;
-                                if (dist >= job_tmax) break;
+                                if (dist >= job_tmax) { done = true; break; }
                                 const float dens = het_density(M, het_local(M, q.org, q.dir_p, dist));
                                 if (mode <= 1) {
                                     if (dens * invMax > rng_uniform(rng)) {
                                         sampled = true;          // Sample: a real collision; Tr (delta): the ray is absorbed
                                         tr = 0;
+                                        done = true;
                                         break;
                                     }
                                     if (--iter == 0) {
                                         tr = 0;
+                                        done = true;
                                         break;
                                     }
                                 } else {
@@ -2085,15 +2129,22 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevP
                                         const float qq = 1.f - tr;
                                         if (rng_uniform(rng) < qq) {
                                             zero = true;
+                                            done = true;
                                             break;
                                         }
                                         if (mode == 2) tr = 1;
                                         else tr /= (1.f - qq);
                                     }
-                                    if (--iter == 0) break;
+                                    if (--iter == 0) { done = true; break; }
                                 }
                             }
-                            if (mode == 0) {
+                            job_running = !done;
+                            busy = done;
+                            if (!done) {
+                                trk_tr = tr;
+                                trk_dist = dist;
+                                trk_iter = iter;
+                            } else if (mode == 0) {
                                 job_t = dist;
                                 job_sampled = sampled;
                                 job_v = sampled ? v3(M.sigmaS[0] / M.sigmaT[0], M.sigmaS[1] / M.sigmaT[1], M.sigmaS[2] / M.sigmaT[2]) : v3(1.f, 1.f, 1.f);
