@@ -1470,24 +1470,34 @@ __device__ __forceinline__ int f2i_sat(float f)        // float -> int as v_cvt_
     if (f >= 2147483648.f) return 0x7fffffff;
     return (int)f;
 }
-__device__ __forceinline__ float het_d(const DevMedium &m, float px, float py, float pz)                     // medium.h:176-181
-{
-    const int x = f2i_sat(px), y = f2i_sat(py), z = f2i_sat(pz);
-    if (x < 0 || x > m.nx - 1 || y < 0 || y > m.ny - 1 || z < 0 || z > m.nz - 1) return 0.f;
-    return m.density[(size_t)z * (size_t)m.ny * (size_t)m.nx + (size_t)y * (size_t)m.nx + (size_t)x];
-}
 __device__ __forceinline__ float lerp_(float a, float b, float t) { return a + t * (b - a); }               // cutil_math.h:1008-1011
-__device__ __forceinline__ float het_density(const DevMedium &m, V3 p)                                       // medium.h:160-174
+// getDensity (medium.h:160-174) with d() (:176-181) folded in: the eight corners share six coordinate conversions and
+// six range tests (per axis, for psi and psi + 1) instead of doing 24 of each; a corner outside the grid reads as 0.
+__device__ __forceinline__ float het_density(const DevMedium &m, V3 p)
 {
     const V3 ps = v3(p.x * m.nx, p.y * m.ny, p.z * m.nz);
     const V3 psi = v3(__builtin_floorf(ps.x), __builtin_floorf(ps.y), __builtin_floorf(ps.z));
     const V3 delta = ps - psi;
-    float d00 = lerp_(het_d(m, psi.x, psi.y, psi.z), het_d(m, psi.x + 1, psi.y, psi.z), delta.x);
-    float d10 = lerp_(het_d(m, psi.x, psi.y + 1, psi.z), het_d(m, psi.x + 1, psi.y + 1, psi.z), delta.x);
-    float d01 = lerp_(het_d(m, psi.x, psi.y, psi.z + 1), het_d(m, psi.x + 1, psi.y, psi.z + 1), delta.x);
-    float d11 = lerp_(het_d(m, psi.x, psi.y + 1, psi.z + 1), het_d(m, psi.x + 1, psi.y + 1, psi.z + 1), delta.x);
-    float d0 = lerp_(d00, d10, delta.y);
-    float d1 = lerp_(d01, d11, delta.y);
+    const int x0 = f2i_sat(psi.x), x1 = f2i_sat(psi.x + 1), y0 = f2i_sat(psi.y), y1 = f2i_sat(psi.y + 1),
+              z0 = f2i_sat(psi.z), z1 = f2i_sat(psi.z + 1);
+    const bool vx0 = !(x0 < 0 || x0 > m.nx - 1), vx1 = !(x1 < 0 || x1 > m.nx - 1), vy0 = !(y0 < 0 || y0 > m.ny - 1),
+               vy1 = !(y1 < 0 || y1 > m.ny - 1), vz0 = !(z0 < 0 || z0 > m.nz - 1), vz1 = !(z1 < 0 || z1 > m.nz - 1);
+    const int sy = m.nx, sz = m.ny * m.nx;               // int idx = z*ny*nx + y*nx + x
+    const float *g = m.density;
+    const float d000 = (vx0 && vy0 && vz0) ? g[z0 * sz + y0 * sy + x0] : 0.f;
+    const float d100 = (vx1 && vy0 && vz0) ? g[z0 * sz + y0 * sy + x1] : 0.f;
+    const float d010 = (vx0 && vy1 && vz0) ? g[z0 * sz + y1 * sy + x0] : 0.f;
+    const float d110 = (vx1 && vy1 && vz0) ? g[z0 * sz + y1 * sy + x1] : 0.f;
+    const float d001 = (vx0 && vy0 && vz1) ? g[z1 * sz + y0 * sy + x0] : 0.f;
+    const float d101 = (vx1 && vy0 && vz1) ? g[z1 * sz + y0 * sy + x1] : 0.f;
+    const float d011 = (vx0 && vy1 && vz1) ? g[z1 * sz + y1 * sy + x0] : 0.f;
+    const float d111 = (vx1 && vy1 && vz1) ? g[z1 * sz + y1 * sy + x1] : 0.f;
+    const float d00 = lerp_(d000, d100, delta.x);
+    const float d10 = lerp_(d010, d110, delta.x);
+    const float d01 = lerp_(d001, d101, delta.x);
+    const float d11 = lerp_(d011, d111, delta.x);
+    const float d0 = lerp_(d00, d10, delta.y);
+    const float d1 = lerp_(d01, d11, delta.y);
     return lerp_(d0, d1, delta.z);
 }
 __device__ __forceinline__ V3 het_local(const DevMedium &m, V3 o, V3 d, float dist)      // (r(dist) - p0) / (p1 - p0)
@@ -1533,6 +1543,10 @@ constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray p
 // Volpath with density grids or material-less surfaces: an internal fourth value of INTEG (not an integrator type of the
 // ABI; launch_render picks it when DevParams.vpt_walk is set) and the stages of its per-path state machine
 #define PT_IT_VPT_WALK 8
+// 3 waves per SIMD (168 VGPRs) instead of 4: the state machine's registers no longer spill (+16 %, kernel_variants.log)
+#ifndef PT_WALK_WAVES
+#define PT_WALK_WAVES 3
+#endif
 constexpr int kStPath = 0, kStShadow = 1, kStMisStart = 2, kStMis = 3, kStContinue = 4, kStPathB = 5, kStEmit = 6, kStShadowB = 7,
               kStShadowDone = 8, kStMisB = 9;
 constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
@@ -1547,7 +1561,7 @@ constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 #endif
 constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH;
 template <bool COUNT, bool SMALL, int INTEG>
-__global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
+__global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
 {
     __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
     DevParams P = P_in;
@@ -2744,11 +2758,20 @@ __global__ void pt_debug_rng_kernel(uint32_t pixel, uint32_t iter, uint32_t *see
 namespace pt {
 
 // resident 256-thread workgroups per CU for the persistent grid
-int render_kernel_blocks_per_cu(bool count)
+// Volpath runs on the one-ray-at-a-time kernel when the scene has density grids or material-less surfaces
+// (GPT_VPT_WALK forces it: tests compare the two kernels)
+bool render_uses_walk_kernel(const DevParams &P)
+{
+    return P.integrator == GPT_IT_VPT && (P.vpt_walk || getenv("GPT_VPT_WALK"));
+}
+
+int render_kernel_blocks_per_cu(bool count, bool walk)
 {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true, GPT_IT_PT>, 256, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true, GPT_IT_PT>, 256, 0);
+    hipError_t e = walk ? (count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true, PT_IT_VPT_WALK>, 256, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true, PT_IT_VPT_WALK>, 256, 0))
+                        : (count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true, GPT_IT_PT>, 256, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true, GPT_IT_PT>, 256, 0));
     if (e != hipSuccess || n < 1) n = 2;
     if (n > 8) n = 8;
     return n;
@@ -2760,7 +2783,7 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream
                        !getenv("GPT_NO_LDS_SCENE");
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
-    if (P.integrator == GPT_IT_VPT && (P.vpt_walk || getenv("GPT_VPT_WALK"))) {     // (the env forces the general kernel: tests)
+    if (render_uses_walk_kernel(P)) {
         if (count && small) PT_LAUNCH(true, true, PT_IT_VPT_WALK);
         else if (count) PT_LAUNCH(true, false, PT_IT_VPT_WALK);
         else if (small) PT_LAUNCH(false, true, PT_IT_VPT_WALK);

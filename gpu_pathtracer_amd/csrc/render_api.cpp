@@ -34,7 +34,8 @@ hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_
                           hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
 hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream);
-int render_kernel_blocks_per_cu(bool count);
+int render_kernel_blocks_per_cu(bool count, bool walk);
+bool render_uses_walk_kernel(const DevParams &P);
 }  // namespace pt
 
 using namespace pt;
@@ -66,7 +67,7 @@ struct gpt_ctx {
     uint32_t max_batch = 256;             // iterations per path-kernel launch (GPT_MAX_BATCH); also capped by kMaxPlaneBytes
     bool count_next = false;
     int n_cus = 256;
-    int blocks_per_cu[2] = {4, 4};
+    int blocks_per_cu[2][2] = {{4, 4}, {3, 3}};      // [walk kernel][counting build]
     // timing of the path kernel on its own stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -309,8 +310,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
-    ctx->blocks_per_cu[0] = render_kernel_blocks_per_cu(false);
-    ctx->blocks_per_cu[1] = render_kernel_blocks_per_cu(true);
+    for (int w = 0; w < 2; ++w)
+        for (int c = 0; c < 2; ++c) ctx->blocks_per_cu[w][c] = render_kernel_blocks_per_cu(c != 0, w != 0);
 
     // ---- geometry
     std::vector<DevTri> tris((size_t)scene->n_prims);
@@ -559,7 +560,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         ctx->sample_planes = batch_cap;
     }
 
-    const long resident_waves = (long)ctx->n_cus * ctx->blocks_per_cu[count ? 1 : 0] * 4;
+    const long resident_waves = (long)ctx->n_cus * ctx->blocks_per_cu[render_uses_walk_kernel(ctx->P) ? 1 : 0][count ? 1 : 0] * 4;
     for (uint32_t done = 0; done < iter_count; done += batch_cap) {
         DevParams P = ctx->P;
         P.cam = *camera;
