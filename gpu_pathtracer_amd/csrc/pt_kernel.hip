@@ -1463,12 +1463,15 @@ __device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, 
 // het_sample are the shared tracking loop of the PT_IT_VPT_WALK kernel): a density grid in the box p0..p1, sampled by
 // delta tracking; transmittance by delta (0), ratio (1) or residual ratio (2) tracking.  Every loop draws from the
 // path's generator and ends after iterMax steps at the latest.
-__device__ __forceinline__ int f2i_sat(float f)        // float -> int as v_cvt_i32_f32 defines it (truncate, saturate, NaN -> 0)
+__device__ __forceinline__ int f2i_sat(float f)        // float -> int: truncate, saturate, NaN -> 0 - which is v_cvt_i32_f32
 {
-    if (f != f) return 0;
-    if (f <= -2147483648.f) return (int)0x80000000;
-    if (f >= 2147483648.f) return 0x7fffffff;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(f));      // (a C++ cast leaves the out-of-range cases undefined)
+    return r;
+#else
     return (int)f;
+#endif
 }
 __device__ __forceinline__ float lerp_(float a, float b, float t) { return a + t * (b - a); }               // cutil_math.h:1008-1011
 // getDensity (medium.h:160-174) with d() (:176-181) folded in: the eight corners share six coordinate conversions and
@@ -1480,18 +1483,21 @@ __device__ __forceinline__ float het_density(const DevMedium &m, V3 p)
     const V3 delta = ps - psi;
     const int x0 = f2i_sat(psi.x), x1 = f2i_sat(psi.x + 1), y0 = f2i_sat(psi.y), y1 = f2i_sat(psi.y + 1),
               z0 = f2i_sat(psi.z), z1 = f2i_sat(psi.z + 1);
-    const bool vx0 = !(x0 < 0 || x0 > m.nx - 1), vx1 = !(x1 < 0 || x1 > m.nx - 1), vy0 = !(y0 < 0 || y0 > m.ny - 1),
-               vy1 = !(y1 < 0 || y1 > m.ny - 1), vz0 = !(z0 < 0 || z0 > m.nz - 1), vz1 = !(z1 < 0 || z1 > m.nz - 1);
+    // !(x < 0 || x > nx - 1) as one unsigned comparison (nx > 0)
+    const bool vx0 = (unsigned)x0 < (unsigned)m.nx, vx1 = (unsigned)x1 < (unsigned)m.nx, vy0 = (unsigned)y0 < (unsigned)m.ny,
+               vy1 = (unsigned)y1 < (unsigned)m.ny, vz0 = (unsigned)z0 < (unsigned)m.nz, vz1 = (unsigned)z1 < (unsigned)m.nz;
     const int sy = m.nx, sz = m.ny * m.nx;               // int idx = z*ny*nx + y*nx + x
+    const int r00 = z0 * sz + y0 * sy, r10 = z0 * sz + y1 * sy, r01 = z1 * sz + y0 * sy, r11 = z1 * sz + y1 * sy;
     const float *g = m.density;
-    const float d000 = (vx0 && vy0 && vz0) ? g[z0 * sz + y0 * sy + x0] : 0.f;
-    const float d100 = (vx1 && vy0 && vz0) ? g[z0 * sz + y0 * sy + x1] : 0.f;
-    const float d010 = (vx0 && vy1 && vz0) ? g[z0 * sz + y1 * sy + x0] : 0.f;
-    const float d110 = (vx1 && vy1 && vz0) ? g[z0 * sz + y1 * sy + x1] : 0.f;
-    const float d001 = (vx0 && vy0 && vz1) ? g[z1 * sz + y0 * sy + x0] : 0.f;
-    const float d101 = (vx1 && vy0 && vz1) ? g[z1 * sz + y0 * sy + x1] : 0.f;
-    const float d011 = (vx0 && vy1 && vz1) ? g[z1 * sz + y1 * sy + x0] : 0.f;
-    const float d111 = (vx1 && vy1 && vz1) ? g[z1 * sz + y1 * sy + x1] : 0.f;
+    // branch-free: a corner outside the grid reads cell 0 and is then replaced by 0
+    const bool v000 = vx0 && vy0 && vz0, v100 = vx1 && vy0 && vz0, v010 = vx0 && vy1 && vz0, v110 = vx1 && vy1 && vz0,
+               v001 = vx0 && vy0 && vz1, v101 = vx1 && vy0 && vz1, v011 = vx0 && vy1 && vz1, v111 = vx1 && vy1 && vz1;
+    const float g000 = g[v000 ? r00 + x0 : 0], g100 = g[v100 ? r00 + x1 : 0];
+    const float g010 = g[v010 ? r10 + x0 : 0], g110 = g[v110 ? r10 + x1 : 0];
+    const float g001 = g[v001 ? r01 + x0 : 0], g101 = g[v101 ? r01 + x1 : 0];
+    const float g011 = g[v011 ? r11 + x0 : 0], g111 = g[v111 ? r11 + x1 : 0];
+    const float d000 = v000 ? g000 : 0.f, d100 = v100 ? g100 : 0.f, d010 = v010 ? g010 : 0.f, d110 = v110 ? g110 : 0.f;
+    const float d001 = v001 ? g001 : 0.f, d101 = v101 ? g101 : 0.f, d011 = v011 ? g011 : 0.f, d111 = v111 ? g111 : 0.f;
     const float d00 = lerp_(d000, d100, delta.x);
     const float d10 = lerp_(d010, d110, delta.x);
     const float d01 = lerp_(d001, d101, delta.x);
