@@ -51,7 +51,9 @@ const char *gpt_version(void);
 /* BeginRender (src/pathtracer.cu:2568-2695): copy the scene out of the caller's
  * arrays, lay it out for the GPU, allocate the W*H*3 accumulator
  * (kernel_acc_image) and last-sample (kernel_color) planes, both zeroed.
- * `device` is the HIP device ordinal.  The caller keeps ownership of `scene`. */
+ * `device` is the HIP device ordinal.  The caller keeps ownership of `scene`:
+ * every array it points at (density grids of heterogeneous media included) is
+ * read before gpt_begin returns and never afterwards. */
 int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, float epsilon,
               int device, gpt_ctx **out);
 
