@@ -305,6 +305,104 @@ bool read_obj(const std::string &path, ObjMesh &m)
     return true;
 }
 
+// ================================================================= PLY =================
+// Stanford PLY (ascii and binary_little_endian): element vertex with x y z [nx ny nz] [s t | u v | texture_u texture_v],
+// element face with a vertex index list.  The reference reads meshes through assimp (mesh.cpp:4-27) and one shipped scene
+// (veach_bidir) names .ply files; the mesh is handed on in the same per-corner form as an OBJ (normal / uv index = vertex
+// index), so everything downstream - fan triangulation, transform, missing-normal rule - is shared.
+bool read_ply(const std::string &path, ObjMesh &m)
+{
+    FILE *f = gpt_fopen_read(path.c_str());
+    if (!f) return false;
+    struct Prop { std::string name, type, count_type; bool list; };
+    struct Elem { std::string name; long count; std::vector<Prop> props; };
+    std::vector<Elem> elems;
+    bool ascii = false, binary_le = false, header_ok = false;
+    char line[1024];
+    if (!std::fgets(line, sizeof(line), f) || std::strncmp(line, "ply", 3) != 0) { std::fclose(f); return false; }
+    while (std::fgets(line, sizeof(line), f)) {
+        char a[64] = "", b[64] = "", c[64] = "", d[64] = "", e[64] = "";
+        const int n = std::sscanf(line, "%63s %63s %63s %63s %63s", a, b, c, d, e);
+        if (n < 1) continue;
+        const std::string key = a;
+        if (key == "format") { ascii = std::string(b) == "ascii"; binary_le = std::string(b) == "binary_little_endian"; }
+        else if (key == "element" && n >= 3) elems.push_back(Elem{b, std::atol(c), {}});
+        else if (key == "property" && !elems.empty()) {
+            if (std::string(b) == "list" && n >= 5) elems.back().props.push_back(Prop{e, d, c, true});
+            else if (n >= 3) elems.back().props.push_back(Prop{c, b, "", false});
+        } else if (key == "end_header") { header_ok = true; break; }
+    }
+    if (!header_ok || (!ascii && !binary_le)) { std::fclose(f); return false; }
+    auto type_size = [](const std::string &t) {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        return 0;
+    };
+    bool ok = true;
+    auto read_scalar = [&](const std::string &t, double &out) {       // one value of type t -> double
+        if (ascii) return std::fscanf(f, "%lf", &out) == 1;
+        unsigned char buf[8];
+        const int sz = type_size(t);
+        if (sz == 0 || std::fread(buf, 1, (size_t)sz, f) != (size_t)sz) return false;
+        if (t == "char" || t == "int8") out = (signed char)buf[0];
+        else if (t == "uchar" || t == "uint8") out = buf[0];
+        else if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, buf, 2); out = v; }
+        else if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, buf, 2); out = v; }
+        else if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, buf, 4); out = v; }
+        else if (t == "uint" || t == "uint32") { uint32_t v; std::memcpy(&v, buf, 4); out = v; }
+        else if (t == "float" || t == "float32") { float v; std::memcpy(&v, buf, 4); out = v; }
+        else { double v; std::memcpy(&v, buf, 8); out = v; }
+        return true;
+    };
+    bool have_n = false, have_uv = false;
+    for (const Elem &el : elems) {
+        for (long i = 0; i < el.count && ok; ++i) {
+            V3 pos{0, 0, 0}, nor{0, 0, 0};
+            pt::V2 uv{0, 0};
+            std::vector<int> face;
+            for (const Prop &pr : el.props) {
+                if (pr.list) {
+                    double cnt = 0;
+                    if (!read_scalar(pr.count_type, cnt) || cnt < 0 || cnt > 1e6) { ok = false; break; }
+                    const bool is_idx = el.name == "face" && (pr.name == "vertex_indices" || pr.name == "vertex_index");
+                    for (int k = 0; k < (int)cnt; ++k) {
+                        double v = 0;
+                        if (!read_scalar(pr.type, v)) { ok = false; break; }
+                        if (is_idx) face.push_back((int)v);
+                    }
+                } else {
+                    double v = 0;
+                    if (!read_scalar(pr.type, v)) { ok = false; break; }
+                    if (el.name != "vertex") continue;
+                    const float fv = (float)v;
+                    if (pr.name == "x") pos.x = fv; else if (pr.name == "y") pos.y = fv; else if (pr.name == "z") pos.z = fv;
+                    else if (pr.name == "nx") { nor.x = fv; have_n = true; } else if (pr.name == "ny") nor.y = fv; else if (pr.name == "nz") nor.z = fv;
+                    else if (pr.name == "s" || pr.name == "u" || pr.name == "texture_u") { uv.x = fv; have_uv = true; }
+                    else if (pr.name == "t" || pr.name == "v" || pr.name == "texture_v") uv.y = fv;
+                }
+            }
+            if (!ok) break;
+            if (el.name == "vertex") {
+                m.v.push_back(pos);
+                m.vn.push_back(nor);
+                m.vt.push_back(uv);
+            } else if (el.name == "face") {
+                for (int idx : face)
+                    if (idx < 0 || idx >= (int)m.v.size()) ok = false;
+                for (size_t k = 1; ok && k + 1 < face.size(); ++k)
+                    for (int idx : {face[0], face[k], face[k + 1]})
+                        m.corners.push_back(ObjMesh::Corner{idx + 1, have_uv ? idx + 1 : 0, have_n ? idx + 1 : 0});
+            }
+        }
+    }
+    std::fclose(f);
+    if (!have_n) m.vn.clear();
+    if (!have_uv) m.vt.clear();
+    return ok;
+}
+
 gpt_float3 g3(V3 a) { return gpt_float3{a.x, a.y, a.z}; }
 V3 v3of(gpt_float3 a) { return V3{a.x, a.y, a.z}; }
 
@@ -341,7 +439,8 @@ V3 gen_tangent(const gpt_vertex &v1, const gpt_vertex &v2, const gpt_vertex &v3)
 bool load_mesh(const std::string &path, const M4 &trs, int matIdx, int bssrdfIdx, std::vector<Triangle> &out)
 {
     ObjMesh m;
-    if (!read_obj(path, m)) {
+    const bool is_ply = path.size() > 4 && (path.compare(path.size() - 4, 4, ".ply") == 0 || path.compare(path.size() - 4, 4, ".PLY") == 0);
+    if (!(is_ply ? read_ply(path, m) : read_obj(path, m))) {
         gpt_set_error("Error when import model: cannot read \"%s\"", path.c_str());
         return false;
     }
@@ -791,7 +890,13 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
                     if (texMap.find(tf) == texMap.end()) {
                         Texture tex;
                         if (!imageio::load_texture((base + tf).c_str(), tex.width, tex.height, tex.data)) {
-                            gpt_set_error("Error when load texture [%s] (supported: 8-bit non-interlaced PNG, baseline JPEG)", (base + tf).c_str());
+                            FILE *probe = gpt_fopen_read((base + tf).c_str());
+                            if (probe) {
+                                std::fclose(probe);
+                                gpt_set_error("Error when load texture [%s] (supported: 8-bit non-interlaced PNG, baseline and progressive JPEG)", (base + tf).c_str());
+                            } else {
+                                gpt_set_error("Error when load texture [%s]: the file cannot be opened", (base + tf).c_str());
+                            }
                             return false;
                         }
                         scene.textures.push_back(std::move(tex));
