@@ -109,7 +109,7 @@ struct DevParams {
     int32_t n_lights;
     int32_t n_cdf;
     int32_t max_depth;
-    int32_t integrator;         // GPT_IT_PT or GPT_IT_AO
+    int32_t integrator;         // GPT_IT_PT, GPT_IT_AO or GPT_IT_VPT
     float ao_max_dist;          // scene.integrator.maxDist (ao)
     float eps;
     gpt_camera cam;
