@@ -144,6 +144,9 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #ifndef PT_FETCH_T
 #define PT_FETCH_T 12
 #endif
+#ifndef PT_NODE_LOOKAHEAD
+#define PT_NODE_LOOKAHEAD 1      // scenes in global memory fetch two consecutive nodes per node trip (PT_NODE2_LOOKAHEAD); 0: one
+#endif
 #ifndef PT_ASM_IN_COUNT
 #define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
 #endif
@@ -501,9 +504,28 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n" "v_mbcnt_hi_u32_b32 v33, -1, v33\n" "v_lshl_add_u32 v34, v33, 5, %[susp]\n" \
         "ds_write_b128 v34, v[12:15]\n" "ds_write_b128 v34, v[20:23] offset:16\n"
 
+//  node lookahead (scenes in global memory, opt-in): a node trip also fetches the NEXT node in memory (cursor + 32: in
+//  the threaded preorder that is the left child).  A lane whose node is an inner node with a hit box descends to exactly
+//  that node, so it visits it in the same trip - same visits in the same order, one memory round trip instead of two.
+//  At entry: s[66:67] = box hit, vcc = box hit && leaf, v12 already advanced; the second node sits in v[44:51].
+#define PT_NODE2_LOOKAHEAD \
+        "s_andn2_b64 s[66:67], s[66:67], vcc\n" "s_mov_b64 exec, s[66:67]\n" "s_cbranch_execz TP_N2_%=\n" "s_waitcnt vmcnt(0)\n" \
+        "v_sub_f32_e32 v33, v44, v0\n" "v_sub_f32_e32 v34, v47, v0\n" "v_sub_f32_e32 v35, v45, v1\n" "v_sub_f32_e32 v37, v46, v2\n" \
+        "v_sub_f32_e32 v36, v48, v1\n" "v_sub_f32_e32 v38, v49, v2\n" \
+        "v_mul_f32_e32 v33, v8, v33\n" "v_mul_f32_e32 v34, v8, v34\n" "v_mul_f32_e32 v35, v9, v35\n" "v_mul_f32_e32 v36, v9, v36\n" \
+        "v_mul_f32_e32 v37, v10, v37\n" "v_mul_f32_e32 v38, v10, v38\n" \
+        "v_min_f32_e32 v39, v33, v34\n" "v_min_f32_e32 v40, v35, v36\n" "v_min_f32_e32 v41, v37, v38\n" \
+        "v_max_f32_e32 v33, v33, v34\n" "v_max_f32_e32 v35, v35, v36\n" "v_max_f32_e32 v37, v37, v38\n" \
+        "v_min3_f32 v33, v33, v35, v37\n" "v_max3_f32 v39, v39, v40, v41\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v33\n" "v_min_f32_e32 v33, v33, v21\n" "v_cmp_nlt_f32_e64 s[66:67], v33, v39\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" "v_cmp_lt_i32_e32 vcc, -1, v51\n" "v_add_u32_e32 v33, 32, v12\n" \
+        "s_or_b64 s[68:69], vcc, s[66:67]\n" "s_and_b64 vcc, vcc, s[66:67]\n" \
+        "v_cndmask_b32_e64 v12, v50, v33, s[68:69]\n" "v_cndmask_b32_e32 v14, v14, v51, vcc\n" "v_cndmask_b32_e32 v13, v13, v50, vcc\n" \
+        "TP_N2_%=:\n"
+
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
-#define PT_TRACE_ASM(LD_NODE, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
+#define PT_TRACE_ASM(LD_NODE, NODE_W1, NODE_W0, NODE2, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
     asm volatile( \
         "s_mov_b32 s70, 0\n" \
         "s_mov_b32 s76, 0x322bcc77\n" \
@@ -527,12 +549,12 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "s_cbranch_scc0 TP_TRI_%=\n" \
         "s_mov_b64 exec, s[62:63]\n" \
         LD_NODE \
-        WAIT_1 \
+        NODE_W1 \
         "v_sub_f32_e32 v33, v24, v0\n" \
         "v_sub_f32_e32 v34, v27, v0\n" \
         "v_sub_f32_e32 v35, v25, v1\n" \
         "v_sub_f32_e32 v37, v26, v2\n" \
-        WAIT_0 \
+        NODE_W0 \
         "v_sub_f32_e32 v36, v28, v1\n" \
         "v_sub_f32_e32 v38, v29, v2\n" \
         "v_mul_f32_e32 v33, v8, v33\n" \
@@ -560,6 +582,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_cndmask_b32_e64 v12, v30, v33, s[68:69]\n" \
         "v_cndmask_b32_e32 v14, v14, v31, vcc\n" \
         "v_cndmask_b32_e32 v13, v13, v30, vcc\n" \
+        NODE2 \
         "s_mov_b64 exec, -1\n" \
         "s_branch TP_LOOP_%=\n" \
         "TP_TRI_%=:\n" \
@@ -730,7 +753,7 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
     const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n",
+    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "",
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
                  "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
@@ -751,12 +774,24 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
     const int s_tstop = __builtin_amdgcn_readfirstlane(mem.end - mem.first >= 65536 * 32 ? PT_STOP_T : PT_STOP_T_SMALL);
-    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n",
+#if PT_NODE_LOOKAHEAD
+    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
+                 "global_load_dwordx4 v[44:47], v12, %[nodes] offset:32\n" "global_load_dwordx4 v[48:51], v12, %[nodes] offset:48\n",
+                 "s_waitcnt vmcnt(3)\n", "s_waitcnt vmcnt(2)\n", PT_NODE2_LOOKAHEAD,
+                 "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
+                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
+                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
+                 "v3" PT_COMMA "v44" PT_COMMA "v45" PT_COMMA "v46" PT_COMMA "v47" PT_COMMA "v48" PT_COMMA "v49" PT_COMMA "v50" PT_COMMA "v51" PT_COMMA,
+                 [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
+                 [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
+#else
+    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n", "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", "",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
                  "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
                  PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
                  [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
+#endif
 }
 
 // mesh.h:68-95 evaluated once for the final hit

@@ -319,6 +319,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     for (int i = 0; i < scene->n_prims; ++i) pack_triangle(scene->prims[i].triangle, tris[(size_t)i], shade[(size_t)i]);
     std::vector<DevNode> nodes;
     thread_nodes(scene->nodes, scene->n_nodes, nodes);
+    nodes.push_back(DevNode{});       // padding: a node trip may also read the 32 bytes after the node it visits
     std::vector<DevLight> lights((size_t)scene->n_lights);
     for (int i = 0; i < scene->n_lights; ++i) {
         const gpt_area &a = scene->lights[i];
