@@ -1993,6 +1993,34 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 Ld_acc += sav_w * walk_tr * sav_fr * sav_rad * sav_abs / sav_den;              // :1150
                                 stage = kStMisStart;
                                 continue;
+                            } else if (stage == kStMisStart) {
+                                // ---- the BSDF-sampled light ray (:1153-1160)
+                                Ray r;
+                                r.o = ctx_o;
+                                r.d = ctx_d;
+                                const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                                const gpt_material material = P.materials[isect.matIdx];
+                                float usx = rng_uniform(rng);
+                                float usy = rng_uniform(rng);
+                                float usz = rng_uniform(rng);
+                                V3 out, fr;
+                                float pdf;
+                                sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
+                                if (!(is_black(fr) || pdf == 0)) {
+                                    mis_fr = fr;
+                                    mis_cos = fabs_(dot(out, isect.nor));
+                                    mis_pdf = pdf;
+                                    q.org = isect.pos;
+                                    q.dir_p = out;
+                                    q.tmax_s = __builtin_inff();
+                                    q.has_p = true;
+                                    stage = kStMis;
+                                    busy = false;
+                                    break;
+                                }
+                                Li += beta * Ld_acc;
+                                stage = kStContinue;
+                                continue;
                             } else if (stage == kStMis) {
                                 // ---- ... came back (:1161-1205)
                                 bool contributes = false;
@@ -2041,70 +2069,46 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 stage = kStContinue;
                                 continue;
                             } else {
-                                // ---- kStMisStart: the BSDF-sampled light ray (:1153-1160); kStContinue: the continuation
-                                // (:1210-1229) and the roulette (:1232-1238).  Both re-evaluate the hit and sample the BSDF
-                                // with three fresh draws, so they share that code (a lane that has no light ray to trace
-                                // comes round again as kStContinue).  On the last bounce nothing of the continuation reaches
-                                // Li, so it is skipped.
-                                const bool cont = stage == kStContinue;
-                                if (cont && !(bounces + 1 < P.max_depth)) {
-                                    finish = true;
-                                    busy = false;
-                                    break;
-                                }
-                                Ray r;
-                                r.o = ctx_o;
-                                r.d = ctx_d;
-                                const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
-                                const gpt_material material = P.materials[isect.matIdx];
-                                const V3 wo = -ctx_d;
-                                float ux = rng_uniform(rng);
-                                float uy = rng_uniform(rng);
-                                float uz = rng_uniform(rng);
-                                V3 out, fr;
-                                float pdf;
-                                sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
-                                if (!cont) {
-                                    if (!(is_black(fr) || pdf == 0)) {
-                                        mis_fr = fr;
-                                        mis_cos = fabs_(dot(out, isect.nor));
-                                        mis_pdf = pdf;
-                                        q.org = isect.pos;
-                                        q.dir_p = out;
-                                        q.tmax_s = __builtin_inff();
-                                        q.has_p = true;
-                                        stage = kStMis;
-                                        busy = false;
-                                        break;
-                                    }
-                                    Li += beta * Ld_acc;
-                                    stage = kStContinue;
-                                    continue;
-                                }
+                                // ---- kStContinue: the continuation (:1210-1229) and the roulette (:1232-1238).  On the last bounce
+                                // nothing of it reaches Li, so it is skipped.
                                 finish = true;
-                                if (!is_black(fr)) {
-                                    beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
-                                    specular = is_delta(PT_MATERIAL_TYPE(material));
-                                    const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
-                                    int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
-                                    m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
-                                    medium = m2;
-                                    bool kill = false;
-                                    if (bounces > 3) {
-                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
-                                        if (rng_uniform(rng) < illumate)
-                                            kill = true;
-                                        else
-                                            beta /= (1 - illumate);
-                                    }
-                                    if (!kill) {
-                                        q.org = isect.pos;
-                                        q.dir_p = out;
-                                        q.tmax_s = __builtin_inff();
-                                        q.has_p = true;
-                                        finish = false;
-                                        bounces++;
-                                        stage = kStPath;
+                                if (bounces + 1 < P.max_depth) {
+                                    Ray r;
+                                    r.o = ctx_o;
+                                    r.d = ctx_d;
+                                    const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                                    const gpt_material material = P.materials[isect.matIdx];
+                                    const V3 wo = -ctx_d;
+                                    float ux = rng_uniform(rng);
+                                    float uy = rng_uniform(rng);
+                                    float uz = rng_uniform(rng);
+                                    V3 out, fr;
+                                    float pdf;
+                                    sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
+                                    if (!is_black(fr)) {
+                                        beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
+                                        specular = is_delta(PT_MATERIAL_TYPE(material));
+                                        const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
+                                        int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
+                                        m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
+                                        medium = m2;
+                                        bool kill = false;
+                                        if (bounces > 3) {
+                                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                            if (rng_uniform(rng) < illumate)
+                                                kill = true;
+                                            else
+                                                beta /= (1 - illumate);
+                                        }
+                                        if (!kill) {
+                                            q.org = isect.pos;
+                                            q.dir_p = out;
+                                            q.tmax_s = __builtin_inff();
+                                            q.has_p = true;
+                                            finish = false;
+                                            bounces++;
+                                            stage = kStPath;
+                                        }
                                     }
                                 }
                                 busy = false;
