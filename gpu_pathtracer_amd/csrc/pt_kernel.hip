@@ -452,6 +452,8 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 //   v[20:23] result {triangle cursor / index, tmax, b1, b2}   v[24:32] node or triangle data
 //   v33..v43 temporaries (40 VGPRs in all).  The block sits at the
 //   bottom of the register file: with v80..v123 the allocator spilled 17 dwords per lane, here none.
+//   Scenes in global memory also use v3 (one past the last node of the ray's node array) and v[44:51] (the node after
+//   the one being visited: PT_NODE2_LOOKAHEAD).
 //   s[60:61] m_tri  s[62:63] m_more / m_node  s[64:65] m_has / m_busy  s[66:69] scratch masks
 //   s70 next  s71 s72 counts  s76 1e-8f  s77 2^100
 // The kernel always runs full wavefronts (256-thread workgroups, wave-uniform control flow), so exec is
