@@ -144,6 +144,9 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #ifndef PT_FETCH_T
 #define PT_FETCH_T 12
 #endif
+#ifndef PT_TRI_LOOKAHEAD
+#define PT_TRI_LOOKAHEAD 1       // ... and two consecutive triangles per triangle trip (PT_TRI2_LOOKAHEAD); 0: one
+#endif
 #ifndef PT_NODE_LOOKAHEAD
 #define PT_NODE_LOOKAHEAD 1      // scenes in global memory fetch two consecutive nodes per node trip (PT_NODE2_LOOKAHEAD); 0: one
 #endif
@@ -452,8 +455,8 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 //   v[20:23] result {triangle cursor / index, tmax, b1, b2}   v[24:32] node or triangle data
 //   v33..v43 temporaries (40 VGPRs in all).  The block sits at the
 //   bottom of the register file: with v80..v123 the allocator spilled 17 dwords per lane, here none.
-//   Scenes in global memory also use v3 (one past the last node of the ray's node array) and v[44:51] (the node after
-//   the one being visited: PT_NODE2_LOOKAHEAD).
+//   Scenes in global memory also use v3 (one past the last node of the ray's node array) and v[44:52] (the node after
+//   the one being visited, PT_NODE2_LOOKAHEAD, or the triangle after the one being tested, PT_TRI2_LOOKAHEAD).
 //   s[60:61] m_tri  s[62:63] m_more / m_node  s[64:65] m_has / m_busy  s[66:69] scratch masks
 //   s70 next  s71 s72 counts  s76 1e-8f  s77 2^100
 // The kernel always runs full wavefronts (256-thread workgroups, wave-uniform control flow), so exec is
@@ -525,9 +528,109 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_cndmask_b32_e64 v12, v50, v33, s[68:69]\n" "v_cndmask_b32_e32 v14, v14, v51, vcc\n" "v_cndmask_b32_e32 v13, v13, v50, vcc\n" \
         "TP_N2_%=:\n"
 
+//  triangle lookahead (scenes in global memory): a triangle trip fetches two consecutive triangles; a lane whose leaf has
+//  another one (and whose ray the first test did not end) tests it in the same trip, after the first - the order of the
+//  tests and the interval they see are those of two trips.  Same code as the first test on v[44:52].
+#define PT_TRI2_LOOKAHEAD(RAY_END) \
+        "s_mov_b64 exec, s[60:61]\n" "v_cmp_le_i32_e32 vcc, v13, v14\n" "s_and_b64 exec, exec, vcc\n" "s_cbranch_scc0 TP_TRI_END2_%=\n" \
+        "v_add_u32_e32 v13, 48, v13\n" "s_waitcnt vmcnt(0)\n" \
+        "v_mul_f32_e32 v33, v5, v52\n" \
+        "v_mul_f32_e32 v42, v6, v51\n" \
+        "v_sub_f32_e32 v33, v33, v42\n" \
+        "v_mul_f32_e32 v34, v6, v50\n" \
+        "v_mul_f32_e32 v42, v4, v52\n" \
+        "v_sub_f32_e32 v34, v34, v42\n" \
+        "v_mul_f32_e32 v35, v4, v51\n" \
+        "v_mul_f32_e32 v42, v5, v50\n" \
+        "v_sub_f32_e32 v35, v35, v42\n" \
+        "v_mul_f32_e32 v36, v33, v47\n" \
+        "v_mul_f32_e32 v42, v34, v48\n" \
+        "v_add_f32_e32 v36, v36, v42\n" \
+        "v_mul_f32_e32 v42, v35, v49\n" \
+        "v_add_f32_e32 v36, v36, v42\n" \
+        "v_rcp_f32_e32 v38, v36\n" \
+        "v_sub_f32_e32 v44, v0, v44\n" \
+        "v_sub_f32_e32 v45, v1, v45\n" \
+        "v_sub_f32_e32 v46, v2, v46\n" \
+        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n" \
+        "v_fma_f32 v41, -v36, v38, 1.0\n" \
+        "v_fma_f32 v37, v41, v38, v38\n" \
+        "s_cmp_lg_u64 s[66:67], 0\n" \
+        "s_cbranch_scc1 TP_DIV_IEEE2_%=\n" \
+        "TP_DIV_DONE2_%=:\n" \
+        "v_mul_f32_e32 v43, v44, v33\n" \
+        "v_mul_f32_e32 v42, v45, v34\n" \
+        "v_add_f32_e32 v43, v43, v42\n" \
+        "v_mul_f32_e32 v42, v46, v35\n" \
+        "v_add_f32_e32 v43, v43, v42\n" \
+        "v_mul_f32_e32 v33, v45, v49\n" \
+        "v_mul_f32_e32 v42, v46, v48\n" \
+        "v_sub_f32_e32 v33, v33, v42\n" \
+        "v_mul_f32_e32 v34, v46, v47\n" \
+        "v_mul_f32_e32 v42, v44, v49\n" \
+        "v_sub_f32_e32 v34, v34, v42\n" \
+        "v_mul_f32_e32 v35, v44, v48\n" \
+        "v_mul_f32_e32 v42, v45, v47\n" \
+        "v_sub_f32_e32 v35, v35, v42\n" \
+        "v_mul_f32_e32 v43, v43, v37\n" \
+        "v_mul_f32_e32 v38, v4, v33\n" \
+        "v_mul_f32_e32 v42, v5, v34\n" \
+        "v_add_f32_e32 v38, v38, v42\n" \
+        "v_mul_f32_e32 v42, v6, v35\n" \
+        "v_add_f32_e32 v38, v38, v42\n" \
+        "v_mul_f32_e32 v38, v38, v37\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v43\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v38\n" \
+        "v_add_f32_e32 v42, v43, v38\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TP_TRI_END2_%=\n" \
+        "v_mul_f32_e32 v39, v50, v33\n" \
+        "v_mul_f32_e32 v42, v51, v34\n" \
+        "v_add_f32_e32 v39, v39, v42\n" \
+        "v_mul_f32_e32 v42, v52, v35\n" \
+        "v_add_f32_e32 v39, v39, v42\n" \
+        "v_mul_f32_e32 v39, v39, v37\n" \
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n" \
+        "v_cmp_ngt_f32_e64 s[66:67], v39, v21\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TP_TRI_END2_%=\n" \
+        "v_and_b32_e32 v42, 0x100, v11\n" \
+        "v_cmp_ne_u32_e32 vcc, 0, v42\n" \
+        "v_mov_b32_e32 v44, " RAY_END "\n" \
+        "v_mov_b32_e32 v21, v39\n" \
+        "v_subrev_u32_e32 v20, 48, v13\n" \
+        "v_mov_b32_e32 v22, v43\n" \
+        "v_mov_b32_e32 v23, v38\n" \
+        "v_cndmask_b32_e32 v12, v12, v44, vcc\n" \
+        "v_cndmask_b32_e64 v14, v14, -1, vcc\n" \
+        "TP_TRI_END2_%=:\n" "s_branch TP_T2X_%=\n" \
+        "TP_DIV_IEEE2_%=:\n" \
+        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n" \
+        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n" \
+        "v_rcp_f32_e32 v38, v37\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v41, -v37, v38, 1.0\n" \
+        "v_fmac_f32_e32 v38, v41, v38\n" \
+        "v_mul_f32_e32 v40, v39, v38\n" \
+        "v_fma_f32 v41, -v37, v40, v39\n" \
+        "v_fmac_f32_e32 v40, v41, v38\n" \
+        "v_fma_f32 v37, -v37, v40, v39\n" \
+        "v_div_fmas_f32 v37, v37, v38, v40\n" \
+        "v_div_fixup_f32 v37, v37, v36, 1.0\n" \
+        "s_branch TP_DIV_DONE2_%=\n" \
+        "TP_T2X_%=:\n"
+
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
-#define PT_TRACE_ASM(LD_NODE, NODE_W1, NODE_W0, NODE2, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
+#define PT_TRACE_ASM(LD_NODE, NODE_W1, NODE_W0, NODE2, TRI2, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
     asm volatile( \
         "s_mov_b32 s70, 0\n" \
         "s_mov_b32 s76, 0x322bcc77\n" \
@@ -671,6 +774,7 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
         "v_cndmask_b32_e32 v12, v12, v24, vcc\n" \
         "v_cndmask_b32_e64 v14, v14, -1, vcc\n" \
         "TP_TRI_END_%=:\n" \
+        TRI2 \
         "s_mov_b64 exec, -1\n" \
         "s_branch TP_LOOP_%=\n" \
         "TP_DIV_IEEE_%=:\n" \
@@ -755,7 +859,7 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
     const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "",
+    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "", "",
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
                  "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
@@ -780,14 +884,22 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
                  "global_load_dwordx4 v[44:47], v12, %[nodes] offset:32\n" "global_load_dwordx4 v[48:51], v12, %[nodes] offset:48\n",
                  "s_waitcnt vmcnt(3)\n", "s_waitcnt vmcnt(2)\n", PT_NODE2_LOOKAHEAD,
+#if PT_TRI_LOOKAHEAD
+                 PT_TRI2_LOOKAHEAD("v3"),
+                 "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n"
+                 "global_load_dwordx4 v[48:51], v13, %[tris] offset:64\n" "global_load_dword v52, v13, %[tris] offset:80\n" "global_load_dwordx4 v[44:47], v13, %[tris] offset:48\n",
+                 "s_waitcnt vmcnt(4)\n", "s_waitcnt vmcnt(3)\n", PT_GLOBAL_VOTE_WEIGHT,
+#else
+                 "",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
                  "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
+#endif
                  PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
-                 "v3" PT_COMMA "v44" PT_COMMA "v45" PT_COMMA "v46" PT_COMMA "v47" PT_COMMA "v48" PT_COMMA "v49" PT_COMMA "v50" PT_COMMA "v51" PT_COMMA,
+                 "v3" PT_COMMA "v44" PT_COMMA "v45" PT_COMMA "v46" PT_COMMA "v47" PT_COMMA "v48" PT_COMMA "v49" PT_COMMA "v50" PT_COMMA "v51" PT_COMMA "v52" PT_COMMA,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
                  [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
 #else
-    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n", "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", "",
+    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n", "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", "", "",
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
                  "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
                  PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,

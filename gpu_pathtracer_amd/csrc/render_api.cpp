@@ -314,7 +314,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         for (int c = 0; c < 2; ++c) ctx->blocks_per_cu[w][c] = render_kernel_blocks_per_cu(c != 0, w != 0);
 
     // ---- geometry
-    std::vector<DevTri> tris((size_t)scene->n_prims);
+    std::vector<DevTri> tris((size_t)scene->n_prims + 1);      // + padding: a triangle trip may also read the record after the one it tests
     std::vector<DevShade> shade((size_t)scene->n_prims);
     for (int i = 0; i < scene->n_prims; ++i) pack_triangle(scene->prims[i].triangle, tris[(size_t)i], shade[(size_t)i]);
     std::vector<DevNode> nodes;
