@@ -162,10 +162,10 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 // scenes in global memory: a node trip waits on L2/HBM and most of a long ray's steps are node steps, so triangle
 // trips are taken earlier: node trip iff node-waiters >= 2 * triangle-waiters (253k-triangle stand-in at 4K:
 // node-biased 534, plain majority 604, this rule 656, 4x 650, 8x 604 Msamples/s)
-#ifndef PT_GLOBAL_VOTE_WEIGHT
-#define PT_GLOBAL_VOTE_WEIGHT "s_lshl_b32 s72, s72, 1\n"
+#ifndef PT_GLOBAL_VOTE_TRI_SHIFT
 #define PT_GLOBAL_VOTE_TRI_SHIFT 1
 #endif
+#define PT_GLOBAL_VOTE_WEIGHT "s_lshl_b32 s72, s72, " PT_STR(PT_GLOBAL_VOTE_TRI_SHIFT) "\n"
 #ifndef PT_VOTE_TRI_SHIFT
 #define PT_VOTE_TRI_SHIFT 0
 #endif
