@@ -684,6 +684,21 @@ def test_volpath_walk_bit_exact(gpt, what):
         assert_bit_exact(r.read_accum(), ref, f"vpt walk {what}, two calls")
 
 
+def test_volpath_shipped_scene_shape_full_size(gpt):
+    """The reference's default scene at its own size (512 x 512, 17 bounces, 100 x 100 x 40 grid, iterMax 2000), 8 spp:
+    2.1 M samples through the one-ray-at-a-time kernel, every float of the film equal to the oracle's."""
+    scene, cam, _, _, _ = walk_case("shipped_like")
+    W = H = 512
+    spp = 8
+    cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)
+    cam.medium = -1
+    ref, col_o = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "vpt shipped-like 512x512")
+        assert_bit_exact(r.read_color(), col_o, "vpt shipped-like 512x512 last sample")
+
+
 def test_volpath_two_kernels_agree(gpt, monkeypatch):
     """A scene with homogeneous media only runs on the three-rays-per-bounce kernel; forced through the general
     one-ray-at-a-time kernel it has to produce the same film (and both equal the oracle's)."""
