@@ -284,3 +284,36 @@ def test_volpath_oracle_density_grids_and_interfaces():
         assert f1.tobytes() == f8.tobytes() and np.isfinite(f1).all()
         ratio = f1.reshape(-1, 3)[lit].mean(axis=0) / (spp * vac.reshape(-1, 3)[lit].mean(axis=0))
         assert np.allclose(ratio, T * T, rtol=0.04), (tr_type, ratio, T * T)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scenes/cornell_box/geometry/density.d"), reason="the reference tree is not here")
+def test_oracle_reproduces_the_reference_smoke_render():
+    """Pin for Volpath, density-grid media, material-less surfaces, the loader and the filmic tonemap: the reference
+    publishes a render of its default scene (result/heterogeneous.png = scenes/cornell_box/scene.json as shipped, density.d
+    included), kept here box-filtered to 64 x 64 (tests/golden/reference_heterogeneous_64.npy,
+    tools/make_reference_image_fixture.py).  The oracle renders the same scene file at 512 x 512 with 16 samples per
+    pixel, applies Output's filmic curve (pathtracer.cu:199-204,2516-2531) and the PNG writer's flip and 8-bit truncation
+    (imageio.cpp:61-78), and has to land on the same picture up to Monte-Carlo noise: each colour channel's frame mean
+    within 0.008 (of 1; at 16 spp the concave tone curve alone pulls the mean of a noisy image down by ~0.003 against the
+    converged reference), the mean absolute difference of the 64 x 64 blocks below 0.008, no block further off than 0.08.
+    (A wrong phase function, tracking estimator, medium switch at the interface or light sampling shifts the frame mean
+    by several times that: e.g. dropping the medium entirely gives 0.46 / 0.36 / 0.20 against 0.416 / 0.305 / 0.114.)"""
+    from gpu_pathtracer_amd import api
+    want = np.load(os.path.join(ol.ROOT, "tests", "golden", "reference_heterogeneous_64.npy")).astype(np.float64)
+    ls = api.LoadedScene("/root/reference/scenes/cornell_box/scene.json")
+    W, H = ls.width, ls.height
+    assert (W, H) == (512, 512) and ls.desc.integrator_type == st.IT_VPT and ls.desc.max_depth == 17
+    cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)      # the json's camera block
+    cam.medium = ls.camera.medium
+    spp = 16
+    acc, _ = ol.render(ls, cam, W, H, ls.epsilon, 1, spp, kind="soft")
+    lin = acc.reshape(H, W, 3).astype(np.float64) / spp
+    c = np.maximum(0.0, lin - 0.004)
+    img = (c * (6.2 * c + 0.5)) / (c * (6.2 * c + 1.7) + 0.06)
+    img = np.floor(np.clip(img, 0.0, 1.0) * 255.0) / 255.0
+    got = img[::-1].reshape(64, 8, 64, 8, 3).mean(axis=(1, 3))
+    d = np.abs(got - want)
+    assert np.abs(got.mean(axis=(0, 1)) - want.mean(axis=(0, 1))).max() < 0.008, (got.mean(axis=(0, 1)), want.mean(axis=(0, 1)))
+    print("frame means", got.mean(axis=(0, 1)), want.mean(axis=(0, 1)), "block diff mean / max", d.mean(), d.max())
+    assert d.mean() < 0.008 and d.max() < 0.08, (d.mean(), d.max())
+    ls.close()

@@ -1,0 +1,63 @@
+"""tests/golden/reference_heterogeneous_64.npy: the reference's own published render of its default scene
+(/root/reference/result/heterogeneous.png = scenes/cornell_box/scene.json: Volpath, 17 bounces, 100x100x40 density grid
+inside a material-less box), box-filtered from 512x512 to 64x64 (float32 in [0,1], row 0 = top of the image).
+An output of the reference, kept as data; tests/test_oracle_golden.py renders the same scene file with the oracle and
+compares.  Run where /root/reference exists:  python tools/make_reference_image_fixture.py"""
+import os, struct, sys, zlib
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read_png_rgb8(path):
+    b = open(path, "rb").read()
+    pos, idat = 8, b""
+    while pos < len(b):
+        n, = struct.unpack(">I", b[pos:pos + 4])
+        t, d = b[pos + 4:pos + 8], b[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if t == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", d[:10])
+        elif t == b"IDAT":
+            idat += d
+    assert depth == 8 and ctype in (2, 6)
+    ch = 3 if ctype == 2 else 4
+    raw, stride = zlib.decompress(idat), w * ch
+    img = np.zeros((h, stride), np.int32)
+    prev = np.zeros(stride, np.int32)
+    p = 0
+    for y in range(h):
+        f = raw[p]
+        line = np.frombuffer(raw[p + 1:p + 1 + stride], np.uint8).astype(np.int32)
+        p += 1 + stride
+        if f == 0:
+            out = line
+        elif f == 2:
+            out = (line + prev) & 255
+        else:
+            out = np.zeros(stride, np.int32)
+            for i in range(stride):
+                a = out[i - ch] if i >= ch else 0
+                up = prev[i]
+                c = prev[i - ch] if i >= ch else 0
+                if f == 1:
+                    pr = a
+                elif f == 3:
+                    pr = (a + up) >> 1
+                else:
+                    pa, pb, pc = abs(up - c), abs(a - c), abs(a + up - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (up if pb <= pc else c)
+                out[i] = (line[i] + pr) & 255
+        img[y] = out
+        prev = out
+    return img.reshape(h, w, ch)[:, :, :3].astype(np.uint8)
+
+
+if __name__ == "__main__":
+    src = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/result/heterogeneous.png"
+    img = read_png_rgb8(src).astype(np.float64) / 255.0
+    assert img.shape == (512, 512, 3)
+    small = img.reshape(64, 8, 64, 8, 3).mean(axis=(1, 3)).astype(np.float32)
+    out = os.path.join(ROOT, "tests", "golden", "reference_heterogeneous_64.npy")
+    np.save(out, small)
+    print("wrote", out, small.shape, "channel means", small.mean(axis=(0, 1)))
