@@ -6,6 +6,7 @@ per-channel relative RMS <= 1e-4 — is also asserted, in `rel_rms`, and is triv
 the images are identical.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -697,6 +698,35 @@ def test_volpath_shipped_scene_shape_full_size(gpt):
         r.render(cam, 1, spp, reset=True)
         assert_bit_exact(r.read_accum(), ref, "vpt shipped-like 512x512")
         assert_bit_exact(r.read_color(), col_o, "vpt shipped-like 512x512 last sample")
+
+
+def test_volpath_gpu_film_against_the_reference_render(gpt, tmp_path):
+    """End to end on the GPU: the reference's default scene (rebuilt on disk by scenes.write_smoke_scene; it loads to the
+    same scene as the shipped file, tests/test_scene_loader.py) through LoadScene and the one-ray-at-a-time kernel, 16 spp:
+    the film equals the oracle's bit for bit, and - tone-mapped, flipped and truncated like the reference's PNG writer - it
+    lands on the reference's own published render of that scene (result/heterogeneous.png, kept box-filtered as
+    tests/golden/reference_heterogeneous_64.npy) up to Monte-Carlo noise: frame means within 0.008, 64 x 64 blocks within
+    0.008 on average."""
+    want = np.load(os.path.join(ol.ROOT, "tests", "golden", "reference_heterogeneous_64.npy")).astype(np.float64)
+    ls = gpt.LoadedScene(scenes.write_smoke_scene(str(tmp_path / "smoke")))
+    W, H, spp = ls.width, ls.height, 16
+    assert (W, H) == (512, 512) and ls.desc.n_mediums == 2
+    cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)
+    cam.medium = ls.camera.medium
+    ref, _ = ol.render(ls, cam, W, H, ls.epsilon, 1, spp, kind="soft")
+    with gpt.Renderer(ls.desc, W, H, ls.epsilon) as r:
+        r.render(cam, 1, spp, reset=True)
+        acc = r.read_accum()
+    assert_bit_exact(acc, ref, "shipped smoke scene")
+    lin = acc.reshape(H, W, 3).astype(np.float64) / spp
+    c = np.maximum(0.0, lin - 0.004)
+    img = (c * (6.2 * c + 0.5)) / (c * (6.2 * c + 1.7) + 0.06)               # FilmicTonemapping, pathtracer.cu:199-204
+    img = np.floor(np.clip(img, 0.0, 1.0) * 255.0) / 255.0
+    got = img[::-1].reshape(64, 8, 64, 8, 3).mean(axis=(1, 3))
+    d = np.abs(got - want)
+    assert np.abs(got.mean(axis=(0, 1)) - want.mean(axis=(0, 1))).max() < 0.008, (got.mean(axis=(0, 1)), want.mean(axis=(0, 1)))
+    assert d.mean() < 0.008 and d.max() < 0.08, (d.mean(), d.max())
+    ls.close()
 
 
 def test_volpath_two_kernels_agree(gpt, monkeypatch):

@@ -544,3 +544,26 @@ def test_every_reference_scene_file_parses(tmp_path):
     assert list(bad) == ["cornell_box/vol_caustic.json"] and "sphere" in bad["cornell_box/vol_caustic.json"], bad
     assert seen["cornell_box/scene.json"][0] == st.IT_VPT
     assert all(v[0] == st.IT_PT and v[1] > 0 for k, v in seen.items() if not isinstance(v, str) and k != "cornell_box/scene.json")
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scenes/cornell_box/geometry/density.d"), reason="the reference tree is not here")
+def test_rebuilt_smoke_scene_is_the_shipped_scene(tmp_path):
+    """scenes.write_smoke_scene (what the GPU box renders, having no /root/reference) loads to the same scene as the
+    reference's scenes/cornell_box/scene.json: primitives in BVH order, nodes, lights, media and density grid, bit for bit."""
+    a = api.LoadedScene("/root/reference/scenes/cornell_box/scene.json")
+    b = api.LoadedScene(scenes.write_smoke_scene(str(tmp_path / "smoke")))
+    assert (a.width, a.height, a.epsilon, a.camera.medium) == (b.width, b.height, b.epsilon, b.camera.medium)
+    assert (a.desc.integrator_type, a.desc.max_depth, a.desc.n_prims, a.desc.n_nodes, a.desc.n_lights, a.desc.n_mediums) == \
+           (b.desc.integrator_type, b.desc.max_depth, b.desc.n_prims, b.desc.n_nodes, b.desc.n_lights, b.desc.n_mediums)
+    assert tri_fields_equal(a.array("prims", "n_prims", st.PRIMITIVE)["triangle"], b.array("prims", "n_prims", st.PRIMITIVE)["triangle"])
+    assert a.array("nodes", "n_nodes", st.BVH_NODE).tobytes() == b.array("nodes", "n_nodes", st.BVH_NODE).tobytes()
+    ma = np.ctypeslib.as_array(C.cast(a.desc.mediums, C.POINTER(C.c_uint8)), shape=(2 * 104,)).view(st.MEDIUM).copy()
+    mb = np.ctypeslib.as_array(C.cast(b.desc.mediums, C.POINTER(C.c_uint8)), shape=(2 * 104,)).view(st.MEDIUM).copy()
+    ga = np.ctypeslib.as_array(C.cast(int(ma[1]["density"]), C.POINTER(C.c_float)), shape=(400000,))
+    gb = np.ctypeslib.as_array(C.cast(int(mb[1]["density"]), C.POINTER(C.c_float)), shape=(400000,))
+    assert ga.tobytes() == gb.tobytes()
+    for name in st.MEDIUM.names:                     # (field by field: the records' tail padding is not defined)
+        if name != "density":
+            assert ma[name].tobytes() == mb[name].tobytes(), name
+    a.close()
+    b.close()

@@ -2,7 +2,10 @@
 (/root/reference/result/heterogeneous.png = scenes/cornell_box/scene.json: Volpath, 17 bounces, 100x100x40 density grid
 inside a material-less box), box-filtered from 512x512 to 64x64 (float32 in [0,1], row 0 = top of the image).
 An output of the reference, kept as data; tests/test_oracle_golden.py renders the same scene file with the oracle and
-compares.  Run where /root/reference exists:  python tools/make_reference_image_fixture.py"""
+compares.  Also tests/golden/reference_density_grid.npz: the density grid of that scene (scenes/cornell_box/geometry/
+density.d, 100 x 100 x 40 values with six decimals, stored as integer millionths) - input data of the reference, so
+that the GPU box, which has no /root/reference, can render the same scene (tests/scenes.py: write_smoke_scene).
+Run where /root/reference exists:  python tools/make_reference_image_fixture.py"""
 import os, struct, sys, zlib
 import numpy as np
 
@@ -61,3 +64,9 @@ if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden", "reference_heterogeneous_64.npy")
     np.save(out, small)
     print("wrote", out, small.shape, "channel means", small.mean(axis=(0, 1)))
+    d = np.loadtxt("/root/reference/scenes/cornell_box/geometry/density.d", dtype=np.float64)
+    q = np.round(d * 1e6).astype(np.int32)
+    assert q.size == 100 * 100 * 40 and np.abs(q / 1e6 - d).max() < 1e-9
+    out = os.path.join(ROOT, "tests", "golden", "reference_density_grid.npz")
+    np.savez_compressed(out, millionths=q, nx=100, ny=100, nz=40)
+    print("wrote", out, os.path.getsize(out), "bytes")
