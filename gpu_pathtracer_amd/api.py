@@ -13,6 +13,12 @@ from . import scene_types as st
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPT_LIB_PATH") or os.path.join(_HERE, "libgpt.so")   # override: kernel experiments only
+# The library itself reads no environment variable.  What this binding takes from the environment (the path of an
+# experimental build) is recorded here, and bench.py prints it in its JSON line (config.env_overrides).
+ENV_OVERRIDES = {k: os.environ[k] for k in ("GPT_LIB_PATH", "GPT_ALLOW_OLD_LIB") if os.environ.get(k)}
+# Renderer options (gpt_set_option) applied to every Renderer this process creates, e.g. {"lds_scene": 0} to run a whole
+# test suite through the global-memory kernels (pytest --gpt-opt lds_scene=0).  Empty = the library's defaults.
+DEFAULT_OPTIONS = {}
 
 _lib = None
 
@@ -46,6 +52,9 @@ def load():
         "gpt_set_tile_owner": [vp, C.c_int, C.c_int],
         "gpt_set_integrator": [vp, i32, i32, C.c_float],
         "gpt_set_traversal_order": [vp, i32],
+        "gpt_set_option": [vp, C.c_char_p, C.c_int64],
+        "gpt_get_option": [vp, C.c_char_p, C.POINTER(C.c_int64)],
+        "gpt_scene_load_cached": [C.c_char_p, C.c_int, C.POINTER(vp)],
         "gpt_render": [vp, vp, u32, u32, C.c_int, vp],
         "gpt_tonemap": [vp, u32, C.c_int, vp],
         "gpt_synchronize": [vp],
@@ -133,10 +142,10 @@ def camera_init(position, lookat, up=(0, 1, 0), res=(512, 512), fov=60.0, apertu
 class LoadedScene:
     """gpt_scene_load: LoadScene + InitScene of the reference (src/parsescene.cpp:45, src/main.cpp:261-278)."""
 
-    def __init__(self, json_path):
+    def __init__(self, json_path, use_bvh_cache=False):
         self.lib = load()
         self.handle = C.c_void_p()
-        check(self.lib.gpt_scene_load(os.fsencode(json_path), C.byref(self.handle)))
+        check(self.lib.gpt_scene_load_cached(os.fsencode(json_path), int(bool(use_bvh_cache)), C.byref(self.handle)))
         self.desc = st.SceneDesc()
         check(self.lib.gpt_scene_get_desc(self.handle, C.byref(self.desc)))
         w, h, eps = C.c_int32(), C.c_int32(), C.c_float()
@@ -193,6 +202,19 @@ class Renderer:
         self.width, self.height = int(width), int(height)
         self.ctx = C.c_void_p()
         check(self.lib.gpt_begin(C.byref(desc), self.width, self.height, float(epsilon), int(device), C.byref(self.ctx)))
+        self.options_set = {}
+        for k, v in DEFAULT_OPTIONS.items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        """gpt_set_option: "lds_scene", "vpt_walk_kernel", "max_batch", "chunk_iters" (include/gpt.h)"""
+        check(self.lib.gpt_set_option(self.ctx, name.encode(), int(value)))
+        self.options_set[name] = int(value)
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        check(self.lib.gpt_get_option(self.ctx, name.encode(), C.byref(v)))
+        return v.value
 
     def set_tile_owner(self, rank, n_ranks):
         check(self.lib.gpt_set_tile_owner(self.ctx, rank, n_ranks))

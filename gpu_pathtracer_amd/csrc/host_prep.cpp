@@ -62,7 +62,8 @@ struct Builder {
     {
         float value = axis(centers[(size_t)prim], ax);
         int no = (int)((value - start) / (end - start) * kBuckets);
-        return (no == kBuckets) ? no - 1 : no;
+        if (no == kBuckets) no = no - 1;                       // bvh.cpp:78
+        return no < 0 ? 0 : (no > kBuckets - 1 ? kBuckets - 1 : no);   // (never taken for finite input: centroids lie inside the node box)
     }
 
     void emit_leaf(int node, int first, int count)
@@ -95,33 +96,48 @@ struct Builder {
             emit_leaf(node, first, count);
             return;
         }
-        int best_axis = -1, best_bucket = 0;
-        float best_cost = (float)(size_t)count * bbox.surface_area();
+        // Binned SAH (bvh.cpp:55-106): 11 candidate planes per axis, cost = SA(left) * n_left + SA(right) * n_right, an
+        // empty side costs 0, and a split must beat n * SA(parent); ties keep the earlier (axis, plane).  The reference
+        // re-unites the buckets on both sides for every plane; here the right-hand unions come from one sweep from the top
+        // and the left-hand ones grow with the plane.  min/max unions are exact and order-independent, so boxes, counts
+        // and therefore every cost are the same floats.
+        int split_axis = -1, split_plane = 0;
+        float lowest = (float)(size_t)count * bbox.surface_area();
         for (int ax = 0; ax < 3; ++ax) {
-            Box bb[kBuckets];
-            int cnt[kBuckets] = {0};
-            const float start = axis(bbox.lo, ax), end = axis(bbox.hi, ax);
+            Box bin_box[kBuckets];
+            int bin_n[kBuckets] = {0};
+            const float lo = axis(bbox.lo, ax), hi = axis(bbox.hi, ax);
             for (int j = 0; j < count; ++j) {
                 const int p = order[(size_t)(first + j)];
-                const int no = bucket_of(p, ax, start, end);
-                cnt[no]++;
-                bb[no].expand(boxes[(size_t)p]);
+                const int b = bucket_of(p, ax, lo, hi);
+                bin_n[b]++;
+                bin_box[b].expand(boxes[(size_t)p]);
             }
+            Box above[kBuckets];             // above[j] = union of bins j .. 11
+            int n_above[kBuckets];
+            above[kBuckets - 1] = bin_box[kBuckets - 1];
+            n_above[kBuckets - 1] = bin_n[kBuckets - 1];
+            for (int j = kBuckets - 2; j >= 1; --j) {
+                above[j] = above[j + 1];
+                above[j].expand(bin_box[j]);
+                n_above[j] = n_above[j + 1] + bin_n[j];
+            }
+            Box below;                       // union of bins 0 .. j-1
+            int n_below = 0;
             for (int j = 1; j < kBuckets; ++j) {
-                Box b0, b1;
-                int count0 = 0, count1 = 0;
-                for (int k = 0; k < j; ++k) { b0.expand(bb[k]); count0 += cnt[k]; }
-                for (int k = j; k < kBuckets; ++k) { b1.expand(bb[k]); count1 += cnt[k]; }
-                float surface_a = (count0 == 0) ? 0 : b0.surface_area() * count0;
-                float surface_b = (count1 == 0) ? 0 : b1.surface_area() * count1;
-                float cost = surface_a + surface_b;
-                if (cost < best_cost) {
-                    best_cost = cost;
-                    best_axis = ax;
-                    best_bucket = j;
+                below.expand(bin_box[j - 1]);
+                n_below += bin_n[j - 1];
+                const float left = (n_below == 0) ? 0 : below.surface_area() * n_below;
+                const float right = (n_above[j] == 0) ? 0 : above[j].surface_area() * n_above[j];
+                const float sah = left + right;
+                if (sah < lowest) {
+                    lowest = sah;
+                    split_axis = ax;
+                    split_plane = j;
                 }
             }
         }
+        const int best_axis = split_axis, best_bucket = split_plane;
         if (best_axis == -1) {
             emit_leaf(node, first, count);
             return;
@@ -178,6 +194,13 @@ int gpt_bvh_build(const gpt_primitive *prims_in, int32_t n, gpt_primitive *prims
     Box root;
     for (int i = 0; i < n; ++i) {
         const gpt_triangle &t = prims_in[i].triangle;
+        const float c9[9] = {t.v1.v.x, t.v1.v.y, t.v1.v.z, t.v2.v.x, t.v2.v.y, t.v2.v.z, t.v3.v.x, t.v3.v.y, t.v3.v.z};
+        for (float c : c9) {
+            if (!std::isfinite(c)) {      // the reference's bucket index is undefined for such input (bvh.cpp:77)
+                gpt_set_error("gpt_bvh_build: primitive %d has a non-finite vertex coordinate", i);
+                return GPT_ERR_INVALID_ARG;
+            }
+        }
         Box bx;
         bx.expand(V3{t.v1.v.x, t.v1.v.y, t.v1.v.z});
         bx.expand(V3{t.v2.v.x, t.v2.v.y, t.v2.v.z});

@@ -117,7 +117,9 @@ struct Huffman {
         return -1;
     }
 };
-bool inflate_raw(const unsigned char *src, size_t n, std::vector<unsigned char> &out)
+// `limit`: the most bytes the caller can use; a stream that inflates beyond it is refused (crafted files must not
+// exhaust memory)
+bool inflate_raw(const unsigned char *src, size_t n, std::vector<unsigned char> &out, size_t limit)
 {
     static const short lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const short lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -135,6 +137,7 @@ bool inflate_raw(const unsigned char *src, size_t n, std::vector<unsigned char> 
             unsigned len = src[br.pos] | (src[br.pos + 1] << 8);
             br.pos += 4;
             if (br.pos + len > n) return false;
+            if (out.size() + len > limit) return false;
             out.insert(out.end(), src + br.pos, src + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -177,7 +180,7 @@ bool inflate_raw(const unsigned char *src, size_t n, std::vector<unsigned char> 
             for (;;) {
                 int sym = lit.decode(br);
                 if (sym < 0 || br.fail) return false;
-                if (sym < 256) out.push_back((unsigned char)sym);
+                if (sym < 256) { if (out.size() >= limit) return false; out.push_back((unsigned char)sym); }
                 else if (sym == 256) break;
                 else {
                     sym -= 257;
@@ -186,7 +189,7 @@ bool inflate_raw(const unsigned char *src, size_t n, std::vector<unsigned char> 
                     int ds = dist.decode(br);
                     if (ds < 0 || ds >= 30) return false;
                     size_t d = (size_t)dbase[ds] + (size_t)br.bits(dext[ds]);
-                    if (d > out.size()) return false;
+                    if (d > out.size() || out.size() + (size_t)len > limit) return false;
                     size_t from = out.size() - d;
                     for (int k = 0; k < len; ++k) out.push_back(out[from + (size_t)k]);
                 }
@@ -273,6 +276,7 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
         if (pos + 12 + len > d.size()) return false;
         const unsigned char *body = &d[pos + 8];
         if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) return false;
             width = (int)be32(body); height = (int)be32(body + 4);
             depth = body[8]; ctype = body[9]; interlace = body[12];
         } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
@@ -284,9 +288,10 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
     if (width <= 0 || height <= 0 || depth != 8 || interlace != 0 || idat.size() < 6) return false;
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) return false;
+    if ((uint64_t)width * (uint64_t)height > ((uint64_t)1 << 28)) return false;
     std::vector<unsigned char> raw;
-    if (!inflate_raw(idat.data() + 2, idat.size() - 2, raw)) return false;
     const size_t stride = (size_t)width * ch;
+    if (!inflate_raw(idat.data() + 2, idat.size() - 2, raw, (stride + 1) * (size_t)height)) return false;
     if (raw.size() < (stride + 1) * (size_t)height) return false;
     std::vector<unsigned char> img(stride * (size_t)height);
     for (int y = 0; y < height; ++y) {
@@ -851,9 +856,11 @@ bool read_exr_rgb_top_down(const char *path, int &width, int &height, std::vecto
         pos += size;
     }
     ++pos;
-    width = xmax - xmin + 1;
-    height = ymax - ymin + 1;
-    if (width <= 0 || height <= 0 || chans.empty() || compression < 0 || compression > 3) return false;
+    const int64_t w64 = (int64_t)xmax - (int64_t)xmin + 1, h64 = (int64_t)ymax - (int64_t)ymin + 1;
+    if (w64 <= 0 || h64 <= 0 || w64 > (1 << 20) || h64 > (1 << 20) || w64 * h64 > ((int64_t)1 << 28)) return false;
+    width = (int)w64;
+    height = (int)h64;
+    if ( chans.empty() || compression < 0 || compression > 3) return false;
     const int lines_per_block = compression == 3 ? 16 : 1;
     const int n_blocks = (height + lines_per_block - 1) / lines_per_block;
     if (pos + (size_t)n_blocks * 8 > d.size()) return false;
@@ -883,10 +890,11 @@ bool read_exr_rgb_top_down(const char *path, int &width, int &height, std::vecto
     for (int b = 0; b < n_blocks; ++b) {
         uint64_t off = 0;
         for (int k = 7; k >= 0; --k) off = off << 8 | d[pos + (size_t)b * 8 + (size_t)k];
-        if (off + 8 > d.size()) return false;
-        const int y0 = (int)le32((size_t)off) - ymin;
+        if (d.size() < 8 || off > d.size() - 8) return false;          // (no addition: off is a 64-bit field of the file)
+        const int64_t y0_64 = (int64_t)(int32_t)le32((size_t)off) - (int64_t)ymin;
         const uint32_t csize = le32((size_t)off + 4);
-        if (off + 8 + csize > d.size() || y0 < 0 || y0 >= height) return false;
+        if (csize > d.size() - 8 - (size_t)off || y0_64 < 0 || y0_64 >= height) return false;
+        const int y0 = (int)y0_64;
         const int lines = y0 + lines_per_block <= height ? lines_per_block : height - y0;
         const size_t expect = line_bytes * (size_t)lines;
         const unsigned char *src = &d[(size_t)off + 8];
@@ -896,7 +904,7 @@ bool read_exr_rgb_top_down(const char *path, int &width, int &height, std::vecto
             exr_unpredict(raw, tmp);
         } else {
             raw.clear();
-            if (csize < 6 || !inflate_raw(src + 2, csize - 2, raw)) return false;
+            if (csize < 6 || !inflate_raw(src + 2, csize - 2, raw, expect)) return false;
             exr_unpredict(raw, tmp);
         }
         if (raw.size() < expect) return false;

@@ -1802,9 +1802,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     // a lane whose path ends takes the next sample of the tile, whichever pixel it belongs to, and when the item
     // runs out the wave fetches its next item in the same round - it never drains between items, only once, at
     // the end of the launch.  sample s -> pixel s % 64 of the tile, iteration chunk_first + s / 64.
-    uint32_t tx = 0, ty = 0, chunk_first = 0, n_item_samples = 0, next_sample = 0;     // wave-uniform
+    uint32_t tile_xy = 0, slot_base = 0, chunk_first = 0, n_item_samples = 0, next_sample = 0;     // wave-uniform
     bool more_items = true;
-    uint32_t x = 0, y = 0, pixel = 0, iter = 0;
+    uint32_t x = 0, y = 0, plane_slot = 0, iter = 0;      // plane_slot: where the sample goes in its iteration's plane
     {
         // ---- per-path state ---------------------------------------------------------
         Rng rng;
@@ -2649,7 +2649,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 // The sample goes to its iteration's plane as is; the finite-guard of pathtracer.cu:1019-1020
                 // and the accumulation run in iteration order in pt_output_kernel.
                 // one 16-byte store per sample: stores are written through to the fabric per request
-                float4 *dst = reinterpret_cast<float4 *>(P.samples) + (uint64_t)(iter - P.iter_first) * P.plane + pixel;
+                float4 *dst = reinterpret_cast<float4 *>(P.samples) + (uint64_t)(iter - P.iter_first) * P.plane + plane_slot;
                 *dst = make_float4(Li.x, Li.y, Li.z, 0.f);
                 alive = false;
                 q.has_s = q.has_m = q.has_p = false;
@@ -2666,8 +2666,8 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     const uint32_t chunk = t / n_owned;
                     const uint32_t tile_local = t - chunk * n_owned;
                     const uint32_t tile = P.rank + tile_local * P.n_ranks;
-                    tx = tile % P.tiles_x;
-                    ty = tile / P.tiles_x;
+                    tile_xy = (tile % P.tiles_x) | ((tile / P.tiles_x) << 16);      // (one SGPR: the kernel is at the SGPR limit)
+                    slot_base = tile_local * 64u;          // planes are tile-major over this rank's tiles
                     chunk_first = P.iter_first + chunk * P.chunk_iters;
                     const uint32_t chunk_count = (chunk + 1u == P.n_chunks) ? P.iter_count - chunk * P.chunk_iters : P.chunk_iters;
                     n_item_samples = 64u * chunk_count;
@@ -2679,14 +2679,15 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 const uint32_t s = next_sample + (uint32_t)lane_rank(m_idle);
                 next_sample += (uint32_t)popc(m_idle);
                 if (!alive && s < n_item_samples) {
-                    x = tx * 8u + (s & 7u);
-                    y = ty * 8u + ((s >> 3) & 7u);
+                    x = (tile_xy & 0xffffu) * 8u + (s & 7u);
+                    y = (tile_xy >> 16) * 8u + ((s >> 3) & 7u);
                     iter = chunk_first + (s >> 6);
-                    pixel = x + y * P.stride;          // pathtracer.cu:881-883
+                    plane_slot = slot_base + (s & 63u);
                     start = x < P.stride && y < P.rows;
                 }
             }
             if (start) {
+                const uint32_t pixel = x + y * P.stride;          // pathtracer.cu:881-883
                 rng_seed(rng, wang_hash(pixel) + wang_hash(iter));
                 float offsetx = rng_uniform(rng) - 0.5f;
                 float offsety = rng_uniform(rng) - 0.5f;
@@ -2832,16 +2833,18 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
 // Streaming: 16 B per pixel per iteration read, 48 B per pixel read/written once.
 __global__ void __launch_bounds__(256) pt_output_kernel(const DevParams P)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.stride * P.rows) return;
-    const uint32_t x = i % P.stride, y = i / P.stride;
-    const uint32_t tile = (x >> 3) + (y >> 3) * P.tiles_x;
-    if (tile % P.n_ranks != P.rank) return;
+    // one thread per slot of a sample plane: slot = local tile * 64 + pixel in tile (the path kernel's layout),
+    // so a wave reads 1 KB of consecutive samples per iteration
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.plane) return;
+    const uint32_t tile = P.rank + (uint32_t)(i >> 6) * P.n_ranks;
+    const uint32_t x = (tile % P.tiles_x) * 8u + ((uint32_t)i & 7u), y = (tile / P.tiles_x) * 8u + (((uint32_t)i >> 3) & 7u);
+    if (x >= P.stride || y >= P.rows) return;
     const uint32_t pixel = x + y * P.stride;
     V3 col = V3{P.color[3 * pixel], P.color[3 * pixel + 1], P.color[3 * pixel + 2]};
     V3 acc = v3(0.f);
     if (!P.reset) acc = V3{P.acc[3 * pixel], P.acc[3 * pixel + 1], P.acc[3 * pixel + 2]};
-    const float4 *s = reinterpret_cast<const float4 *>(P.samples) + pixel;
+    const float4 *s = reinterpret_cast<const float4 *>(P.samples) + i;
     for (uint32_t k = 0; k < P.iter_count; ++k, s += P.plane) {
         const float4 sv = *s;
         const V3 Li = V3{sv.x, sv.y, sv.z};
@@ -2914,10 +2917,10 @@ namespace pt {
 
 // resident 256-thread workgroups per CU for the persistent grid
 // Volpath runs on the one-ray-at-a-time kernel when the scene has density grids or material-less surfaces
-// (GPT_VPT_WALK forces it: tests compare the two kernels)
-bool render_uses_walk_kernel(const DevParams &P)
+// (`force`: gpt_set_option "vpt_walk_kernel" - tests compare the two kernels)
+bool render_uses_walk_kernel(const DevParams &P, bool force)
 {
-    return P.integrator == GPT_IT_VPT && (P.vpt_walk || getenv("GPT_VPT_WALK"));
+    return P.integrator == GPT_IT_VPT && (P.vpt_walk || force);
 }
 
 int render_kernel_blocks_per_cu(bool count, bool walk)
@@ -2932,13 +2935,17 @@ int render_kernel_blocks_per_cu(bool count, bool walk)
     return n;
 }
 
-hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream)
+bool render_scene_fits_lds(const DevParams &P)
 {
-    const bool small = P.traversal == 0 && 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4 &&
-                       !getenv("GPT_NO_LDS_SCENE");
+    return P.traversal == 0 && 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4;
+}
+
+hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream)
+{
+    const bool small = lds_scene && render_scene_fits_lds(P);
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
-    if (render_uses_walk_kernel(P)) {
+    if (render_uses_walk_kernel(P, force_walk)) {
         if (count && small) PT_LAUNCH(true, true, PT_IT_VPT_WALK);
         else if (count) PT_LAUNCH(true, false, PT_IT_VPT_WALK);
         else if (small) PT_LAUNCH(false, true, PT_IT_VPT_WALK);
@@ -2965,8 +2972,8 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream
 
 hipError_t launch_output(const DevParams &P, hipStream_t stream)
 {
-    const uint32_t n = P.stride * P.rows;
-    hipLaunchKernelGGL(pt_output_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, P);
+    const uint64_t n = P.plane;
+    hipLaunchKernelGGL(pt_output_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 

@@ -118,7 +118,7 @@ struct DevParams {
     float *color;                // kernel_color
     float *out;                  // tonemapped output or nullptr
     float *samples;              // per-iteration sample planes of float4: plane index = iter - iter_first
-    uint64_t plane;              // float4 per plane = W*H
+    uint64_t plane;              // float4 slots per plane: 64 per tile this rank owns (tile-major: local tile * 64 + pixel in tile)
     uint32_t stride;             // 32*(W/32): row stride of the reference's pixel index
     uint32_t rows;               // 4*(H/4)
     uint32_t tiles_x;            // 8x8 tiles per row

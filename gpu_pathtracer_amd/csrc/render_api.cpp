@@ -25,17 +25,17 @@
 #include "host_util.h"
 #include "pt_layout.h"
 #include "../../include/gpt_traversal.h"
-#include "../../include/gpt_traversal.h"
 
 namespace pt {
-hipError_t launch_render(const DevParams &P, bool count, int n_blocks, hipStream_t stream);
+hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream);
+bool render_scene_fits_lds(const DevParams &P);
 hipError_t launch_output(const DevParams &P, hipStream_t stream);
 hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_t rows, uint32_t iter, int filmic,
                           hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
 hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream);
 int render_kernel_blocks_per_cu(bool count, bool walk);
-bool render_uses_walk_kernel(const DevParams &P);
+bool render_uses_walk_kernel(const DevParams &P, bool force);
 }  // namespace pt
 
 using namespace pt;
@@ -58,13 +58,17 @@ struct gpt_ctx {
     float *acc = nullptr, *color = nullptr;
     uint32_t *tile_counter = nullptr;
     unsigned long long *counters = nullptr;
-    uint32_t chunk_override = 0;          // GPT_CHUNK_ITERS (experiments)
+    // gpt_set_option (explicit, readable back with gpt_get_option; nothing here is read from the environment)
+    uint32_t chunk_override = 0;          // "chunk_iters": iterations per work item, 0 = the cost model of gpt_render
+    bool lds_scene = true;                // "lds_scene": stage a small scene in LDS (0: always traverse from global memory)
+    bool force_walk = false;              // "vpt_walk_kernel": Volpath always on the one-ray-at-a-time kernel
     bool media_ok = true;                 // every medium record and medium index is valid ("vpt" can run)
     bool has_interface = false;           // some primitive has no material (matIdx -1): only "vpt" renders such scenes
     int n_mediums = 0;
     float *samples = nullptr;             // per-iteration sample planes, grown on demand
-    uint32_t sample_planes = 0;           // planes allocated
-    uint32_t max_batch = 256;             // iterations per path-kernel launch (GPT_MAX_BATCH); also capped by kMaxPlaneBytes
+    size_t sample_bytes = 0;              // bytes allocated for them
+    uint32_t last_batch_cap = 0;          // iterations per launch the last gpt_render used
+    uint32_t max_batch = 256;             // "max_batch": iterations per path-kernel launch; also capped by the memory budget
     bool count_next = false;
     int n_cus = 256;
     int blocks_per_cu[2][2] = {{4, 4}, {3, 3}};      // [walk kernel][counting build]
@@ -304,7 +308,11 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         gpt_end(ctx);
         return code;
     };
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    // A BLOCKING stream: it is ordered with the legacy default stream like the reference's kernels, which are launched on
+    // the default stream itself (pathtracer.cu:2707-2750).  A caller in the reference's shape - Render(), then a copy or
+    // a GL unmap of `output` on the default stream, src/main.cpp:139-143 - therefore sees the finished frame without
+    // any extra call; gpt_synchronize() is only needed before touching `output` from ANOTHER non-blocking stream.
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault) != hipSuccess) {
         gpt_set_error("gpt_begin: hipStreamCreate failed");
         return fail(GPT_ERR_HIP);
     }
@@ -451,8 +459,6 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     if (hipMalloc(&p, film_bytes) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(color) failed"); return fail(GPT_ERR_HIP); }
     ctx->allocs.push_back(p);
     ctx->color = static_cast<float *>(p);
-    if (const char *e = std::getenv("GPT_CHUNK_ITERS")) ctx->chunk_override = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("GPT_MAX_BATCH")) { int v = std::atoi(e); if (v > 0) ctx->max_batch = (uint32_t)v; }
     if (hipMalloc(&p, 256) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(queue) failed"); return fail(GPT_ERR_HIP); }
     ctx->allocs.push_back(p);
     ctx->tile_counter = static_cast<uint32_t *>(p);
@@ -465,7 +471,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.acc = ctx->acc;
     P.color = ctx->color;
     P.tile_counter = ctx->tile_counter;
-    P.plane = (uint64_t)width * height;
+    P.plane = 0;                                   // set per gpt_render call: 64 slots per owned tile
     P.counters = ctx->counters;
     if (hipDeviceSynchronize() != hipSuccess) { gpt_set_error("gpt_begin: device sync failed"); return fail(GPT_ERR_HIP); }
     *out = ctx;
@@ -504,6 +510,41 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
     return GPT_OK;
 }
 
+int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) { gpt_set_error("gpt_set_option: null argument"); return GPT_ERR_INVALID_ARG; }
+    const std::string n(name);
+    if (n == "lds_scene" && (value == 0 || value == 1)) ctx->lds_scene = value != 0;
+    else if (n == "vpt_walk_kernel" && (value == 0 || value == 1)) ctx->force_walk = value != 0;
+    else if (n == "max_batch" && value >= 1 && value <= 65536) ctx->max_batch = (uint32_t)value;
+    else if (n == "chunk_iters" && value >= 0 && value <= 65536) ctx->chunk_override = (uint32_t)value;
+    else {
+        gpt_set_error("gpt_set_option: unknown option or value out of range: %s = %lld", name, (long long)value);
+        return GPT_ERR_INVALID_ARG;
+    }
+    return GPT_OK;
+}
+
+int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value) { gpt_set_error("gpt_get_option: null argument"); return GPT_ERR_INVALID_ARG; }
+    const std::string n(name);
+    if (n == "lds_scene") *value = ctx->lds_scene ? 1 : 0;
+    else if (n == "vpt_walk_kernel") *value = ctx->force_walk ? 1 : 0;
+    else if (n == "max_batch") *value = ctx->max_batch;
+    else if (n == "chunk_iters") *value = ctx->chunk_override;
+    // read-only: what the renderer actually does with the current scene and settings
+    else if (n == "lds_scene_active") *value = (ctx->lds_scene && render_scene_fits_lds(ctx->P)) ? 1 : 0;
+    else if (n == "walk_kernel_active") *value = render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0;
+    else if (n == "last_batch") *value = ctx->last_batch_cap;
+    else if (n == "sample_plane_bytes") *value = (int64_t)ctx->sample_bytes;
+    else {
+        gpt_set_error("gpt_get_option: unknown option %s", name);
+        return GPT_ERR_INVALID_ARG;
+    }
+    return GPT_OK;
+}
+
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
 {
     if (!ctx || (order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_NEAR_FIRST)) {
@@ -537,35 +578,59 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         HIP_TRY(hipMemsetAsync(ctx->acc, 0, (size_t)ctx->width * ctx->height * 3 * sizeof(float), ctx->stream));
     if (n_owned == 0 || iter_count == 0) return GPT_OK;
 
-    // sample planes for one launch (grown on demand, never shrunk).  A launch has a fixed cost of 0.2-0.6 ms (start-up
-    // and the wait for the last work items), so launches are long: up to 256 iterations, 8.5 GB of planes at 1080p,
-    // and never more than 16 GiB of the 288 (tools/gpu_batch.py: 64 -> 256 iterations per launch is +1.5 % on the full
+    // Sample planes for one launch (grown on demand).  A plane holds one float4 per pixel slot of the tiles THIS rank owns
+    // (tile-major: slot = local tile * 64 + pixel in tile), so a 1/8 shard allocates an eighth.  A launch has a fixed cost
+    // of 0.2-0.6 ms (start-up and the wait for the last work items), so launches are long: up to 256 iterations - 8.5 GB
+    // of planes for a full 1080p frame - but never more than 16 GiB nor 80 % of the free device memory, and a failed
+    // allocation is retried at half the batch (tools/gpu_batch.py: 64 -> 256 iterations per launch is +1.5 % on the full
     // frame and 7.0x -> 7.5x for a 1/8 shard).
-    const size_t kMaxPlaneBytes = (size_t)16 << 30;
-    uint32_t by_memory = (uint32_t)(kMaxPlaneBytes / ((size_t)ctx->P.plane * 4 * sizeof(float)));
+    const size_t plane_bytes = (size_t)n_owned * 64 * 4 * sizeof(float);
+    size_t budget = (size_t)16 << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // what this context already holds for planes counts as available: it is freed before a new allocation
+            const size_t avail = free_b + ctx->sample_bytes;
+            if (avail / 5 * 4 < budget) budget = avail / 5 * 4;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    uint32_t by_memory = (uint32_t)(budget / plane_bytes);
     if (by_memory < 1) by_memory = 1;
     const uint32_t max_batch = ctx->max_batch < by_memory ? ctx->max_batch : by_memory;
-    const uint32_t batch_cap = iter_count < max_batch ? iter_count : max_batch;
-    if (ctx->sample_planes < batch_cap) {
+    uint32_t batch_cap = iter_count < max_batch ? iter_count : max_batch;
+    if (ctx->sample_bytes < plane_bytes * batch_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->samples) {
             HIP_TRY(hipFree(ctx->samples));
             for (auto &a : ctx->allocs) if (a == ctx->samples) a = nullptr;
             ctx->samples = nullptr;
-            ctx->sample_planes = 0;
+            ctx->sample_bytes = 0;
         }
         void *ps = nullptr;
-        HIP_TRY(hipMalloc(&ps, (size_t)ctx->P.plane * 4 * sizeof(float) * batch_cap));
+        for (;;) {
+            const hipError_t e = hipMalloc(&ps, plane_bytes * batch_cap);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();          // clear the sticky error: a later launch must not report it
+            if (batch_cap == 1) {
+                gpt_set_error("gpt_render: cannot allocate one sample plane (%zu bytes): %s", plane_bytes, hipGetErrorString(e));
+                return GPT_ERR_HIP;
+            }
+            batch_cap = (batch_cap + 1) / 2;
+        }
         ctx->allocs.push_back(ps);
         ctx->samples = static_cast<float *>(ps);
-        ctx->sample_planes = batch_cap;
+        ctx->sample_bytes = plane_bytes * batch_cap;
     }
+    ctx->last_batch_cap = batch_cap;
 
-    const long resident_waves = (long)ctx->n_cus * ctx->blocks_per_cu[render_uses_walk_kernel(ctx->P) ? 1 : 0][count ? 1 : 0] * 4;
+    const long resident_waves = (long)ctx->n_cus * ctx->blocks_per_cu[render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0][count ? 1 : 0] * 4;
     for (uint32_t done = 0; done < iter_count; done += batch_cap) {
         DevParams P = ctx->P;
         P.cam = *camera;
         P.samples = ctx->samples;
+        P.plane = (uint64_t)n_owned * 64;
         P.iter_first = iter_first + done;
         P.iter_count = iter_count - done < batch_cap ? iter_count - done : batch_cap;
         P.reset = (reset && done == 0) ? 1 : 0;
@@ -601,7 +666,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
             HIP_TRY(hipEventCreate(&ev.second));
         }
         HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-        HIP_TRY(launch_render(P, count, n_blocks, ctx->stream));
+        HIP_TRY(launch_render(P, count, n_blocks, ctx->lds_scene, ctx->force_walk, ctx->stream));
         HIP_TRY(hipEventRecord(ev.second, ctx->stream));
         ctx->events.push_back(ev);
         HIP_TRY(launch_output(P, ctx->stream));

@@ -22,6 +22,19 @@ def tile_owner_mask(width, height, rank, world):
     return (tile % world == rank) & (x < stride) & (y < rows)
 
 
+def film_owner_mask(width, height, rank, world):
+    """Boolean mask over the W*H pixel slots of the FILM BUFFER (accumulator / last-sample planes): slot
+    p = x + y * stride with stride = 32*(W/32) — the reference's pixel index (src/pathtracer.cu:881-883), which is
+    plain row-major only when W is a multiple of 32 (include/gpt.h "Film state").  Use this one to index the buffer
+    gpt_read_accum returns; tile_owner_mask is the same set as (y, x) coordinates."""
+    stride, rows = 32 * (width // 32), 4 * (height // 4)
+    own = tile_owner_mask(width, height, rank, world)[:rows, :stride]
+    y, x = np.nonzero(own)
+    flat = np.zeros(width * height, dtype=bool)
+    flat[x + y * stride] = True
+    return flat
+
+
 def init_process_group(backend=None):
     import torch
     import torch.distributed as dist

@@ -76,6 +76,16 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
  * order - in practice identical).  Near-first always traverses from global memory. */
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
 
+/* Renderer options, by name; none of them changes a result.  Nothing in the library is steered by environment
+ * variables: what differs from the defaults was set through this call and can be read back.
+ *   "lds_scene"        1 (default): a scene of <= 12 KB is staged in LDS by every workgroup; 0: always global memory
+ *   "vpt_walk_kernel"  0 (default): Volpath picks its kernel from the scene; 1: always the one-ray-at-a-time kernel
+ *   "max_batch"        iterations per path-kernel launch, default 256 (also bounded by free device memory)
+ *   "chunk_iters"      iterations per work item, 0 (default) = cost model
+ * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "last_batch", "sample_plane_bytes". */
+int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value);
+int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value);
+
 /* Render (src/pathtracer.cu:2705-2750), batched: for iter = iter_first ..
  * iter_first+iter_count-1 add one sample per pixel, seeded by (pixel, iter),
  * into the accumulator, exactly as iter_count successive reference calls would
@@ -84,7 +94,11 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
  * on every call like the reference's per-call cudaMemcpy.  If
  * `out_tonemapped_dev` is not NULL it must be a DEVICE pointer to W*H*3 floats
  * (the reference's mapped GL buffer) and receives tonemap(acc / last_iter).
- * Asynchronous: returns after enqueueing on the context's stream. */
+ * Asynchronous: returns after enqueueing on the context's stream.  That stream is a
+ * blocking stream, i.e. ordered with the legacy default stream exactly like the
+ * reference's default-stream launches: a hipMemcpy / default-stream kernel issued after
+ * gpt_render sees the finished film.  Work on a caller's own NON-blocking stream must be
+ * ordered with gpt_synchronize() first. */
 int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint32_t iter_count,
                int reset, float *out_tonemapped_dev);
 
@@ -96,7 +110,12 @@ int gpt_tonemap(gpt_ctx *ctx, uint32_t iter, int filmic, float *out_dev);
 int gpt_synchronize(gpt_ctx *ctx);
 
 /* Film state.  Device pointers stay valid until gpt_end(); W*H*3 floats each,
- * row-major, row 0 = bottom (reference convention, src/imageio.cpp:66). */
+ * row 0 = bottom (reference convention, src/imageio.cpp:66).  Pixel (x, y) lives at
+ * float index 3 * (x + y * stride) with stride = 32 * (W / 32): the reference's pixel
+ * index uses blockDim.x * gridDim.x of its (W/32, H/4) grid as the row stride
+ * (src/pathtracer.cu:881-883, 2707-2709).  For the widths the reference is used with
+ * (multiples of 32) that is plain row-major; other widths skew, here as there, and only
+ * the first stride columns and 4 * (H / 4) rows are rendered. */
 float *gpt_accum_device_ptr(gpt_ctx *ctx);   /* kernel_acc_image: running SUM of samples */
 float *gpt_color_device_ptr(gpt_ctx *ctx);   /* kernel_color: last finite sample */
 int gpt_read_accum(gpt_ctx *ctx, float *host_rgb);        /* synchronises */
@@ -160,6 +179,9 @@ int gpt_camera_init(gpt_camera *camera, const float position[3], const float loo
 /* LoadScene + InitScene (src/parsescene.cpp:45-590, src/main.cpp:261-278):
  * parse a scene JSON, read its OBJ meshes, build the BVH and the light CDF. */
 int gpt_scene_load(const char *json_path, gpt_scene **out);
+/* ... with BVH::LoadOrBuildBVH's cache file <scene dir>/bvh.cache (src/bvh.cpp:189-218) when use_bvh_cache != 0.  The
+ * reference always uses it and silently reuses a stale one; here it is opt-in and carries a content hash. */
+int gpt_scene_load_cached(const char *json_path, int use_bvh_cache, gpt_scene **out);
 int gpt_scene_get_desc(const gpt_scene *scene, gpt_scene_desc *desc_out);
 int gpt_scene_get_config(const gpt_scene *scene, int32_t *width, int32_t *height, float *epsilon,
                          gpt_camera *camera_out);

@@ -9,8 +9,18 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--gpt-opt", action="append", default=[], metavar="NAME=VALUE",
+                     help="renderer option applied to every Renderer of the run (gpt_set_option), e.g. lds_scene=0 sends "
+                          "every scene through the global-memory kernels")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from gpu_pathtracer_amd import api
+    for kv in config.getoption("--gpt-opt"):
+        k, v = kv.split("=")
+        api.DEFAULT_OPTIONS[k] = int(v)
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../gpu_pathtracer_amd/csrc/pathtracer.h"
 
 int main(int argc, char **argv)
@@ -30,9 +32,24 @@ int main(int argc, char **argv)
 
     BeginRender(scene, config.width, config.height, config.epsilon);
     if (!CurrentRenderContext()) return 3;
+    std::vector<float> acc((size_t)config.width * config.height * 3);
+    if (argc > 4 && argv[4][0] == 'o') {
+        // The reference's display loop (src/main.cpp:134-144): Render() into a device `output` buffer, then use that
+        // buffer from the DEFAULT stream straight away - no synchronisation call exists in the reference's interface.
+        float3_t *output = nullptr;
+        if (hipMalloc((void **)&output, acc.size() * sizeof(float)) != hipSuccess) return 5;
+        if (hipMemset(output, 0, acc.size() * sizeof(float)) != hipSuccess) return 5;
+        for (unsigned iter = 1; iter <= spp; ++iter)
+            Render(scene, config.width, config.height, camera, iter, iter == 1, output);
+        if (hipMemcpy(acc.data(), output, acc.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 6;
+        EndRender();
+        FILE *fo = std::fopen(out_file, "wb");
+        std::fwrite(acc.data(), sizeof(float), acc.size(), fo);
+        std::fclose(fo);
+        return 0;
+    }
     for (unsigned iter = 1; iter <= spp; ++iter)
         Render(scene, config.width, config.height, camera, iter, iter == 1, nullptr);
-    std::vector<float> acc((size_t)config.width * config.height * 3);
     if (gpt_read_accum(CurrentRenderContext(), acc.data()) != GPT_OK) return 4;
     EndRender();
     FILE *f = std::fopen(out_file, "wb");

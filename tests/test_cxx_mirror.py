@@ -16,8 +16,8 @@ SCENE = os.path.join(ol.ROOT, "scenes", "cornell_pt", "scene.json")
 
 def build(tmp_path):
     exe = str(tmp_path / "mirror_main")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", CXX, "-o", exe, f"-L{LIBDIR}", "-lgpt", f"-Wl,-rpath,{LIBDIR}",
-                           "-Wl,-rpath,/opt/rocm/lib"])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", CXX, "-o", exe,
+                           f"-L{LIBDIR}", "-lgpt", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -39,6 +39,23 @@ def test_cxx_render_calls_match_oracle(tmp_path):
     cam = ol.cornell_camera(meta, 512, 512)
     ref, _ = ol.render(scene, cam, 512, 512, 0.001, 1, 3)
     assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.gpu
+def test_cxx_output_buffer_is_ordered_with_the_default_stream(tmp_path):
+    """The reference launches on the default stream, so its caller reads `output` right after Render() (src/main.cpp:139-143).
+    The context's stream is a blocking stream: the same caller, with no synchronisation call, gets the finished tonemapped
+    frame - bit for bit the oracle's Output."""
+    exe = build(tmp_path)
+    out_bin = str(tmp_path / "out.bin")
+    spp = 6
+    out = subprocess.run([exe, SCENE, str(spp), out_bin, "output"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    got = np.fromfile(out_bin, dtype=np.float32)
+    scene, meta = ol.load_cornell(8)
+    cam = ol.cornell_camera(meta, 512, 512)
+    _, _, ref = ol.render(scene, cam, 512, 512, 0.001, 1, spp, want_out=True)
+    assert ref.max() > 0.5 and got.tobytes() == ref.tobytes()
 
 
 @pytest.mark.gpu

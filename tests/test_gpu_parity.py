@@ -743,7 +743,9 @@ def test_volpath_two_kernels_agree(gpt, monkeypatch):
     with gpt.Renderer(scene.desc, W, H, eps) as r:
         r.render(cam, 1, spp, reset=True)
         assert_bit_exact(r.read_accum(), ref, "three-ray kernel")
-        monkeypatch.setenv("GPT_VPT_WALK", "1")
+        assert r.get_option("walk_kernel_active") == 0
+        r.set_option("vpt_walk_kernel", 1)
+        assert r.get_option("walk_kernel_active") == 1
         r.render(cam, 1, spp, reset=True)
         assert_bit_exact(r.read_accum(), ref, "one-ray kernel")
 

@@ -22,7 +22,7 @@ W, H, spp = 96, 64, 3
 scene, meta = ol.load_cornell(5)
 cam = ol.cornell_camera(meta, W, H)
 acc, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, rank=rank, n_ranks=world, threads=2)
-own = gd.tile_owner_mask(W, H, rank, world).reshape(-1)
+own = gd.film_owner_mask(W, H, rank, world)
 assert not acc.reshape(-1, 3)[~own].any(), "a rank wrote outside its tiles"
 t = torch.from_numpy(acc.copy())
 gd.reduce_framebuffer(t, dist, root=0)
@@ -58,6 +58,22 @@ def test_two_rank_gloo_reduce_equals_single_rank(tmp_path):
     cam = ol.cornell_camera(meta, W, H)
     full, _ = ol.render(scene, cam, W, H, 0.001, 1, spp)
     assert np.load(out).tobytes() == full.tobytes()
+
+
+def test_film_mask_follows_the_buffer_layout_for_widths_that_are_not_multiples_of_32():
+    """pixel slot = x + y * stride, stride = 32*(W/32) (the reference's index, pathtracer.cu:881-883): the oracle's film for a
+    100-pixel-wide frame has its samples exactly on the slots the flat mask names."""
+    W, H = 100, 70
+    scene, meta = ol.load_cornell(3)
+    cam = ol.cornell_camera(meta, W, H)
+    lit = np.zeros(W * H, dtype=bool)
+    for rank in range(2):
+        acc, _ = ol.render(scene, cam, W, H, 0.001, 1, 2, rank=rank, n_ranks=2, threads=2)
+        own = gd.film_owner_mask(W, H, rank, 2)
+        px = acc.reshape(-1, 3)
+        assert not px[~own].any(), "a rank wrote outside the slots of its tiles"
+        lit |= px.any(axis=1)
+    assert lit.sum() > 0.5 * 96 * 68 and not lit[96 * 68:].any()
 
 
 def test_tile_masks_partition_the_launch_region():

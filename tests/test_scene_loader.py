@@ -281,12 +281,13 @@ def test_exr_writer_roundtrip_through_the_reader(scene_dir):
     assert np.array_equal(data, film[::-1].astype(np.float16).astype(np.float32))          # top-down, half precision
 
 
-def test_bvh_cache_roundtrip_and_staleness(scene_dir, monkeypatch):
+def test_bvh_cache_roundtrip_and_staleness(scene_dir):
     """bvh.cache in the reference's layout (src/bvh.cpp:189-218) + a content hash: reused when the primitives
     match, rebuilt when the scene changed (the reference silently reuses a stale cache)."""
-    monkeypatch.setenv("GPT_BVH_CACHE", "1")
     path = str(scene_dir / "scene.json")
-    a = api.LoadedScene(path)
+    api.LoadedScene(path)
+    assert not (scene_dir / "bvh.cache").exists()               # opt-in: a plain load never touches the scene directory
+    a = api.LoadedScene(path, use_bvh_cache=True)
     cache = scene_dir / "bvh.cache"
     assert cache.exists()
     raw = cache.read_bytes()
@@ -294,19 +295,19 @@ def test_bvh_cache_roundtrip_and_staleness(scene_dir, monkeypatch):
     assert (n_nodes, n_prims) == (27, 36) and len(raw) == 32 + 36 * 176 + 27 * 40 + 8
     prims_a = a.array("prims", "n_prims", st.PRIMITIVE).tobytes()
     mtime = cache.stat().st_mtime_ns
-    b = api.LoadedScene(path)                                   # second load: served from the cache
+    b = api.LoadedScene(path, use_bvh_cache=True)               # second load: served from the cache
     assert cache.stat().st_mtime_ns == mtime
     assert b.array("prims", "n_prims", st.PRIMITIVE).tobytes() == prims_a
     assert b.desc.n_nodes == 27
     # change the geometry: the stale cache must not be used
     obj = (scene_dir / "geometry" / "tall.obj").read_text().replace("v 0.", "v 0.1", 1)
     (scene_dir / "geometry" / "tall.obj").write_text(obj)
-    c = api.LoadedScene(path)
+    c = api.LoadedScene(path, use_bvh_cache=True)
     assert c.array("prims", "n_prims", st.PRIMITIVE).tobytes() != prims_a
     assert cache.read_bytes() != raw                             # rewritten for the new primitives
     # a cache written by the reference has no trailing hash: accepted when the primitive count matches
     cache.write_bytes(cache.read_bytes()[:-8])
-    d = api.LoadedScene(path)
+    d = api.LoadedScene(path, use_bvh_cache=True)
     assert d.desc.n_nodes == c.desc.n_nodes
 
 
@@ -334,6 +335,77 @@ def test_loader_errors(tmp_path, scene_dir):
     with pytest.raises(api.GptError) as e:
         api.LoadedScene(str(scene_dir / "scene.json"))
     assert "sphere" in str(e.value)
+
+
+def test_crafted_image_files_are_refused_not_overrun(scene_dir):
+    """The decoders are hand-written: a short IHDR, an IDAT / ZIP block that inflates far beyond the image, a 64-bit block
+    offset near 2^64 and an absurd dataWindow must all come back as load errors (no out-of-bounds read, no memory blow-up)."""
+    def png(ihdr, idat):
+        def chunk(t, b):
+            return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+    js0 = json.load(open(scene_dir / "scene.json"))
+
+    def load_with_texture(name):
+        js = json.loads(json.dumps(js0))
+        js["material"].append({"name": "tex", "bsdf": "lambertian", "diffuse": name})
+        js["scene"][0]["material"] = "tex"
+        json.dump(js, open(scene_dir / "scene.json", "w"))
+        return api.LoadedScene(str(scene_dir / "scene.json"))
+
+    good = struct.pack(">IIBBBBB", 4, 4, 8, 6, 0, 0, 0)
+    rows = b"".join(b"\x00" + bytes(16) for _ in range(4))
+    open(scene_dir / "ok.png", "wb").write(png(good, zlib.compress(rows)))
+    assert load_with_texture("ok.png").desc.n_textures == 1
+    open(scene_dir / "short_ihdr.png", "wb").write(png(good[:8], zlib.compress(rows)) + bytes(16))
+    open(scene_dir / "bomb.png", "wb").write(png(good, zlib.compress(bytes(64 << 20), 9)))      # 64 MiB from 64 KiB
+    for name in ("short_ihdr.png", "bomb.png"):
+        with pytest.raises(api.GptError):
+            load_with_texture(name)
+
+    def load_with_env(name):
+        js = json.loads(json.dumps(js0))
+        js["light"].append({"infinite": name})
+        json.dump(js, open(scene_dir / "scene.json", "w"))
+        return api.LoadedScene(str(scene_dir / "scene.json"))
+
+    env = scenes.sky_env(8, 4)
+    write_exr(str(scene_dir / "ok.exr"), env, 3, 2)
+    assert load_with_env("ok.exr").desc.n_light_distribution == 4
+    raw = bytearray(open(scene_dir / "ok.exr", "rb").read())
+    table = None
+    # the single 16-line ZIP block: its offset is the only table entry; find it by value
+    for pos in range(len(raw) - 8):
+        if struct.unpack_from("<Q", raw, pos)[0] == pos + 8:
+            table = pos
+            break
+    assert table is not None
+    bad = bytearray(raw)
+    struct.pack_into("<Q", bad, table, 2 ** 64 - 4)                  # off + 8 wraps around
+    open(scene_dir / "wrap.exr", "wb").write(bad)
+    bad = bytearray(raw)
+    block = table + 8
+    comp = zlib.compress(bytes(64 << 20), 9)                          # a ZIP block that inflates to 64 MiB
+    bad[block + 4:] = struct.pack("<i", len(comp)) + comp
+    open(scene_dir / "bomb.exr", "wb").write(bad)
+    bad = bytearray(raw)
+    dw = bad.rindex(b"dataWindow\x00box2i\x00") + len(b"dataWindow\x00box2i\x00") + 4
+    struct.pack_into("<iiii", bad, dw, -2 ** 31, -2 ** 31, 2 ** 31 - 1, 2 ** 31 - 1)
+    open(scene_dir / "window.exr", "wb").write(bad)
+    for name in ("wrap.exr", "bomb.exr", "window.exr"):
+        with pytest.raises(api.GptError):
+            load_with_env(name)
+
+    # a vertex that is not finite: the reference's bucket index would be undefined (bvh.cpp:77)
+    prims = np.zeros(5, dtype=st.PRIMITIVE)
+    prims["triangle"]["v1"]["v"]["x"] = np.arange(5)
+    prims["triangle"]["v2"]["v"]["y"] = 1
+    prims["triangle"]["v3"]["v"]["z"] = 1
+    api.bvh_build(prims)
+    prims["triangle"]["v3"]["v"]["z"][3] = np.inf
+    with pytest.raises(api.GptError) as e:
+        api.bvh_build(prims)
+    assert "non-finite" in str(e.value)
 
 
 def test_shipped_vpt_scene_settings(scene_dir):

@@ -8,6 +8,7 @@ from gpu_pathtracer_amd import api, host
 W, H, D = 1920, 1080, 8
 scene, meta = host.load_baked(os.path.join(%r, "tests", "golden", "cornell_pt.npz"), D)
 cam = host.camera_from_meta(meta, W, H)
+if sys.argv[1] != "auto": api.DEFAULT_OPTIONS["chunk_iters"] = int(sys.argv[1])
 out = {}
 for label, rank, n in (("full", 0, 1), ("shard0of8", 0, 8), ("shard5of8", 5, 8)):
     r = api.Renderer(scene.desc, W, H, 0.001)
@@ -24,9 +25,7 @@ print(json.dumps(out))
 ''' % (ROOT, ROOT)
 ref = None
 for c in sys.argv[1:]:
-    env = dict(os.environ)
-    if c != "auto": env["GPT_CHUNK_ITERS"] = c
-    o = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+    o = subprocess.run([sys.executable, "-c", CHILD, c], capture_output=True, text=True)
     try:
         d = json.loads(o.stdout.strip().splitlines()[-1])
     except Exception:

@@ -83,10 +83,8 @@ while time.time() < t_end:
         ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
     finally:
         lib.oracle_set_traversal(0)
-    if force_global: os.environ["GPT_NO_LDS_SCENE"] = "1"
-    else: os.environ.pop("GPT_NO_LDS_SCENE", None)
-    if force_walk: os.environ["GPT_VPT_WALK"] = "1"
-    else: os.environ.pop("GPT_VPT_WALK", None)
+    api.DEFAULT_OPTIONS["lds_scene"] = 0 if force_global else 1
+    api.DEFAULT_OPTIONS["vpt_walk_kernel"] = 1 if force_walk else 0
     with api.Renderer(scene.desc, W, H, eps) as r:
         r.set_traversal_order(near)
         if rng.random() < 0.5:

@@ -9,16 +9,15 @@ import test_gpu_parity as tg
 from gpu_pathtracer_amd import api, scene_types as st
 
 
-def timed(name, scene, cam, W, H, spp, env=None):
-    if env: os.environ[env] = "1"
+def timed(name, scene, cam, W, H, spp, opt=None):
     with api.Renderer(scene.desc, W, H, 0.001) as r:
+        if opt: r.set_option(opt, 1)
         r.render(cam, 1, 2, reset=True); r.synchronize()
         best = 1e9
         for rep in range(2):
             r.kernel_time_reset(); r.render(cam, 1, spp, reset=True); r.synchronize()
             best = min(best, r.kernel_time()[1])
         acc = r.read_accum()
-    if env: del os.environ[env]
     print(f"{name}: {W}x{H} {spp} spp: {best:.1f} ms -> {W*H*spp/best/1e3:.1f} Msamples/s, mean radiance {acc.reshape(-1,3).mean(0)/spp}", flush=True)
 
 
@@ -30,7 +29,7 @@ W, H = 1920, 1080
 cam = ol.cornell_camera(meta, W, H)
 cam.medium = 0
 timed("fog cornell, three-ray kernel", scene, cam, W, H, 64)
-timed("fog cornell, one-ray kernel (forced)", scene, cam, W, H, 64, env="GPT_VPT_WALK")
+timed("fog cornell, one-ray kernel (forced)", scene, cam, W, H, 64, opt="vpt_walk_kernel")
 scene.desc.set_integrator("pt", 8)
 timed("same scene, Path (media ignored)", scene, cam, W, H, 64)
 
