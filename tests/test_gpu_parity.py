@@ -114,6 +114,34 @@ def test_cornell_matches_reference_golden_values(gpt):
     assert np.allclose(mean, gold["mean"], rtol=2e-5)
 
 
+def test_north_star_tolerance_at_1024_spp_against_the_pinned_oracle(gpt):
+    """north_star: "output radiance must match the reference on identical scene + seed within 1e-4 relative per-channel RMS",
+    at the sample count and depth it names (1024 spp, 8 bounces).  The build of the oracle that is pinned to the reference's
+    numbers is the glibc one: its 256 x 256 / 1024 spp / depth 8 frame mean equals the survey's value from the reference's own
+    code to all nine printed digits (checked here again).  The GPU (soft-math sin / cos) against THAT film: per-channel
+    relative RMS ~1e-6 - the measured size of "same algorithm, last-bit different transcendentals" - against the bar of 1e-4,
+    and the frame mean equal to the survey's to 2e-7 relative.  (Against the soft-math oracle the GPU film is bit-identical:
+    test_cornell_bit_exact.)"""
+    import json
+    gold = json.load(open(os.path.join(ol.GOLDEN, "survey_appendix_b.json")))["radiance_256_1024spp_depth8_mean"]
+    lib = ol.load("libm")
+    scene, meta = ol.load_cornell(8, lib)
+    W = H = 256
+    spp = 1024
+    cam = ol.cornell_camera(meta, W, H, lib)
+    ref, _ = ol.render(scene, cam, W, H, meta["epsilon"], 1, spp, kind="libm", threads=min(64, os.cpu_count() or 1))
+    ref_mean = (ref.reshape(-1, 3) / np.float32(spp)).astype(np.float64).mean(0)
+    assert [float(f"{x:.9g}") for x in ref_mean] == gold
+    with gpt.Renderer(scene.desc, W, H, meta["epsilon"]) as r:
+        r.render(cam, 1, spp, reset=True)
+        got = r.read_accum()
+    rms = rel_rms(got, ref)
+    mean = (got.reshape(-1, 3) / np.float32(spp)).astype(np.float64).mean(0)
+    print("GPU vs libm oracle, 256x256 1024 spp depth 8: relative RMS per channel", rms, "frame mean", mean, "survey", gold)
+    assert (rms <= RMS_TOL).all(), rms
+    assert np.allclose(mean, gold, rtol=2e-7, atol=0), (mean, gold)
+
+
 def test_frame_not_multiple_of_tile(gpt):
     """pixel = x + y*32*(W/32); rows = 4*(H/4) (reference src/pathtracer.cu:881-883,2709)"""
     scene, meta = ol.load_cornell(4)
@@ -701,13 +729,19 @@ def test_volpath_shipped_scene_shape_full_size(gpt):
 
 
 def test_volpath_gpu_film_against_the_reference_render(gpt, tmp_path):
-    """End to end on the GPU: the reference's default scene (rebuilt on disk by scenes.write_smoke_scene; it loads to the
-    same scene as the shipped file, tests/test_scene_loader.py) through LoadScene and the one-ray-at-a-time kernel, 16 spp:
-    the film equals the oracle's bit for bit, and - tone-mapped, flipped and truncated like the reference's PNG writer - it
-    lands on the reference's own published render of that scene (result/heterogeneous.png, kept box-filtered as
-    tests/golden/reference_heterogeneous_64.npy) up to Monte-Carlo noise: frame means within 0.008, 64 x 64 blocks within
-    0.008 on average."""
-    want = np.load(os.path.join(ol.ROOT, "tests", "golden", "reference_heterogeneous_64.npy")).astype(np.float64)
+    """End to end on the GPU against an output of the reference itself: the reference's default scene (rebuilt on disk by
+    scenes.write_smoke_scene; it loads to the same scene as the shipped file, tests/test_scene_loader.py) through LoadScene and
+    the one-ray-at-a-time Volpath kernel.  At 16 spp the film equals the oracle's bit for bit; at 1024 spp (268 M samples,
+    the same kernel continuing the same film) it is pushed through Output's filmic curve and the PNG writer's flip and 8-bit
+    truncation and has to land on result/heterogeneous.png (tests/golden/reference_heterogeneous_64.npy: the published picture
+    in 64 x 64 blocks): every channel's frame mean within 0.001 of 1 (measured 0.0002), blocks within 0.002 on average
+    (0.0009), no block further off than 0.02 (0.009).  What these bounds can tell apart is measured in
+    profiles/r02/reference_image_pin.txt (tools/gpu_reference_image_pin.py): extinction x 0.8 or x 1.25, albedo 0.8 instead of
+    0.9, g = 0.3, maxDepth 9 instead of 17, a grid shifted by 0.03, light radiance x 0.9 and Path instead of Volpath each fail
+    the frame-mean bound alone by factors of 1.1 - 26 and the block bounds by more; swapping ratio tracking for delta tracking
+    (both unbiased) does not, as it must not."""
+    import refimg
+    want = refimg.load("reference_heterogeneous_64.npy")
     ls = gpt.LoadedScene(scenes.write_smoke_scene(str(tmp_path / "smoke")))
     W, H, spp = ls.width, ls.height, 16
     assert (W, H) == (512, 512) and ls.desc.n_mediums == 2
@@ -716,17 +750,36 @@ def test_volpath_gpu_film_against_the_reference_render(gpt, tmp_path):
     ref, _ = ol.render(ls, cam, W, H, ls.epsilon, 1, spp, kind="soft")
     with gpt.Renderer(ls.desc, W, H, ls.epsilon) as r:
         r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "shipped smoke scene")
+        long_spp = 1024
+        r.render(cam, spp + 1, long_spp - spp, reset=False)
         acc = r.read_accum()
-    assert_bit_exact(acc, ref, "shipped smoke scene")
-    lin = acc.reshape(H, W, 3).astype(np.float64) / spp
-    c = np.maximum(0.0, lin - 0.004)
-    img = (c * (6.2 * c + 0.5)) / (c * (6.2 * c + 1.7) + 0.06)               # FilmicTonemapping, pathtracer.cu:199-204
-    img = np.floor(np.clip(img, 0.0, 1.0) * 255.0) / 255.0
-    got = img[::-1].reshape(64, 8, 64, 8, 3).mean(axis=(1, 3))
-    d = np.abs(got - want)
-    assert np.abs(got.mean(axis=(0, 1)) - want.mean(axis=(0, 1))).max() < 0.008, (got.mean(axis=(0, 1)), want.mean(axis=(0, 1)))
-    assert d.mean() < 0.008 and d.max() < 0.08, (d.mean(), d.max())
+    m, bm, bx, means = refimg.compare(acc, long_spp, W, H, want)
+    print("heterogeneous.png: frame-mean diff", m, "block mean", bm, "block max", bx, "frame means", means, want.mean(axis=(0, 1)))
+    assert m < 0.001 and bm < 0.002 and bx < 0.02, (m, bm, bx)
     ls.close()
+
+
+def test_path_gpu_film_against_the_reference_depth_of_field_render(gpt):
+    """Path on the scene of BASELINE configs 1 / 2 against an output of the reference itself: result/cornell_dof.png is the
+    Cornell box with both boxes through the thin-lens camera (tests/test_oracle_golden.py says how its two lens parameters
+    were identified: the shipped json's focalDistance 7.0, apertureRadius 0.5).  256 spp equal the oracle's film bit for bit;
+    4096 spp of the same film, tone-mapped / flipped / truncated like SavePng, land on the published picture: frame means
+    within 0.002 of 1 (measured 0.0013), 64 x 63 blocks within 0.003 on average (0.0013) and 0.03 at worst (0.008).  A pinhole camera, a focal distance of 6.5, maxDepth 5 or a
+    light 10 % dimmer do not (profiles/r02/cornell_dof_pin.txt)."""
+    import test_oracle_golden as tg
+    scene, meta = ol.load_cornell(tg.DOF["depth"])
+    cam = tg.dof_camera(meta)
+    W = H = 512
+    with gpt.Renderer(scene.desc, W, H, meta["epsilon"]) as r:
+        r.render(cam, 1, 8, reset=True)
+        ref, _ = ol.render(scene, cam, W, H, meta["epsilon"], 1, 8, kind="soft")
+        assert_bit_exact(r.read_accum(), ref, "cornell through the thin lens")
+        r.render(cam, 9, 4096 - 8, reset=False)
+        acc = r.read_accum()
+    m, bm, bx = tg.dof_compare(acc, 4096)
+    print("cornell_dof.png: frame-mean diff", m, "block mean", bm, "block max", bx)
+    assert m < 0.002 and bm < 0.003 and bx < 0.03, (m, bm, bx)
 
 
 def test_volpath_two_kernels_agree(gpt, monkeypatch):

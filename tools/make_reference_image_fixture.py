@@ -1,4 +1,5 @@
-"""tests/golden/reference_heterogeneous_64.npy: the reference's own published render of its default scene
+"""tests/golden/reference_{heterogeneous,cornell_dof,volume_caustic}_64.npy: renders the reference's author published
+(result/*.png), box-filtered to 64x64.  reference_heterogeneous_64.npy: the reference's own published render of its default scene
 (/root/reference/result/heterogeneous.png = scenes/cornell_box/scene.json: Volpath, 17 bounces, 100x100x40 density grid
 inside a material-less box), box-filtered from 512x512 to 64x64 (float32 in [0,1], row 0 = top of the image).
 An output of the reference, kept as data; tests/test_oracle_golden.py renders the same scene file with the oracle and
@@ -56,14 +57,21 @@ def read_png_rgb8(path):
     return img.reshape(h, w, ch)[:, :, :3].astype(np.uint8)
 
 
-if __name__ == "__main__":
-    src = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/result/heterogeneous.png"
-    img = read_png_rgb8(src).astype(np.float64) / 255.0
+def box_filtered(name):
+    img = read_png_rgb8("/root/reference/result/%s.png" % name).astype(np.float64) / 255.0
     assert img.shape == (512, 512, 3)
     small = img.reshape(64, 8, 64, 8, 3).mean(axis=(1, 3)).astype(np.float32)
-    out = os.path.join(ROOT, "tests", "golden", "reference_heterogeneous_64.npy")
+    out = os.path.join(ROOT, "tests", "golden", "reference_%s_64.npy" % name)
     np.save(out, small)
     print("wrote", out, small.shape, "channel means", small.mean(axis=(0, 1)))
+
+
+if __name__ == "__main__":
+    box_filtered("heterogeneous")
+    # result/cornell_dof.png: the Cornell box with its two boxes (the geometry of BASELINE config 1 / 2) through the
+    # thin-lens camera; result/volume_caustic.png: scenes/cornell_box/vol_caustic.json (a glass sphere in a scattering gas)
+    box_filtered("cornell_dof")
+    box_filtered("volume_caustic")
     d = np.loadtxt("/root/reference/scenes/cornell_box/geometry/density.d", dtype=np.float64)
     q = np.round(d * 1e6).astype(np.int32)
     assert q.size == 100 * 100 * 40 and np.abs(q / 1e6 - d).max() < 1e-9
