@@ -481,6 +481,66 @@ def test_config5_stress_scene_4k(gpt):
     full_size_properties(gpt, scene, cam, W, H, 0.001, 1, 1024, 411)
 
 
+# ---- the BASELINE config 3-5 stand-ins SURVEY.md 8(d) defines from the reference's shipped meshes --------------------------
+
+@pytest.fixture(scope="module")
+def standin(gpt, tmp_path_factory):
+    """name -> LoadedScene: the stand-in's scene directory is written from tests/golden/meshes.npz and read back through the
+    product loader (OBJ reader, smooth normals for the meshes without vn, TRS, BVH build), like a scene of the reference"""
+    cache = {}
+
+    def get(which):
+        if which not in cache:
+            cache[which] = gpt.LoadedScene(scenes.write_standin_scene(str(tmp_path_factory.mktemp(which)), which))
+        return cache[which]
+    yield get
+    for ls in cache.values():
+        ls.close()
+
+
+def test_config3_standin_shaderball_full_hd(gpt, standin):
+    """BASELINE config 3 as SURVEY.md 8(d) restates it: sphere.obj x 3 + cube-subdiv.obj (no vn: generated normals) on the floor
+    under the shaderball camera and light, materials LTELogo / Outer (anisotropic, remapped) / Glass / Plastic_Black /
+    checker texture; 1920 x 1080, depth 10, epsilon 0.0005."""
+    ls = standin("c3")
+    assert (ls.width, ls.height) == (1920, 1080) and ls.desc.n_prims == 27270
+    full = full_size_properties(gpt, ls, ls.camera, ls.width, ls.height, ls.epsilon, 2, 128, 37)
+    assert (full.reshape(1080, 1920, 3).sum(-1) > 0).mean() > 0.5
+
+
+def test_config4_standin_environment_light_full_hd(gpt, standin):
+    """BASELINE config 4 as SURVEY.md 8(d) restates it: the config-5 geometry (dragon, bunny2, teapot, 9 spheres in the Cornell
+    walls: 248 572 triangles) without the area light under a procedural 1024 x 512 sky with an explicit rotation; depth 7;
+    the frame is the sum of its tile shards (what the framebuffer reduce adds up)."""
+    ls = standin("c4")
+    assert ls.desc.n_prims == 248572 and ls.desc.n_lights == 0
+    full_size_properties(gpt, ls, ls.camera, ls.width, ls.height, ls.epsilon, 1, 256, 90)
+
+
+def test_config5_standin_dragon_bunny_teapot_4k(gpt, standin):
+    """BASELINE config 5 as SURVEY.md 8(d) restates it: Cornell walls + dragon.obj (100 000 triangles) + bunny2.obj (69 666) +
+    teapot.obj (6 320) + light (the 175 998-primitive / 112 947-node tree of the survey, tests/test_standins.py) padded with 9
+    instances of sphere.obj to 248 574 triangles; 3840 x 2160, 16 bounces."""
+    ls = standin("c5")
+    assert (ls.width, ls.height, ls.desc.max_depth) == (3840, 2160, 16) and ls.desc.n_prims == 248574
+    full_size_properties(gpt, ls, ls.camera, ls.width, ls.height, ls.epsilon, 1, 1024, 411)
+
+
+def test_config5_standin_near_first_and_small_frame(gpt, standin):
+    """The same scene at 480 x 270, 4 spp, whole frame against the oracle, in the reference's traversal order and nearer-child-first."""
+    ls = standin("c5")
+    W, H, spp = 480, 272, 4
+    cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)
+    ref, _ = ol.render(ls, cam, W, H, ls.epsilon, 1, spp, kind="soft", threads=min(64, os.cpu_count() or 1))
+    with gpt.Renderer(ls.desc, W, H, ls.epsilon) as r:
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "config 5 stand-in")
+        r.set_traversal_order(True)
+        r.render(cam, 1, spp, reset=True)
+        near = r.read_accum()
+    assert (rel_rms(near, ref) <= RMS_TOL).all()
+
+
 # ---- edge cases -----------------------------------------------------------------------------------------
 
 def test_edge_cases_empty_scene_tiny_frames_single_triangle(gpt):

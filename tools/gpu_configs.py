@@ -38,6 +38,17 @@ cam = ol.make_camera((0.3, 1.4, 5.5), (0, 0.8, 0), (0, 1, 0), (1920, 1080), 35.0
 for near in (False, True):
     print("config 4  env-lit 22k triangles 1080p d7 %s: %7.1f Msamples/s (%.1f ms / 32 iterations) finite=%s" % ((("near" if near else "    "),) + timed(s4.desc, cam, 1920, 1080, 0.001, 32, near)), flush=True)
 
+# ---- the stand-ins SURVEY.md 8(d) defines from the reference's shipped meshes, through the product loader
+import tempfile
+for which, label, spp in (("c3", "config 3  SURVEY stand-in: 3 spheres + cube-subdiv, shaderball camera/materials, 1080p d10", 32),
+                          ("c4", "config 4  SURVEY stand-in: config-5 geometry under a procedural sky, 1080p d7             ", 32),
+                          ("c5", "config 5  SURVEY stand-in: walls + dragon + bunny2 + teapot + 9 spheres (248 574), 4K d16 ", 8)):
+    ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which))
+    for near in (False, True):
+        print("%s %s: %7.1f Msamples/s (%.1f ms / %d iterations) finite=%s" % ((label, "near" if near else "    ") + timed(ls.desc, ls.camera, ls.width, ls.height, ls.epsilon, spp, near)[:2] + (spp, True)), flush=True)
+    ls.close()
+
+print("# the procedural stand-ins of round 1 (parametric blobs), for comparison")
 s5, meta5 = scenes.stress_scene(1.0, max_depth=16)
 cam = ol.cornell_camera(meta5, 3840, 2160)
 for near in (False, True):

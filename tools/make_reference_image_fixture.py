@@ -1,4 +1,4 @@
-"""tests/golden/reference_{heterogeneous,cornell_dof,volume_caustic}_64.npy: renders the reference's author published
+"""tests/golden/reference_{heterogeneous,cornell_dof}_64.npy: renders the reference's author published
 (result/*.png), box-filtered to 64x64.  reference_heterogeneous_64.npy: the reference's own published render of its default scene
 (/root/reference/result/heterogeneous.png = scenes/cornell_box/scene.json: Volpath, 17 bounces, 100x100x40 density grid
 inside a material-less box), box-filtered from 512x512 to 64x64 (float32 in [0,1], row 0 = top of the image).
@@ -69,9 +69,9 @@ def box_filtered(name):
 if __name__ == "__main__":
     box_filtered("heterogeneous")
     # result/cornell_dof.png: the Cornell box with its two boxes (the geometry of BASELINE config 1 / 2) through the
-    # thin-lens camera; result/volume_caustic.png: scenes/cornell_box/vol_caustic.json (a glass sphere in a scattering gas)
+    # thin-lens camera.  (result/volume_caustic.png does not match the shipped vol_caustic.json - that file's light mesh is
+    # 5 x 4 mm, the picture's is the Cornell light - so it cannot serve as a pin.)
     box_filtered("cornell_dof")
-    box_filtered("volume_caustic")
     d = np.loadtxt("/root/reference/scenes/cornell_box/geometry/density.d", dtype=np.float64)
     q = np.round(d * 1e6).astype(np.int32)
     assert q.size == 100 * 100 * 40 and np.abs(q / 1e6 - d).max() < 1e-9
