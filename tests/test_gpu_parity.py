@@ -503,7 +503,7 @@ def test_config3_standin_shaderball_full_hd(gpt, standin):
     under the shaderball camera and light, materials LTELogo / Outer (anisotropic, remapped) / Glass / Plastic_Black /
     checker texture; 1920 x 1080, depth 10, epsilon 0.0005."""
     ls = standin("c3")
-    assert (ls.width, ls.height) == (1920, 1080) and ls.desc.n_prims == 27270
+    assert (ls.width, ls.height) == (1920, 1080) and ls.desc.n_prims == 27268
     full = full_size_properties(gpt, ls, ls.camera, ls.width, ls.height, ls.epsilon, 2, 128, 37)
     assert (full.reshape(1080, 1920, 3).sum(-1) > 0).mean() > 0.5
 
