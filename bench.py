@@ -2,21 +2,37 @@
 """Headline benchmark: Msamples/s of the path-tracing hot path on the BASELINE.json configuration.
 
 Workload (config.workload): BASELINE.json configs[1] — cornell_box, 1920x1080, 8 bounces, area light + MIS,
-1024 spp — rendered as K steps of SPP_PER_STEP iterations (default 16 x 64 = 1024 spp).  A "step" is one
-gpt_render() call = one launch of the path kernel over the whole frame for SPP_PER_STEP iterations.
-Inputs (scene, camera, film) are resident in HBM before the timed region starts.
+1024 spp — rendered as K steps of SPP_PER_STEP iterations (default 16 x 64 = 1024 spp).  A "step" is SPP_PER_STEP
+iterations of the path kernel over the whole frame.  Inputs (scene, camera, film) are resident in HBM before the timed
+region starts.
 
 N GPUs (launched by torch.distributed.run, one rank per GPU): every rank holds the whole scene, owns the 8x8
 pixel tiles t with t % N == rank, and the timed region ends with ONE RCCL sum-reduce of the float3 accumulator
-to rank 0 (disjoint supports, so the result is bit-identical to 1 GPU).  Total work is fixed as N grows
-("strong").
+to rank 0 (disjoint supports, so the result is bit-identical to 1 GPU), issued by the library itself (gpt_reduce_film).
+Total work is fixed as N grows ("strong").
 
-Prints one JSON line on rank 0.  Nothing here reads /root/reference.
+What the JSON line carries besides the contract's fields (rank 0, N = 1):
+  roofline      the bound of the dominant kernel on this workload is VALU issue (the 7.4 KB scene lives in LDS), so the
+                headline fraction is wave64 VALU instructions per second against 1024 SIMDs x 2.4 GHz / 2 cycles
+                (/opt/skills/guides/MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc").  The instruction count is MEASURED IN
+                THIS RUN: bench.py re-runs one launch of the same binary under `rocprofv3 --pmc` (counters in their own
+                passes, --kernel-trace only).  roofline.hbm keeps the HBM picture: SURVEY.md 8(d)'s algorithmic bytes (of
+                the reference's algorithm and of this kernel's own ray counts), the counter-measured traffic and its
+                fraction of the 8 TB/s peak.
+  cpu_baseline  the oracle (CPU restatement) on one host core, bounded sample; host CPU model and core count.
+  parity        GPU film against the pinned (glibc) oracle at 256x256 / 1024 spp / depth 8: per-channel relative RMS.
+Nothing here reads /root/reference.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +41,8 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, MAX_DEPTH, EPS = 1920, 1080, 8, 0.001
 SPP_PER_STEP = 64
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2.0   # 256 CUs x 4 SIMDs, max clock, cycles per wave64 VALU instruction (same guide)
+KERNEL = "pt_render_kernel<false, true, 1>"        # counting off, scene staged in LDS, Path integrator
 
 
 def algorithmic_bytes_per_sample(c):
@@ -41,6 +59,18 @@ def algorithmic_bytes_per_sample(c):
 B_ALG_CONFIG2 = 11917.5
 
 
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the same algorithm, same BVH) on ONE host core, bounded sample.
     Its work counters are the reference algorithm's N_node/N_prim/N_bounce/N_shadow, i.e. the inputs of
@@ -49,14 +79,96 @@ def cpu_baseline():
     import oracle_lib as ol
     scene, meta = ol.load_cornell(MAX_DEPTH)
     cam = ol.cornell_camera(meta, WIDTH, HEIGHT)
-    spp = 2
+    spp = 8
     t = time.perf_counter()
     ol.render(scene, cam, WIDTH, HEIGHT, EPS, 1, spp, kind="soft", threads=1)
     dt = time.perf_counter() - t
     cpu_baseline.b_alg = algorithmic_bytes_per_sample(ol.counters("soft"))
+    model, cores = host_cpu()
     return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "host_cpu": model, "host_cores_total": cores,
             "sample": f"same scene/camera/frame, iterations 1-{spp} ({WIDTH * HEIGHT * spp} samples), "
                       f"oracle/liboracle_soft.so single thread, {dt:.1f} s"}
+
+
+def parity_check(api):
+    """north_star's tolerance at its own sample count: GPU film vs the pinned (glibc) oracle, Cornell 256x256, depth 8.
+    1024 spp when the host has the cores for it (67 M oracle samples), 128 spp otherwise.  The oracle is the checker."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    cores = os.cpu_count() or 1
+    spp = 1024 if cores >= 32 else 128
+    lib = ol.load("libm")
+    scene, meta = ol.load_cornell(MAX_DEPTH, lib)
+    cam = ol.cornell_camera(meta, 256, 256, lib)
+    t = time.perf_counter()
+    ref, _ = ol.render(scene, cam, 256, 256, EPS, 1, spp, kind="libm", threads=min(64, cores))
+    dt = time.perf_counter() - t
+    with api.Renderer(scene.desc, 256, 256, EPS) as r:
+        r.render(cam, 1, spp, reset=True)
+        got = r.read_accum()
+    a, b = got.reshape(-1, 3).astype(np.float64), ref.reshape(-1, 3).astype(np.float64)
+    rms = np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))
+    out = {"rms": [float(x) for x in rms], "tolerance": 1e-4, "ok": bool((rms <= 1e-4).all()),
+           "what": f"GPU film vs oracle/liboracle_libm.so, cornell 256x256, {spp} spp, depth 8, per-channel relative RMS "
+                   f"of the linear radiance (oracle {dt:.1f} s on {min(64, cores)} threads)",
+           "gpu_frame_mean": [float(x) for x in (a / spp).mean(0)]}
+    if spp == 1024:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "survey_appendix_b.json")))["radiance_256_1024spp_depth8_mean"]
+        out["oracle_mean_equals_survey_value"] = [float(f"{x:.9g}") for x in (b / spp).mean(0)] == gold
+    return out
+
+
+# ---- counters measured in this run -------------------------------------------------------------------------------------------
+
+def counter_child():
+    """Run under rocprofv3 by live_counters(): two launches of the headline kernel (64 iterations at 1080p each)."""
+    from gpu_pathtracer_amd import api, host
+    scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
+    cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
+    with api.Renderer(scene.desc, WIDTH, HEIGHT, EPS) as r:
+        r.render(cam, 1, SPP_PER_STEP, reset=True)
+        r.render(cam, SPP_PER_STEP + 1, SPP_PER_STEP, reset=False)
+        r.synchronize()
+
+
+def rocprof_pass(counters, workdir, tag):
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    out = os.path.join(workdir, tag)
+    env = dict(os.environ, TMPDIR=workdir)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", tag, "--",
+                                                          sys.executable, os.path.abspath(__file__), "--counter-child"]
+    p = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=600)
+    vals = {}
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "pt_render_kernel" in row.get("Kernel_Name", ""):
+                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    if not vals:
+        raise RuntimeError(f"rocprofv3 pass {tag} produced no counters (rc {p.returncode}): {p.stderr[-300:]}")
+    return {k: sum(v) / len(v) for k, v in vals.items()}, max(len(v) for v in vals.values())
+
+
+def live_counters():
+    """SQ instruction counters and the two HBM traffic counters of the headline kernel, each set in its own rocprofv3 pass
+    (TCC: FETCH_SIZE and WRITE_SIZE do not fit one pass; /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"), on
+    64-iteration launches of the same libgpt.so."""
+    work = tempfile.mkdtemp(prefix="gpt_pmc_")
+    try:
+        sq, n = rocprof_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU",
+                              "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"], work, "sq")
+        fetch, _ = rocprof_pass(["FETCH_SIZE"], work, "fetch")
+        write, _ = rocprof_pass(["WRITE_SIZE"], work, "write")
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    sq.update(fetch)
+    sq.update(write)
+    sq["launches_averaged"] = n
+    sq["iterations_per_launch"] = SPP_PER_STEP
+    return sq
 
 
 def main():
@@ -65,14 +177,20 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)       # 4 x 64 iterations = one full-size launch
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 passes (roofline fields that need them are null)")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.counter_child:
+        return counter_child()
 
     import numpy as np
     import torch
     from gpu_pathtracer_amd import api, host
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if os.environ.get("GPT_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    share_gpu = bool(os.environ.get("GPT_BENCH_SHARE_GPU"))       # every rank on GPU 0: functional check of the N-rank path on a 1-GPU box
+    local_rank = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -80,12 +198,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm.  GPT_BENCH_BACKEND=gloo + GPT_BENCH_SHARE_GPU=1 runs the same N-rank code
-        # path with every rank on GPU 0 (functional check on a 1-GPU box; RCCL refuses duplicate devices).
-        backend = os.environ.get("GPT_BENCH_BACKEND", "nccl")
+        # torch.distributed is the rendezvous (it carries the RCCL unique id to the ranks) and the barrier; the framebuffer
+        # reduce itself is issued by the library (gpt_reduce_film -> ncclReduce on the renderer's stream).  With
+        # GPT_BENCH_SHARE_GPU=1 (all ranks on GPU 0; RCCL refuses duplicate devices) the same code path runs over gloo.
+        backend = "gloo" if share_gpu else os.environ.get("GPT_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -94,15 +214,15 @@ def main():
     scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
     cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
     n_floats = WIDTH * HEIGHT * 3
-    # the film IS the reduce buffer: torch tensors bound as accumulator / last-sample planes
-    acc = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
-    col = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
     out = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
 
     r = api.Renderer(scene.desc, WIDTH, HEIGHT, EPS, device=local_rank)
-    r.bind_film(acc.data_ptr(), col.data_ptr())
     r.set_tile_owner(rank, world)
+    comm = None
+    if world > 1:
+        from gpu_pathtracer_amd import distributed as gd
+        comm = gd.FilmReducer(r, dist, rank, world, native=(backend == "nccl"))
 
     def barrier():
         r.synchronize()
@@ -114,13 +234,14 @@ def main():
         # K steps of SPP_PER_STEP iterations each, handed to the renderer in one call: it cuts them into launches of
         # up to 256 iterations (a launch has a fixed cost; the reference's one-iteration-per-Render is the other extreme)
         r.render(cam, 1, steps * SPP_PER_STEP, reset=True)
-        r.synchronize()
-        if dist is not None:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)     # the one collective: float3 framebuffer over xGMI
-            torch.cuda.synchronize()                           # the reduce runs on torch's streams, Output on ours
+        if comm is not None:
+            comm.reduce(root=0)                                 # the one collective: float3 framebuffer over xGMI
         if rank == 0:
-            r.tonemap(steps * SPP_PER_STEP, bool(cam.filmic), out.data_ptr())   # Output on the root
-            r.synchronize()
+            if comm is not None:
+                comm.tonemap_reduced(steps * SPP_PER_STEP, bool(cam.filmic), out.data_ptr())
+            else:
+                r.tonemap(steps * SPP_PER_STEP, bool(cam.filmic), out.data_ptr())   # Output
+        r.synchronize()
 
     if args.warmup > 0:
         job(args.warmup)
@@ -139,42 +260,88 @@ def main():
 
     samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
     if rank == 0:
-        img = acc.cpu().numpy().reshape(-1, 3) / np.float32(args.steps * SPP_PER_STEP)
+        acc_host = comm.read_reduced() if comm is not None else r.read_accum()
+        img = acc_host.reshape(-1, 3) / np.float32(args.steps * SPP_PER_STEP)
         finite = bool(np.isfinite(img).all())
-        import hashlib
-        frame_sha1 = hashlib.sha1(acc.cpu().numpy().tobytes()).hexdigest()[:16]
+        frame_sha1 = hashlib.sha1(acc_host.tobytes()).hexdigest()[:16]
+        lib_sha1 = hashlib.sha1(open(api.LIB_PATH, "rb").read()).hexdigest()[:16]
+        options = {k: r.get_option(k) for k in ("lds_scene", "lds_scene_active", "max_batch", "last_batch", "chunk_iters", "sample_plane_bytes")}
         cpu = None
         b_alg = B_ALG_CONFIG2
-        if world == 1 and not args.no_cpu_baseline:
+        single = world == 1
+        if single and not args.no_cpu_baseline:
             cpu = cpu_baseline()
             b_alg = cpu_baseline.b_alg      # algorithmic bytes of the reference algorithm on this workload
         # this rank's launches cover its own tiles: samples per launch on this rank
         samples_per_launch = samples / world / max(1, launches)
         avg_ms = kernel_ms / max(1, launches)
-        achieved = b_alg * samples_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+
+        # the kernel's OWN ray counts (it does not trace rays that provably cannot contribute): counting build, 2 iterations
+        b_alg_kernel = None
+        square = None
+        if single:
+            r.enable_counters(True)
+            r.render(cam, 1, 2, reset=True)
+            b_alg_kernel = algorithmic_bytes_per_sample(r.read_counters())
+            r.enable_counters(False)
+            # the camera is framed for a square image - at 16:9, 44 % of the primary rays miss the box and
+            # cost one traversal each.  The same scene at 1080 x 1080 (every pixel sees the box), same kernel:
+            sq_cam = host.camera_from_meta(meta, 1088, 1080)
+            with api.Renderer(scene.desc, 1088, 1080, EPS, device=local_rank) as rs:
+                rs.render(sq_cam, 1, 64, reset=True)
+                rs.synchronize()
+                rs.kernel_time_reset()
+                ts = time.perf_counter()
+                rs.render(sq_cam, 1, 256, reset=True)
+                rs.synchronize()
+                square = {"frame": "1088x1080 (square framing: every primary ray enters the box)", "spp": 256,
+                          "value": 1088 * 1080 * 256 / (time.perf_counter() - ts) / 1e6, "unit": "Msamples/s"}
+
+        live, live_err = None, None
+        if single and not args.no_counters:
             try:
-                rec = json.load(open(pmc))          # counters were taken on 256-iteration launches: scale to this run's
-                traffic = rec.get("hbm_bytes_per_launch") * (samples / world / max(1, launches)) / (WIDTH * HEIGHT * rec.get("iterations_per_launch", 256))
-            except Exception:
-                traffic = None
-        # the compute-side picture next to the (logical) HBM figure: wave-level VALU instructions issued per second
-        # against what 1024 SIMDs can issue (one fp32 wave64 instruction per ~2.43 cycles, measured with
-        # tools/micro/issue_rate.hip); instruction counts come from the committed SQ counter pass
-        valu = None
-        sq = os.path.join(ROOT, "profiles", "pmc_sq.json")
-        if os.path.exists(sq) and world == 1:
-            try:
-                rec = json.load(open(sq))
-                n_valu = rec.get("valu_insts_per_launch") * samples_per_launch / (WIDTH * HEIGHT * rec.get("iterations_per_launch", 256))
-                peak_issue = 1024 * 2.4e9 / 2.43
-                valu = {"insts_per_launch": n_valu, "achieved_per_s": n_valu / (avg_ms * 1e-3), "peak_per_s": peak_issue,
-                        "frac": n_valu / (avg_ms * 1e-3) / peak_issue,
-                        "active_lanes_of_64": json.load(open(sq)).get("active_lanes_per_valu_inst")}
-            except Exception:
-                valu = None
+                live = live_counters()
+            except Exception as e:          # rocprofv3 missing or refused: say so, print nulls
+                live_err = f"{type(e).__name__}: {e}"[:300]
+        per_sample = None
+        if live:
+            n_per_launch_samples = WIDTH * HEIGHT * live["iterations_per_launch"]
+            per_sample = {k: live[k] / n_per_launch_samples for k in live if k.startswith(("SQ_", "FETCH", "WRITE"))}
+        peak_issue = N_SIMD * CLOCK_HZ / VALU_CYCLES
+        roof = {"bound": "valu_issue", "achieved": None, "peak": peak_issue / 1e9, "unit": "G wave64-VALU-instructions/s", "frac": None,
+                "traffic": None, "kernel": f"pt::{KERNEL} (counting off, scene staged in LDS, Path integrator)",
+                "avg_launch_ms": avg_ms, "launches": launches,
+                "iterations_per_launch": args.steps * SPP_PER_STEP / max(1, launches), "samples_per_launch": samples_per_launch,
+                "peak_is": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
+                "counters": "rocprofv3 --pmc on 64-iteration launches of this libgpt.so, inside this run" if live else None,
+                "counters_error": live_err}
+        hbm = {"algorithmic_bytes_per_sample": b_alg, "algorithmic_bytes_per_sample_kernel_counts": b_alg_kernel,
+               "algorithmic_GBps": b_alg * samples_per_launch / (avg_ms * 1e-3) / 1e9,
+               "note": "algorithmic = reference-layout bytes of SURVEY.md 8(d): logical traffic; the 7.4 KB scene is LDS-resident, "
+                       "so it exceeds the 8 TB/s HBM peak by construction and is not a fraction of a physical roof",
+               "counter_traffic_bytes_per_launch": None, "counter_GBps": None, "frac_of_peak": None, "peak_GBps": HBM_PEAK_GBS}
+        if per_sample:
+            n_valu = per_sample["SQ_INSTS_VALU"] * samples_per_launch
+            lanes = live["SQ_THREAD_CYCLES_VALU"] / live["SQ_ACTIVE_INST_VALU"]
+            roof.update({"achieved": n_valu / (avg_ms * 1e-3) / 1e9, "frac": n_valu / (avg_ms * 1e-3) / peak_issue,
+                         "valu_insts_per_launch": n_valu, "valu_insts_per_sample_lane": per_sample["SQ_INSTS_VALU"] * 64,
+                         "salu_insts_per_launch": per_sample["SQ_INSTS_SALU"] * samples_per_launch,
+                         "lds_insts_per_launch": per_sample["SQ_INSTS_LDS"] * samples_per_launch,
+                         "active_lanes_of_64": lanes, "useful_frac": n_valu / (avg_ms * 1e-3) / peak_issue * lanes / 64.0,
+                         "wait_any_over_wave_cycles": live["SQ_WAIT_ANY"] / live["SQ_WAVE_CYCLES"],
+                         "wait_inst_any_over_wave_cycles": live["SQ_WAIT_INST_ANY"] / live["SQ_WAVE_CYCLES"]})
+            # HBM: FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md "HBM")
+            traffic = (2.0 * per_sample["FETCH_SIZE"] + per_sample["WRITE_SIZE"]) * 1024.0 * samples_per_launch
+            roof["traffic"] = traffic
+            hbm.update({"counter_traffic_bytes_per_launch": traffic, "counter_GBps": traffic / (avg_ms * 1e-3) / 1e9,
+                        "frac_of_peak": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "compulsory_bytes_per_launch": 16.0 * samples_per_launch,
+                        "fetch_KiB_raw_per_launch": per_sample["FETCH_SIZE"] * samples_per_launch,
+                        "write_KiB_per_launch": per_sample["WRITE_SIZE"] * samples_per_launch})
+        roof["hbm"] = hbm
+        par = None
+        if single and not args.no_parity:
+            par = parity_check(api)
         line = {
             "metric": "Msamples/s at 1920x1080, 8-bounce PT",
             "value": samples / dt_max / 1e6,
@@ -187,16 +354,17 @@ def main():
                                    f"{args.steps * SPP_PER_STEP} spp ({args.steps} steps x {SPP_PER_STEP} iterations)",
                        "scene": "cornell_pt (36 triangles, 27 BVH nodes)", "spp_per_step": SPP_PER_STEP,
                        "tiles": "8x8 pixels, tile % n_gpus == rank", "all_finite": finite,
-                       "accumulator_sha1": frame_sha1,
+                       "accumulator_sha1": frame_sha1, "libgpt_sha1": lib_sha1,
+                       "renderer_options": options, "options_set": dict(r.options_set),
+                       "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND") if os.environ.get(k)}),
+                       "reduce": (comm.kind if comm is not None else None),
+                       "square_frame": square,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pt::pt_render_kernel<false, true, 1> (counting off, scene staged in LDS, Path integrator)", "avg_launch_ms": avg_ms, "launches": launches,
-                         "iterations_per_launch": args.steps * SPP_PER_STEP / max(1, launches),
-                         "algorithmic_bytes_per_sample": b_alg, "valu_issue": valu,
-                         "note": "algorithmic = reference-layout bytes (SURVEY.md 8d); the 7.4 KB scene is "
-                                 "cache-resident, so this logical figure can exceed the HBM peak"},
+            "roofline": roof,
         }
+        if par is not None:
+            line["parity"] = par
+            line["parity_rms"] = max(par["rms"])
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -57,6 +57,12 @@ def load():
         "gpt_scene_load_cached": [C.c_char_p, C.c_int, C.POINTER(vp)],
         "gpt_render": [vp, vp, u32, u32, C.c_int, vp],
         "gpt_tonemap": [vp, u32, C.c_int, vp],
+        "gpt_tonemap_from": [vp, vp, u32, C.c_int, vp],
+        "gpt_comm_unique_id": [vp],
+        "gpt_comm_init": [vp, C.c_int, C.c_int, vp],
+        "gpt_reduce_film": [vp, C.c_int],
+        "gpt_read_reduced": [vp, vp],
+        "gpt_comm_destroy": [vp],
         "gpt_synchronize": [vp],
         "gpt_read_accum": [vp, vp],
         "gpt_read_color": [vp, vp],
@@ -94,7 +100,7 @@ def load():
             raise
         fn.argtypes = args
         fn.restype = C.c_int
-    for name in ("gpt_accum_device_ptr", "gpt_color_device_ptr"):
+    for name in ("gpt_accum_device_ptr", "gpt_color_device_ptr", "gpt_reduced_device_ptr"):
         fn = getattr(lib, name)
         fn.argtypes = [vp]
         fn.restype = vp
@@ -240,8 +246,28 @@ class Renderer:
     def tonemap(self, iteration, filmic, out_dev):
         check(self.lib.gpt_tonemap(self.ctx, int(iteration), int(bool(filmic)), out_dev))
 
+    def tonemap_from(self, acc_dev, iteration, filmic, out_dev):
+        check(self.lib.gpt_tonemap_from(self.ctx, acc_dev, int(iteration), int(bool(filmic)), out_dev))
+
     def synchronize(self):
         check(self.lib.gpt_synchronize(self.ctx))
+
+    # ---- multi-GPU film reduce (RCCL inside the library) ----
+    def comm_init(self, rank, n_ranks, unique_id):
+        """unique_id: the 128 bytes rank 0 got from comm_unique_id(); also sets the tile ownership"""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        check(self.lib.gpt_comm_init(self.ctx, int(rank), int(n_ranks), buf))
+
+    def reduce_film(self, root=0):
+        check(self.lib.gpt_reduce_film(self.ctx, int(root)))
+
+    def reduced_ptr(self):
+        return self.lib.gpt_reduced_device_ptr(self.ctx)
+
+    def read_reduced(self):
+        a = np.empty(self.width * self.height * 3, dtype=np.float32)
+        check(self.lib.gpt_read_reduced(self.ctx, st.ptr(a)))
+        return a
 
     def accum_ptr(self):
         return self.lib.gpt_accum_device_ptr(self.ctx)
@@ -312,6 +338,13 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0; hand the bytes to every rank)"""
+    buf = (C.c_char * 128)()
+    check(load().gpt_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def debug_math(fn, x, y=None, device=0):

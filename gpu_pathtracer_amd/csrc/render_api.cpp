@@ -13,6 +13,8 @@
 //     travels in the kernel arguments;
 //   * errors come back as codes + gpt_last_error(), never __debugbreak().
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>           // types and prototypes only: the library is opened at run time (gpt_comm_init)
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -77,6 +79,10 @@ struct gpt_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     uint32_t timed_launches = 0;
     double timed_ms = 0.0;
+    // multi-GPU film reduce (gpt_comm_init / gpt_reduce_film)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
 };
 
 namespace {
@@ -680,12 +686,154 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
 
 int gpt_tonemap(gpt_ctx *ctx, uint32_t iter, int filmic, float *out_dev)
 {
-    if (!ctx || !out_dev || iter == 0) {
+    return gpt_tonemap_from(ctx, ctx ? ctx->acc : nullptr, iter, filmic, out_dev);
+}
+
+int gpt_tonemap_from(gpt_ctx *ctx, const float *acc_dev, uint32_t iter, int filmic, float *out_dev)
+{
+    if (!ctx || !acc_dev || !out_dev || iter == 0) {
         gpt_set_error("gpt_tonemap: invalid argument");
         return GPT_ERR_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(launch_tonemap(ctx->acc, out_dev, ctx->P.stride, ctx->P.rows, iter, filmic, ctx->stream));
+    HIP_TRY(launch_tonemap(acc_dev, out_dev, ctx->P.stride, ctx->P.rows, iter, filmic, ctx->stream));
+    return GPT_OK;
+}
+
+// ---- multi-GPU: pixel tiles across ranks, ONE sum-reduce of the float3 accumulator ------------------------
+// RCCL is opened at run time: a single-GPU caller never needs it, and a process that already holds an RCCL (a PyTorch
+// process: the wheel bundles its own librccl.so.1 next to its HIP runtime) gets that same copy by soname.
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl *rccl()
+{
+    static Rccl lib;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            lib.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib.handle) break;
+        }
+        if (lib.handle) {
+            lib.GetUniqueId = reinterpret_cast<decltype(lib.GetUniqueId)>(dlsym(lib.handle, "ncclGetUniqueId"));
+            lib.CommInitRank = reinterpret_cast<decltype(lib.CommInitRank)>(dlsym(lib.handle, "ncclCommInitRank"));
+            lib.CommDestroy = reinterpret_cast<decltype(lib.CommDestroy)>(dlsym(lib.handle, "ncclCommDestroy"));
+            lib.Reduce = reinterpret_cast<decltype(lib.Reduce)>(dlsym(lib.handle, "ncclReduce"));
+            lib.GetErrorString = reinterpret_cast<decltype(lib.GetErrorString)>(dlsym(lib.handle, "ncclGetErrorString"));
+            if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommDestroy || !lib.Reduce || !lib.GetErrorString) {
+                dlclose(lib.handle);
+                lib.handle = nullptr;
+            }
+        }
+    }
+    if (!lib.handle) {
+        gpt_set_error("RCCL (librccl.so.1) cannot be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+        return nullptr;
+    }
+    return &lib;
+}
+}  // namespace
+
+int gpt_comm_unique_id(void *id128)
+{
+    if (!id128) { gpt_set_error("gpt_comm_unique_id: null argument"); return GPT_ERR_INVALID_ARG; }
+    Rccl *L = rccl();
+    if (!L) return GPT_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    const ncclResult_t e = L->GetUniqueId(&id);
+    if (e != ncclSuccess) { gpt_set_error("ncclGetUniqueId: %s", L->GetErrorString(e)); return GPT_ERR_HIP; }
+    static_assert(sizeof(id) == 128, "the ABI passes the RCCL unique id as 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return GPT_OK;
+}
+
+int gpt_comm_init(gpt_ctx *ctx, int rank, int n_ranks, const void *id128)
+{
+    if (!ctx || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        gpt_set_error("gpt_comm_init: invalid argument (rank %d of %d)", rank, n_ranks);
+        return GPT_ERR_INVALID_ARG;
+    }
+    if (ctx->comm) { gpt_set_error("gpt_comm_init: the context already has a communicator"); return GPT_ERR_INVALID_ARG; }
+    Rccl *L = rccl();
+    if (!L) return GPT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    const ncclResult_t e = L->CommInitRank(&ctx->comm, n_ranks, id, rank);
+    if (e != ncclSuccess) {
+        ctx->comm = nullptr;
+        gpt_set_error("ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, L->GetErrorString(e));
+        return GPT_ERR_HIP;
+    }
+    ctx->comm_rank = rank;
+    ctx->comm_size = n_ranks;
+    return gpt_set_tile_owner(ctx, rank, n_ranks);
+}
+
+static int ensure_reduced(gpt_ctx *ctx)
+{
+    if (ctx->reduced) return GPT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, (size_t)ctx->width * ctx->height * 3 * sizeof(float)));
+    ctx->allocs.push_back(p);
+    ctx->reduced = static_cast<float *>(p);
+    return GPT_OK;
+}
+
+int gpt_reduce_film(gpt_ctx *ctx, int root)
+{
+    if (!ctx || !ctx->comm || root < 0 || root >= ctx->comm_size) {
+        gpt_set_error("gpt_reduce_film: no communicator (gpt_comm_init) or root %d out of range", root);
+        return GPT_ERR_INVALID_ARG;
+    }
+    Rccl *L = rccl();
+    if (!L) return GPT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // The receive buffer is NOT the accumulator: acc keeps exactly this rank's tiles, so progressive rendering
+    // (gpt_render with reset = 0, then another reduce) never counts the other ranks' tiles twice on the root.
+    if (ctx->comm_rank == root) {
+        const int rc = ensure_reduced(ctx);
+        if (rc != GPT_OK) return rc;
+    }
+    const size_t count = (size_t)ctx->width * ctx->height * 3;
+    const ncclResult_t e = L->Reduce(ctx->acc, ctx->comm_rank == root ? ctx->reduced : nullptr, count, ncclFloat32, ncclSum, root, ctx->comm,
+                                     ctx->stream);
+    if (e != ncclSuccess) { gpt_set_error("ncclReduce: %s", L->GetErrorString(e)); return GPT_ERR_HIP; }
+    return GPT_OK;
+}
+
+float *gpt_reduced_device_ptr(gpt_ctx *ctx)
+{
+    if (!ctx || ensure_reduced(ctx) != GPT_OK) return nullptr;
+    return ctx->reduced;
+}
+
+int gpt_read_reduced(gpt_ctx *ctx, float *host_rgb)
+{
+    if (!ctx || !ctx->reduced) { gpt_set_error("gpt_read_reduced: nothing has been reduced on this rank"); return GPT_ERR_INVALID_ARG; }
+    return gpt_copy_to_host(ctx, ctx->reduced, host_rgb, (size_t)ctx->width * ctx->height * 3);
+}
+
+int gpt_comm_destroy(gpt_ctx *ctx)
+{
+    if (!ctx || !ctx->comm) return GPT_OK;
+    Rccl *L = rccl();
+    if (L) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)L->CommDestroy(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->comm_size = 1;
+    ctx->comm_rank = 0;
     return GPT_OK;
 }
 
@@ -743,6 +891,7 @@ int gpt_bind_film(gpt_ctx *ctx, float *acc_dev, float *color_dev)
 int gpt_end(gpt_ctx *ctx)
 {
     if (!ctx) return GPT_OK;
+    (void)gpt_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }

@@ -49,9 +49,58 @@ def init_process_group(backend=None):
     return dist, rank, world
 
 
+class FilmReducer:
+    """The one collective of the path.  native=True: the library's own RCCL reduce (gpt_comm_init / gpt_reduce_film) on the
+    renderer's stream - torch.distributed only carries the 128-byte RCCL id to the ranks.  native=False: the same N-rank
+    code path (tile ownership, a receive buffer that is not the accumulator, Output from the reduced frame) over a
+    torch.distributed backend that can run every rank on ONE GPU (gloo) - a functional check where RCCL, which refuses
+    duplicate devices, cannot run."""
+
+    def __init__(self, renderer, dist, rank, world, native=True):
+        from . import api
+        self.r, self.dist, self.rank, self.world, self.native = renderer, dist, rank, world, native
+        self.kind = "rccl ncclReduce issued by libgpt.so (gpt_reduce_film)" if native else f"torch.distributed {dist.get_backend()} reduce (all ranks share one GPU)"
+        if native:
+            box = [api.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            renderer.comm_init(rank, world, box[0])
+        else:
+            import torch
+            renderer.set_tile_owner(rank, world)
+            n = renderer.width * renderer.height * 3
+            self.acc = torch.zeros(n, dtype=torch.float32, device="cuda")       # the film itself: bound as the accumulator
+            self.col = torch.zeros(n, dtype=torch.float32, device="cuda")
+            self.recv = torch.zeros(n, dtype=torch.float32, device="cuda")      # the root's reduced frame
+            renderer.bind_film(self.acc.data_ptr(), self.col.data_ptr())
+
+    def reduce(self, root=0):
+        if self.native:
+            self.r.reduce_film(root)
+            return
+        import torch
+        self.r.synchronize()                    # torch's streams do not know the renderer's
+        self.recv.copy_(self.acc)
+        self.dist.reduce(self.recv, dst=root, op=self.dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+
+    def reduced_ptr(self):
+        return self.r.reduced_ptr() if self.native else self.recv.data_ptr()
+
+    def tonemap_reduced(self, iteration, filmic, out_dev):
+        self.r.tonemap_from(self.reduced_ptr(), iteration, filmic, out_dev)
+
+    def read_reduced(self):
+        if self.native:
+            return self.r.read_reduced()
+        self.r.synchronize()
+        return self.recv.cpu().numpy()
+
+
 def reduce_framebuffer(acc, dist, root=0):
-    """acc: torch tensor (W*H*3,) float32 — this rank's accumulator (zeros outside its tiles).
-    In place; after the call the root holds the whole frame."""
-    if dist is not None:
-        dist.reduce(acc, dst=root, op=dist.ReduceOp.SUM)
-    return acc
+    """acc: torch tensor (W*H*3,) float32 - this rank's accumulator (zeros outside its tiles).  Returns the reduced frame on
+    the root (a NEW tensor: acc itself keeps only this rank's tiles, so a later progressive render + reduce stays right)."""
+    if dist is None:
+        return acc
+    out = acc.clone()
+    dist.reduce(out, dst=root, op=dist.ReduceOp.SUM)
+    return out

@@ -107,7 +107,28 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
  * reduce.  `out_dev` is a device pointer. */
 int gpt_tonemap(gpt_ctx *ctx, uint32_t iter, int filmic, float *out_dev);
 
+/* ... the same pass reading any W*H*3 accumulator in device memory (e.g. a reduced frame) */
+int gpt_tonemap_from(gpt_ctx *ctx, const float *acc_dev, uint32_t iter, int filmic, float *out_dev);
+
 int gpt_synchronize(gpt_ctx *ctx);
+
+/* ---- multi-GPU: one process per GPU, pixel tiles across ranks, ONE framebuffer reduce -------------------------------
+ * The path shards embarrassingly (every pixel-sample is independent, src/pathtracer.cu:888): every rank holds the whole
+ * scene and renders the 8x8 tiles t with t % n_ranks == rank; the frame is assembled by one RCCL sum-reduce of the fp32
+ * W*H*3 accumulator over xGMI, issued on the renderer's own stream right behind the render.  Disjoint supports: the sum
+ * adds zeros, so the root's frame is bit-identical to a 1-GPU render.  A caller shaped like src/main.cpp:134-144 becomes
+ *     gpt_comm_unique_id(id) on rank 0, hand the 128 bytes to every rank (MPI, a file, torch.distributed ...);
+ *     gpt_begin(...); gpt_comm_init(ctx, rank, n, id);                     // also sets the tile ownership
+ *     per frame: gpt_render(ctx, cam, 1, spp, 1, NULL); gpt_reduce_film(ctx, 0);
+ *                rank 0: gpt_tonemap_from(ctx, gpt_reduced_device_ptr(ctx), spp, filmic, output);
+ * The reduce RECEIVES into a separate buffer on the root (gpt_reduced_device_ptr): the accumulator of every rank keeps
+ * exactly its own tiles, so progressive rendering (reset = 0) followed by another reduce stays correct. */
+int gpt_comm_unique_id(void *id128);                                         /* 128 bytes (ncclUniqueId) */
+int gpt_comm_init(gpt_ctx *ctx, int rank, int n_ranks, const void *id128);
+int gpt_reduce_film(gpt_ctx *ctx, int root);                                 /* asynchronous, on the context's stream */
+float *gpt_reduced_device_ptr(gpt_ctx *ctx);                                 /* the root's whole frame (sum of samples) */
+int gpt_read_reduced(gpt_ctx *ctx, float *host_rgb);                         /* synchronises */
+int gpt_comm_destroy(gpt_ctx *ctx);                                          /* also done by gpt_end */
 
 /* Film state.  Device pointers stay valid until gpt_end(); W*H*3 floats each,
  * row 0 = bottom (reference convention, src/imageio.cpp:66).  Pixel (x, y) lives at

@@ -25,9 +25,10 @@ acc, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, rank=rank, n_ranks=world, th
 own = gd.film_owner_mask(W, H, rank, world)
 assert not acc.reshape(-1, 3)[~own].any(), "a rank wrote outside its tiles"
 t = torch.from_numpy(acc.copy())
-gd.reduce_framebuffer(t, dist, root=0)
+out = gd.reduce_framebuffer(t, dist, root=0)
+assert t.numpy().tobytes() == acc.tobytes(), "the send buffer keeps this rank's tiles only"
 if rank == 0:
-    np.save(sys.argv[2], t.numpy())
+    np.save(sys.argv[2], out.numpy())
 dist.barrier()
 dist.destroy_process_group()
 '''

@@ -1,0 +1,76 @@
+"""The N-rank path on GPU hardware: the library's RCCL reduce (as far as one GPU can exercise it) and bench.py's two-rank code
+path with both ranks on GPU 0.  The 1 / 2 / 4 / 8-GPU curve itself is measured by the driver on an 8-GPU node."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_reduce_inside_the_library_single_rank_communicator(gpt):
+    """gpt_comm_unique_id -> gpt_comm_init -> gpt_reduce_film on a communicator of one rank: RCCL is opened, initialised and
+    its ncclReduce runs on the renderer's stream behind the render.  The reduced frame is a separate buffer (the accumulator
+    keeps this rank's tiles), so a progressive render (reset = 0) followed by another reduce does not count anything twice."""
+    scene, meta = ol.load_cornell(8)
+    W, H = 256, 192
+    cam = ol.cornell_camera(meta, W, H)
+    ref4, _ = ol.render(scene, cam, W, H, 0.001, 1, 4, kind="soft")
+    ref9, _ = ol.render(scene, cam, W, H, 0.001, 1, 9, kind="soft")
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        r.comm_init(0, 1, gpt.comm_unique_id())
+        r.render(cam, 1, 4, reset=True)
+        r.reduce_film(0)
+        assert r.read_reduced().tobytes() == ref4.tobytes()
+        r.render(cam, 5, 5, reset=False)                      # progressive: the reference's normal mode
+        r.reduce_film(0)
+        assert r.read_reduced().tobytes() == ref9.tobytes()
+        assert r.read_accum().tobytes() == ref9.tobytes()
+        out = np.zeros(W * H * 3, np.float32)
+        import torch
+        o = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        r.tonemap_from(r.reduced_ptr(), 9, True, o.data_ptr())
+        r.synchronize()
+        _, _, want = ol.render(scene, cam, W, H, 0.001, 1, 9, kind="soft", want_out=True)
+        assert o.cpu().numpy().tobytes() == want.tobytes()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_bench(extra_env, args, launcher=()):
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable] + list(launcher) + [os.path.join(ol.ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ol.ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_on_one_gpu_gives_the_one_rank_frame():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on GPU 0: tile
+    ownership, per-rank sample planes, the reduce into a separate buffer and Output from the reduced frame.  The film's hash
+    equals the single-rank run's.  (RCCL refuses two ranks on one device, so the reduce travels over gloo here; the library's
+    own ncclReduce is covered by the test above.)"""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-parity"]
+    one = run_bench({}, ["--gpus", "1"] + common)
+    two = run_bench({"GPT_BENCH_SHARE_GPU": "1"}, ["--gpus", "2"] + common,
+                    launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(free_port())])
+    assert one["config"]["all_finite"] and two["config"]["all_finite"]
+    assert two["n_gpus"] == 2 and "gloo" in two["config"]["reduce"]
+    assert two["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
+    # each rank allocates sample planes for its own tiles only
+    assert two["config"]["renderer_options"]["sample_plane_bytes"] * 2 <= one["config"]["renderer_options"]["sample_plane_bytes"] + 64 * 16 * 128
