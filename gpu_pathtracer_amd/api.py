@@ -225,9 +225,11 @@ class Renderer:
     def set_tile_owner(self, rank, n_ranks):
         check(self.lib.gpt_set_tile_owner(self.ctx, rank, n_ranks))
 
-    def set_traversal_order(self, near_first):
-        """False: the reference's order (default); True: nearer child first (include/gpt_traversal.h)"""
-        check(self.lib.gpt_set_traversal_order(self.ctx, 1 if near_first else 0))
+    def set_traversal_order(self, order):
+        """"reference" / False / 0: the reference's order (default); "near" / True / 1: the same tree, nearer child first
+        (include/gpt_traversal.h); "wide" / 2: the 4-wide tree walked by four lanes per ray (include/gpt_wide_bvh.h)"""
+        code = {"reference": 0, "near": 1, "wide": 2}.get(order, order)
+        check(self.lib.gpt_set_traversal_order(self.ctx, int(code)))
 
     def set_integrator(self, kind, value):
         """"pt": value = maxDepth; "ao": value = maxDist (the reference reads both from the scene on every Render call)"""

@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "pt_layout.h"
+#include "../../include/gpt_wide_bvh.h"
 
 namespace pt {
 
@@ -436,6 +437,205 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
                 }
             }
         }
+        }
+    }
+}
+
+// ---- GPT_TRAVERSAL_WIDE4: four lanes per ray on the 4-wide tree (include/gpt_wide_bvh.h) --------------------------------
+// The walk of one ray is the one the header specifies (and oracle/pt_oracle.c restates one ray at a time).  Here a ray
+// belongs to a GROUP of four consecutive lanes, 16 rays per wave:
+//   wide node  lane k of the group loads child k (32 bytes: the group reads one 128-byte record, one cache line) and tests
+//              its box; a quad of DPP moves shows every lane all four entry distances, each hit lane computes its rank and
+//              writes its child to the group's stack in LDS so that the nearest pops first
+//   leaf       lane k tests triangle k of the leaf (Moeller-Trumbore, the same instructions as trace_pool<>), each lane
+//              keeps the best hit IT has seen, and only the interval's end is shared (quad minimum by DPP); when the ray is
+//              done the lane holding the best of the four writes the result
+// Against one ray per lane on the binary tree: a node step is one dependent fetch for four boxes instead of one, all four
+// lanes of a busy group work (the vote between node and triangle lanes and its idle halves are gone), and the four
+// requests of a group fall into one cache line.
+// The stack: kWideStackDepth entries per group in LDS (the region the binary loop uses for suspended rays); deeper entries
+// go to a slice of P.wide_stack in global memory (3 * depth + 1 <= GPT_WIDE_STACK_MAX is checked by the host).
+constexpr int kWideStackDepth = 24;
+constexpr int kWideStackOff = kSuspOff + 32;                      // after 16 group records of 32 bytes
+constexpr int kWideSpillStride = GPT_WIDE_STACK_MAX + 8;
+static_assert(kWideStackOff * 16 + 16 * kWideStackDepth * 4 <= kWaveCarryFloat4 * 16, "the group stacks fit the suspend region");
+#ifndef PT_WIDE_FETCH_GROUPS
+#define PT_WIDE_FETCH_GROUPS 2                                    // idle groups that trigger a refill
+#endif
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+// quad_perm controls: broadcast of lane j of every group of four, and the two butterfly steps
+constexpr int kQuad0 = 0x00, kQuad1 = 0x55, kQuad2 = 0xAA, kQuad3 = 0xFF, kQuadSwap1 = 0xB1, kQuadSwap2 = 0x4E;
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool, int n_rays, Counters &cnt)
+{
+    const unsigned lane = threadIdx.x & 63u, sub = lane & 3u, grp = lane >> 2, grp_shift = lane & ~3u;
+    unsigned *stk = reinterpret_cast<unsigned *>(pool + kWideStackOff) + grp * kWideStackDepth;
+    volatile unsigned *spill = P.wide_stack + ((size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u + grp) * kWideSpillStride;
+    const char *wnodes = reinterpret_cast<const char *>(P.wide);
+    const char *tris = reinterpret_cast<const char *>(P.tris);
+    const float tmin_ray = P.eps;
+    constexpr unsigned long long kLeaders = 0x1111111111111111ull;
+
+    int next = 0;                          // wave-uniform: first ray of the fetch order nobody has taken yet
+    int slot = -1, any_hit = 0;            // group-uniform from here ...
+    V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
+    float tmax = 0.f;
+    unsigned cur = GPT_WIDE_NONE;
+    int sp = 0;
+    int bprim = -1;                        // ... this lane's own best hit
+    float bt = 0.f, bb1 = 0.f, bb2 = 0.f;
+
+    for (;;) {
+        const bool has = slot >= 0;
+        const bool fin = has && cur == GPT_WIDE_NONE;
+        const unsigned long long m_has = ballot(has), m_fin = ballot(fin);
+        if (m_fin != 0ull) {
+            // ---- finished rays: the best of the four lanes' hits (nearer; exactly as near: the larger primitive index)
+            const int p0 = dpp_i<kQuad0>(bprim), p1 = dpp_i<kQuad1>(bprim), p2 = dpp_i<kQuad2>(bprim), p3 = dpp_i<kQuad3>(bprim);
+            const float t0 = dpp_f<kQuad0>(bt), t1 = dpp_f<kQuad1>(bt), t2 = dpp_f<kQuad2>(bt), t3 = dpp_f<kQuad3>(bt);
+            bool win = bprim >= 0;
+            if (sub != 0u && p0 >= 0 && (t0 < bt || (t0 == bt && p0 > bprim))) win = false;
+            if (sub != 1u && p1 >= 0 && (t1 < bt || (t1 == bt && p1 > bprim))) win = false;
+            if (sub != 2u && p2 >= 0 && (t2 < bt || (t2 == bt && p2 > bprim))) win = false;
+            if (sub != 3u && p3 >= 0 && (t3 < bt || (t3 == bt && p3 > bprim))) win = false;
+            const bool none = (p0 & p1 & p2 & p3) < 0;
+            if (fin && (win || (none && sub == 0u))) {
+                pool[2 * slot + 1] = make_float4(__int_as_float(none ? -1 : bprim), none ? tmax : bt, bb1, bb2);
+                atomicAnd(reinterpret_cast<unsigned *>(pool + kPendOff) + (slot & 63), ~(1u << (slot >> 6)));
+            }
+            if (fin) slot = -1;
+        }
+        const unsigned long long m_busy = m_has & ~m_fin;
+        const int n_idle = 16 - popc(m_busy & kLeaders);
+        if (next < n_rays && n_idle >= PT_WIDE_FETCH_GROUPS) {
+            // ---- refill: idle groups take the next rays of the fetch order, in group order
+            const int nth = next + lane_rank(~m_busy & kLeaders) - (sub != 0u ? 1 : 0);
+            if (slot < 0 && nth < n_rays) {
+                const int mine = (int)reinterpret_cast<const unsigned short *>(pool + kOrderOff)[nth];
+                const float4 r0 = pool[2 * mine];
+                const float4 r1 = pool[2 * mine + 1];
+                const int tag = __float_as_int(r1.w);
+                const float4 ro = pool[2 * kPoolSlots + (tag & 255)];
+                slot = mine;
+                any_hit = tag & 256;
+                o = V3{ro.x, ro.y, ro.z};
+                d = V3{r0.x, r0.y, r0.z};
+                inv = V3{r1.x, r1.y, r1.z};
+                tmax = r0.w;
+                cur = 0u;                  // wide node 0
+                sp = 0;
+                bprim = -1;
+                bt = bb1 = bb2 = 0.f;
+            }
+            next += n_idle;
+            continue;
+        }
+        if (m_busy == 0ull) break;
+
+        const bool leaf = has && !fin && (cur >> 31) != 0u;
+        const bool inner = has && !fin && (cur >> 31) == 0u;
+        const int lf_first = (int)(cur & 0x07ffffffu), lf_count = (int)((cur >> 27) & 15u) + 1;
+        const bool tri_lane = leaf && (int)sub < lf_count;
+        // both kinds of fetch go out before either is used
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, q0 = a, q1 = a;
+        float e2z = 0.f;
+        if (inner) {
+            const float4 *np = reinterpret_cast<const float4 *>(wnodes + (size_t)cur + 32u * sub);
+            a = np[0];
+            b = np[1];
+        }
+        if (tri_lane) {
+            const char *tp = tris + (size_t)(lf_first + (int)sub) * 48u;
+            q0 = *reinterpret_cast<const float4 *>(tp);
+            q1 = *reinterpret_cast<const float4 *>(tp + 16);
+            e2z = *reinterpret_cast<const float *>(tp + 32);
+        }
+        if (ballot(inner) != 0ull) {
+            // ---- a wide node: four boxes, bbox.h:77-96 each ---------------------------------
+            const float t1 = (a.x - o.x) * inv.x;
+            const float t2 = (a.w - o.x) * inv.x;
+            const float t3 = (a.y - o.y) * inv.y;
+            const float t4 = (b.x - o.y) * inv.y;
+            const float t5 = (a.z - o.z) * inv.z;
+            const float t6 = (b.y - o.z) * inv.z;
+            const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
+            const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
+            const int ref = __float_as_int(b.z), count = __float_as_int(b.w);
+            const bool hit = inner && count != 0 && !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
+            if (COUNT && inner && sub == 0u) { cnt.node_visits++; }
+            // order key (gpt_wide_key): the distance as a sortable integer, slot in the two lowest bits; a child that is not hit
+            // gets the largest key, so it is never counted as popping before a hit one
+            const unsigned ubits = __float_as_uint(tn == tn ? tn : -__builtin_inff());
+            const unsigned mono = ubits ^ ((unsigned)((int)ubits >> 31) | 0x80000000u);
+            const unsigned key = hit ? ((mono & ~3u) | sub) : 0xffffffffu;
+            const unsigned gh = (unsigned)(ballot(hit) >> grp_shift) & 15u;       // the group's hit children
+            const int nhit = __builtin_popcount(gh);
+            const unsigned k0 = (unsigned)dpp_i<kQuad0>((int)key), k1 = (unsigned)dpp_i<kQuad1>((int)key), k2 = (unsigned)dpp_i<kQuad2>((int)key), k3 = (unsigned)dpp_i<kQuad3>((int)key);
+            const int rank = (k0 < key ? 1 : 0) + (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);      // hit children that pop before this one
+            if (hit) {
+                const unsigned entry = count < 0 ? (unsigned)ref : (0x80000000u | ((unsigned)(count - 1) << 27) | (unsigned)ref);
+                const int at = sp + nhit - 1 - rank;
+                if (at < kWideStackDepth) stk[at] = entry;
+                else spill[at] = entry;
+            }
+            wave_lds_fence();
+            if (inner) {
+                sp += nhit;
+                if (sp > 0) {
+                    --sp;
+                    cur = sp < kWideStackDepth ? stk[sp] : spill[sp];
+                } else {
+                    cur = GPT_WIDE_NONE;
+                }
+            }
+        }
+        if (ballot(leaf) != 0ull) {
+            // ---- a leaf: up to four triangles, mesh.h:45-67 each, all against the same interval ----------------
+            const int prim = lf_first + (int)sub;
+            const V3 v1 = V3{q0.x, q0.y, q0.z};
+            const V3 e1 = V3{q0.w, q1.x, q1.y};
+            const V3 e2 = V3{q1.z, q1.w, e2z};
+            const V3 s1 = cross(d, e2);
+            const float divisor = dot(s1, e1);
+            const float invDivisor = 1.0f / divisor;           // == (float)(1.0 / divisor), see trace_pool<>
+            const V3 s = o - v1;
+            const float b1 = dot(s, s1) * invDivisor;
+            const V3 s2 = cross(s, e1);
+            const float b2 = dot(d, s2) * invDivisor;
+            const float tt = dot(e2, s2) * invDivisor;
+            const bool accept = tri_lane && !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) &&
+                                !(b2 < 0.0f || b1 + b2 > 1.0f) && !(tt < tmin_ray || tt > tmax);
+            if (COUNT && tri_lane) { cnt.prim_tests++; }
+            if (accept && (bprim < 0 || tt < bt || (tt == bt && prim > bprim))) {
+                bprim = prim;
+                bt = tt;
+                bb1 = b1;
+                bb2 = b2;
+            }
+            float nearest = (accept && tt == tt) ? tt : __builtin_inff();
+            {
+                const float n1 = dpp_f<kQuadSwap1>(nearest);
+                nearest = n1 < nearest ? n1 : nearest;             // (a NaN distance never becomes the interval's end)
+                const float n2 = dpp_f<kQuadSwap2>(nearest);
+                nearest = n2 < nearest ? n2 : nearest;
+            }
+            const unsigned ga = (unsigned)(ballot(accept) >> grp_shift) & 15u;
+            if (leaf) {
+                if (nearest < tmax) tmax = nearest;
+                if (any_hit != 0 && ga != 0u) {                     // IntersectP: the first accepted triangle ends the ray
+                    cur = GPT_WIDE_NONE;
+                    sp = 0;
+                } else if (lf_count > 4) {
+                    cur = 0x80000000u | ((unsigned)(lf_count - 5) << 27) | (unsigned)(lf_first + 4);
+                } else if (sp > 0) {
+                    --sp;
+                    cur = sp < kWideStackDepth ? stk[sp] : spill[sp];
+                } else {
+                    cur = GPT_WIDE_NONE;
+                }
+            }
         }
     }
 }
@@ -906,6 +1106,451 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
                  [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
 #endif
+}
+
+
+// ---- trace_pool_wide<>, hand-scheduled -------------------------------------------------------------------------------------
+// The instruction-for-instruction twin of trace_pool_wide<> above (which stays the specification and runs in the counting
+// build), for the same reason trace_pool_lds_asm exists: the compiler's version of this loop is ~600 instructions per trip
+// (109 register copies for loop phis, 40 exec save / restore pairs, 64-bit address arithmetic per lane), the loop below ~190.
+// Floating-point instructions and their order are those of the C++ twin (box test and triangle test are the blocks of
+// PT_TRACE_ASM), so the films are bit-identical; tests/test_gpu_parity.py runs both.
+//
+// One trip serves every busy group, whatever it is working on: the fetches of the groups at a wide node (2 x dwordx4 per
+// lane: lane k reads child k) and of the groups at a leaf (3 loads per lane: lane k reads triangle k) go out together, then
+// the node block and the leaf block run under their own lane masks.
+//
+// Register map (all clobbered):
+//   v[0:2] origin  v[4:6] dir  v7 tmax as loaded  v[8:10] 1/dir  v11 tag (owner | any-hit << 8)
+//   v12 current entry (wide node: byte offset; leaf: bit 31 | count-1 << 27 | first triangle; -1: none)   v13 stack size
+//   v14 LDS address of the group's stack   v15 LDS address of the ray's slot (-1: idle group)
+//   v16 32 * (lane & 3)   v17 lane & ~3   v18 lane & 3   v19 end of the ray's interval (group-uniform)
+//   v[20:23] this lane's best hit {triangle index or -1, t, b1, b2}   v[24:31] child record   v[44:52] triangle record
+//   v53 byte offset of the group's slice of the spill stack   v54 (lane & 3) != 0   v[32:43] temporaries
+//   s[60:61] lanes of groups at a leaf  s[62:63] ... at a wide node  s[64:65] lanes of busy groups  s[66:69],s[72:73] scratch masks
+//   s70 next ray  s71 scratch  s[74:75] lanes with a triangle to test  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] 0x1111...
+#define PT_WIDE_POP /* exec: the lanes that pop; v13 > 0: take the top entry, else the ray is finished */ \
+        "v_cmp_lt_i32_e32 vcc, 0, v13\n" \
+        "v_mov_b32_e32 v12, -1\n" \
+        "s_and_b64 exec, exec, vcc\n" \
+        "s_cbranch_execz TW_POPPED_%=\n" \
+        "v_add_u32_e32 v13, -1, v13\n" \
+        "v_cmp_gt_i32_e32 vcc, %[depth], v13\n" \
+        "s_mov_b64 s[72:73], exec\n" \
+        "s_and_b64 exec, exec, vcc\n" \
+        "v_lshl_add_u32 v33, v13, 2, v14\n" \
+        "ds_read_b32 v12, v33\n" \
+        "s_andn2_b64 exec, s[72:73], vcc\n" \
+        "s_cbranch_execz TW_POP_LDS_%=\n" \
+        "v_lshl_add_u32 v33, v13, 2, v53\n" \
+        "global_load_dword v12, v33, %[spill] sc0 sc1\n" \
+        "s_waitcnt vmcnt(0)\n" \
+        "TW_POP_LDS_%=:\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "TW_POPPED_%=:\n"
+
+__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane)
+{
+    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
+    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
+    const unsigned long long s_nodes = uniform64((unsigned long long)P.wide), s_tris = uniform64((unsigned long long)P.tris);
+    const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_stack = s_pool + kWideStackOff * 16;
+    // this group's slice of the spill stack, in bytes (wave-uniform part + 4 * stride * group)
+    const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u + (lane >> 2)) * (unsigned)(kWideSpillStride * 4);
+    asm volatile(
+        "s_mov_b32 s70, 0\n"
+        "s_mov_b32 s76, 0x322bcc77\n"
+        "s_mov_b32 s77, 0x71800000\n"
+        "s_mov_b32 s80, 0x11111111\n"                      /* s[80:81]: the first lane of every group */
+        "s_mov_b32 s81, 0x11111111\n"
+        "s_mov_b64 s[64:65], 0\n"
+        "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
+        "v_and_b32_e32 v18, 3, v33\n"
+        "v_lshlrev_b32_e32 v16, 5, v18\n"
+        "v_and_b32_e32 v17, 60, v33\n"
+        "v_lshrrev_b32_e32 v34, 2, v33\n"
+        "v_mul_u32_u24_e32 v34, %[depth4], v34\n"
+        "v_add_u32_e32 v14, %[stack], v34\n"
+        "v_mov_b32_e32 v53, %[vspill]\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v18\n"
+        "v_cndmask_b32_e64 v54, 0, 1, vcc\n"
+        "v_mov_b32_e32 v12, -1\n"
+        "v_mov_b32_e32 v13, 0\n"
+        "v_mov_b32_e32 v15, -1\n"
+        "v_mov_b32_e32 v20, -1\n"
+        "s_branch TW_FILL_%=\n"
+        /* ---------------------------------------------------------------- loop header */
+        "TW_LOOP_%=:\n"
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"             /* groups with a ray */
+        "v_cmp_eq_u32_e64 s[66:67], -1, v12\n"             /* ... that is finished */
+        "s_and_b64 s[68:69], s[64:65], s[66:67]\n"
+        "s_cbranch_scc1 TW_FIN_%=\n"
+        "TW_TRIP_%=:\n"
+        "v_cmp_gt_i32_e64 s[60:61], 0, v12\n"
+        "s_and_b64 s[60:61], s[60:61], s[64:65]\n"         /* at a leaf (bit 31 set, not -1: busy groups only) */
+        "s_andn2_b64 s[62:63], s[64:65], s[60:61]\n"       /* at a wide node */
+        /* ---- fetches of both kinds */
+        "s_mov_b64 exec, s[60:61]\n"
+        "v_bfe_u32 v34, v12, 27, 4\n"                      /* count - 1 */
+        "v_and_b32_e32 v35, 0x7ffffff, v12\n"
+        "v_cmp_le_u32_e32 vcc, v18, v34\n"
+        "v_add_u32_e32 v32, v35, v18\n"                    /* this lane's triangle */
+        "v_lshlrev_b32_e32 v36, 4, v32\n"
+        "v_lshl_add_u32 v36, v32, 5, v36\n"                /* * 48 */
+        "s_and_b64 s[74:75], s[60:61], vcc\n"
+        "s_mov_b64 exec, s[74:75]\n"
+        "global_load_dwordx4 v[48:51], v36, %[tris] offset:16\n"
+        "global_load_dword v52, v36, %[tris] offset:32\n"
+        "global_load_dwordx4 v[44:47], v36, %[tris]\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_add_u32_e32 v33, v12, v16\n"
+        "s_mov_b64 s[78:79], 0\n"
+        "global_load_dwordx4 v[24:27], v33, %[nodes]\n"
+        "global_load_dwordx4 v[28:31], v33, %[nodes] offset:16\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_cbranch_execz TW_LEAF_%=\n"
+        /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
+        "v_sub_f32_e32 v33, v24, v0\n"
+        "v_sub_f32_e32 v34, v27, v0\n"
+        "v_sub_f32_e32 v35, v25, v1\n"
+        "v_sub_f32_e32 v37, v26, v2\n"
+        "v_sub_f32_e32 v36, v28, v1\n"
+        "v_sub_f32_e32 v38, v29, v2\n"
+        "v_mul_f32_e32 v33, v8, v33\n"
+        "v_mul_f32_e32 v34, v8, v34\n"
+        "v_mul_f32_e32 v35, v9, v35\n"
+        "v_mul_f32_e32 v36, v9, v36\n"
+        "v_mul_f32_e32 v37, v10, v37\n"
+        "v_mul_f32_e32 v38, v10, v38\n"
+        "v_min_f32_e32 v39, v33, v34\n"
+        "v_min_f32_e32 v40, v35, v36\n"
+        "v_min_f32_e32 v41, v37, v38\n"
+        "v_max_f32_e32 v33, v33, v34\n"
+        "v_max_f32_e32 v35, v35, v36\n"
+        "v_max_f32_e32 v37, v37, v38\n"
+        "v_min3_f32 v33, v33, v35, v37\n"                  /* tf */
+        "v_max3_f32 v39, v39, v40, v41\n"                  /* tn */
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v33\n"
+        "v_min_f32_e32 v33, v33, v19\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v33, v39\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v31\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"              /* hit: box && the child exists */
+        /* order key: sortable integer of tn (NaN -> -inf), slot in the two lowest bits; not hit: the largest key */
+        "v_cmp_u_f32_e32 vcc, v39, v39\n"
+        "v_mov_b32_e32 v40, 0xff800000\n"
+        "v_cndmask_b32_e32 v39, v39, v40, vcc\n"
+        "v_ashrrev_i32_e32 v40, 31, v39\n"
+        "v_or_b32_e32 v40, 0x80000000, v40\n"
+        "v_xor_b32_e32 v39, v40, v39\n"
+        "v_and_or_b32 v39, v39, -4, v18\n"
+        "v_cndmask_b32_e64 v39, -1, v39, s[66:67]\n"
+        /* the group's hit count */
+        "v_lshrrev_b64 v[40:41], v17, s[66:67]\n"
+        "v_and_b32_e32 v40, 15, v40\n"
+        "v_bcnt_u32_b32 v41, v40, 0\n"                     /* nhit */
+        /* rank = how many of the four keys are smaller */
+        "v_mov_b32_dpp v33, v39 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v34, v39 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v35, v39 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v36, v39 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_e32 v42, 0\n"
+        "v_cmp_lt_u32_e32 vcc, v33, v39\n"
+        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v34, v39\n"
+        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v35, v39\n"
+        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v36, v39\n"
+        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"        /* rank */
+        /* this child as an entry */
+        "v_add_u32_e32 v33, -1, v31\n"
+        "v_lshlrev_b32_e32 v33, 27, v33\n"
+        "v_or_b32_e32 v33, 0x80000000, v33\n"
+        "v_or_b32_e32 v33, v33, v30\n"
+        "v_cmp_gt_i32_e32 vcc, 0, v31\n"
+        "v_cndmask_b32_e32 v33, v33, v30, vcc\n"           /* entry */
+        /* the nearest hit child (rank 0) becomes the current entry of all four lanes: OR over the group of (rank == 0 ? entry : 0) */
+        "v_cmp_eq_u32_e32 vcc, 0, v42\n"
+        "s_and_b64 vcc, vcc, s[66:67]\n"
+        "v_cndmask_b32_e32 v34, 0, v33, vcc\n"
+        "s_nop 1\n"
+        "v_or_b32_dpp v34, v34, v34 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "s_nop 1\n"
+        "v_or_b32_dpp v34, v34, v34 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        /* the others go to the stack: position sp + nhit - 1 - rank (rank 1 on top) */
+        "v_cmp_lt_u32_e32 vcc, 0, v42\n"
+        "s_and_b64 s[68:69], vcc, s[66:67]\n"              /* hit and not the nearest */
+        "v_add_u32_e32 v35, v13, v41\n"
+        "v_sub_u32_e32 v35, v35, v42\n"
+        "v_add_u32_e32 v35, -1, v35\n"                     /* at = sp + nhit - 1 - rank: rank 1 ends on top at sp + nhit - 2, the rank-0 slot stays free */
+        "v_cmp_gt_i32_e32 vcc, %[depth], v35\n"
+        "s_and_b64 exec, s[68:69], vcc\n"
+        "v_lshl_add_u32 v36, v35, 2, v14\n"
+        "ds_write_b32 v36, v33\n"
+        "s_andn2_b64 exec, s[68:69], vcc\n"
+        "s_cbranch_execz TW_PUSHED_%=\n"
+        "v_lshl_add_u32 v36, v35, 2, v53\n"
+        "global_store_dword v36, v33, %[spill] sc0 sc1\n"
+        "s_waitcnt vmcnt(0)\n"
+        "TW_PUSHED_%=:\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        /* nhit > 0: sp += nhit - 1, current = nearest;  nhit == 0: pop */
+        "v_cmp_lt_u32_e32 vcc, 0, v41\n"
+        "v_add_u32_e32 v35, -1, v41\n"
+        "v_cndmask_b32_e32 v35, 0, v35, vcc\n"
+        "v_add_u32_e32 v13, v13, v35\n"
+        "v_cndmask_b32_e32 v12, v12, v34, vcc\n"
+        "s_andn2_b64 s[78:79], s[62:63], vcc\n"            /* the groups without a hit child pop */
+        /* ---------------------------------------------------------------- leaf: up to four triangles (exec = s[74:75]) */
+        "TW_LEAF_%=:\n"
+        "s_mov_b64 exec, s[74:75]\n"
+        "s_cbranch_execz TW_LEAF_END_%=\n"
+        "v_mul_f32_e32 v33, v5, v52\n"
+        "v_mul_f32_e32 v42, v6, v51\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v6, v50\n"
+        "v_mul_f32_e32 v42, v4, v52\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v4, v51\n"
+        "v_mul_f32_e32 v42, v5, v50\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v36, v33, v47\n"
+        "v_mul_f32_e32 v42, v34, v48\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_mul_f32_e32 v42, v35, v49\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_rcp_f32_e32 v38, v36\n"
+        "v_sub_f32_e32 v44, v0, v44\n"
+        "v_sub_f32_e32 v45, v1, v45\n"
+        "v_sub_f32_e32 v46, v2, v46\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
+        "v_fma_f32 v41, -v36, v38, 1.0\n"
+        "v_fma_f32 v37, v41, v38, v38\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TW_DIV_IEEE_%=\n"
+        "TW_DIV_DONE_%=:\n"
+        "v_mul_f32_e32 v43, v44, v33\n"
+        "v_mul_f32_e32 v42, v45, v34\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v42, v46, v35\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v33, v45, v49\n"
+        "v_mul_f32_e32 v42, v46, v48\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v46, v47\n"
+        "v_mul_f32_e32 v42, v44, v49\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v44, v48\n"
+        "v_mul_f32_e32 v42, v45, v47\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v43, v43, v37\n"                    /* b1 */
+        "v_mul_f32_e32 v38, v4, v33\n"
+        "v_mul_f32_e32 v42, v5, v34\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v42, v6, v35\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v38, v38, v37\n"                    /* b2 */
+        "v_mul_f32_e32 v39, v50, v33\n"
+        "v_mul_f32_e32 v42, v51, v34\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v42, v52, v35\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v39, v39, v37\n"                    /* tt */
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"
+        "v_add_f32_e32 v42, v43, v38\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, v39, v19\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 s[66:67], s[66:67], exec\n"             /* accepted */
+        /* this lane's best hit: nearer, or exactly as near with a larger triangle index */
+        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
+        "v_cmp_lt_f32_e32 vcc, v39, v21\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_eq_f32_e32 vcc, v39, v21\n"
+        "v_cmp_gt_i32_e64 s[72:73], v32, v20\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "s_and_b64 exec, s[68:69], s[66:67]\n"
+        "v_mov_b32_e32 v20, v32\n"
+        "v_mov_b32_e32 v21, v39\n"
+        "v_mov_b32_e32 v22, v43\n"
+        "v_mov_b32_e32 v23, v38\n"
+        "TW_LEAF_END_%=:\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        "s_cbranch_execz TW_POP_%=\n"
+        /* the nearest accepted distance of the group ends the interval (NaN distances do not) */
+        "s_and_b64 s[66:67], s[66:67], s[74:75]\n"         /* (no triangle lanes at all: nothing was accepted) */
+        "v_mov_b32_e32 v40, 0x7f800000\n"
+        "v_cmp_o_f32_e32 vcc, v39, v39\n"
+        "s_and_b64 vcc, vcc, s[66:67]\n"
+        "v_cndmask_b32_e32 v40, v40, v39, vcc\n"
+        "s_nop 1\n"
+        "v_mov_b32_dpp v41, v40 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_cmp_lt_f32_e32 vcc, v41, v40\n"
+        "v_cndmask_b32_e32 v40, v40, v41, vcc\n"
+        "s_nop 1\n"
+        "v_mov_b32_dpp v41, v40 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_cmp_lt_f32_e32 vcc, v41, v40\n"
+        "v_cndmask_b32_e32 v40, v40, v41, vcc\n"
+        "v_cmp_lt_f32_e32 vcc, v40, v19\n"
+        "v_cndmask_b32_e32 v19, v19, v40, vcc\n"
+        /* any-hit rays end at the first accepted triangle; a longer leaf goes on with its next four; else pop */
+        "v_lshrrev_b64 v[40:41], v17, s[66:67]\n"
+        "v_and_b32_e32 v40, 15, v40\n"
+        "v_and_b32_e32 v41, 0x100, v11\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v40\n"
+        "v_cmp_ne_u32_e64 s[68:69], 0, v41\n"
+        "s_and_b64 s[68:69], s[68:69], vcc\n"              /* the ray is over */
+        "v_bfe_u32 v42, v12, 27, 4\n"
+        "v_cmp_lt_u32_e32 vcc, 3, v42\n"                   /* more than four triangles were left */
+        "v_add_u32_e32 v41, 0xe0000004, v12\n"             /* first += 4, count -= 4 */
+        "s_andn2_b64 s[72:73], s[60:61], s[68:69]\n"
+        "s_andn2_b64 s[66:67], s[72:73], vcc\n"            /* pop */
+        "v_cndmask_b32_e32 v12, v12, v41, vcc\n"
+        "s_or_b64 s[78:79], s[78:79], s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v12, -1, s[68:69]\n"
+        "v_cndmask_b32_e64 v13, v13, 0, s[68:69]\n"
+        /* ---------------------------------------------------------------- pop */
+        "TW_POP_%=:\n"
+        "s_mov_b64 exec, s[78:79]\n"
+        "s_cbranch_execz TW_POP_NONE_%=\n"
+        PT_WIDE_POP
+        "TW_POP_NONE_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TW_LOOP_%=\n"
+        /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
+        "TW_DIV_IEEE_%=:\n"
+        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
+        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
+        "v_rcp_f32_e32 v38, v37\n"
+        "s_nop 0\n"
+        "v_fma_f32 v41, -v37, v38, 1.0\n"
+        "v_fmac_f32_e32 v38, v41, v38\n"
+        "v_mul_f32_e32 v40, v39, v38\n"
+        "v_fma_f32 v41, -v37, v40, v39\n"
+        "v_fmac_f32_e32 v40, v41, v38\n"
+        "v_fma_f32 v37, -v37, v40, v39\n"
+        "v_div_fmas_f32 v37, v37, v38, v40\n"
+        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
+        "s_branch TW_DIV_DONE_%=\n"
+        /* ---------------------------------------------------------------- finished rays (s[68:69]) */
+        "TW_FIN_%=:\n"
+        "s_mov_b64 exec, s[68:69]\n"
+        /* the best of the four lanes' hits, by two exchanges: take the partner's when it has one and this lane has none, or it
+           is nearer, or exactly as near with a larger triangle index */
+        "s_nop 1\n"
+        "v_mov_b32_dpp v33, v20 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v34, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v35, v22 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v36, v23 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n"
+        "v_cmp_lt_f32_e32 vcc, v34, v21\n"
+        "s_or_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_eq_f32_e32 vcc, v34, v21\n"
+        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
+        "s_or_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_lt_i32_e32 vcc, -1, v33\n"
+        "s_and_b64 vcc, vcc, s[66:67]\n"
+        "v_cndmask_b32_e32 v20, v20, v33, vcc\n"
+        "v_cndmask_b32_e32 v21, v21, v34, vcc\n"
+        "v_cndmask_b32_e32 v22, v22, v35, vcc\n"
+        "v_cndmask_b32_e32 v23, v23, v36, vcc\n"
+        "s_nop 1\n"
+        "v_mov_b32_dpp v33, v20 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v34, v21 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v35, v22 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_mov_b32_dpp v36, v23 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n"
+        "v_cmp_lt_f32_e32 vcc, v34, v21\n"
+        "s_or_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_eq_f32_e32 vcc, v34, v21\n"
+        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
+        "s_or_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_lt_i32_e32 vcc, -1, v33\n"
+        "s_and_b64 vcc, vcc, s[66:67]\n"
+        "v_cndmask_b32_e32 v20, v20, v33, vcc\n"
+        "v_cndmask_b32_e32 v21, v21, v34, vcc\n"
+        "v_cndmask_b32_e32 v22, v22, v35, vcc\n"
+        "v_cndmask_b32_e32 v23, v23, v36, vcc\n"
+        /* a miss reports the end of the interval, like the other loops */
+        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
+        "v_cndmask_b32_e32 v21, v21, v19, vcc\n"
+        /* lane 0 of the group writes the result into the second half of the ray's slot and tells the owner */
+        "v_cmp_eq_u32_e32 vcc, 0, v18\n"
+        "s_and_b64 exec, s[68:69], vcc\n"
+        "ds_write_b128 v15, v[20:23] offset:16\n"
+        PT_FINISH_PENDING
+        "s_mov_b64 exec, s[68:69]\n"
+        "v_mov_b32_e32 v15, -1\n"
+        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"
+        "s_mov_b64 exec, -1\n"
+        /* ---------------------------------------------------------------- refill: idle groups take the next rays */
+        "TW_FILL_%=:\n"
+        "s_cmp_ge_i32 s70, %[rays]\n"
+        "s_cbranch_scc1 TW_EMPTY_%=\n"
+        "s_and_b64 s[66:67], s[64:65], s[80:81]\n"
+        "s_bcnt1_i32_b64 s71, s[66:67]\n"                  /* busy groups */
+        "s_cmp_gt_u32 s71, %[maxbusy]\n"
+        "s_cbranch_scc1 TW_TRIP_%=\n"
+        "s_andn2_b64 s[66:67], s[80:81], s[64:65]\n"   /* first lanes of the idle groups */
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
+        "v_sub_u32_e32 v33, v33, v54\n"                    /* the group's rank among the idle ones */
+        "v_add_u32_e32 v33, s70, v33\n"
+        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
+        "s_andn2_b64 s[66:67], vcc, s[64:65]\n"
+        "s_sub_i32 s71, 16, s71\n"
+        "s_add_i32 s70, s70, s71\n"
+        "s_mov_b64 exec, s[66:67]\n"
+        "v_lshl_add_u32 v34, v33, 1, %[order]\n"
+        "ds_read_u16 v34, v34\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_lshl_add_u32 v15, v34, 5, %[pool]\n"
+        "ds_read_b128 v[4:7], v15\n"
+        "ds_read_b128 v[8:11], v15 offset:16\n"
+        "v_mov_b32_e32 v12, 0\n"
+        "v_mov_b32_e32 v13, 0\n"
+        "v_mov_b32_e32 v20, -1\n"
+        "v_mov_b32_e32 v21, 0\n"
+        "v_mov_b32_e32 v22, 0\n"
+        "v_mov_b32_e32 v23, 0\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32_e32 v33, 0xff, v11\n"
+        "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
+        "ds_read_b96 v[0:2], v33 offset:%[org]\n"
+        "v_mov_b32_e32 v19, v7\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TW_LOOP_%=\n"
+        "TW_EMPTY_%=:\n"
+        "s_cmp_lg_u64 s[64:65], 0\n"
+        "s_cbranch_scc1 TW_TRIP_%=\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        :
+        : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [tris] "s"(s_tris), [spill] "s"(s_spill),
+          [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [vspill] "v"(v_spill),
+          [depth] "n"(kWideStackDepth), [depth4] "n"(kWideStackDepth * 4), [maxbusy] "n"(16 - PT_WIDE_FETCH_GROUPS), [org] "n"(2 * kPoolSlots * 16)
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
+          "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
+          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -1715,9 +2360,14 @@ constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 #define PT_TRACE_BATCH 32
 #endif
 constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH;
-template <bool COUNT, bool SMALL, int INTEG>
-__global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : PT_MIN_WAVES) pt_render_kernel(const DevParams P_in)
+#ifndef PT_WIDE_WAVES
+#define PT_WIDE_WAVES 4
+#endif
+// WIDE: scenes in global memory walked with four lanes per ray on the 4-wide tree (GPT_TRAVERSAL_WIDE4, trace_pool_wide<>)
+template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
+__global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES)) pt_render_kernel(const DevParams P_in)
 {
+    static_assert(!(WIDE && SMALL), "the wide tree is walked from global memory");
     __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
     DevParams P = P_in;
     if (SMALL) {
@@ -2751,6 +3401,11 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     trace_pool<COUNT, false>(P, pool, L.n_rays, cnt, mem);
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
+            } else if (WIDE) {
+                if (COUNT)                          // the counting build runs the C++ twin (it has the counters)
+                    trace_pool_wide<COUNT>(P, pool, n_new, cnt);
+                else
+                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane);
             } else {
                 GlobalScene mem;
                 mem.nodes = reinterpret_cast<const char *>(P.nodes);
@@ -2923,9 +3578,17 @@ bool render_uses_walk_kernel(const DevParams &P, bool force)
     return P.integrator == GPT_IT_VPT && (P.vpt_walk || force);
 }
 
-int render_kernel_blocks_per_cu(bool count, bool walk)
+int render_kernel_blocks_per_cu(bool count, bool walk, bool wide)
 {
     int n = 0;
+    if (wide) {
+        hipError_t ew = walk ? (count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, false, PT_IT_VPT_WALK, true>, 256, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, false, PT_IT_VPT_WALK, true>, 256, 0))
+                             : (count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, false, GPT_IT_PT, true>, 256, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, false, GPT_IT_PT, true>, 256, 0));
+        if (ew != hipSuccess || n < 1) n = 2;
+        return n > 8 ? 8 : n;
+    }
     hipError_t e = walk ? (count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true, PT_IT_VPT_WALK>, 256, 0)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<false, true, PT_IT_VPT_WALK>, 256, 0))
                         : (count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pt_render_kernel<true, true, GPT_IT_PT>, 256, 0)
@@ -2945,7 +3608,13 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_
     const bool small = lds_scene && render_scene_fits_lds(P);
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
-    if (render_uses_walk_kernel(P, force_walk)) {
+#define PT_LAUNCH_WIDE(C, I) hipLaunchKernelGGL((pt_render_kernel<C, false, I, true>), dim3(n_blocks), dim3(256), 0, stream, P)
+    if (P.traversal == GPT_TRAVERSAL_WIDE4) {
+        if (render_uses_walk_kernel(P, force_walk)) { if (count) PT_LAUNCH_WIDE(true, PT_IT_VPT_WALK); else PT_LAUNCH_WIDE(false, PT_IT_VPT_WALK); }
+        else if (P.integrator == GPT_IT_VPT) { if (count) PT_LAUNCH_WIDE(true, GPT_IT_VPT); else PT_LAUNCH_WIDE(false, GPT_IT_VPT); }
+        else if (!ao) { if (count) PT_LAUNCH_WIDE(true, GPT_IT_PT); else PT_LAUNCH_WIDE(false, GPT_IT_PT); }
+        else { if (count) PT_LAUNCH_WIDE(true, GPT_IT_AO); else PT_LAUNCH_WIDE(false, GPT_IT_AO); }
+    } else if (render_uses_walk_kernel(P, force_walk)) {
         if (count && small) PT_LAUNCH(true, true, PT_IT_VPT_WALK);
         else if (count) PT_LAUNCH(true, false, PT_IT_VPT_WALK);
         else if (small) PT_LAUNCH(false, true, PT_IT_VPT_WALK);
@@ -2967,6 +3636,7 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_
         else PT_LAUNCH(false, false, GPT_IT_AO);
     }
 #undef PT_LAUNCH
+#undef PT_LAUNCH_WIDE
     return hipGetLastError();
 }
 

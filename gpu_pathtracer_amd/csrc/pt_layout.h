@@ -48,6 +48,20 @@ struct alignas(16) DevTri {
 };
 static_assert(sizeof(DevTri) == 48, "DevTri");
 
+// One child of a wide node (include/gpt_wide_bvh.h), in the register layout of DevNode: two dwordx4.
+//   count < 0: another wide node, ref = its BYTE offset (index * 128);  count > 0: a leaf, ref = index of its first
+//   triangle, count triangles;  count = 0: empty
+struct alignas(16) DevWideChild {
+    float bmin[3];
+    float bmax[3];
+    int32_t ref;
+    int32_t count;
+};
+struct alignas(16) DevWideNode {
+    DevWideChild c[4];
+};
+static_assert(sizeof(DevWideNode) == 128, "DevWideNode");
+
 struct alignas(16) DevShade {
     float n1[3], n2[3], n3[3];   // vertex normals
     float uv1[2], uv2[2], uv3[2];
@@ -136,6 +150,9 @@ struct DevParams {
     const struct DevMedium *mediums;
     const int32_t *prim_media;         // per primitive (BVH order): mediumInside, mediumOutside
     int32_t vpt_walk;                  // Volpath: density grids or material-less surfaces -> the one-ray-at-a-time kernel
+    // GPT_TRAVERSAL_WIDE4 only (include/gpt_wide_bvh.h)
+    const struct DevWideNode *wide;    // the 4-wide tree; child k of node w at byte offset 128 * w + 32 * k
+    uint32_t *wide_stack;              // overflow of the per-ray LDS stacks: kWideSpill entries per ray group of every resident wave
 };
 
 }  // namespace pt

@@ -27,6 +27,7 @@
 #include "host_util.h"
 #include "pt_layout.h"
 #include "../../include/gpt_traversal.h"
+#include "../../include/gpt_wide_bvh.h"
 
 namespace pt {
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream);
@@ -36,7 +37,7 @@ hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_
                           hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
 hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream);
-int render_kernel_blocks_per_cu(bool count, bool walk);
+int render_kernel_blocks_per_cu(bool count, bool walk, bool wide);
 bool render_uses_walk_kernel(const DevParams &P, bool force);
 }  // namespace pt
 
@@ -74,12 +75,15 @@ struct gpt_ctx {
     bool count_next = false;
     int n_cus = 256;
     int blocks_per_cu[2][2] = {{4, 4}, {3, 3}};      // [walk kernel][counting build]
+    int blocks_per_cu_wide[2][2] = {{4, 4}, {3, 3}}; // ... of the GPT_TRAVERSAL_WIDE4 kernels
     // timing of the path kernel on its own stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     uint32_t timed_launches = 0;
     double timed_ms = 0.0;
     // multi-GPU film reduce (gpt_comm_init / gpt_reduce_film)
+    bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
+    int wide_depth = 0, n_wide = 0;
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
@@ -325,7 +329,10 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
     for (int w = 0; w < 2; ++w)
-        for (int c = 0; c < 2; ++c) ctx->blocks_per_cu[w][c] = render_kernel_blocks_per_cu(c != 0, w != 0);
+        for (int c = 0; c < 2; ++c) {
+            ctx->blocks_per_cu[w][c] = render_kernel_blocks_per_cu(c != 0, w != 0, false);
+            ctx->blocks_per_cu_wide[w][c] = render_kernel_blocks_per_cu(c != 0, w != 0, true);
+        }
 
     // ---- geometry
     std::vector<DevTri> tris((size_t)scene->n_prims + 1);      // + padding: a triangle trip may also read the record after the one it tests
@@ -334,6 +341,28 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     std::vector<DevNode> nodes;
     thread_nodes(scene->nodes, scene->n_nodes, nodes);
     nodes.push_back(DevNode{});       // padding: a node trip may also read the 32 bytes after the node it visits
+    // the 4-wide tree of GPT_TRAVERSAL_WIDE4 (include/gpt_wide_bvh.h), derived from the reference's tree
+    std::vector<DevWideNode> wide_dev;
+    if (scene->n_nodes > 0 && scene->n_prims < (1 << 27)) {
+        const int32_t cap = gpt_wide_capacity(scene->n_nodes, scene->n_prims);
+        std::vector<gpt_wide_node> wide((size_t)cap);
+        int32_t depth = 0;
+        const int32_t n_wide = gpt_wide_build(scene->nodes, scene->n_nodes, scene->prims, wide.data(), cap, &depth);
+        if (n_wide > 0 && 3 * depth + 1 <= GPT_WIDE_STACK_MAX && (int64_t)n_wide * (int64_t)sizeof(DevWideNode) < INT32_MAX) {
+            wide_dev.resize((size_t)n_wide);
+            for (int32_t w = 0; w < n_wide; ++w)
+                for (int k = 0; k < 4; ++k) {
+                    const gpt_wide_child &c = wide[(size_t)w].c[k];
+                    DevWideChild &d = wide_dev[(size_t)w].c[k];
+                    for (int a = 0; a < 3; ++a) { d.bmin[a] = c.bmin[a]; d.bmax[a] = c.bmax[a]; }
+                    d.ref = c.count < 0 ? c.ref * (int32_t)sizeof(DevWideNode) : c.ref;
+                    d.count = c.count;
+                }
+            ctx->wide_ok = true;
+            ctx->wide_depth = depth;
+            ctx->n_wide = n_wide;
+        }
+    }
     std::vector<DevLight> lights((size_t)scene->n_lights);
     for (int i = 0; i < scene->n_lights; ++i) {
         const gpt_area &a = scene->lights[i];
@@ -349,6 +378,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     DevParams &P = ctx->P;
     if ((rc = dev_upload(ctx, nodes.data(), nodes.size(), &P.nodes)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, tris.data(), tris.size(), &P.tris)) != GPT_OK) return fail(rc);
+    if ((rc = dev_upload(ctx, wide_dev.data(), wide_dev.size(), &P.wide)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, shade.data(), shade.size(), &P.shade)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, scene->materials, (size_t)scene->n_materials, &P.materials)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, lights.data(), lights.size(), &P.lights)) != GPT_OK) return fail(rc);
@@ -553,9 +583,23 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
 
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
 {
-    if (!ctx || (order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_NEAR_FIRST)) {
+    if (!ctx || (order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_NEAR_FIRST && order != GPT_TRAVERSAL_WIDE4)) {
         gpt_set_error("gpt_set_traversal_order: invalid argument");
         return GPT_ERR_INVALID_ARG;
+    }
+    if (order == GPT_TRAVERSAL_WIDE4) {
+        if (!ctx->wide_ok) {
+            gpt_set_error("gpt_set_traversal_order: the scene has no wide tree (empty scene, or deeper than %d wide levels)", (GPT_WIDE_STACK_MAX - 1) / 3);
+            return GPT_ERR_UNSUPPORTED;
+        }
+        if (!ctx->P.wide_stack) {          // spill space of the per-ray stacks: one slice per ray group of every wave that can be resident
+            void *p = nullptr;
+            const size_t n = (size_t)ctx->n_cus * 8 * 4 * 16 * (GPT_WIDE_STACK_MAX + 8);
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipMalloc(&p, n * sizeof(uint32_t)));
+            ctx->allocs.push_back(p);
+            ctx->P.wide_stack = static_cast<uint32_t *>(p);
+        }
     }
     ctx->P.traversal = order;
     return GPT_OK;
@@ -631,7 +675,8 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     }
     ctx->last_batch_cap = batch_cap;
 
-    const long resident_waves = (long)ctx->n_cus * ctx->blocks_per_cu[render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0][count ? 1 : 0] * 4;
+    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4;
+    const long resident_waves = (long)ctx->n_cus * (wide ? ctx->blocks_per_cu_wide : ctx->blocks_per_cu)[render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0][count ? 1 : 0] * 4;
     for (uint32_t done = 0; done < iter_count; done += batch_cap) {
         DevParams P = ctx->P;
         P.cam = *camera;

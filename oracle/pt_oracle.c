@@ -67,6 +67,7 @@
 #include "../include/gpt_types.h"
 #include "../include/gpt_softmath.h"
 #include "../include/gpt_traversal.h"
+#include "../include/gpt_wide_bvh.h"
 
 #ifdef ORACLE_SOFTMATH
 #define M_SIN(x)   gpt_sinf(x)
@@ -283,6 +284,8 @@ typedef struct {
     gpt_infinite inf;     /* copy; isvalid = 0 when desc->infinite is NULL */
     float eps;
     const unsigned char *order;   /* near-first traversal: one gpt_node_order_code per node; NULL = reference order */
+    const gpt_wide_node *wide;    /* GPT_TRAVERSAL_WIDE4: the 4-wide tree (include/gpt_wide_bvh.h); NULL otherwise */
+    int n_wide;
 } scene_t;
 
 /* ---- AABB slab test: bbox.h:77-96 ------------------------------------------ */
@@ -304,6 +307,35 @@ static inline int bbox_intersect(const gpt_bvh_node *n, const ray_t *r)
 }
 
 /* ---- triangle: mesh.h:45-98 -------------------------------------------------- */
+/* the hit record of mesh.h:68-95 for a triangle, the ray's (t, b1, b2) on it */
+static inline void fill_isect(const gpt_triangle *t, const ray_t *ray, float tt, float b1, float b2, isect_t *isect)
+{
+    f3 e1 = sub3(t->v2.v, t->v1.v);
+    f3 e2 = sub3(t->v3.v, t->v1.v);
+    f3 dpdu, dpdv;
+    f2 duv1 = sub2(t->v2.uv, t->v1.uv);
+    f2 duv2 = sub2(t->v3.uv, t->v1.uv);
+    float det = duv1.x * duv2.y - duv1.y * duv2.x;
+    if ((double)fabsf(det) < 1e-8) {
+        f3 nn = normalize3(cross3(e1, e2));
+        make_coordinate(nn, &dpdu, &dpdv);
+    } else {
+        float invDet = 1 / det;
+        dpdu = scl3(sub3(scl3(e1, duv2.y), scl3(e2, duv1.y)), invDet);
+        dpdv = scl3(add3(scl3(e1, -duv2.x), scl3(e2, duv1.x)), invDet);
+    }
+    (void)dpdu;
+    isect->pos = ray_at(ray, tt);
+    float b0 = 1.f - b1 - b2;
+    isect->nor = normalize3(add3(add3(scl3(t->v1.n, b0), scl3(t->v2.n, b1)), scl3(t->v3.n, b2)));
+    isect->uv = add2(add2(scl2(t->v1.uv, b0), scl2(t->v2.uv, b1)), scl2(t->v3.uv, b2));
+    isect->matIdx = t->matIdx;
+    isect->lightIdx = t->lightIdx;
+    isect->mediumInside = t->mediumInside;      /* mesh.h:93-94 */
+    isect->mediumOutside = t->mediumOutside;
+    isect->dpdu = normalize3(cross3(isect->nor, normalize3(dpdv)));
+}
+
 static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isect)
 {
     f3 e1 = sub3(t->v2.v, t->v1.v);
@@ -326,30 +358,7 @@ static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isec
         return 0;
 
     ray->tmax = tt;
-    if (isect) {
-        f3 dpdu, dpdv;
-        f2 duv1 = sub2(t->v2.uv, t->v1.uv);
-        f2 duv2 = sub2(t->v3.uv, t->v1.uv);
-        float det = duv1.x * duv2.y - duv1.y * duv2.x;
-        if ((double)fabsf(det) < 1e-8) {
-            f3 nn = normalize3(cross3(e1, e2));
-            make_coordinate(nn, &dpdu, &dpdv);
-        } else {
-            float invDet = 1 / det;
-            dpdu = scl3(sub3(scl3(e1, duv2.y), scl3(e2, duv1.y)), invDet);
-            dpdv = scl3(add3(scl3(e1, -duv2.x), scl3(e2, duv1.x)), invDet);
-        }
-        (void)dpdu;
-        isect->pos = ray_at(ray, tt);
-        float b0 = 1.f - b1 - b2;
-        isect->nor = normalize3(add3(add3(scl3(t->v1.n, b0), scl3(t->v2.n, b1)), scl3(t->v3.n, b2)));
-        isect->uv = add2(add2(scl2(t->v1.uv, b0), scl2(t->v2.uv, b1)), scl2(t->v3.uv, b2));
-        isect->matIdx = t->matIdx;
-        isect->lightIdx = t->lightIdx;
-        isect->mediumInside = t->mediumInside;      /* mesh.h:93-94 */
-        isect->mediumOutside = t->mediumOutside;
-        isect->dpdu = normalize3(cross3(isect->nor, normalize3(dpdv)));
-    }
+    if (isect) fill_isect(t, ray, tt, b1, b2, isect);
     return 1;
 }
 
@@ -368,8 +377,116 @@ static inline void push_children(const scene_t *sc, const gpt_bvh_node *node, in
     }
 }
 
+/* ---- GPT_TRAVERSAL_WIDE4: the walk of include/gpt_wide_bvh.h ------------------------------------------------------
+ * Same box arithmetic (bbox.h:77-96, with the box's entry distance kept as the order key) and the same triangle test
+ * (mesh.h:45-67) as above; only the order of the tests is the wide tree's.  The GPU does this with four lanes per ray: the
+ * four boxes of a node in one step, the triangles of a leaf four at a time against the same interval. */
+static inline int wide_box(const gpt_wide_child *c, const ray_t *r, f3 inv_dir, float ray_tmax, float *tn_out)
+{
+    float t1 = (c->bmin[0] - r->o.x) * inv_dir.x;
+    float t2 = (c->bmax[0] - r->o.x) * inv_dir.x;
+    float t3 = (c->bmin[1] - r->o.y) * inv_dir.y;
+    float t4 = (c->bmax[1] - r->o.y) * inv_dir.y;
+    float t5 = (c->bmin[2] - r->o.z) * inv_dir.z;
+    float t6 = (c->bmax[2] - r->o.z) * inv_dir.z;
+    float tmin = gpt_fmaxf(gpt_fmaxf(gpt_fminf(t1, t2), gpt_fminf(t3, t4)), gpt_fminf(t5, t6));
+    float tmax = gpt_fminf(gpt_fminf(gpt_fmaxf(t1, t2), gpt_fmaxf(t3, t4)), gpt_fmaxf(t5, t6));
+    *tn_out = tmin;
+    if (tmax <= 0.00001f) return 0;
+    if (tmin > tmax) return 0;
+    if (tmin > ray_tmax) return 0;
+    return 1;
+}
+
+/* mesh.h:45-67 without the side effects: accepted -> (tt, b1, b2) */
+static inline int tri_test(const gpt_triangle *t, const ray_t *ray, float ray_tmax, float *tt_out, float *b1_out, float *b2_out)
+{
+    f3 e1 = sub3(t->v2.v, t->v1.v);
+    f3 e2 = sub3(t->v3.v, t->v1.v);
+    f3 s1 = cross3(ray->d, e2);
+    float divisor = dot3(s1, e1);
+    if (fabsf(divisor) < 1e-8f)
+        return 0;
+    float invDivisor = (float)(1.0 / (double)divisor);
+    f3 s = sub3(ray->o, t->v1.v);
+    float b1 = dot3(s, s1) * invDivisor;
+    if (b1 < 0.0 || b1 > 1.0)
+        return 0;
+    f3 s2 = cross3(s, e1);
+    float b2 = dot3(ray->d, s2) * invDivisor;
+    if (b2 < 0.0 || b1 + b2 > 1.0)
+        return 0;
+    float tt = dot3(e2, s2) * invDivisor;
+    if (tt < ray->tmin || tt > ray_tmax)
+        return 0;
+    *tt_out = tt; *b1_out = b1; *b2_out = b2;
+    return 1;
+}
+
+static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any_hit)
+{
+    uint32_t stack[GPT_WIDE_STACK_MAX + 4];
+    int sp = 0;
+    uint32_t cur = 0;                                  /* wide node 0 */
+    const f3 inv_dir = mk3(1.f / ray->d.x, 1.f / ray->d.y, 1.f / ray->d.z);
+    float tmax = ray->tmax;
+    int best_prim = -1;
+    float best_t = 0.f, best_b1 = 0.f, best_b2 = 0.f;
+    if (sc->n_wide <= 0) return 0;
+    while (cur != GPT_WIDE_NONE) {
+        if (!gpt_wide_entry_is_leaf(cur)) {
+            const gpt_wide_node *node = &sc->wide[cur];
+            t_cnt.node_visits++;
+            int hit[4], nhit = 0;
+            uint32_t key[4];
+            for (int k = 0; k < 4; ++k) {
+                float tn = 0.f;
+                hit[k] = node->c[k].count != 0 && wide_box(&node->c[k], ray, inv_dir, tmax, &tn);
+                key[k] = gpt_wide_key(tn, k);
+                nhit += hit[k];
+            }
+            for (int k = 0; k < 4; ++k) {
+                if (!hit[k]) continue;
+                int rank = 0;                          /* hit children that pop before child k */
+                for (int j = 0; j < 4; ++j)
+                    if (hit[j] && key[j] < key[k]) rank++;
+                const gpt_wide_child *c = &node->c[k];
+                stack[sp + nhit - 1 - rank] = c->count < 0 ? (uint32_t)c->ref : gpt_wide_leaf_entry(c->ref, c->count);
+            }
+            sp += nhit;
+            cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
+        } else {
+            const int first = gpt_wide_entry_first(cur), count = gpt_wide_entry_count(cur);
+            const int m = count < 4 ? count : 4;
+            float nearest = INFINITY;
+            int accepted = 0;
+            for (int k = 0; k < m; ++k) {              /* all against the same interval */
+                float tt, b1, b2;
+                t_cnt.prim_tests++;
+                if (!tri_test(&sc->d->prims[first + k].triangle, ray, tmax, &tt, &b1, &b2)) continue;
+                accepted = 1;
+                if (tt < nearest) nearest = tt;
+                if (best_prim < 0 || tt < best_t || (tt == best_t && first + k > best_prim)) {
+                    best_prim = first + k; best_t = tt; best_b1 = b1; best_b2 = b2;
+                }
+            }
+            if (accepted) {
+                if (nearest < tmax) tmax = nearest;
+                if (any_hit) return 1;
+            }
+            if (count > 4) cur = gpt_wide_leaf_entry(first + 4, count - 4);
+            else cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
+        }
+    }
+    if (best_prim < 0) return 0;
+    ray->tmax = best_t;
+    if (isect) fill_isect(&sc->d->prims[best_prim].triangle, ray, best_t, best_b1, best_b2, isect);
+    return 1;
+}
+
 static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
 {
+    if (sc->wide) { t_cnt.closest_rays++; return intersect_wide(sc, ray, isect, 0); }
     int stack[64];
     int top = 0;
     int ret = 0;
@@ -403,6 +520,7 @@ static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
 
 static int intersect_any(const scene_t *sc, ray_t *ray)
 {
+    if (sc->wide) { t_cnt.shadow_rays++; return intersect_wide(sc, ray, NULL, 1); }
     int stack[64];
     int top = 0;
     int node_idx = 0;
@@ -1568,6 +1686,17 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
             if (!desc->nodes[i].is_leaf) order[i] = (unsigned char)gpt_node_order_code(desc->nodes, i);
     }
     sc.order = order;
+    gpt_wide_node *wide = NULL;
+    sc.wide = NULL;
+    sc.n_wide = 0;
+    if (g_traversal == GPT_TRAVERSAL_WIDE4 && desc->n_nodes > 0) {
+        const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
+        int depth = 0;
+        wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
+        sc.n_wide = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, wide, cap, &depth);
+        if (sc.n_wide < 0 || 3 * depth + 1 > GPT_WIDE_STACK_MAX) { free(wide); free(order); return -3; }
+        sc.wide = wide;
+    }
 
 #pragma omp parallel num_threads(n_threads)
     {
@@ -1609,13 +1738,14 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
         }
     }
     free(order);
+    free(wide);
     return 0;
 }
 
-/* GPT_TRAVERSAL_REFERENCE (default) or GPT_TRAVERSAL_NEAR_FIRST for the following oracle_render calls */
+/* GPT_TRAVERSAL_REFERENCE (default), GPT_TRAVERSAL_NEAR_FIRST or GPT_TRAVERSAL_WIDE4 for the following oracle_render calls */
 API int oracle_set_traversal(int mode)
 {
-    if (mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_NEAR_FIRST) return -1;
+    if (mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_NEAR_FIRST && mode != GPT_TRAVERSAL_WIDE4) return -1;
     g_traversal = mode;
     return 0;
 }

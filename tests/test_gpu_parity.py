@@ -541,6 +541,93 @@ def test_config5_standin_near_first_and_small_frame(gpt, standin):
     assert (rel_rms(near, ref) <= RMS_TOL).all()
 
 
+# ---- GPT_TRAVERSAL_WIDE4: the 4-wide tree, four lanes per ray (include/gpt_wide_bvh.h) ------------------------------------
+
+def wide_both(gpt, scene, cam, W, H, eps, spp, what, threads=None):
+    """GPU and oracle in the wide mode: bit-identical; and the wide film against the reference-order film: north_star's bar"""
+    lib = ol.load("soft")
+    ref_order, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft", threads=threads)
+    assert lib.oracle_set_traversal(2) == 0
+    try:
+        want, col = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft", threads=threads)
+    finally:
+        lib.oracle_set_traversal(0)
+    with gpt.Renderer(scene.desc, W, H, eps) as r:
+        r.set_traversal_order("wide")
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), want, what + " (wide)")
+        assert_bit_exact(r.read_color(), col, what + " (wide) last sample")
+        r.enable_counters(True)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), want, what + " (wide, counting build)")
+        c = r.read_counters()
+        r.enable_counters(False)
+        r.set_traversal_order("reference")
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref_order, what + " (back in the reference order)")
+    rms = rel_rms(want, ref_order)
+    assert (rms <= RMS_TOL).all(), f"{what}: wide vs reference order, rel RMS {rms}"
+    return c, int(np.count_nonzero(want != ref_order))
+
+
+def test_wide_traversal_matches_the_oracle_and_the_reference_order(gpt):
+    """Material zoo under area + environment light (36 triangles: a wide tree of a few nodes), triangle soups with leaves of
+    every size, the 22k-triangle procedural scene: GPU == oracle bit for bit in the wide mode, and the film within 1e-4
+    relative RMS of the reference-order film (measured: identical)."""
+    scene, meta = scenes.zoo_scene(max_depth=8, with_env=True)
+    wide_both(gpt, scene, ol.cornell_camera(meta, 160, 128), 160, 128, 0.001, 6, "zoo + env")
+    soup = scenes.random_soup(3000, 11, mats=(2, 5, 7, 13), size=0.2)
+    scene, meta = scenes.zoo_scene(max_depth=6, extra=soup)
+    wide_both(gpt, scene, ol.cornell_camera(meta, 128, 128), 128, 128, 0.001, 4, "soup")
+    scene, meta = scenes.stress_scene(0.3, max_depth=12)
+    c, n_diff = wide_both(gpt, scene, ol.cornell_camera(meta, 192, 128), 192, 128, 0.001, 4, "22k triangles")
+    assert c["node_visits"] > 0 and c["prim_tests"] > 0
+
+
+def test_wide_traversal_flat_leaves_ao_and_volpath(gpt):
+    """A finely tessellated flat sheet is ONE leaf of the reference's tree (bvh.cpp:43: a box thinner than 1e-4 is never split):
+    the wide tree turns it into a subtree of index ranges.  Also the other integrators on the wide tree: Ao, Volpath with
+    homogeneous fog (three rays per bounce) and with a density grid behind a material-less box (one ray at a time)."""
+    n = 24
+    xs = np.linspace(-0.8, 0.8, n + 1, dtype=np.float32)
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            p = [(xs[i], 0.9, xs[j]), (xs[i + 1], 0.9, xs[j]), (xs[i + 1], 0.9, xs[j + 1]), (xs[i], 0.9, xs[j + 1])]
+            tris.append(scenes.make_tri(p[0], p[1], p[2], (0, 1, 0), (0, 1, 0), (0, 1, 0), mat=5 if (i + j) % 3 else 7))
+            tris.append(scenes.make_tri(p[0], p[2], p[3], (0, 1, 0), (0, 1, 0), (0, 1, 0), mat=2))
+    sheet = np.zeros(len(tris), dtype=st.PRIMITIVE)
+    for k, t in enumerate(tris):
+        sheet[k] = t
+    scene, meta = scenes.zoo_scene(max_depth=6, extra=sheet)
+    leaf_sizes = scene.nodes["end"][scene.nodes["is_leaf"] != 0] - scene.nodes["start"][scene.nodes["is_leaf"] != 0] + 1
+    assert leaf_sizes.max() > 64                      # the sheet: one reference leaf
+    cam = ol.make_camera((0.2, 1.7, 3.4), (0, 0.8, 0), (0, 1, 0), (128, 96), 40.0)
+    wide_both(gpt, scene, cam, 128, 96, 0.001, 4, "flat sheet")
+    scene.desc.set_integrator("ao", 0.7)
+    wide_both(gpt, scene, cam, 128, 96, 0.001, 4, "ao")
+    scene, cam, W, H, spp = walk_case("smoke_large_scene")
+    wide_both(gpt, scene, cam, W, H, 0.001, spp, "volpath walk")
+    fog = st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.3)
+    scene, meta = scenes.stress_scene(0.3, max_depth=8)
+    scene.set_mediums([fog])
+    scene.desc.set_integrator("vpt", 8)
+    cam = ol.cornell_camera(meta, 128, 96)
+    cam.medium = 0
+    wide_both(gpt, scene, cam, 128, 96, 0.001, 3, "volpath fog")
+
+
+def test_wide_traversal_on_the_config5_standin(gpt, standin):
+    """The dragon / bunny / teapot scene (248 574 triangles, 16 bounces) at 480 x 272: wide GPU == wide oracle, and the
+    wide film against the reference-order film."""
+    ls = standin("c5")
+    W, H, spp = 480, 272, 4
+    cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)
+    c, n_diff = wide_both(gpt, ls, cam, W, H, ls.epsilon, spp, "config 5 stand-in", threads=min(64, os.cpu_count() or 1))
+    print("config-5 stand-in, wide: node visits / sample", c["node_visits"] / c["samples"], "triangle tests / sample",
+          c["prim_tests"] / c["samples"], "floats that differ from the reference-order film:", n_diff)
+
+
 # ---- edge cases -----------------------------------------------------------------------------------------
 
 def test_edge_cases_empty_scene_tiny_frames_single_triangle(gpt):

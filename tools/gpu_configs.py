@@ -9,7 +9,7 @@ from gpu_pathtracer_amd import api, host
 
 def timed(desc, cam, W, H, eps, spp, near=False):
     with api.Renderer(desc, W, H, eps) as r:
-        r.set_traversal_order(near)
+        r.set_traversal_order(near)          # False / True / "wide"
         r.render(cam, 1, 2, reset=True); r.synchronize()
         best = 1e9
         for rep in range(3):
@@ -44,8 +44,8 @@ for which, label, spp in (("c3", "config 3  SURVEY stand-in: 3 spheres + cube-su
                           ("c4", "config 4  SURVEY stand-in: config-5 geometry under a procedural sky, 1080p d7             ", 32),
                           ("c5", "config 5  SURVEY stand-in: walls + dragon + bunny2 + teapot + 9 spheres (248 574), 4K d16 ", 8)):
     ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which))
-    for near in (False, True):
-        print("%s %s: %7.1f Msamples/s (%.1f ms / %d iterations) finite=%s" % ((label, "near" if near else "    ") + timed(ls.desc, ls.camera, ls.width, ls.height, ls.epsilon, spp, near)[:2] + (spp, True)), flush=True)
+    for near in (False, True, "wide"):
+        print("%s %s: %7.1f Msamples/s (%.1f ms / %d iterations) finite=%s" % ((label, {False: "    ", True: "near", "wide": "wide"}[near]) + timed(ls.desc, ls.camera, ls.width, ls.height, ls.epsilon, spp, near)[:2] + (spp, True)), flush=True)
     ls.close()
 
 print("# the procedural stand-ins of round 1 (parametric blobs), for comparison")
