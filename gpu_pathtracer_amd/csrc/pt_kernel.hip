@@ -462,6 +462,18 @@ static_assert(kWideStackOff * 16 + 16 * kWideStackDepth * 4 <= kWaveCarryFloat4 
 #ifndef PT_WIDE_FETCH_GROUPS
 #define PT_WIDE_FETCH_GROUPS 2                                    // idle groups that trigger a refill
 #endif
+// A block of a trip costs the wave the same whether one group or sixteen take part.  Groups at a leaf wait until
+// PT_WIDE_LEAF_MIN of them have gathered (or no group is at a wide node), and the other way round with PT_WIDE_NODE_MIN.
+#ifndef PT_WIDE_STOP_GROUPS
+#define PT_WIDE_STOP_GROUPS 4                                     // a dry pool with at most this many groups still busy ends the drain
+#endif
+static_assert(PT_WIDE_STOP_GROUPS <= 16 - PT_WIDE_FETCH_GROUPS, "a resumed drain starts with a refill");
+#ifndef PT_WIDE_LEAF_MIN
+#define PT_WIDE_LEAF_MIN 4
+#endif
+#ifndef PT_WIDE_NODE_MIN
+#define PT_WIDE_NODE_MIN 1
+#endif
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
 // quad_perm controls: broadcast of lane j of every group of four, and the two butterfly steps
@@ -534,8 +546,19 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         }
         if (m_busy == 0ull) break;
 
-        const bool leaf = has && !fin && (cur >> 31) != 0u;
-        const bool inner = has && !fin && (cur >> 31) == 0u;
+        bool leaf = has && !fin && (cur >> 31) != 0u;
+        bool inner = has && !fin && (cur >> 31) == 0u;
+        {
+            const int n_leaf = popc(ballot(leaf) & kLeaders), n_inner = popc(ballot(inner) & kLeaders);
+            if (n_leaf < PT_WIDE_LEAF_MIN && n_inner > 0) leaf = false;                      // the leaves wait
+            else if (n_inner < PT_WIDE_NODE_MIN && n_leaf > 0) inner = false;                // the wide nodes wait
+        }
+        if (COUNT && lane == 0u) {          // utilisation probes: trips, busy groups, trips with a node block / a leaf block
+            cnt.w_trip++;
+            cnt.l_trip += (uint32_t)popc(m_busy & kLeaders);
+            if (ballot(inner) != 0ull) cnt.w_node++;
+            if (ballot(leaf) != 0ull) cnt.w_prim++;
+        }
         const int lf_first = (int)(cur & 0x07ffffffu), lf_count = (int)((cur >> 27) & 15u) + 1;
         const bool tri_lane = leaf && (int)sub < lf_count;
         // both kinds of fetch go out before either is used
@@ -1126,7 +1149,7 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 //   v14 LDS address of the group's stack   v15 LDS address of the ray's slot (-1: idle group)
 //   v16 32 * (lane & 3)   v17 lane & ~3   v18 lane & 3   v19 end of the ray's interval (group-uniform)
 //   v[20:23] this lane's best hit {triangle index or -1, t, b1, b2}   v[24:31] child record   v[44:52] triangle record
-//   v53 byte offset of the group's slice of the spill stack   v54 (lane & 3) != 0   v[32:43] temporaries
+//   v53 byte offset of the group's slice of the spill stack   v54 (lane & 3) != 0   v55 LDS address of the group's record   v[32:43] temporaries
 //   s[60:61] lanes of groups at a leaf  s[62:63] ... at a wide node  s[64:65] lanes of busy groups  s[66:69],s[72:73] scratch masks
 //   s70 next ray  s71 scratch  s[74:75] lanes with a triangle to test  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] 0x1111...
 #define PT_WIDE_POP /* exec: the lanes that pop; v13 > 0: take the top entry, else the ray is finished */ \
@@ -1149,14 +1172,53 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
         "s_waitcnt lgkmcnt(0)\n" \
         "TW_POPPED_%=:\n"
 
-__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane)
+#define PT_WIDE_MERGE_BEST /* all four lanes of a group end up with the group's best hit */ \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v33, v20 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_mov_b32_dpp v34, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_mov_b32_dpp v35, v22 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_mov_b32_dpp v36, v23 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n" \
+        "v_cmp_lt_f32_e32 vcc, v34, v21\n" \
+        "s_or_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_eq_f32_e32 vcc, v34, v21\n" \
+        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n" \
+        "s_and_b64 vcc, vcc, s[72:73]\n" \
+        "s_or_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_lt_i32_e32 vcc, -1, v33\n" \
+        "s_and_b64 vcc, vcc, s[66:67]\n" \
+        "v_cndmask_b32_e32 v20, v20, v33, vcc\n" \
+        "v_cndmask_b32_e32 v21, v21, v34, vcc\n" \
+        "v_cndmask_b32_e32 v22, v22, v35, vcc\n" \
+        "v_cndmask_b32_e32 v23, v23, v36, vcc\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v33, v20 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_mov_b32_dpp v34, v21 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_mov_b32_dpp v35, v22 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_mov_b32_dpp v36, v23 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n" \
+        "v_cmp_lt_f32_e32 vcc, v34, v21\n" \
+        "s_or_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_eq_f32_e32 vcc, v34, v21\n" \
+        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n" \
+        "s_and_b64 vcc, vcc, s[72:73]\n" \
+        "s_or_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_lt_i32_e32 vcc, -1, v33\n" \
+        "s_and_b64 vcc, vcc, s[66:67]\n" \
+        "v_cndmask_b32_e32 v20, v20, v33, vcc\n" \
+        "v_cndmask_b32_e32 v21, v21, v34, vcc\n" \
+        "v_cndmask_b32_e32 v22, v22, v35, vcc\n" \
+        "v_cndmask_b32_e32 v23, v23, v36, vcc\n"
+
+__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
     const unsigned long long s_nodes = uniform64((unsigned long long)P.wide), s_tris = uniform64((unsigned long long)P.tris);
     const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
-    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_stack = s_pool + kWideStackOff * 16;
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_stack = s_pool + kWideStackOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
     // this group's slice of the spill stack, in bytes (wave-uniform part + 4 * stride * group)
     const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u + (lane >> 2)) * (unsigned)(kWideSpillStride * 4);
     asm volatile(
@@ -1177,10 +1239,27 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_mov_b32_e32 v53, %[vspill]\n"
         "v_cmp_ne_u32_e32 vcc, 0, v18\n"
         "v_cndmask_b32_e64 v54, 0, 1, vcc\n"
-        "v_mov_b32_e32 v12, -1\n"
-        "v_mov_b32_e32 v13, 0\n"
-        "v_mov_b32_e32 v15, -1\n"
-        "v_mov_b32_e32 v20, -1\n"
+        /* every group resumes the ray it was walking when the last drain stopped (its record: {entry, stack size, end of the
+           interval, slot} {best hit}); direction and origin come back from the ray's slot */
+        "v_lshrrev_b32_e32 v34, 2, v33\n"
+        "v_lshl_add_u32 v55, v34, 5, %[susp]\n"
+        "ds_read_b128 v[40:43], v55\n"
+        "ds_read_b128 v[20:23], v55 offset:16\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_mov_b32_e32 v12, v40\n"
+        "v_mov_b32_e32 v13, v41\n"
+        "v_mov_b32_e32 v19, v42\n"
+        "v_mov_b32_e32 v15, v43\n"
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"
+        "s_mov_b64 exec, s[64:65]\n"
+        "ds_read_b128 v[4:7], v15\n"
+        "ds_read_b128 v[8:11], v15 offset:16\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32_e32 v33, 0xff, v11\n"
+        "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
+        "ds_read_b96 v[0:2], v33 offset:%[org]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
         "s_branch TW_FILL_%=\n"
         /* ---------------------------------------------------------------- loop header */
         "TW_LOOP_%=:\n"
@@ -1192,6 +1271,22 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_gt_i32_e64 s[60:61], 0, v12\n"
         "s_and_b64 s[60:61], s[60:61], s[64:65]\n"         /* at a leaf (bit 31 set, not -1: busy groups only) */
         "s_andn2_b64 s[62:63], s[64:65], s[60:61]\n"       /* at a wide node */
+        /* too few groups at a leaf: they wait (unless nobody is at a wide node); else too few at a wide node: those wait */
+        "s_and_b64 s[66:67], s[60:61], s[80:81]\n"
+        "s_bcnt1_i32_b64 s71, s[66:67]\n"
+        "s_and_b64 s[66:67], s[62:63], s[80:81]\n"
+        "s_bcnt1_i32_b64 s72, s[66:67]\n"
+        "s_cmp_ge_u32 s71, %[leafmin]\n"
+        "s_cbranch_scc1 TW_VOTE_NODE_%=\n"
+        "s_cmp_eq_u32 s72, 0\n"
+        "s_cbranch_scc1 TW_VOTED_%=\n"
+        "s_mov_b64 s[60:61], 0\n"
+        "s_branch TW_VOTED_%=\n"
+        "TW_VOTE_NODE_%=:\n"
+        "s_cmp_ge_u32 s72, %[nodemin]\n"
+        "s_cbranch_scc1 TW_VOTED_%=\n"
+        "s_mov_b64 s[62:63], 0\n"
+        "TW_VOTED_%=:\n"
         /* ---- fetches of both kinds */
         "s_mov_b64 exec, s[60:61]\n"
         "v_bfe_u32 v34, v12, 27, 4\n"                      /* count - 1 */
@@ -1253,18 +1348,14 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_and_b32_e32 v40, 15, v40\n"
         "v_bcnt_u32_b32 v41, v40, 0\n"                     /* nhit */
         /* rank = how many of the four keys are smaller */
-        "v_mov_b32_dpp v33, v39 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v34, v39 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v35, v39 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v36, v39 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
         "v_mov_b32_e32 v42, 0\n"
-        "v_cmp_lt_u32_e32 vcc, v33, v39\n"
+        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 0 < this key */
         "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v34, v39\n"
+        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 1 < this key */
         "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v35, v39\n"
+        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 2 < this key */
         "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v36, v39\n"
+        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 3 < this key */
         "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"        /* rank */
         /* this child as an entry */
         "v_add_u32_e32 v33, -1, v31\n"
@@ -1449,44 +1540,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---------------------------------------------------------------- finished rays (s[68:69]) */
         "TW_FIN_%=:\n"
         "s_mov_b64 exec, s[68:69]\n"
-        /* the best of the four lanes' hits, by two exchanges: take the partner's when it has one and this lane has none, or it
-           is nearer, or exactly as near with a larger triangle index */
-        "s_nop 1\n"
-        "v_mov_b32_dpp v33, v20 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v34, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v35, v22 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v36, v23 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n"
-        "v_cmp_lt_f32_e32 vcc, v34, v21\n"
-        "s_or_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_eq_f32_e32 vcc, v34, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n"
-        "s_and_b64 vcc, vcc, s[72:73]\n"
-        "s_or_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_lt_i32_e32 vcc, -1, v33\n"
-        "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e32 v20, v20, v33, vcc\n"
-        "v_cndmask_b32_e32 v21, v21, v34, vcc\n"
-        "v_cndmask_b32_e32 v22, v22, v35, vcc\n"
-        "v_cndmask_b32_e32 v23, v23, v36, vcc\n"
-        "s_nop 1\n"
-        "v_mov_b32_dpp v33, v20 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v34, v21 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v35, v22 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_mov_b32_dpp v36, v23 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n"
-        "v_cmp_lt_f32_e32 vcc, v34, v21\n"
-        "s_or_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_eq_f32_e32 vcc, v34, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n"
-        "s_and_b64 vcc, vcc, s[72:73]\n"
-        "s_or_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_lt_i32_e32 vcc, -1, v33\n"
-        "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e32 v20, v20, v33, vcc\n"
-        "v_cndmask_b32_e32 v21, v21, v34, vcc\n"
-        "v_cndmask_b32_e32 v22, v22, v35, vcc\n"
-        "v_cndmask_b32_e32 v23, v23, v36, vcc\n"
+        PT_WIDE_MERGE_BEST
         /* a miss reports the end of the interval, like the other loops */
         "v_cmp_gt_i32_e32 vcc, 0, v20\n"
         "v_cndmask_b32_e32 v21, v21, v19, vcc\n"
@@ -1537,20 +1591,40 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_waitcnt lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
         "s_branch TW_LOOP_%=\n"
+        /* a dry pool: drain to the end, unless this round had new rays and only a few groups are still busy - then the drain
+           ends, the busy groups park their rays and the owners of those rays sit out the shading round */
         "TW_EMPTY_%=:\n"
-        "s_cmp_lg_u64 s[64:65], 0\n"
+        "s_cmp_eq_u64 s[64:65], 0\n"
+        "s_cbranch_scc1 TW_DONE_%=\n"
+        "s_cmp_eq_u32 %[allow], 0\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
+        "s_and_b64 s[66:67], s[64:65], s[80:81]\n"
+        "s_bcnt1_i32_b64 s71, s[66:67]\n"
+        "s_cmp_gt_u32 s71, %[tstop]\n"
+        "s_cbranch_scc1 TW_TRIP_%=\n"
+        "TW_DONE_%=:\n"
+        PT_WIDE_MERGE_BEST
+        "v_cmp_eq_u32_e32 vcc, 0, v18\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_mov_b32_e32 v40, v12\n"
+        "v_mov_b32_e32 v41, v13\n"
+        "v_mov_b32_e32 v42, v19\n"
+        "v_mov_b32_e32 v43, v15\n"
+        "ds_write_b128 v55, v[40:43]\n"
+        "ds_write_b128 v55, v[20:23] offset:16\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
         :
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [tris] "s"(s_tris), [spill] "s"(s_spill),
-          [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [vspill] "v"(v_spill),
-          [depth] "n"(kWideStackDepth), [depth4] "n"(kWideStackDepth * 4), [maxbusy] "n"(16 - PT_WIDE_FETCH_GROUPS), [org] "n"(2 * kPoolSlots * 16)
+          [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [susp] "s"(s_susp), [allow] "s"(s_allow), [vspill] "v"(v_spill),
+          [tstop] "n"(PT_WIDE_STOP_GROUPS),
+          [depth] "n"(kWideStackDepth), [depth4] "n"(kWideStackDepth * 4), [maxbusy] "n"(16 - PT_WIDE_FETCH_GROUPS), [org] "n"(2 * kPoolSlots * 16),
+          [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
           "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
-          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
+          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -2412,6 +2486,13 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;
         pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+    }
+    if (WIDE) {                                         // trace_pool_wide_asm: 16 group records {entry, stack size, interval end, slot} {best hit}: idle
+        wave_lds_fence();
+        if (lane < 16u) {
+            pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
+            pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+        }
     }
     bool waiting = false;                               // carry: some of this path's rays are still being traced
     // Volpath: the medium the path ray travels in (-1 = none), the one the pending direct-light rays travel in, and
@@ -3405,7 +3486,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 if (COUNT)                          // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
                 else
-                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane);
+                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0);
             } else {
                 GlobalScene mem;
                 mem.nodes = reinterpret_cast<const char *>(P.nodes);

@@ -6,7 +6,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import scenes, oracle_lib as ol
 from gpu_pathtracer_amd import api
 which = sys.argv[1] if len(sys.argv) > 1 else "c5"
-near = len(sys.argv) > 2 and sys.argv[2] == "near"
+near = {"near": True, "wide": "wide"}.get(sys.argv[2], False) if len(sys.argv) > 2 else False
 ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which, 1920, 1080))
 W, H = 1920, 1080
 cam = ls.camera
@@ -19,12 +19,14 @@ with api.Renderer(ls.desc, W, H, ls.epsilon) as r:
     r.render(cam, 1, 16, reset=True); r.synchronize()
     n, ms = r.kernel_time()
 s = c["samples"]
-print(f"{which}{' near-first' if near else ''}: {ls.desc.n_prims} triangles, {ls.desc.n_nodes} nodes, 1920x1080, depth {ls.desc.max_depth}: {W*H*16/ms/1e3:.1f} Msamples/s")
+print(f"{which} {near if near else 'reference order'}: {ls.desc.n_prims} triangles, {ls.desc.n_nodes} nodes, 1920x1080, depth {ls.desc.max_depth}: {W*H*16/ms/1e3:.1f} Msamples/s")
 print(f"per sample: closest-hit rays {c['closest_rays']/s:.2f}, shadow rays {c['shadow_rays']/s:.2f}, bounces {c['bounce_iters']/s:.2f}, "
       f"node visits {c['node_visits']/s:.1f}, triangle tests {c['prim_tests']/s:.1f}")
 rays = c['closest_rays'] + c['shadow_rays']
 print(f"per ray: node visits {c['node_visits']/rays:.1f}, triangle tests {c['prim_tests']/rays:.1f}")
-if c["w_node"]:
+if near == "wide":
+    print(f"wide: trips per 64 samples {c['w_trip']*64/s:.1f}, busy groups per trip {c['l_trip']/max(1,c['w_trip']):.2f} of 16, trips with a node block {c['w_node']/max(1,c['w_trip']):.2f}, with a leaf block {c['w_prim']/max(1,c['w_trip']):.2f}")
+elif c["w_node"]:
     print(f"wave trips per sample-lane: node {c['w_node']*64/s:.1f} (lanes active {c['node_visits']/c['w_node']:.1f} of 64), "
           f"triangle {c['w_prim']*64/s:.1f} (lanes active {c['prim_tests']/max(1,c['w_prim']):.1f} of 64)")
 tot = c["cyc_trace"] + c["cyc_shade"]
