@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 passes (roofline fields that need them are null)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-square", action="store_true", help="skip the square-frame figure and the counting render (a rocprofv3 --stats run then sees "
+                                                             "only the headline kernel's full-size launches)")
     ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.counter_child:
@@ -279,7 +281,7 @@ def main():
         # the kernel's OWN ray counts (it does not trace rays that provably cannot contribute): counting build, 2 iterations
         b_alg_kernel = None
         square = None
-        if single:
+        if single and not args.no_square:
             r.enable_counters(True)
             r.render(cam, 1, 2, reset=True)
             b_alg_kernel = algorithmic_bytes_per_sample(r.read_counters())
