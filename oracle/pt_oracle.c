@@ -423,6 +423,7 @@ static inline int tri_test(const gpt_triangle *t, const ray_t *ray, float ray_tm
     return 1;
 }
 
+static int g_wide_stack_max = 0;          /* deepest stack any ray of the last oracle_render needed (test instrumentation) */
 static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any_hit)
 {
     uint32_t stack[GPT_WIDE_STACK_MAX + 4];
@@ -454,6 +455,7 @@ static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any
                 stack[sp + nhit - 1 - rank] = c->count < 0 ? (uint32_t)c->ref : gpt_wide_leaf_entry(c->ref, c->count);
             }
             sp += nhit;
+            if (sp > g_wide_stack_max) g_wide_stack_max = sp;      /* (benign race between threads: a maximum of monotone writes) */
             cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
         } else {
             const int first = gpt_wide_entry_first(cur), count = gpt_wide_entry_count(cur);
@@ -1689,6 +1691,7 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     gpt_wide_node *wide = NULL;
     sc.wide = NULL;
     sc.n_wide = 0;
+    g_wide_stack_max = 0;
     if (g_traversal == GPT_TRAVERSAL_WIDE4 && desc->n_nodes > 0) {
         const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
         int depth = 0;
@@ -1741,6 +1744,9 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     free(wide);
     return 0;
 }
+
+/* deepest traversal stack of the last GPT_TRAVERSAL_WIDE4 render (the GPU keeps 24 entries per ray in LDS and spills the rest) */
+API int oracle_wide_stack_max(void) { return g_wide_stack_max; }
 
 /* GPT_TRAVERSAL_REFERENCE (default), GPT_TRAVERSAL_NEAR_FIRST or GPT_TRAVERSAL_WIDE4 for the following oracle_render calls */
 API int oracle_set_traversal(int mode)

@@ -617,6 +617,83 @@ def test_wide_traversal_flat_leaves_ao_and_volpath(gpt):
     wide_both(gpt, scene, cam, 128, 96, 0.001, 3, "volpath fog")
 
 
+def chain_scene(n, max_depth=3):
+    """A hand-made reference-layout BVH that is one long chain: inner node i = {the rest of the chain (left), triangle i (right)}.
+    n parallel sheets stacked along z, seen from the far end, so that at every wide node the rest of the chain is the nearest
+    child and three leaves stay pending: the traversal stack of the wide walk grows to ~n entries."""
+    import ctypes as C
+    prims = np.zeros(n + 2, dtype=st.PRIMITIVE)
+    for k in range(n):
+        z = np.float32(0.04 * k)
+        w = np.float32(1.0 + 0.01 * k)
+        prims[k] = scenes.make_tri((-w, -w, z), (w, -w, z), (0.0, 1.5 * w, z), (0, 0, 1), (0, 0, 1), (0, 0, 1), mat=2 if k % 3 else 5)
+    zl = np.float32(0.04 * n + 0.5)                     # the light: two triangles beyond the last sheet, facing the stack
+    prims[n] = scenes.make_tri((-0.4, -0.4, zl), (0.4, -0.4, zl), (0.4, 0.4, zl), (0, 0, -1), (0, 0, -1), (0, 0, -1), mat=4, light=0)
+    prims[n + 1] = scenes.make_tri((-0.4, -0.4, zl), (0.4, 0.4, zl), (-0.4, 0.4, zl), (0, 0, -1), (0, 0, -1), (0, 0, -1), mat=4, light=1)
+    total = n + 2
+
+    def tri_box(i):
+        t = prims[i]["triangle"]
+        p = np.array([[t[v]["v"][c] for c in "xyz"] for v in ("v1", "v2", "v3")], np.float32)
+        return p.min(0), p.max(0)
+    nodes = []
+
+    def build(i):
+        idx = len(nodes)
+        nodes.append(None)
+        if i == total - 1:
+            lo, hi = tri_box(i)
+            nodes[idx] = (lo, hi, -1, 1, i, i)
+            return idx, lo, hi
+        _, llo, lhi = build(i + 1)
+        r = len(nodes)
+        rlo, rhi = tri_box(i)
+        nodes.append((rlo, rhi, -1, 1, i, i))
+        lo, hi = np.minimum(llo, rlo), np.maximum(lhi, rhi)
+        nodes[idx] = (lo, hi, r, 0, -1, -1)
+        return idx, lo, hi
+    build(0)
+    arr = np.zeros(len(nodes), dtype=st.BVH_NODE)
+    for k, (lo, hi, second, leaf, a, b) in enumerate(nodes):
+        arr[k]["fmin"] = st.f3(lo); arr[k]["fmax"] = st.f3(hi)
+        arr[k]["second_child_offset"], arr[k]["is_leaf"], arr[k]["start"], arr[k]["end"] = second, leaf, a, b
+    lights = np.zeros(2, dtype=st.AREA)
+    for li in range(2):
+        lights[li]["triangle"] = prims[n + li]["triangle"]
+        lights[li]["radiance"] = st.f3((9.0, 8.0, 6.0))
+        lights[li]["medium"] = -1
+    lib = ol.load("soft")
+    cdf = np.zeros(4, dtype=np.float32)
+    ncdf = lib.oracle_light_distribution(st.ptr(lights), 2, None, st.ptr(cdf))
+    return ol.Scene(prims, arr, scenes.material_table(), lights, cdf[:ncdf].copy(), max_depth, textures=[scenes.checker_texture()])
+
+
+def test_wide_traversal_stack_spills_past_its_lds_entries(gpt):
+    """The wide walk keeps 24 stack entries per ray in LDS and spills deeper ones to global memory.  A 36-sheet chain makes every
+    ray that looks down the stack hold more than 24 pending entries (the oracle reports the deepest stack it needed)."""
+    scene = chain_scene(36)
+    W, H, spp = 64, 48, 3
+    cam = ol.make_camera((0.05, 0.1, 4.5), (0.0, 0.1, 0.0), (0, 1, 0), (W, H), 35.0)
+    lib = ol.load("soft")
+    lib.oracle_wide_stack_max.restype = C.c_int
+    wide_both(gpt, scene, cam, W, H, 0.001, spp, "chain")
+    assert lib.oracle_set_traversal(2) == 0
+    try:
+        ol.render(scene, cam, W, H, 0.001, 1, 1, kind="soft")
+        deepest = lib.oracle_wide_stack_max()
+    finally:
+        lib.oracle_set_traversal(0)
+    assert deepest > 24, deepest
+    too_deep = chain_scene(71)                          # 3 * depth + 1 > 64: the wide mode is refused, the other orders still render
+    with gpt.Renderer(too_deep.desc, W, H, 0.001) as r:
+        with pytest.raises(gpt.GptError):
+            r.set_traversal_order("wide")
+        far_cam = ol.make_camera((0.05, 0.1, 7.5), (0.0, 0.1, 0.0), (0, 1, 0), (W, H), 35.0)
+        r.render(far_cam, 1, 2, reset=True)         # (stackless on the GPU; the reference's own 64-entry stack would overflow here)
+        got = r.read_accum()
+        assert np.isfinite(got).all() and got.max() > 0
+
+
 def test_wide_traversal_on_the_config5_standin(gpt, standin):
     """The dragon / bunny / teapot scene (248 574 triangles, 16 bounces) at 480 x 272: wide GPU == wide oracle, and the
     wide film against the reference-order film."""
@@ -626,6 +703,36 @@ def test_wide_traversal_on_the_config5_standin(gpt, standin):
     c, n_diff = wide_both(gpt, ls, cam, W, H, ls.epsilon, spp, "config 5 stand-in", threads=min(64, os.cpu_count() or 1))
     print("config-5 stand-in, wide: node visits / sample", c["node_visits"] / c["samples"], "triangle tests / sample",
           c["prim_tests"] / c["samples"], "floats that differ from the reference-order film:", n_diff)
+
+
+def test_renderer_options_are_explicit_and_readable(gpt):
+    """Nothing in the library is steered by the environment: options are set by name, refused when unknown or out of range, and
+    what the renderer actually does can be read back.  None of them changes the film."""
+    scene, meta = ol.load_cornell(6)
+    W, H = 96, 64
+    cam = ol.cornell_camera(meta, W, H)
+    ref, _ = ol.render(scene, cam, W, H, 0.001, 1, 5, kind="soft")
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        assert (r.get_option("lds_scene"), r.get_option("lds_scene_active"), r.get_option("max_batch"), r.get_option("chunk_iters")) == (1, 1, 256, 0)
+        r.render(cam, 1, 5, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "defaults")
+        assert r.get_option("last_batch") == 5 and r.get_option("sample_plane_bytes") >= 5 * (W // 8) * (H // 8) * 64 * 16
+        r.set_option("lds_scene", 0)
+        r.set_option("max_batch", 2)
+        r.set_option("chunk_iters", 1)
+        assert r.get_option("lds_scene_active") == 0
+        r.render(cam, 1, 5, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "global memory, launches of 2 iterations, 1-iteration work items")
+        assert r.get_option("last_batch") == 2
+        for name, value in (("lds_scene", 2), ("max_batch", 0), ("no_such_option", 1), ("lds_scene_active", 1)):
+            with pytest.raises(gpt.GptError):
+                r.set_option(name, value)
+        with pytest.raises(gpt.GptError):
+            r.get_option("no_such_option")
+        r.set_traversal_order("wide")
+        assert r.get_option("lds_scene_active") == 0          # the wide tree is walked from global memory
+        with pytest.raises(gpt.GptError):
+            r.set_traversal_order(3)
 
 
 # ---- edge cases -----------------------------------------------------------------------------------------
