@@ -224,7 +224,9 @@ def main():
     comm = None
     if world > 1:
         from gpu_pathtracer_amd import distributed as gd
-        comm = gd.FilmReducer(r, dist, rank, world, native=(backend == "nccl"))
+        # GPT_BENCH_TRY_NATIVE (test hook): attempt the library's RCCL set-up even where it must fail (two ranks on one GPU),
+        # to exercise the agreed fall-back to the torch.distributed reduce
+        comm = gd.FilmReducer(r, dist, rank, world, native=(backend == "nccl" or bool(os.environ.get("GPT_BENCH_TRY_NATIVE"))))
 
     def barrier():
         r.synchronize()
@@ -358,7 +360,7 @@ def main():
                        "tiles": "8x8 pixels, tile % n_gpus == rank", "all_finite": finite,
                        "accumulator_sha1": frame_sha1, "libgpt_sha1": lib_sha1,
                        "renderer_options": options, "options_set": dict(r.options_set),
-                       "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND") if os.environ.get(k)}),
+                       "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND", "GPT_BENCH_TRY_NATIVE") if os.environ.get(k)}),
                        "reduce": (comm.kind if comm is not None else None),
                        "square_frame": square,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},

@@ -260,6 +260,9 @@ class Renderer:
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         check(self.lib.gpt_comm_init(self.ctx, int(rank), int(n_ranks), buf))
 
+    def comm_destroy(self):
+        check(self.lib.gpt_comm_destroy(self.ctx))
+
     def reduce_film(self, root=0):
         check(self.lib.gpt_reduce_film(self.ctx, int(root)))
 

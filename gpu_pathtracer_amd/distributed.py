@@ -60,11 +60,31 @@ class FilmReducer:
         from . import api
         self.r, self.dist, self.rank, self.world, self.native = renderer, dist, rank, world, native
         self.kind = "rccl ncclReduce issued by libgpt.so (gpt_reduce_film)" if native else f"torch.distributed {dist.get_backend()} reduce (all ranks share one GPU)"
+        self.native_error = None
         if native:
-            box = [api.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            renderer.comm_init(rank, world, box[0])
-        else:
+            # every rank must end up on the same path: agree on the outcome of the RCCL set-up before using it
+            ok = 1
+            try:
+                box = [None]
+                if rank == 0:
+                    try:
+                        box[0] = api.comm_unique_id()
+                    except Exception as e:            # RCCL cannot be loaded: tell the others through the broadcast
+                        self.native_error = str(e)
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is None:
+                    raise RuntimeError(self.native_error or "rank 0 could not create an RCCL id")
+                renderer.comm_init(rank, world, box[0])
+            except Exception as e:
+                ok, self.native_error = 0, str(e)
+            import torch
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                renderer.comm_destroy()
+                self.native = native = False
+                self.kind = f"torch.distributed {dist.get_backend()} reduce (the library's RCCL path failed: {self.native_error})"
+        if not native:
             import torch
             renderer.set_tile_owner(rank, world)
             n = renderer.width * renderer.height * 3

@@ -72,5 +72,11 @@ def test_two_rank_bench_on_one_gpu_gives_the_one_rank_frame():
     assert one["config"]["all_finite"] and two["config"]["all_finite"]
     assert two["n_gpus"] == 2 and "gloo" in two["config"]["reduce"]
     assert two["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
+    # the library's own RCCL set-up attempted where it must fail (RCCL refuses two ranks on one device): every rank sees the
+    # failure, they agree on it, and the job falls back to the torch.distributed reduce - same film
+    fb = run_bench({"GPT_BENCH_SHARE_GPU": "1", "GPT_BENCH_TRY_NATIVE": "1"}, ["--gpus", "2"] + common,
+                   launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                             "--master-port", str(free_port())])
+    assert "RCCL path failed" in fb["config"]["reduce"] and fb["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
     # each rank allocates sample planes for its own tiles only
     assert two["config"]["renderer_options"]["sample_plane_bytes"] * 2 <= one["config"]["renderer_options"]["sample_plane_bytes"] + 64 * 16 * 128
