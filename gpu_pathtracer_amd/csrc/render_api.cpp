@@ -72,6 +72,7 @@ struct gpt_ctx {
     size_t sample_bytes = 0;              // bytes allocated for them
     uint32_t last_batch_cap = 0;          // iterations per launch the last gpt_render used
     uint32_t max_batch = 256;             // "max_batch": iterations per path-kernel launch; also capped by the memory budget
+    bool max_batch_set = false;           // ... as set by the caller (else: 256 x the number of ranks sharing the frame)
     bool count_next = false;
     int n_cus = 256;
     int blocks_per_cu[2][2] = {{4, 4}, {3, 3}};      // [walk kernel][counting build]
@@ -552,7 +553,7 @@ int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value)
     const std::string n(name);
     if (n == "lds_scene" && (value == 0 || value == 1)) ctx->lds_scene = value != 0;
     else if (n == "vpt_walk_kernel" && (value == 0 || value == 1)) ctx->force_walk = value != 0;
-    else if (n == "max_batch" && value >= 1 && value <= 65536) ctx->max_batch = (uint32_t)value;
+    else if (n == "max_batch" && value >= 1 && value <= 65536) { ctx->max_batch = (uint32_t)value; ctx->max_batch_set = true; }
     else if (n == "chunk_iters" && value >= 0 && value <= 65536) ctx->chunk_override = (uint32_t)value;
     else {
         gpt_set_error("gpt_set_option: unknown option or value out of range: %s = %lld", name, (long long)value);
@@ -648,7 +649,10 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     }
     uint32_t by_memory = (uint32_t)(budget / plane_bytes);
     if (by_memory < 1) by_memory = 1;
-    const uint32_t max_batch = ctx->max_batch < by_memory ? ctx->max_batch : by_memory;
+    // unless the caller fixed it, a rank that owns 1/N of the tiles takes N times the iterations per launch: the same plane
+    // memory and the same work per launch as one GPU with the whole frame, so the fixed cost of a launch stays amortised
+    const uint64_t wanted = ctx->max_batch_set ? (uint64_t)ctx->max_batch : (uint64_t)ctx->max_batch * n_ranks;
+    const uint32_t max_batch = wanted < by_memory ? (uint32_t)wanted : by_memory;
     uint32_t batch_cap = iter_count < max_batch ? iter_count : max_batch;
     if (ctx->sample_bytes < plane_bytes * batch_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));

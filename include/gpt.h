@@ -80,7 +80,8 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
  * variables: what differs from the defaults was set through this call and can be read back.
  *   "lds_scene"        1 (default): a scene of <= 12 KB is staged in LDS by every workgroup; 0: always global memory
  *   "vpt_walk_kernel"  0 (default): Volpath picks its kernel from the scene; 1: always the one-ray-at-a-time kernel
- *   "max_batch"        iterations per path-kernel launch, default 256 (also bounded by free device memory)
+ *   "max_batch"        iterations per path-kernel launch; default 256 x the number of ranks sharing the frame (a rank's sample
+ *                      planes cover its own tiles only), always bounded by 16 GiB and by the free device memory
  *   "chunk_iters"      iterations per work item, 0 (default) = cost model
  * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "last_batch", "sample_plane_bytes". */
 int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value);
