@@ -713,7 +713,8 @@ def test_renderer_options_are_explicit_and_readable(gpt):
     cam = ol.cornell_camera(meta, W, H)
     ref, _ = ol.render(scene, cam, W, H, 0.001, 1, 5, kind="soft")
     with gpt.Renderer(scene.desc, W, H, 0.001) as r:
-        assert (r.get_option("lds_scene"), r.get_option("lds_scene_active"), r.get_option("max_batch"), r.get_option("chunk_iters")) == (1, 1, 256, 0)
+        lds = gpt.DEFAULT_OPTIONS.get("lds_scene", 1)           # (the suite can be run with --gpt-opt lds_scene=0)
+        assert (r.get_option("lds_scene"), r.get_option("lds_scene_active"), r.get_option("max_batch"), r.get_option("chunk_iters")) == (lds, lds, 256, 0)
         r.render(cam, 1, 5, reset=True)
         assert_bit_exact(r.read_accum(), ref, "defaults")
         assert r.get_option("last_batch") == 5 and r.get_option("sample_plane_bytes") >= 5 * (W // 8) * (H // 8) * 64 * 16
