@@ -67,7 +67,8 @@ while time.time() < t_end:
     else:
         cam = ol.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.2, 2.5)), float(rng.uniform(3, 8))), (0, 1, 0), (0, 1, 0), (W, H), float(rng.uniform(15, 70)))
     ao = bool(rng.random() < 0.2) and not vpt
-    near = bool(rng.random() < 0.3)
+    order = int(rng.choice([0, 0, 1, 2, 2]))            # reference / nearer child first / 4-wide tree, four lanes per ray
+    near = order
     force_global = bool(rng.random() < 0.4)
     eps = float(rng.choice([0.001, 0.0005, 0.01]))
     if ao:
@@ -78,7 +79,10 @@ while time.time() < t_end:
         scene.desc.set_integrator("vpt", depth)
         cam.medium = cam_medium
         force_walk = bool(rng.random() < 0.3)
-    lib.oracle_set_traversal(1 if near else 0)
+    lib.oracle_set_traversal(order)
+    if order == 2 and len(scene.nodes) == 0:
+        order = near = 0
+        lib.oracle_set_traversal(0)
     try:
         ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
     finally:
@@ -86,7 +90,8 @@ while time.time() < t_end:
     api.DEFAULT_OPTIONS["lds_scene"] = 0 if force_global else 1
     api.DEFAULT_OPTIONS["vpt_walk_kernel"] = 1 if force_walk else 0
     with api.Renderer(scene.desc, W, H, eps) as r:
-        r.set_traversal_order(near)
+        if len(scene.nodes) or order != 2:          # (an empty scene has no wide tree: refused, see gpt_set_traversal_order)
+            r.set_traversal_order(order)
         if rng.random() < 0.5:
             r.render(cam, 1, spp, reset=True)
         else:                                   # split the iterations into two calls
@@ -95,7 +100,7 @@ while time.time() < t_end:
             if k < spp: r.render(cam, k + 1, spp - k, reset=False)
         got = r.read_accum()
     bad = int(np.count_nonzero(got.view(np.uint32) != ref.view(np.uint32)))
-    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} near {near} global {force_global}"
+    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} order {order} global {force_global}"
     if bad:
         n_bad += 1
         print("MISMATCH", bad, tag, flush=True)
