@@ -7,6 +7,8 @@ import numpy as np
 import oracle_lib as ol
 from gpu_pathtracer_amd import scene_types as st
 
+PRIM = st.PRIMITIVE
+
 # primitive ranges of tests/golden/cornell_pt.npz before BVH reordering
 CORNELL_PARTS = {"floor": (0, 2), "ceil": (2, 4), "back": (4, 6), "left": (6, 8), "right": (8, 10),
                  "short": (10, 22), "tall": (22, 34), "light": (34, 36)}
@@ -122,6 +124,28 @@ def random_soup(n, seed, lo=(-0.9, 0.05, -0.9), hi=(0.9, 1.9, 0.9), size=0.12, m
         fn = fn / ln if ln > 0 else np.array([0, 1, 0], np.float32)
         uvs = rng.random((3, 2)).astype(np.float32)
         out[k] = make_tri(p[0], p[1], p[2], fn, fn, fn, uvs[0], uvs[1], uvs[2], int(mats[k % len(mats)]))
+    return out
+
+
+def big_soup(n, seed, lo=(-0.95, 0.02, -0.95), hi=(0.95, 1.95, 0.95), size=0.02, mats=(2, 5, 7, 13)):
+    """n small random triangles, vectorised (random_soup builds them one by one): for scenes of a million primitives"""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    c = (lo + (hi - lo) * rng.random((n, 1, 3)).astype(np.float32)).astype(np.float32)
+    p = (c + (rng.random((n, 3, 3)).astype(np.float32) - np.float32(0.5)) * np.float32(size)).astype(np.float32)
+    fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]).astype(np.float32)
+    ln = np.sqrt((fn * fn).sum(-1, keepdims=True), dtype=np.float32)
+    fn = np.where(ln > 0, fn / np.where(ln > 0, ln, 1), np.array([0, 1, 0], np.float32)).astype(np.float32)
+    uv = rng.random((n, 3, 2)).astype(np.float32)
+    out = np.zeros(n, dtype=PRIM)
+    t = out["triangle"]
+    for k, name in enumerate(("v1", "v2", "v3")):
+        for a, comp in enumerate("xyz"):
+            t[name]["v"][comp] = p[:, k, a]
+            t[name]["n"][comp] = fn[:, a]
+        t[name]["uv"] = uv[:, k]
+    t["matIdx"] = np.asarray(mats, np.int32)[np.arange(n) % len(mats)]
+    t["bssrdfIdx"] = t["lightIdx"] = t["mediumInside"] = t["mediumOutside"] = -1
     return out
 
 

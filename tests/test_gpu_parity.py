@@ -383,6 +383,31 @@ def test_large_scene_in_global_memory(gpt, scale, W, H, spp):
     assert 0 < cg["node_visits"] <= co["node_visits"]
 
 
+def test_million_triangle_scene_all_traversal_orders(gpt):
+    """Size: 1.2 M triangles in the Cornell box (a 750k-node tree: 216 MB of threaded node arrays, a 370k-node wide tree), 12 bounces,
+    the three traversal orders, each against the oracle in the same mode, and the wide film against the reference-order film."""
+    extra = scenes.big_soup(1_200_000, 3)
+    scene, meta = scenes.zoo_scene(max_depth=12, extra=extra, assign={})
+    assert len(scene.prims) == 1_200_036 and len(scene.nodes) > 600_000
+    W, H, spp = 96, 64, 2
+    cam = ol.cornell_camera(meta, W, H)
+    threads = min(64, os.cpu_count() or 1)
+    lib = ol.load("soft")
+    films = {}
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        for order in (0, 1, 2):
+            assert lib.oracle_set_traversal(order) == 0
+            try:
+                want, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", threads=threads)
+            finally:
+                lib.oracle_set_traversal(0)
+            r.set_traversal_order(order)
+            r.render(cam, 1, spp, reset=True)
+            films[order] = r.read_accum()
+            assert_bit_exact(films[order], want, f"1.2 M triangles, traversal order {order}")
+    assert (rel_rms(films[2], films[0]) <= RMS_TOL).all() and (rel_rms(films[1], films[0]) <= RMS_TOL).all()
+
+
 # ---- BASELINE.json full size: size-independent properties -------------------------------------
 
 def test_full_hd_properties(gpt):
