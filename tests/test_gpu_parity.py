@@ -1062,6 +1062,29 @@ def test_path_gpu_film_against_the_reference_depth_of_field_render(gpt):
     assert m < 0.002 and bm < 0.003 and bx < 0.03, (m, bm, bx)
 
 
+def test_volpath_glass_sphere_in_gas_scene_file(gpt, tmp_path):
+    """The shape of the reference's scenes/cornell_box/vol_caustic.json through LoadScene: a glass sphere (the shipped sphere.obj,
+    8 064 smooth-shaded triangles, standing in for the json's analytic sphere) inside a scattering gas that a material-less front
+    face closes in; `inside` / `outside` on a mesh WITH a material, the camera outside the medium.  GPU film == oracle film."""
+    ls = gpt.LoadedScene(scenes.write_vol_caustic_scene(str(tmp_path / "volc")))
+    assert ls.desc.integrator_type == st.IT_VPT and ls.desc.n_mediums == 1 and ls.desc.n_prims == 8064 + 12 + 2
+    W, H, spp = 128, 128, 3
+    cam = ol.make_camera((0, 1.0, 6.8), (0, 1.0, 0), (0, 1, 0), (W, H), 19.5, 0.0, 7.0)
+    cam.medium = ls.camera.medium
+    assert cam.medium == -1
+    ref, _ = ol.render(ls, cam, W, H, ls.epsilon, 1, spp, kind="soft", threads=min(64, os.cpu_count() or 1))
+    assert np.isfinite(ref).all() and ref.mean() > 0
+    with gpt.Renderer(ls.desc, W, H, ls.epsilon) as r:
+        assert r.get_option("walk_kernel_active") == 1               # a material-less surface: the one-ray-at-a-time kernel
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), ref, "glass sphere in gas")
+        r.set_traversal_order("wide")
+        r.render(cam, 1, spp, reset=True)
+        wide = r.read_accum()
+    assert (rel_rms(wide, ref) <= RMS_TOL).all()
+    ls.close()
+
+
 def test_volpath_two_kernels_agree(gpt, monkeypatch):
     """A scene with homogeneous media only runs on the three-rays-per-bounce kernel; forced through the general
     one-ray-at-a-time kernel it has to produce the same film (and both equal the oracle's)."""

@@ -69,8 +69,10 @@ def box_filtered(name):
 if __name__ == "__main__":
     box_filtered("heterogeneous")
     # result/cornell_dof.png: the Cornell box with its two boxes (the geometry of BASELINE config 1 / 2) through the
-    # thin-lens camera.  (result/volume_caustic.png does not match the shipped vol_caustic.json - that file's light mesh is
-    # 5 x 4 mm, the picture's is the Cornell light - so it cannot serve as a pin.)
+    # thin-lens camera.  (result/volume_caustic.png cannot serve as a pin: the shipped vol_caustic.json names a 5 x 4 mm light
+    # mesh while the picture shows the Cornell light, and with that light (tests/scenes.py: write_vol_caustic_scene) Volpath
+    # converges, for every maxDepth >= 33, to a frame 7 - 12 % darker than the picture: its scene differs in something the
+    # repository does not record.)
     box_filtered("cornell_dof")
     d = np.loadtxt("/root/reference/scenes/cornell_box/geometry/density.d", dtype=np.float64)
     q = np.round(d * 1e6).astype(np.int32)
