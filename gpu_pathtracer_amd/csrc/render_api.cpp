@@ -274,6 +274,18 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
             return GPT_ERR_INVALID_ARG;
         }
     }
+    // the tree is walked by index on the host (threading, wide collapse) and by offset on the device: refuse one whose links
+    // leave the arrays (the reference trusts its own builder; a caller-supplied tree gets checked once)
+    for (int i = 0; i < scene->n_nodes; ++i) {
+        const gpt_bvh_node &nd = scene->nodes[i];
+        const bool ok = nd.is_leaf ? ((nd.start == -1 && nd.end == -1) || (nd.start >= 0 && nd.end >= nd.start && nd.end < scene->n_prims))
+                                   : (i + 1 < scene->n_nodes && nd.second_child_offset > i + 1 && nd.second_child_offset < scene->n_nodes);
+        if (!ok) {
+            gpt_set_error("gpt_begin: BVH node %d is inconsistent (leaf %d, second child %d, primitives %d..%d; %d nodes, %d primitives)", i,
+                          (int)nd.is_leaf, nd.second_child_offset, nd.start, nd.end, scene->n_nodes, scene->n_prims);
+            return GPT_ERR_INVALID_ARG;
+        }
+    }
     // ---- media and material-less surfaces, checked before any device work (same answer with and without a GPU)
     bool has_interface = false, media_ok = scene->n_mediums == 0 || scene->mediums != nullptr;
     for (int i = 0; i < scene->n_prims; ++i) {

@@ -118,6 +118,18 @@ def test_begin_without_gpu_fails_loudly():
     assert "no HIP device" in str(e.value) or "gpt error -4" in str(e.value) or "gpt error -3" in str(e.value)
 
 
+def test_inconsistent_bvh_is_refused_before_any_device_work():
+    """gpt_begin takes the caller's tree as it is (a Scene built by the reference's own loader can be passed): links that leave
+    the arrays are an error code, not a crash - with or without a GPU."""
+    lib = api.load()
+    for field, index, value in (("second_child_offset", 0, 10_000), ("second_child_offset", 0, 1), ("end", 5, 10_000), ("start", 5, -7)):
+        scene, _ = ol.load_cornell(4)
+        scene.nodes[field][index] = value
+        ctx = C.c_void_p()
+        rc = lib.gpt_begin(C.byref(scene.desc), 64, 64, C.c_float(0.001), 0, C.byref(ctx))
+        assert rc == -1 and b"BVH node" in lib.gpt_last_error(), (field, index, value, lib.gpt_last_error())
+
+
 def test_unsupported_integrator_is_refused():
     scene, _ = ol.load_cornell(4)
     scene.desc.integrator_type = 3      # "lt" (light tracing): out of scope for this library
