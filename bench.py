@@ -228,6 +228,12 @@ def main():
         # to exercise the agreed fall-back to the torch.distributed reduce
         comm = gd.FilmReducer(r, dist, rank, world, native=(backend == "nccl" or bool(os.environ.get("GPT_BENCH_TRY_NATIVE"))))
 
+    if comm is not None:
+        # RCCL builds its rings and buffers on the first collective of a communicator: do that once outside the timed region,
+        # whatever --warmup says (the film is still zero here)
+        comm.reduce(root=0)
+        r.synchronize()
+
     def barrier():
         r.synchronize()
         torch.cuda.synchronize()
