@@ -141,7 +141,7 @@ def rocprof_pass(counters, workdir, tag):
         env.pop(k, None)
     cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", tag, "--",
                                                           sys.executable, os.path.abspath(__file__), "--counter-child"]
-    p = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=150)     # a pass takes ~6 s; a hang must not cost the bench line
     vals = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
