@@ -686,6 +686,10 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
 // restored to all ones.
 // gfx950 hazards honoured by hand: >= 2 wait states between a VALU write of VCC/SGPR and a VALU read of it
 // (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
+// code placement of the hand-written loops (experiment hook): e.g. -DPT_LOOP_ALIGN='".p2align 6\n"'
+#ifndef PT_LOOP_ALIGN
+#define PT_LOOP_ALIGN ""
+#endif
 #define PT_COMMA ,
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
@@ -861,6 +865,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_mov_b64 s[64:65], 0\n" \
         ENTRY_STATE \
         "s_branch TP_FILL_%=\n" \
+        PT_LOOP_ALIGN \
         "TP_LOOP_%=:\n" \
         "v_cmp_le_i32_e64 s[60:61], v13, v14\n" \
         "v_cmp_gt_i32_e64 s[62:63], " RAY_END ", v12\n" \
@@ -1262,6 +1267,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_mov_b64 exec, -1\n"
         "s_branch TW_FILL_%=\n"
         /* ---------------------------------------------------------------- loop header */
+        PT_LOOP_ALIGN
         "TW_LOOP_%=:\n"
         "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"             /* groups with a ray */
         "v_cmp_eq_u32_e64 s[66:67], -1, v12\n"             /* ... that is finished */
