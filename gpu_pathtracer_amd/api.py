@@ -75,6 +75,7 @@ def load():
         "gpt_enable_counters": [vp, C.c_int],
         "gpt_read_counters": [vp, vp],
         "gpt_read_probe_counters": [vp, vp],
+        "gpt_debug_trace": [vp, vp, C.c_int, vp, vp],
         "gpt_debug_math": [C.c_int, C.c_int, vp, vp, vp, C.c_int],
         "gpt_debug_rng": [C.c_int, u32, u32, vp, vp, C.c_int],
         "gpt_bvh_build": [vp, i32, vp, vp, C.POINTER(i32), vp],
@@ -302,6 +303,15 @@ class Renderer:
 
     def bind_film(self, acc_dev=None, color_dev=None):
         check(self.lib.gpt_bind_film(self.ctx, acc_dev, color_dev))
+
+    def trace_rays(self, rays8):
+        """gpt_debug_trace: rays8 (n, 8) float32 = origin, direction, tmax, any_hit -> (prim (n,) int32, tb (n, 3) float32)"""
+        rays8 = np.ascontiguousarray(rays8, dtype=np.float32).reshape(-1, 8)
+        n = len(rays8)
+        prim = np.zeros(n, dtype=np.int32)
+        tb = np.zeros((n, 3), dtype=np.float32)
+        check(self.lib.gpt_debug_trace(self.ctx, st.ptr(rays8), n, st.ptr(prim), st.ptr(tb)))
+        return prim, tb
 
     def kernel_time(self):
         n, ms = C.c_uint32(0), C.c_double(0)

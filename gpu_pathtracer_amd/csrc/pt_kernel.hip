@@ -3622,6 +3622,117 @@ __global__ void __launch_bounds__(256) pt_tonemap_kernel(const float *acc, float
     out[3 * i + 2] = o.z;
 }
 
+// The traversal operators alone - Intersect / IntersectP (pathtracer.cu:214-296) - for a list of rays, through the SAME pools and
+// the SAME hand-scheduled loops as the render kernel (scene in LDS, in global memory with suspended drains, or the 4-wide walk):
+// gpt_debug_trace.  Ray i = rays[2 i] {origin.xyz, tmax}, rays[2 i + 1] {direction.xyz, any_hit != 0}; out[i] = {primitive or -1,
+// t, b1, b2}.  One ray per lane per round.
+template <bool SMALL, bool WIDE>
+__global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_trace_rays_kernel(const DevParams P_in, const float4 *rays, int n, float4 *out)
+{
+    __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
+    DevParams P = P_in;
+    if (SMALL) {         // the staging of pt_render_kernel (nodes and triangles only matter here)
+        const float4 *gn = reinterpret_cast<const float4 *>(P_in.nodes);
+        const float4 *gt = reinterpret_cast<const float4 *>(P_in.tris);
+        const int o_tri = 2 * P.n_nodes;
+        const int lds_nodes = (int)lds_address(lds_scene), lds_tris = lds_nodes + o_tri * 16;
+        for (int i = threadIdx.x; i < 2 * P.n_nodes; i += 256) {
+            float4 v = gn[i];
+            if (i & 1) {
+                if (__float_as_int(v.w) >= 0) {
+                    v.z = __int_as_float(__float_as_int(v.z) + lds_tris);
+                    v.w = __int_as_float(__float_as_int(v.w) + lds_tris);
+                } else {
+                    v.z = __int_as_float(__float_as_int(v.z) + lds_nodes);
+                }
+            }
+            lds_scene[i] = v;
+        }
+        for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[o_tri + i] = gt[i];
+        __syncthreads();
+    }
+    constexpr bool CARRY = !SMALL;
+    constexpr int kWaveFloat4 = CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4;
+    __shared__ float4 lds_pool[4 * kWaveFloat4];
+    float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
+    const unsigned lane = threadIdx.x & 63u;
+    if (CARRY) {
+        reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;
+        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
+        pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+    }
+    if (WIDE) {
+        wave_lds_fence();
+        if (lane < 16u) {
+            pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
+            pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+        }
+    }
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)cnt;
+    const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = (int)gridDim.x * 4;
+    for (int base = wave * 64; base < n; base += n_waves * 64) {      // wave-uniform
+        const int i = base + (int)lane;
+        const bool valid = i < n;
+        RaySet q;
+        q.org = q.dir_p = q.dir_m = q.dir_s = v3(0.f);
+        q.tmax_s = 0.f;
+        q.has_p = q.has_m = q.has_s = false;
+        q.mis_any = false;
+        if (valid) {
+            const float4 a = rays[2 * i], b = rays[2 * i + 1];
+            q.org = V3{a.x, a.y, a.z};
+            q.tmax_s = a.w;
+            if (b.w != 0.f) { q.dir_s = V3{b.x, b.y, b.z}; q.has_s = true; }
+            else { q.dir_p = V3{b.x, b.y, b.z}; q.has_p = true; }
+        }
+        PoolLayout L;
+        int n_new = 0;
+        if (CARRY) {
+            n_new = pool_deposit_fixed<true>(pool, q, lane, valid);
+            L.m_p = L.m_m = L.m_s = 0ull;
+            L.n_p = L.n_m = L.n_rays = 0;
+        } else {
+            L = pool_deposit<true>(pool, q, lane);
+        }
+        wave_lds_fence();
+        if (SMALL) {
+            LdsScene mem;
+            mem.first = (int)lds_address(lds_scene);
+            mem.end = mem.first + 32 * P.n_nodes;
+            mem.tri_bias = mem.end;
+            trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
+        } else {
+            // a drain may stop with rays parked (the render kernel shades in between): go on until every ray is back
+            for (int round = 0;; ++round) {
+                const int fresh = round == 0 ? n_new : 0;
+                if (WIDE) {
+                    trace_pool_wide_asm(lds_address(pool), fresh, P, lane, fresh > 0);
+                } else {
+                    GlobalScene mem;
+                    mem.nodes = reinterpret_cast<const char *>(P.nodes);
+                    mem.tris = reinterpret_cast<const char *>(P.tris);
+                    mem.first = 0;
+                    mem.end = 32 * P.n_nodes;
+                    mem.tri_bias = 0;
+                    mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
+                    trace_pool_global_asm(lds_address(pool), fresh, mem, P.eps, fresh > 0);
+                }
+                wave_lds_fence();
+                const bool pending = valid && reinterpret_cast<const volatile unsigned *>(pool + kPendOff)[lane] != 0u;
+                if (!__any(pending)) break;
+            }
+        }
+        wave_lds_fence();
+        if (valid) {
+            const int sl = CARRY ? (q.has_s ? 128 + (int)lane : (int)lane) : (q.has_s ? L.n_p + L.n_m + lane_rank(L.m_s) : lane_rank(L.m_p));
+            const RayResult rr = pool_result(pool, sl);
+            out[i] = make_float4(__int_as_float(rr.prim), rr.t, rr.b1, rr.b2);
+        }
+        wave_lds_fence();
+    }
+}
+
 // elementary-operation probes for the parity tests (gpt_debug_math / gpt_debug_rng)
 __global__ void pt_debug_math_kernel(int fn, const float *x, const float *y, float *out, int n)
 {
@@ -3724,6 +3835,16 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_
     }
 #undef PT_LAUNCH
 #undef PT_LAUNCH_WIDE
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_rays(const DevParams &P, bool lds_scene, const float4 *rays, int n, float4 *out, hipStream_t stream)
+{
+    const bool small = lds_scene && render_scene_fits_lds(P);
+    const int n_blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    if (P.traversal == GPT_TRAVERSAL_WIDE4) hipLaunchKernelGGL((pt_trace_rays_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
+    else if (small) hipLaunchKernelGGL((pt_trace_rays_kernel<true, false>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
+    else hipLaunchKernelGGL((pt_trace_rays_kernel<false, false>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ namespace pt {
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream);
 bool render_scene_fits_lds(const DevParams &P);
 hipError_t launch_output(const DevParams &P, hipStream_t stream);
+hipError_t launch_trace_rays(const DevParams &P, bool lds_scene, const float4 *rays, int n, float4 *out, hipStream_t stream);
 hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_t rows, uint32_t iter, int filmic,
                           hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
@@ -1008,6 +1009,46 @@ int gpt_read_counters(gpt_ctx *ctx, uint64_t out6[6])
     unsigned long long tmp[6];
     HIP_TRY(hipMemcpy(tmp, ctx->counters, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < 6; ++i) out6[i] = tmp[i];
+    return GPT_OK;
+}
+
+int gpt_debug_trace(gpt_ctx *ctx, const float *rays8, int n, int32_t *prim_out, float *tb_out)
+{
+    if (!ctx || !rays8 || !prim_out || !tb_out || n <= 0) { gpt_set_error("gpt_debug_trace: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    if (ctx->P.n_nodes <= 0) {
+        for (int i = 0; i < n; ++i) { prim_out[i] = -1; tb_out[3 * i] = rays8[8 * i + 6]; tb_out[3 * i + 1] = tb_out[3 * i + 2] = 0.f; }
+        return GPT_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<float4> h((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        const float *r = rays8 + 8 * (size_t)i;
+        h[2 * (size_t)i] = make_float4(r[0], r[1], r[2], r[6]);
+        h[2 * (size_t)i + 1] = make_float4(r[3], r[4], r[5], r[7] != 0.f ? 1.f : 0.f);
+    }
+    float4 *d_rays = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, h.size() * sizeof(float4)));
+    if (hipMalloc((void **)&d_out, (size_t)n * sizeof(float4)) != hipSuccess) { (void)hipFree(d_rays); gpt_set_error("gpt_debug_trace: hipMalloc failed"); return GPT_ERR_HIP; }
+    int rc = GPT_OK;
+    std::vector<float4> res((size_t)n);
+    if (hipMemcpy(d_rays, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess ||
+        launch_trace_rays(ctx->P, ctx->lds_scene, d_rays, n, d_out, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(res.data(), d_out, res.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) {
+        gpt_set_error("gpt_debug_trace: %s", hipGetErrorString(hipGetLastError()));
+        rc = GPT_ERR_HIP;
+    }
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    if (rc != GPT_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        int32_t prim;
+        std::memcpy(&prim, &res[(size_t)i].x, 4);
+        prim_out[i] = prim;
+        tb_out[3 * (size_t)i] = res[(size_t)i].y;
+        tb_out[3 * (size_t)i + 1] = res[(size_t)i].z;
+        tb_out[3 * (size_t)i + 2] = res[(size_t)i].w;
+    }
     return GPT_OK;
 }
 

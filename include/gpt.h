@@ -182,6 +182,11 @@ int gpt_read_probe_counters(gpt_ctx *ctx, uint64_t out16[16]);
  * on, for parity tests against the CPU oracle: fn 0 sin, 1 cos, 2 tan, 3 atan,
  * 4 acos, 5 pow(x,y), 6 x/y, 7 sqrt, 8 1/sqrt.  Host pointers. */
 int gpt_debug_math(int device, int fn, const float *x, const float *y, float *out, int n);
+/* The traversal operators alone (Intersect / IntersectP, src/pathtracer.cu:214-296; BBox::Intersect, src/bbox.h:77-96;
+ * Triangle::Intersect, src/mesh.h:45-67) on the device, through the render kernel's own ray pools and traversal loops, in the
+ * context's current traversal order and memory path.  Ray i = rays8[8 i ..] = {origin.xyz, direction.xyz, tmax, any_hit != 0},
+ * tmin = the context's epsilon.  prim_out[i] = hit primitive (BVH order) or -1, tb_out[3 i ..] = {t, b1, b2}.  Host pointers. */
+int gpt_debug_trace(gpt_ctx *ctx, const float *rays8, int n, int32_t *prim_out, float *tb_out);
 /* first n uniform draws of the (pixel, iter) stream, evaluated on the device */
 int gpt_debug_rng(int device, uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n);
 

@@ -306,6 +306,10 @@ static inline int bbox_intersect(const gpt_bvh_node *n, const ray_t *r)
     return 1;
 }
 
+/* the last accepted hit of this thread's current ray: primitive index and barycentrics (for oracle_trace_rays) */
+static __thread int t_hit_prim;
+static __thread float t_hit_b1, t_hit_b2;
+
 /* ---- triangle: mesh.h:45-98 -------------------------------------------------- */
 /* the hit record of mesh.h:68-95 for a triangle, the ray's (t, b1, b2) on it */
 static inline void fill_isect(const gpt_triangle *t, const ray_t *ray, float tt, float b1, float b2, isect_t *isect)
@@ -358,6 +362,8 @@ static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isec
         return 0;
 
     ray->tmax = tt;
+    t_hit_b1 = b1;
+    t_hit_b2 = b2;
     if (isect) fill_isect(t, ray, tt, b1, b2, isect);
     return 1;
 }
@@ -474,7 +480,10 @@ static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any
             }
             if (accepted) {
                 if (nearest < tmax) tmax = nearest;
-                if (any_hit) return 1;
+                if (any_hit) {
+                    ray->tmax = best_t; t_hit_prim = best_prim; t_hit_b1 = best_b1; t_hit_b2 = best_b2;
+                    return 1;
+                }
             }
             if (count > 4) cur = gpt_wide_leaf_entry(first + 4, count - 4);
             else cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
@@ -482,6 +491,7 @@ static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any
     }
     if (best_prim < 0) return 0;
     ray->tmax = best_t;
+    t_hit_prim = best_prim; t_hit_b1 = best_b1; t_hit_b2 = best_b2;
     if (isect) fill_isect(&sc->d->prims[best_prim].triangle, ray, best_t, best_b1, best_b2, isect);
     return 1;
 }
@@ -507,8 +517,10 @@ static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
                     const gpt_primitive *prim = &sc->d->prims[i];
                     t_cnt.prim_tests++;
                     if (prim->type == GPT_GT_TRIANGLE) {
-                        if (tri_intersect(&prim->triangle, ray, isect))
+                        if (tri_intersect(&prim->triangle, ray, isect)) {
                             ret = 1;
+                            t_hit_prim = i;
+                        }
                     }
                     /* GT_LINES / GT_SPHERE: out of scope */
                 }
@@ -540,8 +552,10 @@ static int intersect_any(const scene_t *sc, ray_t *ray)
                     const gpt_primitive *prim = &sc->d->prims[i];
                     t_cnt.prim_tests++;
                     if (prim->type == GPT_GT_TRIANGLE) {
-                        if (tri_intersect(&prim->triangle, ray, NULL))
+                        if (tri_intersect(&prim->triangle, ray, NULL)) {
+                            t_hit_prim = i;
                             return 1;
+                        }
                     }
                 }
             }
@@ -1739,6 +1753,51 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
             g_cnt.closest_rays += t_cnt.closest_rays;
             g_cnt.samples += t_cnt.samples;
         }
+    }
+    free(order);
+    free(wide);
+    return 0;
+}
+
+/* The traversal operators alone (Intersect / IntersectP, pathtracer.cu:214-296) for a list of rays, in the current traversal
+ * mode: ray i = rays8[8 i ..] = {origin.xyz, direction.xyz, tmax, any_hit != 0}; tmin = eps.  prim_out[i] = index of the hit
+ * primitive (BVH order) or -1; tb_out[3 i ..] = {t, b1, b2} of the hit. */
+API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *rays8, int n, int32_t *prim_out, float *tb_out, int n_threads)
+{
+    scene_t sc;
+    sc.d = desc;
+    sc.eps = eps;
+    memset(&sc.inf, 0, sizeof(sc.inf));
+    unsigned char *order = NULL;
+    if (g_traversal == GPT_TRAVERSAL_NEAR_FIRST && desc->n_nodes > 0) {
+        order = (unsigned char *)calloc((size_t)desc->n_nodes, 1);
+        for (int i = 0; i < desc->n_nodes; ++i)
+            if (!desc->nodes[i].is_leaf) order[i] = (unsigned char)gpt_node_order_code(desc->nodes, i);
+    }
+    sc.order = order;
+    gpt_wide_node *wide = NULL;
+    sc.wide = NULL;
+    sc.n_wide = 0;
+    if (g_traversal == GPT_TRAVERSAL_WIDE4 && desc->n_nodes > 0) {
+        const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
+        int depth = 0;
+        wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
+        sc.n_wide = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, wide, cap, &depth);
+        if (sc.n_wide < 0 || 3 * depth + 1 > GPT_WIDE_STACK_MAX) { free(wide); free(order); return -3; }
+        sc.wide = wide;
+    }
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 256)
+    for (int i = 0; i < n; ++i) {
+        const float *r = rays8 + 8 * (size_t)i;
+        ray_t ray = mk_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), eps, r[6]);
+        t_hit_prim = -1;
+        t_hit_b1 = t_hit_b2 = 0.f;
+        const int hit = r[7] != 0.f ? intersect_any(&sc, &ray) : intersect_closest(&sc, &ray, NULL);
+        prim_out[i] = hit ? t_hit_prim : -1;
+        tb_out[3 * (size_t)i] = ray.tmax;
+        tb_out[3 * (size_t)i + 1] = hit ? t_hit_b1 : 0.f;
+        tb_out[3 * (size_t)i + 2] = hit ? t_hit_b2 : 0.f;
     }
     free(order);
     free(wide);

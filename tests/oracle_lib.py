@@ -40,6 +40,9 @@ def load(kind="soft"):
     lib.oracle_math_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.oracle_get_counters.argtypes = [C.c_void_p]
     lib.oracle_uses_softmath.restype = C.c_int
+    lib.oracle_trace_rays.restype = C.c_int
+    lib.oracle_trace_rays.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_wide_stack_max.restype = C.c_int
     _libs[kind] = lib
     return lib
 
@@ -156,6 +159,23 @@ def render(scene, cam, width, height, eps, iter_first, iter_count, reset=True, a
                            st.ptr(acc), st.ptr(color), st.ptr(out) if want_out else None, rank, n_ranks, threads)
     assert rc == 0
     return (acc, color, out) if want_out else (acc, color)
+
+
+def trace_rays(scene, eps, rays8, order=0, kind="soft", threads=None):
+    """The traversal operators alone (Intersect / IntersectP) in traversal order `order` (0 reference, 1 near-first, 2 wide):
+    rays8 (n, 8) = origin, direction, tmax, any_hit -> (prim (n,) int32, tb (n, 3) = t, b1, b2)"""
+    lib = load(kind)
+    rays8 = np.ascontiguousarray(rays8, dtype=np.float32).reshape(-1, 8)
+    n = len(rays8)
+    prim = np.zeros(n, dtype=np.int32)
+    tb = np.zeros((n, 3), dtype=np.float32)
+    assert lib.oracle_set_traversal(order) == 0
+    try:
+        rc = lib.oracle_trace_rays(C.byref(scene.desc), eps, st.ptr(rays8), n, st.ptr(prim), st.ptr(tb), threads or min(64, os.cpu_count() or 1))
+    finally:
+        lib.oracle_set_traversal(0)
+    assert rc == 0
+    return prim, tb
 
 
 def counters(kind="soft"):

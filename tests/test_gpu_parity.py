@@ -88,6 +88,80 @@ def test_rng_stream_bit_exact(gpt):
         assert s == seed.value and u.tobytes() == uo.tobytes()
 
 
+# ---- the traversal operators on their own -------------------------------------------------
+
+def operator_rays(n, seed, lo=(-1.0, 0.0, -1.0), hi=(1.0, 2.0, 1.0)):
+    """n rays for Intersect / IntersectP: origins inside (and some outside) the box, random and axis-aligned directions (zero
+    components make 1/d infinite and 0 * inf = NaN in the slab test), origins exactly ON the walls, intervals that end before,
+    on and after surfaces, zero / infinite / NaN interval ends, NaN and zero directions; a third of them any-hit rays."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    r = np.zeros((n, 8), np.float32)
+    r[:, 0:3] = lo + (hi - lo) * rng.random((n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.sqrt((d * d).sum(-1, keepdims=True), dtype=np.float32)
+    r[:, 3:6] = d
+    r[:, 6] = np.inf
+    k = np.arange(n)
+    axis = k % 7 == 0                                     # axis-aligned directions
+    r[axis, 3:6] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, axis.sum())] * rng.choice(np.float32([-1, 1]), (axis.sum(), 1))
+    wall = k % 11 == 0                                    # origin exactly on a wall of the box
+    ax = rng.integers(0, 3, wall.sum())
+    r[np.nonzero(wall)[0], ax] = np.where(rng.random(wall.sum()) < 0.5, lo[ax], hi[ax])
+    outside = k % 13 == 0
+    r[outside, 0:3] = r[outside, 0:3] * np.float32(3.0) + np.float32([0, -1, 4])
+    short = k % 5 == 0
+    r[short, 6] = rng.random(short.sum()).astype(np.float32) * np.float32(2.5)
+    r[k % 97 == 0, 6] = 0.0
+    r[k % 101 == 0, 6] = np.nan
+    r[k % 103 == 0, 3] = np.nan
+    r[k % 107 == 0, 3:6] = 0.0
+    r[:, 7] = (k % 3 == 0).astype(np.float32)
+    return r
+
+
+@pytest.mark.parametrize("what", ["cornell_lds", "cornell_global", "soup_global", "config5_standin"])
+def test_traversal_operators_against_the_oracle(gpt, standin, what):
+    """Intersect and IntersectP (pathtracer.cu:214-296, with bbox.h:77-96 and mesh.h:45-67 under them) as operators: a list of
+    rays in, (primitive, t, b1, b2) out - through the render kernel's own ray pools and hand-scheduled loops (LDS-resident scene,
+    global memory with drains that stop and resume, the 4-wide walk) against the oracle's walk in the same order, bit for bit,
+    edge cases included."""
+    if what == "config5_standin":
+        scene, eps, n = standin("c5"), 0.001, 200_000
+    elif what == "soup_global":
+        scene, _ = scenes.zoo_scene(max_depth=4, extra=scenes.random_soup(3000, 5, size=0.3))
+        eps, n = 0.001, 120_000
+    else:
+        scene, _ = ol.load_cornell(4)
+        eps, n = 0.001, 120_000
+    rays = operator_rays(n, 17)
+    with gpt.Renderer(scene.desc, 64, 64, eps) as r:
+        if what == "cornell_global":
+            r.set_option("lds_scene", 0)
+        for order in ((0, 1, 2) if what != "cornell_lds" else (0,)):
+            r.set_traversal_order(order)
+            prim, tb = r.trace_rays(rays)
+            want_prim, want_tb = ol.trace_rays(scene, eps, rays, order)
+            hit = want_prim >= 0
+            assert 0.3 < hit.mean() < 0.999
+            assert np.array_equal(prim, want_prim), f"{what} order {order}: {np.count_nonzero(prim != want_prim)} of {n} rays hit another primitive"
+            same = (tb.view(np.uint32) == want_tb.view(np.uint32)) | (np.isnan(tb) & np.isnan(want_tb))
+            assert same[hit].all(), f"{what} order {order}: (t, b1, b2) differ on {np.count_nonzero(~same[hit].all(axis=1))} hits"
+        if what != "cornell_lds":
+            # The orders among each other, on the rays whose direction is a proper vector: whether an any-hit ray is blocked does
+            # not depend on the order; and the wide walk finds the reference order's closest hit on EVERY ray, ties included (its
+            # rule for equal distances - the larger primitive index - is what "the later primitive wins" comes to), while the
+            # nearer-child-first order differs on a few exactly-equal hits (axis-aligned rays through shared edges).
+            proper = ~np.isnan(rays).any(axis=1) & (np.abs(rays[:, 3:6]).sum(axis=1) > 0)
+            res = {order: ol.trace_rays(scene, eps, rays, order) for order in (0, 1, 2)}
+            closest, anyhit = proper & (rays[:, 7] == 0), proper & (rays[:, 7] != 0)
+            for order in (1, 2):
+                assert np.array_equal(res[order][0][anyhit] >= 0, res[0][0][anyhit] >= 0)
+            assert np.array_equal(res[2][0][closest], res[0][0][closest])
+            assert res[2][1][closest].tobytes() == res[0][1][closest].tobytes()
+            assert np.count_nonzero(res[1][0][closest] != res[0][0][closest]) < 0.005 * closest.sum()
+
+
 # ---- Cornell: the reference's shipped geometry --------------------------------------
 
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 1, 4), (128, 128, 4, 4), (256, 256, 16, 8), (160, 96, 8, 17),

@@ -226,6 +226,26 @@ def test_near_first_traversal_agrees_with_the_reference_order():
     assert lib.oracle_set_traversal(7) == -1
 
 
+def test_traversal_operators_do_not_depend_on_the_order():
+    """Intersect / IntersectP as operators (oracle_trace_rays) on 60 000 rays with edge cases (axis-aligned directions, origins on
+    the walls, short / zero intervals): whether an any-hit ray is blocked is the same in all three orders, and the wide walk finds
+    the reference order's closest hit - primitive, t, b1, b2 - on every ray with a proper direction, exactly equal hits included."""
+    import scenes
+    import test_gpu_parity as tg
+    rays = tg.operator_rays(60_000, 23)
+    proper = ~np.isnan(rays).any(axis=1) & (np.abs(rays[:, 3:6]).sum(axis=1) > 0)
+    closest, anyhit = proper & (rays[:, 7] == 0), proper & (rays[:, 7] != 0)
+    for scene in (ol.load_cornell(4)[0], scenes.zoo_scene(max_depth=4, extra=scenes.random_soup(2000, 5, size=0.3))[0]):
+        res = {order: ol.trace_rays(scene, 0.001, rays, order, threads=8) for order in (0, 1, 2)}
+        assert 0.3 < (res[0][0] >= 0).mean() < 0.999
+        for order in (1, 2):
+            assert np.array_equal(res[order][0][anyhit] >= 0, res[0][0][anyhit] >= 0)
+        assert np.array_equal(res[2][0][closest], res[0][0][closest])
+        assert res[2][1][closest].tobytes() == res[0][1][closest].tobytes()
+        hit = res[0][0] >= 0
+        assert (res[0][1][hit & proper & ~np.isnan(rays[:, 6]), 0] >= 0.001).all()             # tmin = epsilon
+
+
 def test_wide_traversal_agrees_with_the_reference_order():
     """include/gpt_wide_bvh.h: the 4-wide tree collapsed from the reference's tree, walked nearest child first with an
     order-free rule for equal distances (the larger primitive index).  Same boxes, same box and triangle arithmetic: the film
