@@ -72,6 +72,7 @@ struct gpt_ctx {
     float *samples = nullptr;             // per-iteration sample planes, grown on demand
     size_t sample_bytes = 0;              // bytes allocated for them
     uint32_t last_batch_cap = 0;          // iterations per launch the last gpt_render used
+    double last_trace_ms = 0.0;           // kernel time of the last gpt_debug_trace (HIP events)
     uint32_t max_batch = 256;             // "max_batch": iterations per path-kernel launch; also capped by the memory budget
     bool max_batch_set = false;           // ... as set by the caller (else: 256 x the number of ranks sharing the frame)
     bool count_next = false;
@@ -588,6 +589,7 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "walk_kernel_active") *value = render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0;
     else if (n == "last_batch") *value = ctx->last_batch_cap;
     else if (n == "sample_plane_bytes") *value = (int64_t)ctx->sample_bytes;
+    else if (n == "last_trace_us") *value = (int64_t)(ctx->last_trace_ms * 1000.0);
     else {
         gpt_set_error("gpt_get_option: unknown option %s", name);
         return GPT_ERR_INVALID_ARG;
@@ -1031,13 +1033,24 @@ int gpt_debug_trace(gpt_ctx *ctx, const float *rays8, int n, int32_t *prim_out, 
     if (hipMalloc((void **)&d_out, (size_t)n * sizeof(float4)) != hipSuccess) { (void)hipFree(d_rays); gpt_set_error("gpt_debug_trace: hipMalloc failed"); return GPT_ERR_HIP; }
     int rc = GPT_OK;
     std::vector<float4> res((size_t)n);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
     if (hipMemcpy(d_rays, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess ||
+        hipEventRecord(e0, ctx->stream) != hipSuccess ||
         launch_trace_rays(ctx->P, ctx->lds_scene, d_rays, n, d_out, ctx->stream) != hipSuccess ||
+        hipEventRecord(e1, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess ||
         hipMemcpy(res.data(), d_out, res.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) {
         gpt_set_error("gpt_debug_trace: %s", hipGetErrorString(hipGetLastError()));
         rc = GPT_ERR_HIP;
     }
+    if (rc == GPT_OK) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->last_trace_ms = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(d_rays);
     (void)hipFree(d_out);
     if (rc != GPT_OK) return rc;

@@ -89,7 +89,8 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
  *   "max_batch"        iterations per path-kernel launch; default 256 x the number of ranks sharing the frame (a rank's sample
  *                      planes cover its own tiles only), always bounded by 16 GiB and by the free device memory
  *   "chunk_iters"      iterations per work item, 0 (default) = cost model
- * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "last_batch", "sample_plane_bytes". */
+ * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "last_batch", "sample_plane_bytes", "last_trace_us" (kernel
+ * time of the last gpt_debug_trace). */
 int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value);
 int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value);
 
