@@ -441,62 +441,63 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
     }
 }
 
-// ---- GPT_TRAVERSAL_WIDE4: four lanes per ray on the 4-wide tree (include/gpt_wide_bvh.h) --------------------------------
-// The walk of one ray is the one the header specifies (and oracle/pt_oracle.c restates one ray at a time).  Here a ray
-// belongs to a GROUP of four consecutive lanes, 16 rays per wave:
-//   wide node  lane k of the group loads child k (32 bytes: the group reads one 128-byte record, one cache line) and tests
-//              its box; a quad of DPP moves shows every lane all four entry distances, each hit lane computes its rank and
-//              writes its child to the group's stack in LDS so that the nearest pops first
-//   leaf       lane k tests triangle k of the leaf (Moeller-Trumbore, the same instructions as trace_pool<>), each lane
-//              keeps the best hit IT has seen, and only the interval's end is shared (quad minimum by DPP); when the ray is
-//              done the lane holding the best of the four writes the result
-// Against one ray per lane on the binary tree: a node step is one dependent fetch for four boxes instead of one, all four
-// lanes of a busy group work (the vote between node and triangle lanes and its idle halves are gone), and the four
-// requests of a group fall into one cache line.
-// The stack: kWideStackDepth entries per group in LDS (the region the binary loop uses for suspended rays); deeper entries
-// go to a slice of P.wide_stack in global memory (3 * depth + 1 <= GPT_WIDE_STACK_MAX is checked by the host).
-constexpr int kWideStackDepth = 24;
-constexpr int kWideStackOff = kSuspOff + 32;                      // after 16 group records of 32 bytes
+// ---- GPT_TRAVERSAL_WIDE4: one lane per ray on the 4-wide tree (include/gpt_wide_bvh.h) ------------------------------------
+// The walk of one ray is the one the header specifies (and oracle/pt_oracle.c restates).  One lane owns one ray, as in the
+// binary loops, but a node step loads ONE 128-byte record (seven dwordx4: six planes of four boxes and the four children's
+// ready-made stack entries) and tests all four boxes; the hit children are ordered nearest first by a five-exchange sorting
+// network on (key, entry) pairs, the nearest becomes the current entry and the others go to the ray's stack.  Against the
+// binary loop: a quarter of the dependent fetches, about half the bytes through the vector cache, and no half-empty
+// lookahead halves.  A leaf step tests one triangle (Moeller-Trumbore, the same instructions as trace_pool<>).
+// A trip serves both kinds of lanes: the fetches of the lanes at a wide node and of the lanes at a leaf go out together,
+// then the node block and the triangle block run under their own lane masks.
+// The stack: kWideStackDepth entries per lane in LDS, level-major (level l of lane i at word 64 l + i: conflict-free for any
+// mix of levels); deeper entries go to the wave's slice of P.wide_stack in global memory, in the same arrangement
+// (3 * depth + 1 <= GPT_WIDE_STACK_MAX is checked by the host).
+constexpr int kWideStackDepth = 12;
+constexpr int kWideStackOff = kWaveCarryFloat4;                   // after the carry layout's regions
+constexpr int kWaveWideFloat4 = kWaveCarryFloat4 + 16 * kWideStackDepth;      // one level of 64 lanes = 16 float4
 constexpr int kWideSpillStride = GPT_WIDE_STACK_MAX + 8;
-static_assert(kWideStackOff * 16 + 16 * kWideStackDepth * 4 <= kWaveCarryFloat4 * 16, "the group stacks fit the suspend region");
-#ifndef PT_WIDE_FETCH_GROUPS
-#define PT_WIDE_FETCH_GROUPS 2                                    // idle groups that trigger a refill
+#ifndef PT_WIDE_FETCH_T
+#define PT_WIDE_FETCH_T 12                                        // idle lanes that trigger a refill
 #endif
-// A block of a trip costs the wave the same whether one group or sixteen take part.  Groups at a leaf wait until
-// PT_WIDE_LEAF_MIN of them have gathered (or no group is at a wide node), and the other way round with PT_WIDE_NODE_MIN.
-#ifndef PT_WIDE_STOP_GROUPS
-#define PT_WIDE_STOP_GROUPS 4                                     // a dry pool with at most this many groups still busy ends the drain
+#ifndef PT_WIDE_STOP_T
+#define PT_WIDE_STOP_T 24                                         // a dry pool with at most this many rays in flight ends the drain
 #endif
-static_assert(PT_WIDE_STOP_GROUPS <= 16 - PT_WIDE_FETCH_GROUPS, "a resumed drain starts with a refill");
+static_assert(PT_WIDE_STOP_T < 64 - PT_WIDE_FETCH_T, "a resumed drain starts with a refill");
+// A block of a trip costs the wave the same whether one lane or sixty-four take part.  Lanes at a leaf wait until
+// PT_WIDE_LEAF_MIN of them have gathered (or no lane is at a wide node), and the other way round with PT_WIDE_NODE_MIN.
 #ifndef PT_WIDE_LEAF_MIN
-#define PT_WIDE_LEAF_MIN 4
+#define PT_WIDE_LEAF_MIN 8
 #endif
 #ifndef PT_WIDE_NODE_MIN
 #define PT_WIDE_NODE_MIN 1
 #endif
-template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
-// quad_perm controls: broadcast of lane j of every group of four, and the two butterfly steps
-constexpr int kQuad0 = 0x00, kQuad1 = 0x55, kQuad2 = 0xAA, kQuad3 = 0xFF, kQuadSwap1 = 0xB1, kQuadSwap2 = 0x4E;
+
+// one compare-exchange of the sorting network: afterwards ka <= kb (the entries travel with their keys)
+__device__ __forceinline__ void wide_cex(unsigned &ka, unsigned &ea, unsigned &kb, unsigned &eb)
+{
+    const bool swap = kb < ka;
+    const unsigned k0 = swap ? kb : ka, k1 = swap ? ka : kb, e0 = swap ? eb : ea, e1 = swap ? ea : eb;
+    ka = k0; kb = k1; ea = e0; eb = e1;
+}
 
 template <bool COUNT>
 __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool, int n_rays, Counters &cnt)
 {
-    const unsigned lane = threadIdx.x & 63u, sub = lane & 3u, grp = lane >> 2, grp_shift = lane & ~3u;
-    unsigned *stk = reinterpret_cast<unsigned *>(pool + kWideStackOff) + grp * kWideStackDepth;
-    volatile unsigned *spill = P.wide_stack + ((size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u + grp) * kWideSpillStride;
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned *stk = reinterpret_cast<unsigned *>(pool + kWideStackOff) + lane;
+    volatile unsigned *spill = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (64u * kWideSpillStride) + lane;
     const char *wnodes = reinterpret_cast<const char *>(P.wide);
     const char *tris = reinterpret_cast<const char *>(P.tris);
     const float tmin_ray = P.eps;
-    constexpr unsigned long long kLeaders = 0x1111111111111111ull;
 
     int next = 0;                          // wave-uniform: first ray of the fetch order nobody has taken yet
-    int slot = -1, any_hit = 0;            // group-uniform from here ...
+    int slot = -1, any_hit = 0;
     V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
     float tmax = 0.f;
     unsigned cur = GPT_WIDE_NONE;
     int sp = 0;
-    int bprim = -1;                        // ... this lane's own best hit
+    int bprim = -1;
     float bt = 0.f, bb1 = 0.f, bb2 = 0.f;
 
     for (;;) {
@@ -504,26 +505,17 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         const bool fin = has && cur == GPT_WIDE_NONE;
         const unsigned long long m_has = ballot(has), m_fin = ballot(fin);
         if (m_fin != 0ull) {
-            // ---- finished rays: the best of the four lanes' hits (nearer; exactly as near: the larger primitive index)
-            const int p0 = dpp_i<kQuad0>(bprim), p1 = dpp_i<kQuad1>(bprim), p2 = dpp_i<kQuad2>(bprim), p3 = dpp_i<kQuad3>(bprim);
-            const float t0 = dpp_f<kQuad0>(bt), t1 = dpp_f<kQuad1>(bt), t2 = dpp_f<kQuad2>(bt), t3 = dpp_f<kQuad3>(bt);
-            bool win = bprim >= 0;
-            if (sub != 0u && p0 >= 0 && (t0 < bt || (t0 == bt && p0 > bprim))) win = false;
-            if (sub != 1u && p1 >= 0 && (t1 < bt || (t1 == bt && p1 > bprim))) win = false;
-            if (sub != 2u && p2 >= 0 && (t2 < bt || (t2 == bt && p2 > bprim))) win = false;
-            if (sub != 3u && p3 >= 0 && (t3 < bt || (t3 == bt && p3 > bprim))) win = false;
-            const bool none = (p0 & p1 & p2 & p3) < 0;
-            if (fin && (win || (none && sub == 0u))) {
-                pool[2 * slot + 1] = make_float4(__int_as_float(none ? -1 : bprim), none ? tmax : bt, bb1, bb2);
+            if (fin) {       // a miss reports the end of the interval, like the other loops
+                pool[2 * slot + 1] = make_float4(__int_as_float(bprim), bprim < 0 ? tmax : bt, bb1, bb2);
                 atomicAnd(reinterpret_cast<unsigned *>(pool + kPendOff) + (slot & 63), ~(1u << (slot >> 6)));
+                slot = -1;
             }
-            if (fin) slot = -1;
         }
         const unsigned long long m_busy = m_has & ~m_fin;
-        const int n_idle = 16 - popc(m_busy & kLeaders);
-        if (next < n_rays && n_idle >= PT_WIDE_FETCH_GROUPS) {
-            // ---- refill: idle groups take the next rays of the fetch order, in group order
-            const int nth = next + lane_rank(~m_busy & kLeaders) - (sub != 0u ? 1 : 0);
+        const int n_idle = 64 - popc(m_busy);
+        if (next < n_rays && n_idle >= PT_WIDE_FETCH_T) {
+            // ---- refill: idle lanes take the next rays of the fetch order, in lane order
+            const int nth = next + lane_rank(~m_busy);
             if (slot < 0 && nth < n_rays) {
                 const int mine = (int)reinterpret_cast<const unsigned short *>(pool + kOrderOff)[nth];
                 const float4 r0 = pool[2 * mine];
@@ -549,74 +541,73 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         bool leaf = has && !fin && (cur >> 31) != 0u;
         bool inner = has && !fin && (cur >> 31) == 0u;
         {
-            const int n_leaf = popc(ballot(leaf) & kLeaders), n_inner = popc(ballot(inner) & kLeaders);
+            const int n_leaf = popc(ballot(leaf)), n_inner = popc(ballot(inner));
             if (n_leaf < PT_WIDE_LEAF_MIN && n_inner > 0) leaf = false;                      // the leaves wait
             else if (n_inner < PT_WIDE_NODE_MIN && n_leaf > 0) inner = false;                // the wide nodes wait
         }
-        if (COUNT && lane == 0u) {          // utilisation probes: trips, busy groups, trips with a node block / a leaf block
-            cnt.w_trip++;
-            cnt.l_trip += (uint32_t)popc(m_busy & kLeaders);
-            if (ballot(inner) != 0ull) cnt.w_node++;
-            if (ballot(leaf) != 0ull) cnt.w_prim++;
+        if (COUNT) {                        // utilisation probes: trips, busy lanes, trips with a node block / a triangle block
+            const bool any_inner = ballot(inner) != 0ull, any_leaf = ballot(leaf) != 0ull;
+            if (lane == 0u) {
+                cnt.w_trip++;
+                cnt.l_trip += (uint32_t)popc(m_busy);
+                if (any_inner) cnt.w_node++;
+                if (any_leaf) cnt.w_prim++;
+            }
         }
-        const int lf_first = (int)(cur & 0x07ffffffu), lf_count = (int)((cur >> 27) & 15u) + 1;
-        const bool tri_lane = leaf && (int)sub < lf_count;
-        // both kinds of fetch go out before either is used
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, q0 = a, q1 = a;
-        float e2z = 0.f;
+        bool pop = false;
         if (inner) {
-            const float4 *np = reinterpret_cast<const float4 *>(wnodes + (size_t)cur + 32u * sub);
-            a = np[0];
-            b = np[1];
-        }
-        if (tri_lane) {
-            const char *tp = tris + (size_t)(lf_first + (int)sub) * 48u;
-            q0 = *reinterpret_cast<const float4 *>(tp);
-            q1 = *reinterpret_cast<const float4 *>(tp + 16);
-            e2z = *reinterpret_cast<const float *>(tp + 32);
-        }
-        if (ballot(inner) != 0ull) {
             // ---- a wide node: four boxes, bbox.h:77-96 each ---------------------------------
-            const float t1 = (a.x - o.x) * inv.x;
-            const float t2 = (a.w - o.x) * inv.x;
-            const float t3 = (a.y - o.y) * inv.y;
-            const float t4 = (b.x - o.y) * inv.y;
-            const float t5 = (a.z - o.z) * inv.z;
-            const float t6 = (b.y - o.z) * inv.z;
-            const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
-            const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
-            const int ref = __float_as_int(b.z), count = __float_as_int(b.w);
-            const bool hit = inner && count != 0 && !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
-            if (COUNT && inner && sub == 0u) { cnt.node_visits++; }
-            // order key (gpt_wide_key): the distance as a sortable integer, slot in the two lowest bits; a child that is not hit
-            // gets the largest key, so it is never counted as popping before a hit one
-            const unsigned ubits = __float_as_uint(tn == tn ? tn : -__builtin_inff());
-            const unsigned mono = ubits ^ ((unsigned)((int)ubits >> 31) | 0x80000000u);
-            const unsigned key = hit ? ((mono & ~3u) | sub) : 0xffffffffu;
-            const unsigned gh = (unsigned)(ballot(hit) >> grp_shift) & 15u;       // the group's hit children
-            const int nhit = __builtin_popcount(gh);
-            const unsigned k0 = (unsigned)dpp_i<kQuad0>((int)key), k1 = (unsigned)dpp_i<kQuad1>((int)key), k2 = (unsigned)dpp_i<kQuad2>((int)key), k3 = (unsigned)dpp_i<kQuad3>((int)key);
-            const int rank = (k0 < key ? 1 : 0) + (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);      // hit children that pop before this one
-            if (hit) {
-                const unsigned entry = count < 0 ? (unsigned)ref : (0x80000000u | ((unsigned)(count - 1) << 27) | (unsigned)ref);
-                const int at = sp + nhit - 1 - rank;
-                if (at < kWideStackDepth) stk[at] = entry;
-                else spill[at] = entry;
+            const float4 *np = reinterpret_cast<const float4 *>(wnodes + (size_t)cur);
+            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            const uint4 en = *reinterpret_cast<const uint4 *>(np + 6);
+            if (COUNT) cnt.node_visits++;
+            const float blx[4] = {lx.x, lx.y, lx.z, lx.w}, bly[4] = {ly.x, ly.y, ly.z, ly.w}, blz[4] = {lz.x, lz.y, lz.z, lz.w};
+            const float bhx[4] = {hx.x, hx.y, hx.z, hx.w}, bhy[4] = {hy.x, hy.y, hy.z, hy.w}, bhz[4] = {hz.x, hz.y, hz.z, hz.w};
+            unsigned e[4] = {en.x, en.y, en.z, en.w}, key[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t1 = (blx[k] - o.x) * inv.x;
+                const float t2 = (bhx[k] - o.x) * inv.x;
+                const float t3 = (bly[k] - o.y) * inv.y;
+                const float t4 = (bhy[k] - o.y) * inv.y;
+                const float t5 = (blz[k] - o.z) * inv.z;
+                const float t6 = (bhz[k] - o.z) * inv.z;
+                const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
+                const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
+                const bool hit = e[k] != GPT_WIDE_NONE && !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
+                // order key (gpt_wide_key): the bit pattern of max(tn, +0), slot in the two lowest bits; a child that is not hit
+                // gets the largest key and sorts behind every hit one
+                key[k] = hit ? ((__float_as_uint(tn > 0.0f ? tn : 0.0f) & ~3u) | (unsigned)k) : 0xffffffffu;
             }
-            wave_lds_fence();
-            if (inner) {
-                sp += nhit;
-                if (sp > 0) {
-                    --sp;
-                    cur = sp < kWideStackDepth ? stk[sp] : spill[sp];
-                } else {
-                    cur = GPT_WIDE_NONE;
-                }
+            wide_cex(key[0], e[0], key[1], e[1]);
+            wide_cex(key[2], e[2], key[3], e[3]);
+            wide_cex(key[0], e[0], key[2], e[2]);
+            wide_cex(key[1], e[1], key[3], e[3]);
+            wide_cex(key[1], e[1], key[2], e[2]);
+            if (key[0] == 0xffffffffu) {
+                pop = true;
+            } else {
+                // the nearest is visited next; the others are pushed farthest first: sorted child j ends at sp' - j, sp' the new size
+                const int top = sp + 3 - (key[1] == 0xffffffffu ? 1 : 0) - (key[2] == 0xffffffffu ? 1 : 0) - (key[3] == 0xffffffffu ? 1 : 0);
+#pragma unroll
+                for (int j = 3; j >= 1; --j)
+                    if (key[j] != 0xffffffffu) {
+                        const int at = top - j;
+                        if (at < kWideStackDepth) stk[64 * at] = e[j];
+                        else spill[64 * at] = e[j];
+                    }
+                sp = top;
+                cur = e[0];
             }
         }
-        if (ballot(leaf) != 0ull) {
-            // ---- a leaf: up to four triangles, mesh.h:45-67 each, all against the same interval ----------------
-            const int prim = lf_first + (int)sub;
+        if (leaf) {
+            // ---- a leaf: its first triangle, mesh.h:45-67 -------------------------------------
+            const int prim = (int)(cur & 0x07ffffffu), left = (int)((cur >> 27) & 15u);      // left = triangles after this one
+            const char *tp = tris + (size_t)prim * 48u;
+            const float4 q0 = *reinterpret_cast<const float4 *>(tp);
+            const float4 q1 = *reinterpret_cast<const float4 *>(tp + 16);
+            const float e2z = *reinterpret_cast<const float *>(tp + 32);
+            if (COUNT) cnt.prim_tests++;
             const V3 v1 = V3{q0.x, q0.y, q0.z};
             const V3 e1 = V3{q0.w, q1.x, q1.y};
             const V3 e2 = V3{q1.z, q1.w, e2z};
@@ -628,36 +619,34 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
             const V3 s2 = cross(s, e1);
             const float b2 = dot(d, s2) * invDivisor;
             const float tt = dot(e2, s2) * invDivisor;
-            const bool accept = tri_lane && !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) &&
+            const bool accept = !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) &&
                                 !(b2 < 0.0f || b1 + b2 > 1.0f) && !(tt < tmin_ray || tt > tmax);
-            if (COUNT && tri_lane) { cnt.prim_tests++; }
-            if (accept && (bprim < 0 || tt < bt || (tt == bt && prim > bprim))) {
-                bprim = prim;
-                bt = tt;
-                bb1 = b1;
-                bb2 = b2;
-            }
-            float nearest = (accept && tt == tt) ? tt : __builtin_inff();
-            {
-                const float n1 = dpp_f<kQuadSwap1>(nearest);
-                nearest = n1 < nearest ? n1 : nearest;             // (a NaN distance never becomes the interval's end)
-                const float n2 = dpp_f<kQuadSwap2>(nearest);
-                nearest = n2 < nearest ? n2 : nearest;
-            }
-            const unsigned ga = (unsigned)(ballot(accept) >> grp_shift) & 15u;
-            if (leaf) {
-                if (nearest < tmax) tmax = nearest;
-                if (any_hit != 0 && ga != 0u) {                     // IntersectP: the first accepted triangle ends the ray
-                    cur = GPT_WIDE_NONE;
-                    sp = 0;
-                } else if (lf_count > 4) {
-                    cur = 0x80000000u | ((unsigned)(lf_count - 5) << 27) | (unsigned)(lf_first + 4);
-                } else if (sp > 0) {
-                    --sp;
-                    cur = sp < kWideStackDepth ? stk[sp] : spill[sp];
-                } else {
-                    cur = GPT_WIDE_NONE;
+            bool ended = false;
+            if (accept) {
+                if (bprim < 0 || tt < bt || (tt == bt && prim > bprim)) {
+                    bprim = prim;
+                    bt = tt;
+                    bb1 = b1;
+                    bb2 = b2;
                 }
+                if (tt < tmax) tmax = tt;                      // (a NaN distance never becomes the interval's end)
+                ended = any_hit != 0;                          // IntersectP: the first accepted triangle ends the ray
+            }
+            if (ended) {
+                cur = GPT_WIDE_NONE;
+                sp = 0;
+            } else if (left > 0) {
+                cur = 0x80000000u | ((unsigned)(left - 1) << 27) | (unsigned)(prim + 1);
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            if (sp > 0) {
+                --sp;
+                cur = sp < kWideStackDepth ? stk[64 * sp] : spill[64 * sp];
+            } else {
+                cur = GPT_WIDE_NONE;
             }
         }
     }
@@ -1139,122 +1128,70 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 
 // ---- trace_pool_wide<>, hand-scheduled -------------------------------------------------------------------------------------
 // The instruction-for-instruction twin of trace_pool_wide<> above (which stays the specification and runs in the counting
-// build), for the same reason trace_pool_lds_asm exists: the compiler's version of this loop is ~600 instructions per trip
-// (109 register copies for loop phis, 40 exec save / restore pairs, 64-bit address arithmetic per lane), the loop below ~190.
-// Floating-point instructions and their order are those of the C++ twin (box test and triangle test are the blocks of
-// PT_TRACE_ASM), so the films are bit-identical; tests/test_gpu_parity.py runs both.
+// build), for the same reason trace_pool_lds_asm exists.  Floating-point instructions and their order are those of the C++
+// twin (the box test and the triangle test are the blocks of PT_TRACE_ASM), so the films are bit-identical;
+// tests/test_gpu_parity.py runs both.
 //
-// One trip serves every busy group, whatever it is working on: the fetches of the groups at a wide node (2 x dwordx4 per
-// lane: lane k reads child k) and of the groups at a leaf (3 loads per lane: lane k reads triangle k) go out together, then
-// the node block and the leaf block run under their own lane masks.
+// One trip serves every busy lane, whatever it is working on: the fetches of the lanes at a wide node (7 x dwordx4: one
+// 128-byte record per lane) and of the lanes at a leaf (3 loads: one triangle) go out together, then the node block and
+// the triangle block run under their own lane masks - on the SAME registers: a lane is at one or at the other.
 //
 // Register map (all clobbered):
 //   v[0:2] origin  v[4:6] dir  v7 tmax as loaded  v[8:10] 1/dir  v11 tag (owner | any-hit << 8)
-//   v12 current entry (wide node: byte offset; leaf: bit 31 | count-1 << 27 | first triangle; -1: none)   v13 stack size
-//   v14 LDS address of the group's stack   v15 LDS address of the ray's slot (-1: idle group)
-//   v16 32 * (lane & 3)   v17 lane & ~3   v18 lane & 3   v19 end of the ray's interval (group-uniform)
-//   v[20:23] this lane's best hit {triangle index or -1, t, b1, b2}   v[24:31] child record   v[44:52] triangle record
-//   v53 byte offset of the group's slice of the spill stack   v54 (lane & 3) != 0   v55 LDS address of the group's record   v[32:43] temporaries
-//   s[60:61] lanes of groups at a leaf  s[62:63] ... at a wide node  s[64:65] lanes of busy groups  s[66:69],s[72:73] scratch masks
-//   s70 next ray  s71 scratch  s[74:75] lanes with a triangle to test  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] 0x1111...
-#define PT_WIDE_POP /* exec: the lanes that pop; v13 > 0: take the top entry, else the ray is finished */ \
-        "v_cmp_lt_i32_e32 vcc, 0, v13\n" \
-        "v_mov_b32_e32 v12, -1\n" \
-        "s_and_b64 exec, exec, vcc\n" \
-        "s_cbranch_execz TW_POPPED_%=\n" \
-        "v_add_u32_e32 v13, -1, v13\n" \
-        "v_cmp_gt_i32_e32 vcc, %[depth], v13\n" \
-        "s_mov_b64 s[72:73], exec\n" \
-        "s_and_b64 exec, exec, vcc\n" \
-        "v_lshl_add_u32 v33, v13, 2, v14\n" \
-        "ds_read_b32 v12, v33\n" \
-        "s_andn2_b64 exec, s[72:73], vcc\n" \
-        "s_cbranch_execz TW_POP_LDS_%=\n" \
-        "v_lshl_add_u32 v33, v13, 2, v53\n" \
-        "global_load_dword v12, v33, %[spill] sc0 sc1\n" \
-        "s_waitcnt vmcnt(0)\n" \
-        "TW_POP_LDS_%=:\n" \
-        "s_waitcnt lgkmcnt(0)\n" \
-        "TW_POPPED_%=:\n"
+//   v12 current entry (wide node: byte offset; leaf: bit 31 | triangles after the first << 27 | first triangle; -1: none)
+//   v13 stack size   v14 end of the ray's interval   v15 LDS address of the ray's slot (-1: idle lane)
+//   v16 byte offset of the lane's column of the wave's spill slice   v17 LDS address of the lane's suspend record
+//   v18 LDS address of the lane's stack column - 768 (level l at v18 + 768 + 256 l)
+//   v[20:23] best hit {triangle index or -1, t, b1, b2}
+//   lanes at a wide node: v[24:47] six planes of four boxes, v[48:51] the children's entries, v[52:55] their keys, v[56:64] temporaries
+//   lanes at a leaf:      v[24:32] the triangle record, v[33:43] temporaries (as in PT_TRACE_ASM), v52 the triangle's index, v53 its byte offset
+//   s[60:61] lanes at a leaf  s[62:63] lanes at a wide node  s[64:65] lanes with a ray / busy lanes  s[66:69],s[72:75] scratch masks
+//   s70 next ray  s71 s72 counts  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] node lanes with a hit child
+#ifndef PT_WIDE_ASM
+#define PT_WIDE_ASM 1
+#endif
+#ifndef PT_WIDE_PROBE
+#define PT_WIDE_PROBE 0          // 1: the loop counts its trips, node / triangle blocks and the lanes in them (probe builds)
+#endif
+#if PT_WIDE_PROBE
+#define PT_WIDE_PROBE_TRIP \
+        "s_bcnt1_i32_b64 s71, s[62:63]\n" "s_bcnt1_i32_b64 s72, s[60:61]\n" \
+        "v_add_u32_e32 %[pr_trips], 1, %[pr_trips]\n" "v_add_u32_e32 %[pr_nlanes], s71, %[pr_nlanes]\n" "v_add_u32_e32 %[pr_tlanes], s72, %[pr_tlanes]\n" \
+        "s_min_u32 s71, s71, 1\n" "s_min_u32 s72, s72, 1\n" \
+        "v_add_u32_e32 %[pr_nblk], s71, %[pr_nblk]\n" "v_add_u32_e32 %[pr_tblk], s72, %[pr_tblk]\n" \
+        "s_bcnt1_i32_b64 s71, s[64:65]\n" "v_add_u32_e32 %[pr_busy], s71, %[pr_busy]\n"
+#else
+#define PT_WIDE_PROBE_TRIP
+#endif
+struct WideProbe { unsigned trips, nlanes, tlanes, nblk, tblk, busy; };
 
-#define PT_WIDE_MERGE_BEST /* all four lanes of a group end up with the group's best hit */ \
-        "s_nop 1\n" \
-        "v_mov_b32_dpp v33, v20 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_mov_b32_dpp v34, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_mov_b32_dpp v35, v22 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_mov_b32_dpp v36, v23 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n" \
-        "v_cmp_lt_f32_e32 vcc, v34, v21\n" \
-        "s_or_b64 s[66:67], s[66:67], vcc\n" \
-        "v_cmp_eq_f32_e32 vcc, v34, v21\n" \
-        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n" \
-        "s_and_b64 vcc, vcc, s[72:73]\n" \
-        "s_or_b64 s[66:67], s[66:67], vcc\n" \
-        "v_cmp_lt_i32_e32 vcc, -1, v33\n" \
-        "s_and_b64 vcc, vcc, s[66:67]\n" \
-        "v_cndmask_b32_e32 v20, v20, v33, vcc\n" \
-        "v_cndmask_b32_e32 v21, v21, v34, vcc\n" \
-        "v_cndmask_b32_e32 v22, v22, v35, vcc\n" \
-        "v_cndmask_b32_e32 v23, v23, v36, vcc\n" \
-        "s_nop 1\n" \
-        "v_mov_b32_dpp v33, v20 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_mov_b32_dpp v34, v21 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_mov_b32_dpp v35, v22 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_mov_b32_dpp v36, v23 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-        "v_cmp_gt_i32_e64 s[66:67], 0, v20\n" \
-        "v_cmp_lt_f32_e32 vcc, v34, v21\n" \
-        "s_or_b64 s[66:67], s[66:67], vcc\n" \
-        "v_cmp_eq_f32_e32 vcc, v34, v21\n" \
-        "v_cmp_gt_i32_e64 s[72:73], v33, v20\n" \
-        "s_and_b64 vcc, vcc, s[72:73]\n" \
-        "s_or_b64 s[66:67], s[66:67], vcc\n" \
-        "v_cmp_lt_i32_e32 vcc, -1, v33\n" \
-        "s_and_b64 vcc, vcc, s[66:67]\n" \
-        "v_cndmask_b32_e32 v20, v20, v33, vcc\n" \
-        "v_cndmask_b32_e32 v21, v21, v34, vcc\n" \
-        "v_cndmask_b32_e32 v22, v22, v35, vcc\n" \
-        "v_cndmask_b32_e32 v23, v23, v36, vcc\n"
-
-__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop)
+__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop, WideProbe &pr)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
     const unsigned long long s_nodes = uniform64((unsigned long long)P.wide), s_tris = uniform64((unsigned long long)P.tris);
     const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
-    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_stack = s_pool + kWideStackOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const unsigned s_stack = s_pool + kWideStackOff * 16 - 768;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
-    // this group's slice of the spill stack, in bytes (wave-uniform part + 4 * stride * group)
-    const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u + (lane >> 2)) * (unsigned)(kWideSpillStride * 4);
+    // this lane's column of the wave's spill slice, in bytes (level l at + 256 l)
+    const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)(64 * kWideSpillStride) + lane) * 4u;
     asm volatile(
         "s_mov_b32 s70, 0\n"
         "s_mov_b32 s76, 0x322bcc77\n"
         "s_mov_b32 s77, 0x71800000\n"
-        "s_mov_b32 s80, 0x11111111\n"                      /* s[80:81]: the first lane of every group */
-        "s_mov_b32 s81, 0x11111111\n"
         "s_mov_b64 s[64:65], 0\n"
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
         "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
-        "v_and_b32_e32 v18, 3, v33\n"
-        "v_lshlrev_b32_e32 v16, 5, v18\n"
-        "v_and_b32_e32 v17, 60, v33\n"
-        "v_lshrrev_b32_e32 v34, 2, v33\n"
-        "v_mul_u32_u24_e32 v34, %[depth4], v34\n"
-        "v_add_u32_e32 v14, %[stack], v34\n"
-        "v_mov_b32_e32 v53, %[vspill]\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v18\n"
-        "v_cndmask_b32_e64 v54, 0, 1, vcc\n"
-        /* every group resumes the ray it was walking when the last drain stopped (its record: {entry, stack size, end of the
+        "v_lshl_add_u32 v18, v33, 2, %[stack]\n"
+        "v_lshl_add_u32 v17, v33, 5, %[susp]\n"
+        "v_mov_b32_e32 v16, %[vspill]\n"
+        /* every lane resumes the ray it was walking when the last drain stopped (its record: {entry, stack size, end of the
            interval, slot} {best hit}); direction and origin come back from the ray's slot */
-        "v_lshrrev_b32_e32 v34, 2, v33\n"
-        "v_lshl_add_u32 v55, v34, 5, %[susp]\n"
-        "ds_read_b128 v[40:43], v55\n"
-        "ds_read_b128 v[20:23], v55 offset:16\n"
+        "ds_read_b128 v[12:15], v17\n"
+        "ds_read_b128 v[20:23], v17 offset:16\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_mov_b32_e32 v12, v40\n"
-        "v_mov_b32_e32 v13, v41\n"
-        "v_mov_b32_e32 v19, v42\n"
-        "v_mov_b32_e32 v15, v43\n"
         "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"
         "s_mov_b64 exec, s[64:65]\n"
         "ds_read_b128 v[4:7], v15\n"
@@ -1269,19 +1206,17 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---------------------------------------------------------------- loop header */
         PT_LOOP_ALIGN
         "TW_LOOP_%=:\n"
-        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"             /* groups with a ray */
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"             /* lanes with a ray */
         "v_cmp_eq_u32_e64 s[66:67], -1, v12\n"             /* ... that is finished */
         "s_and_b64 s[68:69], s[64:65], s[66:67]\n"
         "s_cbranch_scc1 TW_FIN_%=\n"
         "TW_TRIP_%=:\n"
         "v_cmp_gt_i32_e64 s[60:61], 0, v12\n"
-        "s_and_b64 s[60:61], s[60:61], s[64:65]\n"         /* at a leaf (bit 31 set, not -1: busy groups only) */
+        "s_and_b64 s[60:61], s[60:61], s[64:65]\n"         /* at a leaf (bit 31 set, not -1: busy lanes only) */
         "s_andn2_b64 s[62:63], s[64:65], s[60:61]\n"       /* at a wide node */
-        /* too few groups at a leaf: they wait (unless nobody is at a wide node); else too few at a wide node: those wait */
-        "s_and_b64 s[66:67], s[60:61], s[80:81]\n"
-        "s_bcnt1_i32_b64 s71, s[66:67]\n"
-        "s_and_b64 s[66:67], s[62:63], s[80:81]\n"
-        "s_bcnt1_i32_b64 s72, s[66:67]\n"
+        /* too few lanes at a leaf: they wait (unless nobody is at a wide node); else too few at a wide node: those wait */
+        "s_bcnt1_i32_b64 s71, s[60:61]\n"
+        "s_bcnt1_i32_b64 s72, s[62:63]\n"
         "s_cmp_ge_u32 s71, %[leafmin]\n"
         "s_cbranch_scc1 TW_VOTE_NODE_%=\n"
         "s_cmp_eq_u32 s72, 0\n"
@@ -1293,156 +1228,237 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cbranch_scc1 TW_VOTED_%=\n"
         "s_mov_b64 s[62:63], 0\n"
         "TW_VOTED_%=:\n"
-        /* ---- fetches of both kinds */
+        PT_WIDE_PROBE_TRIP
+        /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
+           wait for everything) */
         "s_mov_b64 exec, s[60:61]\n"
-        "v_bfe_u32 v34, v12, 27, 4\n"                      /* count - 1 */
-        "v_and_b32_e32 v35, 0x7ffffff, v12\n"
-        "v_cmp_le_u32_e32 vcc, v18, v34\n"
-        "v_add_u32_e32 v32, v35, v18\n"                    /* this lane's triangle */
-        "v_lshlrev_b32_e32 v36, 4, v32\n"
-        "v_lshl_add_u32 v36, v32, 5, v36\n"                /* * 48 */
-        "s_and_b64 s[74:75], s[60:61], vcc\n"
-        "s_mov_b64 exec, s[74:75]\n"
-        "global_load_dwordx4 v[48:51], v36, %[tris] offset:16\n"
-        "global_load_dword v52, v36, %[tris] offset:32\n"
-        "global_load_dwordx4 v[44:47], v36, %[tris]\n"
+        "v_and_b32_e32 v52, 0x7ffffff, v12\n"              /* the leaf's first triangle */
+        "v_lshlrev_b32_e32 v53, 4, v52\n"
+        "v_lshl_add_u32 v53, v52, 5, v53\n"                /* * 48 */
+        "global_load_dwordx4 v[28:31], v53, %[tris] offset:16\n"
+        "global_load_dword v32, v53, %[tris] offset:32\n"
+        "global_load_dwordx4 v[24:27], v53, %[tris]\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v33, v12, v16\n"
+        "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
+        "global_load_dwordx4 v[36:39], v12, %[nodes] offset:48\n"
+        "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
+        "global_load_dwordx4 v[40:43], v12, %[nodes] offset:64\n"
+        "global_load_dwordx4 v[32:35], v12, %[nodes] offset:32\n"
+        "global_load_dwordx4 v[44:47], v12, %[nodes] offset:80\n"
+        "global_load_dwordx4 v[48:51], v12, %[nodes] offset:96\n"
         "s_mov_b64 s[78:79], 0\n"
-        "global_load_dwordx4 v[24:27], v33, %[nodes]\n"
-        "global_load_dwordx4 v[28:31], v33, %[nodes] offset:16\n"
-        "s_waitcnt vmcnt(0)\n"
         "s_cbranch_execz TW_LEAF_%=\n"
-        /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
-        "v_sub_f32_e32 v33, v24, v0\n"
-        "v_sub_f32_e32 v34, v27, v0\n"
-        "v_sub_f32_e32 v35, v25, v1\n"
-        "v_sub_f32_e32 v37, v26, v2\n"
-        "v_sub_f32_e32 v36, v28, v1\n"
-        "v_sub_f32_e32 v38, v29, v2\n"
-        "v_mul_f32_e32 v33, v8, v33\n"
-        "v_mul_f32_e32 v34, v8, v34\n"
-        "v_mul_f32_e32 v35, v9, v35\n"
-        "v_mul_f32_e32 v36, v9, v36\n"
-        "v_mul_f32_e32 v37, v10, v37\n"
-        "v_mul_f32_e32 v38, v10, v38\n"
-        "v_min_f32_e32 v39, v33, v34\n"
-        "v_min_f32_e32 v40, v35, v36\n"
-        "v_min_f32_e32 v41, v37, v38\n"
-        "v_max_f32_e32 v33, v33, v34\n"
-        "v_max_f32_e32 v35, v35, v36\n"
-        "v_max_f32_e32 v37, v37, v38\n"
-        "v_min3_f32 v33, v33, v35, v37\n"                  /* tf */
-        "v_max3_f32 v39, v39, v40, v41\n"                  /* tn */
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v33\n"
-        "v_min_f32_e32 v33, v33, v19\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v33, v39\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v31\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"              /* hit: box && the child exists */
-        /* order key: sortable integer of tn (NaN -> -inf), slot in the two lowest bits; not hit: the largest key */
-        "v_cmp_u_f32_e32 vcc, v39, v39\n"
-        "v_mov_b32_e32 v40, 0xff800000\n"
-        "v_cndmask_b32_e32 v39, v39, v40, vcc\n"
-        "v_ashrrev_i32_e32 v40, 31, v39\n"
-        "v_or_b32_e32 v40, 0x80000000, v40\n"
-        "v_xor_b32_e32 v39, v40, v39\n"
-        "v_and_or_b32 v39, v39, -4, v18\n"
-        "v_cndmask_b32_e64 v39, -1, v39, s[66:67]\n"
-        /* the group's hit count */
-        "v_lshrrev_b64 v[40:41], v17, s[66:67]\n"
-        "v_and_b32_e32 v40, 15, v40\n"
-        "v_bcnt_u32_b32 v41, v40, 0\n"                     /* nhit */
-        /* rank = how many of the four keys are smaller */
-        "v_mov_b32_e32 v42, 0\n"
-        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 0 < this key */
-        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
-        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 1 < this key */
-        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
-        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 2 < this key */
-        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"
-        "v_sub_co_u32_dpp v33, vcc, v39, v39 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   /* borrow: key of lane 3 < this key */
-        "v_addc_co_u32_e32 v42, vcc, 0, v42, vcc\n"        /* rank */
-        /* this child as an entry */
-        "v_add_u32_e32 v33, -1, v31\n"
-        "v_lshlrev_b32_e32 v33, 27, v33\n"
-        "v_or_b32_e32 v33, 0x80000000, v33\n"
-        "v_or_b32_e32 v33, v33, v30\n"
-        "v_cmp_gt_i32_e32 vcc, 0, v31\n"
-        "v_cndmask_b32_e32 v33, v33, v30, vcc\n"           /* entry */
-        /* the nearest hit child (rank 0) becomes the current entry of all four lanes: OR over the group of (rank == 0 ? entry : 0) */
-        "v_cmp_eq_u32_e32 vcc, 0, v42\n"
-        "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e32 v34, 0, v33, vcc\n"
-        "s_nop 1\n"
-        "v_or_b32_dpp v34, v34, v34 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "s_nop 1\n"
-        "v_or_b32_dpp v34, v34, v34 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        /* the others go to the stack: position sp + nhit - 1 - rank (rank 1 on top) */
-        "v_cmp_lt_u32_e32 vcc, 0, v42\n"
-        "s_and_b64 s[68:69], vcc, s[66:67]\n"              /* hit and not the nearest */
-        "v_add_u32_e32 v35, v13, v41\n"
-        "v_sub_u32_e32 v35, v35, v42\n"
-        "v_add_u32_e32 v35, -1, v35\n"                     /* at = sp + nhit - 1 - rank: rank 1 ends on top at sp + nhit - 2, the rank-0 slot stays free */
-        "v_cmp_gt_i32_e32 vcc, %[depth], v35\n"
-        "s_and_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v36, v35, 2, v14\n"
-        "ds_write_b32 v36, v33\n"
-        "s_andn2_b64 exec, s[68:69], vcc\n"
-        "s_cbranch_execz TW_PUSHED_%=\n"
-        "v_lshl_add_u32 v36, v35, 2, v53\n"
-        "global_store_dword v36, v33, %[spill] sc0 sc1\n"
         "s_waitcnt vmcnt(0)\n"
+        /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
+        "v_sub_f32_e32 v56, v24, v0\n"
+        "v_sub_f32_e32 v57, v36, v0\n"
+        "v_sub_f32_e32 v58, v28, v1\n"
+        "v_sub_f32_e32 v60, v32, v2\n"
+        "v_sub_f32_e32 v59, v40, v1\n"
+        "v_sub_f32_e32 v61, v44, v2\n"
+        "v_mul_f32_e32 v56, v8, v56\n"
+        "v_mul_f32_e32 v57, v8, v57\n"
+        "v_mul_f32_e32 v58, v9, v58\n"
+        "v_mul_f32_e32 v59, v9, v59\n"
+        "v_mul_f32_e32 v60, v10, v60\n"
+        "v_mul_f32_e32 v61, v10, v61\n"
+        "v_min_f32_e32 v62, v56, v57\n"
+        "v_min_f32_e32 v63, v58, v59\n"
+        "v_min_f32_e32 v64, v60, v61\n"
+        "v_max_f32_e32 v56, v56, v57\n"
+        "v_max_f32_e32 v58, v58, v59\n"
+        "v_max_f32_e32 v60, v60, v61\n"
+        "v_min3_f32 v56, v56, v58, v60\n"
+        "v_max3_f32 v62, v62, v63, v64\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
+        "v_min_f32_e32 v56, v56, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
+        "v_max_f32_e32 v62, 0, v62\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v48\n"
+        "v_and_or_b32 v62, v62, -4, 0\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v52, -1, v62, s[66:67]\n"
+        "v_sub_f32_e32 v56, v25, v0\n"
+        "v_sub_f32_e32 v57, v37, v0\n"
+        "v_sub_f32_e32 v58, v29, v1\n"
+        "v_sub_f32_e32 v60, v33, v2\n"
+        "v_sub_f32_e32 v59, v41, v1\n"
+        "v_sub_f32_e32 v61, v45, v2\n"
+        "v_mul_f32_e32 v56, v8, v56\n"
+        "v_mul_f32_e32 v57, v8, v57\n"
+        "v_mul_f32_e32 v58, v9, v58\n"
+        "v_mul_f32_e32 v59, v9, v59\n"
+        "v_mul_f32_e32 v60, v10, v60\n"
+        "v_mul_f32_e32 v61, v10, v61\n"
+        "v_min_f32_e32 v62, v56, v57\n"
+        "v_min_f32_e32 v63, v58, v59\n"
+        "v_min_f32_e32 v64, v60, v61\n"
+        "v_max_f32_e32 v56, v56, v57\n"
+        "v_max_f32_e32 v58, v58, v59\n"
+        "v_max_f32_e32 v60, v60, v61\n"
+        "v_min3_f32 v56, v56, v58, v60\n"
+        "v_max3_f32 v62, v62, v63, v64\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
+        "v_min_f32_e32 v56, v56, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
+        "v_max_f32_e32 v62, 0, v62\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v49\n"
+        "v_and_or_b32 v62, v62, -4, 1\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v53, -1, v62, s[66:67]\n"
+        "v_sub_f32_e32 v56, v26, v0\n"
+        "v_sub_f32_e32 v57, v38, v0\n"
+        "v_sub_f32_e32 v58, v30, v1\n"
+        "v_sub_f32_e32 v60, v34, v2\n"
+        "v_sub_f32_e32 v59, v42, v1\n"
+        "v_sub_f32_e32 v61, v46, v2\n"
+        "v_mul_f32_e32 v56, v8, v56\n"
+        "v_mul_f32_e32 v57, v8, v57\n"
+        "v_mul_f32_e32 v58, v9, v58\n"
+        "v_mul_f32_e32 v59, v9, v59\n"
+        "v_mul_f32_e32 v60, v10, v60\n"
+        "v_mul_f32_e32 v61, v10, v61\n"
+        "v_min_f32_e32 v62, v56, v57\n"
+        "v_min_f32_e32 v63, v58, v59\n"
+        "v_min_f32_e32 v64, v60, v61\n"
+        "v_max_f32_e32 v56, v56, v57\n"
+        "v_max_f32_e32 v58, v58, v59\n"
+        "v_max_f32_e32 v60, v60, v61\n"
+        "v_min3_f32 v56, v56, v58, v60\n"
+        "v_max3_f32 v62, v62, v63, v64\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
+        "v_min_f32_e32 v56, v56, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
+        "v_max_f32_e32 v62, 0, v62\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v50\n"
+        "v_and_or_b32 v62, v62, -4, 2\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v54, -1, v62, s[66:67]\n"
+        "v_sub_f32_e32 v56, v27, v0\n"
+        "v_sub_f32_e32 v57, v39, v0\n"
+        "v_sub_f32_e32 v58, v31, v1\n"
+        "v_sub_f32_e32 v60, v35, v2\n"
+        "v_sub_f32_e32 v59, v43, v1\n"
+        "v_sub_f32_e32 v61, v47, v2\n"
+        "v_mul_f32_e32 v56, v8, v56\n"
+        "v_mul_f32_e32 v57, v8, v57\n"
+        "v_mul_f32_e32 v58, v9, v58\n"
+        "v_mul_f32_e32 v59, v9, v59\n"
+        "v_mul_f32_e32 v60, v10, v60\n"
+        "v_mul_f32_e32 v61, v10, v61\n"
+        "v_min_f32_e32 v62, v56, v57\n"
+        "v_min_f32_e32 v63, v58, v59\n"
+        "v_min_f32_e32 v64, v60, v61\n"
+        "v_max_f32_e32 v56, v56, v57\n"
+        "v_max_f32_e32 v58, v58, v59\n"
+        "v_max_f32_e32 v60, v60, v61\n"
+        "v_min3_f32 v56, v56, v58, v60\n"
+        "v_max3_f32 v62, v62, v63, v64\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
+        "v_min_f32_e32 v56, v56, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
+        "v_max_f32_e32 v62, 0, v62\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v51\n"
+        "v_and_or_b32 v62, v62, -4, 3\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v55, -1, v62, s[66:67]\n"
+        /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange */
+        "v_cmp_lt_u32_e32 vcc, v53, v52\n"
+        "v_min_u32_e32 v56, v52, v53\n"
+        "v_max_u32_e32 v53, v52, v53\n"
+        "v_cndmask_b32_e32 v57, v48, v49, vcc\n"
+        "v_cndmask_b32_e32 v49, v49, v48, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v55, v54\n"
+        "v_min_u32_e32 v52, v54, v55\n"
+        "v_max_u32_e32 v55, v54, v55\n"
+        "v_cndmask_b32_e32 v48, v50, v51, vcc\n"
+        "v_cndmask_b32_e32 v51, v51, v50, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v52, v56\n"
+        "v_min_u32_e32 v54, v56, v52\n"
+        "v_max_u32_e32 v52, v56, v52\n"
+        "v_cndmask_b32_e32 v50, v57, v48, vcc\n"
+        "v_cndmask_b32_e32 v48, v48, v57, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v55, v53\n"
+        "v_min_u32_e32 v56, v53, v55\n"
+        "v_max_u32_e32 v55, v53, v55\n"
+        "v_cndmask_b32_e32 v57, v49, v51, vcc\n"
+        "v_cndmask_b32_e32 v51, v51, v49, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v52, v56\n"
+        "v_min_u32_e32 v53, v56, v52\n"
+        "v_max_u32_e32 v52, v56, v52\n"
+        "v_cndmask_b32_e32 v49, v57, v48, vcc\n"
+        "v_cndmask_b32_e32 v48, v48, v57, vcc\n"
+        /* sorted: keys v54 <= v53 <= v52 <= v55, entries v50, v49, v48, v51 (a child that is not hit: key -1, sorts last) */
+        "v_cmp_ne_u32_e64 s[66:67], -1, v53\n"
+        "v_cmp_ne_u32_e64 s[68:69], -1, v52\n"
+        "v_cmp_ne_u32_e64 s[72:73], -1, v55\n"
+        "v_cmp_ne_u32_e64 s[80:81], -1, v54\n"             /* the node has a hit child */
+        "s_nop 0\n"
+        "v_addc_co_u32_e64 v56, s[74:75], v13, 0, s[66:67]\n"
+        "v_addc_co_u32_e64 v56, s[74:75], v56, 0, s[68:69]\n"
+        "v_addc_co_u32_e64 v56, s[74:75], v56, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
+        /* the others are pushed farthest first: sorted child j ends at level size' - j */
+        "v_cmp_lt_u32_e64 s[74:75], %[depth], v56\n"
+        "v_lshl_add_u32 v57, v56, 8, v18\n"                /* address of level size' - 3 */
+        "s_cmp_lg_u64 s[74:75], 0\n"
+        "s_cbranch_scc1 TW_PUSH_SLOW_%=\n"
+        "s_mov_b64 exec, s[72:73]\n"
+        "ds_write_b32 v57, v51\n"
+        "s_mov_b64 exec, s[68:69]\n"
+        "ds_write_b32 v57, v48 offset:256\n"
+        "s_mov_b64 exec, s[66:67]\n"
+        "ds_write_b32 v57, v49 offset:512\n"
         "TW_PUSHED_%=:\n"
         "s_mov_b64 exec, s[62:63]\n"
-        /* nhit > 0: sp += nhit - 1, current = nearest;  nhit == 0: pop */
-        "v_cmp_lt_u32_e32 vcc, 0, v41\n"
-        "v_add_u32_e32 v35, -1, v41\n"
-        "v_cndmask_b32_e32 v35, 0, v35, vcc\n"
-        "v_add_u32_e32 v13, v13, v35\n"
-        "v_cndmask_b32_e32 v12, v12, v34, vcc\n"
-        "s_andn2_b64 s[78:79], s[62:63], vcc\n"            /* the groups without a hit child pop */
-        /* ---------------------------------------------------------------- leaf: up to four triangles (exec = s[74:75]) */
+        "v_cndmask_b32_e64 v13, v13, v56, s[80:81]\n"
+        "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
+        "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
+        /* ---------------------------------------------------------------- leaf: one triangle (exec = s[60:61]) */
         "TW_LEAF_%=:\n"
-        "s_mov_b64 exec, s[74:75]\n"
-        "s_cbranch_execz TW_LEAF_END_%=\n"
-        "v_mul_f32_e32 v33, v5, v52\n"
-        "v_mul_f32_e32 v42, v6, v51\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        "s_cbranch_execz TW_POP_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_mul_f32_e32 v33, v5, v32\n"
+        "v_mul_f32_e32 v42, v6, v31\n"
         "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v6, v50\n"
-        "v_mul_f32_e32 v42, v4, v52\n"
+        "v_mul_f32_e32 v34, v6, v30\n"
+        "v_mul_f32_e32 v42, v4, v32\n"
         "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v4, v51\n"
-        "v_mul_f32_e32 v42, v5, v50\n"
+        "v_mul_f32_e32 v35, v4, v31\n"
+        "v_mul_f32_e32 v42, v5, v30\n"
         "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v36, v33, v47\n"
-        "v_mul_f32_e32 v42, v34, v48\n"
+        "v_mul_f32_e32 v36, v33, v27\n"
+        "v_mul_f32_e32 v42, v34, v28\n"
         "v_add_f32_e32 v36, v36, v42\n"
-        "v_mul_f32_e32 v42, v35, v49\n"
+        "v_mul_f32_e32 v42, v35, v29\n"
         "v_add_f32_e32 v36, v36, v42\n"
         "v_rcp_f32_e32 v38, v36\n"
-        "v_sub_f32_e32 v44, v0, v44\n"
-        "v_sub_f32_e32 v45, v1, v45\n"
-        "v_sub_f32_e32 v46, v2, v46\n"
+        "v_sub_f32_e32 v24, v0, v24\n"
+        "v_sub_f32_e32 v25, v1, v25\n"
+        "v_sub_f32_e32 v26, v2, v26\n"
         "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
         "v_fma_f32 v41, -v36, v38, 1.0\n"
         "v_fma_f32 v37, v41, v38, v38\n"
         "s_cmp_lg_u64 s[66:67], 0\n"
         "s_cbranch_scc1 TW_DIV_IEEE_%=\n"
         "TW_DIV_DONE_%=:\n"
-        "v_mul_f32_e32 v43, v44, v33\n"
-        "v_mul_f32_e32 v42, v45, v34\n"
+        "v_mul_f32_e32 v43, v24, v33\n"
+        "v_mul_f32_e32 v42, v25, v34\n"
         "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v42, v46, v35\n"
+        "v_mul_f32_e32 v42, v26, v35\n"
         "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v33, v45, v49\n"
-        "v_mul_f32_e32 v42, v46, v48\n"
+        "v_mul_f32_e32 v33, v25, v29\n"
+        "v_mul_f32_e32 v42, v26, v28\n"
         "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v46, v47\n"
-        "v_mul_f32_e32 v42, v44, v49\n"
+        "v_mul_f32_e32 v34, v26, v27\n"
+        "v_mul_f32_e32 v42, v24, v29\n"
         "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v44, v48\n"
-        "v_mul_f32_e32 v42, v45, v47\n"
+        "v_mul_f32_e32 v35, v24, v28\n"
+        "v_mul_f32_e32 v42, v25, v27\n"
         "v_sub_f32_e32 v35, v35, v42\n"
         "v_mul_f32_e32 v43, v43, v37\n"                    /* b1 */
         "v_mul_f32_e32 v38, v4, v33\n"
@@ -1451,12 +1467,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_mul_f32_e32 v42, v6, v35\n"
         "v_add_f32_e32 v38, v38, v42\n"
         "v_mul_f32_e32 v38, v38, v37\n"                    /* b2 */
-        "v_mul_f32_e32 v39, v50, v33\n"
-        "v_mul_f32_e32 v42, v51, v34\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v42, v52, v35\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v39, v39, v37\n"                    /* tt */
         "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
         "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
@@ -1467,67 +1477,107 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TW_TRI_END_%=\n"
+        "v_mul_f32_e32 v39, v30, v33\n"
+        "v_mul_f32_e32 v42, v31, v34\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v42, v32, v35\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v39, v39, v37\n"                    /* tt */
         "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v39, v14\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, v39, v19\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 s[66:67], s[66:67], exec\n"             /* accepted */
-        /* this lane's best hit: nearer, or exactly as near with a larger triangle index */
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TW_TRI_END_%=\n"
+        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
+           distance that is not NaN and nearer than the interval's end becomes the interval's end */
         "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
         "v_cmp_lt_f32_e32 vcc, v39, v21\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_eq_f32_e32 vcc, v39, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v32, v20\n"
+        "v_cmp_gt_i32_e64 s[72:73], v52, v20\n"
         "s_and_b64 vcc, vcc, s[72:73]\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "s_and_b64 exec, s[68:69], s[66:67]\n"
-        "v_mov_b32_e32 v20, v32\n"
+        "v_cmp_lt_f32_e32 vcc, v39, v14\n"
+        "s_mov_b64 s[72:73], exec\n"
+        "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
+        "v_and_b32_e32 v42, 0x100, v11\n"
+        "s_and_b64 exec, exec, s[68:69]\n"
+        "v_mov_b32_e32 v20, v52\n"
         "v_mov_b32_e32 v21, v39\n"
         "v_mov_b32_e32 v22, v43\n"
         "v_mov_b32_e32 v23, v38\n"
-        "TW_LEAF_END_%=:\n"
+        "s_mov_b64 exec, s[72:73]\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v42\n"                   /* IntersectP: the first accepted triangle ends the ray */
+        "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
+        "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
+        "TW_TRI_END_%=:\n"
         "s_mov_b64 exec, s[60:61]\n"
-        "s_cbranch_execz TW_POP_%=\n"
-        /* the nearest accepted distance of the group ends the interval (NaN distances do not) */
-        "s_and_b64 s[66:67], s[66:67], s[74:75]\n"         /* (no triangle lanes at all: nothing was accepted) */
-        "v_mov_b32_e32 v40, 0x7f800000\n"
-        "v_cmp_o_f32_e32 vcc, v39, v39\n"
-        "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e32 v40, v40, v39, vcc\n"
-        "s_nop 1\n"
-        "v_mov_b32_dpp v41, v40 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_cmp_lt_f32_e32 vcc, v41, v40\n"
-        "v_cndmask_b32_e32 v40, v40, v41, vcc\n"
-        "s_nop 1\n"
-        "v_mov_b32_dpp v41, v40 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-        "v_cmp_lt_f32_e32 vcc, v41, v40\n"
-        "v_cndmask_b32_e32 v40, v40, v41, vcc\n"
-        "v_cmp_lt_f32_e32 vcc, v40, v19\n"
-        "v_cndmask_b32_e32 v19, v19, v40, vcc\n"
-        /* any-hit rays end at the first accepted triangle; a longer leaf goes on with its next four; else pop */
-        "v_lshrrev_b64 v[40:41], v17, s[66:67]\n"
-        "v_and_b32_e32 v40, 15, v40\n"
-        "v_and_b32_e32 v41, 0x100, v11\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v40\n"
-        "v_cmp_ne_u32_e64 s[68:69], 0, v41\n"
-        "s_and_b64 s[68:69], s[68:69], vcc\n"              /* the ray is over */
+        /* a ray that goes on: the leaf's next triangle if it has one, else pop */
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
         "v_bfe_u32 v42, v12, 27, 4\n"
-        "v_cmp_lt_u32_e32 vcc, 3, v42\n"                   /* more than four triangles were left */
-        "v_add_u32_e32 v41, 0xe0000004, v12\n"             /* first += 4, count -= 4 */
-        "s_andn2_b64 s[72:73], s[60:61], s[68:69]\n"
-        "s_andn2_b64 s[66:67], s[72:73], vcc\n"            /* pop */
-        "v_cndmask_b32_e32 v12, v12, v41, vcc\n"
-        "s_or_b64 s[78:79], s[78:79], s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v12, -1, s[68:69]\n"
-        "v_cndmask_b32_e64 v13, v13, 0, s[68:69]\n"
-        /* ---------------------------------------------------------------- pop */
+        "v_add_u32_e32 v41, 0xf8000001, v12\n"             /* first + 1, one triangle fewer */
+        "v_cmp_lt_u32_e64 s[66:67], 0, v42\n"
+        "s_nop 0\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v12, v41, s[66:67]\n"
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
+        /* ---------------------------------------------------------------- pop (s[78:79]) */
         "TW_POP_%=:\n"
         "s_mov_b64 exec, s[78:79]\n"
         "s_cbranch_execz TW_POP_NONE_%=\n"
-        PT_WIDE_POP
+        "v_cmp_lt_i32_e32 vcc, 0, v13\n"
+        "v_mov_b32_e32 v12, -1\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "s_cbranch_execz TW_POP_NONE_%=\n"
+        "v_add_u32_e32 v13, -1, v13\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
+        "s_mov_b64 s[72:73], exec\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "v_lshl_add_u32 v56, v13, 8, v18\n"
+        "ds_read_b32 v12, v56 offset:768\n"
+        "s_andn2_b64 exec, s[72:73], vcc\n"
+        "s_cbranch_execz TW_POP_LDS_%=\n"
+        "v_lshl_add_u32 v56, v13, 8, v16\n"
+        "global_load_dword v12, v56, %[spill] sc0 sc1\n"
+        "s_waitcnt vmcnt(0)\n"
+        "TW_POP_LDS_%=:\n"
+        "s_waitcnt lgkmcnt(0)\n"
         "TW_POP_NONE_%=:\n"
         "s_mov_b64 exec, -1\n"
         "s_branch TW_LOOP_%=\n"
+        /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
+        "TW_PUSH_SLOW_%=:\n"
+        "v_add_u32_e32 v57, -3, v56\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
+        "s_and_b64 exec, s[72:73], vcc\n"
+        "v_lshl_add_u32 v58, v57, 8, v18\n"
+        "ds_write_b32 v58, v51 offset:768\n"
+        "s_andn2_b64 exec, s[72:73], vcc\n"
+        "v_lshl_add_u32 v58, v57, 8, v16\n"
+        "global_store_dword v58, v51, %[spill] sc0 sc1\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_add_u32_e32 v57, -2, v56\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
+        "s_and_b64 exec, s[68:69], vcc\n"
+        "v_lshl_add_u32 v58, v57, 8, v18\n"
+        "ds_write_b32 v58, v48 offset:768\n"
+        "s_andn2_b64 exec, s[68:69], vcc\n"
+        "v_lshl_add_u32 v58, v57, 8, v16\n"
+        "global_store_dword v58, v48, %[spill] sc0 sc1\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_add_u32_e32 v57, -1, v56\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
+        "s_and_b64 exec, s[66:67], vcc\n"
+        "v_lshl_add_u32 v58, v57, 8, v18\n"
+        "ds_write_b32 v58, v49 offset:768\n"
+        "s_andn2_b64 exec, s[66:67], vcc\n"
+        "v_lshl_add_u32 v58, v57, 8, v16\n"
+        "global_store_dword v58, v49, %[spill] sc0 sc1\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_branch TW_PUSHED_%=\n"
         /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
         "TW_DIV_IEEE_%=:\n"
         "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
@@ -1546,41 +1596,31 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---------------------------------------------------------------- finished rays (s[68:69]) */
         "TW_FIN_%=:\n"
         "s_mov_b64 exec, s[68:69]\n"
-        PT_WIDE_MERGE_BEST
         /* a miss reports the end of the interval, like the other loops */
         "v_cmp_gt_i32_e32 vcc, 0, v20\n"
-        "v_cndmask_b32_e32 v21, v21, v19, vcc\n"
-        /* lane 0 of the group writes the result into the second half of the ray's slot and tells the owner */
-        "v_cmp_eq_u32_e32 vcc, 0, v18\n"
-        "s_and_b64 exec, s[68:69], vcc\n"
+        "v_cndmask_b32_e32 v21, v21, v14, vcc\n"
         "ds_write_b128 v15, v[20:23] offset:16\n"
         PT_FINISH_PENDING
-        "s_mov_b64 exec, s[68:69]\n"
         "v_mov_b32_e32 v15, -1\n"
         "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"
         "s_mov_b64 exec, -1\n"
-        /* ---------------------------------------------------------------- refill: idle groups take the next rays */
+        /* ---------------------------------------------------------------- refill: idle lanes take the next rays */
         "TW_FILL_%=:\n"
         "s_cmp_ge_i32 s70, %[rays]\n"
         "s_cbranch_scc1 TW_EMPTY_%=\n"
-        "s_and_b64 s[66:67], s[64:65], s[80:81]\n"
-        "s_bcnt1_i32_b64 s71, s[66:67]\n"                  /* busy groups */
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
         "s_cmp_gt_u32 s71, %[maxbusy]\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
-        "s_andn2_b64 s[66:67], s[80:81], s[64:65]\n"   /* first lanes of the idle groups */
+        "s_not_b64 s[66:67], s[64:65]\n"
         "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
         "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
-        "v_sub_u32_e32 v33, v33, v54\n"                    /* the group's rank among the idle ones */
         "v_add_u32_e32 v33, s70, v33\n"
         "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
-        "s_andn2_b64 s[66:67], vcc, s[64:65]\n"
-        "s_sub_i32 s71, 16, s71\n"
+        "s_and_b64 s[66:67], vcc, s[66:67]\n"
+        "s_sub_i32 s71, 64, s71\n"
         "s_add_i32 s70, s70, s71\n"
         "s_mov_b64 exec, s[66:67]\n"
-        "v_lshl_add_u32 v34, v33, 1, %[order]\n"
-        "ds_read_u16 v34, v34\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_lshl_add_u32 v15, v34, 5, %[pool]\n"
+        PT_FETCH_ORDERED
         "ds_read_b128 v[4:7], v15\n"
         "ds_read_b128 v[8:11], v15 offset:16\n"
         "v_mov_b32_e32 v12, 0\n"
@@ -1593,44 +1633,40 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_and_b32_e32 v33, 0xff, v11\n"
         "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
         "ds_read_b96 v[0:2], v33 offset:%[org]\n"
-        "v_mov_b32_e32 v19, v7\n"
+        "v_mov_b32_e32 v14, v7\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
         "s_branch TW_LOOP_%=\n"
-        /* a dry pool: drain to the end, unless this round had new rays and only a few groups are still busy - then the drain
-           ends, the busy groups park their rays and the owners of those rays sit out the shading round */
+        /* a dry pool: drain to the end, unless this round had new rays and only a few rays are still in flight - then the
+           drain ends, the lanes park their rays and the owners of those rays sit out the shading round */
         "TW_EMPTY_%=:\n"
         "s_cmp_eq_u64 s[64:65], 0\n"
         "s_cbranch_scc1 TW_DONE_%=\n"
         "s_cmp_eq_u32 %[allow], 0\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
-        "s_and_b64 s[66:67], s[64:65], s[80:81]\n"
-        "s_bcnt1_i32_b64 s71, s[66:67]\n"
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
         "s_cmp_gt_u32 s71, %[tstop]\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
         "TW_DONE_%=:\n"
-        PT_WIDE_MERGE_BEST
-        "v_cmp_eq_u32_e32 vcc, 0, v18\n"
-        "s_mov_b64 exec, vcc\n"
-        "v_mov_b32_e32 v40, v12\n"
-        "v_mov_b32_e32 v41, v13\n"
-        "v_mov_b32_e32 v42, v19\n"
-        "v_mov_b32_e32 v43, v15\n"
-        "ds_write_b128 v55, v[40:43]\n"
-        "ds_write_b128 v55, v[20:23] offset:16\n"
+        "ds_write_b128 v17, v[12:15]\n"
+        "ds_write_b128 v17, v[20:23] offset:16\n"
         "s_waitcnt lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
+#if PT_WIDE_PROBE
+        : [pr_trips] "+v"(pr.trips), [pr_nlanes] "+v"(pr.nlanes), [pr_tlanes] "+v"(pr.tlanes), [pr_nblk] "+v"(pr.nblk), [pr_tblk] "+v"(pr.tblk), [pr_busy] "+v"(pr.busy)
+#else
         :
+#endif
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [tris] "s"(s_tris), [spill] "s"(s_spill),
           [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [susp] "s"(s_susp), [allow] "s"(s_allow), [vspill] "v"(v_spill),
-          [tstop] "n"(PT_WIDE_STOP_GROUPS),
-          [depth] "n"(kWideStackDepth), [depth4] "n"(kWideStackDepth * 4), [maxbusy] "n"(16 - PT_WIDE_FETCH_GROUPS), [org] "n"(2 * kPoolSlots * 16),
+          [tstop] "n"(PT_WIDE_STOP_T), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
-          "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+          "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
-          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+          "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -2441,9 +2477,9 @@ constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 #endif
 constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH;
 #ifndef PT_WIDE_WAVES
-#define PT_WIDE_WAVES 4
+#define PT_WIDE_WAVES 3                 // 168 registers and 52 KB of LDS per workgroup: the per-lane stacks and the 67-register loop fit without scratch
 #endif
-// WIDE: scenes in global memory walked with four lanes per ray on the 4-wide tree (GPT_TRAVERSAL_WIDE4, trace_pool_wide<>)
+// WIDE: scenes in global memory walked on the 4-wide tree, one lane per ray (GPT_TRAVERSAL_WIDE4, trace_pool_wide<>)
 template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
 __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES)) pt_render_kernel(const DevParams P_in)
 {
@@ -2484,7 +2520,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         P.materials = reinterpret_cast<const gpt_material *>(lds_scene + o_mat);
     }
     constexpr bool CARRY = !SMALL;                      // scenes in global memory: fixed slots, drains may stop early
-    constexpr int kWaveFloat4 = CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4;
+    constexpr int kWaveFloat4 = WIDE ? kWaveWideFloat4 : (CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4);
     __shared__ float4 lds_pool[4 * kWaveFloat4];        // one private ray pool per wavefront
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
     const unsigned lane = threadIdx.x & 63u;
@@ -2493,12 +2529,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
-    if (WIDE) {                                         // trace_pool_wide_asm: 16 group records {entry, stack size, interval end, slot} {best hit}: idle
-        wave_lds_fence();
-        if (lane < 16u) {
-            pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
-            pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-        }
+    if (WIDE) {                                         // trace_pool_wide_asm: a lane's record is {entry, stack size, interval end, slot} {best hit}: idle
+        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
+        pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
     bool waiting = false;                               // carry: some of this path's rays are still being traced
     // Volpath: the medium the path ray travels in (-1 = none), the one the pending direct-light rays travel in, and
@@ -2507,6 +2540,8 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     bool poison_occluded = false;
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    WideProbe wprobe = {0, 0, 0, 0, 0, 0};
+    (void)wprobe;
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
     unsigned long long cyc_direct = 0, cyc_hit = 0, cyc_regen = 0, cyc_sub = 0;                                // ... split of cyc_shade
 #define PT_SUBPHASE(acc)                                                                     \
@@ -3489,10 +3524,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
             } else if (WIDE) {
-                if (COUNT)                          // the counting build runs the C++ twin (it has the counters)
+                if (COUNT || !PT_WIDE_ASM)          // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
                 else
-                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0);
+                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0, wprobe);
             } else {
                 GlobalScene mem;
                 mem.nodes = reinterpret_cast<const char *>(P.nodes);
@@ -3537,6 +3572,16 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         }
     }
 
+#if PT_WIDE_PROBE
+    if (WIDE && !COUNT && lane == 0) {      // probe builds: what the hand-scheduled wide loop counted (per wave)
+        atomicAdd(&P.counters[0], (unsigned long long)wprobe.nlanes);
+        atomicAdd(&P.counters[1], (unsigned long long)wprobe.tlanes);
+        atomicAdd(&P.counters[6], (unsigned long long)wprobe.nblk);
+        atomicAdd(&P.counters[7], (unsigned long long)wprobe.tblk);
+        atomicAdd(&P.counters[8], (unsigned long long)wprobe.trips);
+        atomicAdd(&P.counters[9], (unsigned long long)wprobe.busy);
+    }
+#endif
     if (COUNT) {
         atomicAdd(&P.counters[0], (unsigned long long)cnt.node_visits);
         atomicAdd(&P.counters[1], (unsigned long long)cnt.prim_tests);
@@ -3627,7 +3672,7 @@ __global__ void __launch_bounds__(256) pt_tonemap_kernel(const float *acc, float
 // gpt_debug_trace.  Ray i = rays[2 i] {origin.xyz, tmax}, rays[2 i + 1] {direction.xyz, any_hit != 0}; out[i] = {primitive or -1,
 // t, b1, b2}.  One ray per lane per round.
 template <bool SMALL, bool WIDE>
-__global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_trace_rays_kernel(const DevParams P_in, const float4 *rays, int n, float4 *out)
+__global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_trace_rays_kernel(const DevParams P_in, const float4 *rays, int n, float4 *out)
 {
     __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
     DevParams P = P_in;
@@ -3652,7 +3697,7 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_trace_rays_kernel(const 
         __syncthreads();
     }
     constexpr bool CARRY = !SMALL;
-    constexpr int kWaveFloat4 = CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4;
+    constexpr int kWaveFloat4 = WIDE ? kWaveWideFloat4 : (CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4);
     __shared__ float4 lds_pool[4 * kWaveFloat4];
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
     const unsigned lane = threadIdx.x & 63u;
@@ -3662,14 +3707,13 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_trace_rays_kernel(const 
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
     if (WIDE) {
-        wave_lds_fence();
-        if (lane < 16u) {
-            pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
-            pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-        }
+        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
+        pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)cnt;
+    WideProbe wprobe = {0, 0, 0, 0, 0, 0};
+    (void)wprobe;
     const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = (int)gridDim.x * 4;
     for (int base = wave * 64; base < n; base += n_waves * 64) {      // wave-uniform
         const int i = base + (int)lane;
@@ -3707,7 +3751,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) pt_trace_rays_kernel(const 
             for (int round = 0;; ++round) {
                 const int fresh = round == 0 ? n_new : 0;
                 if (WIDE) {
-                    trace_pool_wide_asm(lds_address(pool), fresh, P, lane, fresh > 0);
+                    if (PT_WIDE_ASM) trace_pool_wide_asm(lds_address(pool), fresh, P, lane, fresh > 0, wprobe);
+                    else trace_pool_wide<false>(P, pool, fresh, cnt);
                 } else {
                     GlobalScene mem;
                     mem.nodes = reinterpret_cast<const char *>(P.nodes);
@@ -3841,7 +3886,10 @@ hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_
 hipError_t launch_trace_rays(const DevParams &P, bool lds_scene, const float4 *rays, int n, float4 *out, hipStream_t stream)
 {
     const bool small = lds_scene && render_scene_fits_lds(P);
-    const int n_blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    int n_blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+    // the wide walk's spill stacks are indexed by workgroup: never more workgroups than that buffer has slices
+    if (P.traversal == GPT_TRAVERSAL_WIDE4 && n_blocks > (int)P.wide_stack_blocks) n_blocks = (int)P.wide_stack_blocks;
+    if (n_blocks < 1) n_blocks = 1;
     if (P.traversal == GPT_TRAVERSAL_WIDE4) hipLaunchKernelGGL((pt_trace_rays_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
     else if (small) hipLaunchKernelGGL((pt_trace_rays_kernel<true, false>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
     else hipLaunchKernelGGL((pt_trace_rays_kernel<false, false>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);

@@ -48,17 +48,15 @@ struct alignas(16) DevTri {
 };
 static_assert(sizeof(DevTri) == 48, "DevTri");
 
-// One child of a wide node (include/gpt_wide_bvh.h), in the register layout of DevNode: two dwordx4.
-//   count < 0: another wide node, ref = its BYTE offset (index * 128);  count > 0: a leaf, ref = index of its first
-//   triangle, count triangles;  count = 0: empty
-struct alignas(16) DevWideChild {
-    float bmin[3];
-    float bmax[3];
-    int32_t ref;
-    int32_t count;
-};
+// A wide node (include/gpt_wide_bvh.h) as ONE lane reads it: the four children's boxes as a structure of arrays (six dwordx4),
+// then what the walk pushes for each child, ready made:
+//   another wide node: its BYTE offset (index * 128; bit 31 clear);  a leaf: bit 31 | (count - 1) << 27 | first triangle;
+//   empty: 0xffffffff (GPT_WIDE_NONE; never hit)
 struct alignas(16) DevWideNode {
-    DevWideChild c[4];
+    float lo_x[4], lo_y[4], lo_z[4];
+    float hi_x[4], hi_y[4], hi_z[4];
+    uint32_t entry[4];
+    uint32_t pad[4];
 };
 static_assert(sizeof(DevWideNode) == 128, "DevWideNode");
 
@@ -151,8 +149,9 @@ struct DevParams {
     const int32_t *prim_media;         // per primitive (BVH order): mediumInside, mediumOutside
     int32_t vpt_walk;                  // Volpath: density grids or material-less surfaces -> the one-ray-at-a-time kernel
     // GPT_TRAVERSAL_WIDE4 only (include/gpt_wide_bvh.h)
-    const struct DevWideNode *wide;    // the 4-wide tree; child k of node w at byte offset 128 * w + 32 * k
-    uint32_t *wide_stack;              // overflow of the per-ray LDS stacks: kWideSpill entries per ray group of every resident wave
+    const struct DevWideNode *wide;    // the 4-wide tree; node w at byte offset 128 * w
+    uint32_t *wide_stack;              // overflow of the per-ray LDS stacks: 64 * kWideSpillStride entries per wave of the widest grid
+    uint32_t wide_stack_blocks;        // workgroups that buffer was sized for (no wide kernel is launched with more)
 };
 
 }  // namespace pt

@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>           // types and prototypes only: the library is opened at run time (gpt_comm_init)
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -365,14 +366,17 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         const int32_t n_wide = gpt_wide_build(scene->nodes, scene->n_nodes, scene->prims, wide.data(), cap, &depth);
         if (n_wide > 0 && 3 * depth + 1 <= GPT_WIDE_STACK_MAX && (int64_t)n_wide * (int64_t)sizeof(DevWideNode) < INT32_MAX) {
             wide_dev.resize((size_t)n_wide);
-            for (int32_t w = 0; w < n_wide; ++w)
+            for (int32_t w = 0; w < n_wide; ++w) {
+                DevWideNode &d = wide_dev[(size_t)w];
+                std::memset(&d, 0, sizeof(d));
                 for (int k = 0; k < 4; ++k) {
                     const gpt_wide_child &c = wide[(size_t)w].c[k];
-                    DevWideChild &d = wide_dev[(size_t)w].c[k];
-                    for (int a = 0; a < 3; ++a) { d.bmin[a] = c.bmin[a]; d.bmax[a] = c.bmax[a]; }
-                    d.ref = c.count < 0 ? c.ref * (int32_t)sizeof(DevWideNode) : c.ref;
-                    d.count = c.count;
+                    d.lo_x[k] = c.bmin[0]; d.lo_y[k] = c.bmin[1]; d.lo_z[k] = c.bmin[2];
+                    d.hi_x[k] = c.bmax[0]; d.hi_y[k] = c.bmax[1]; d.hi_z[k] = c.bmax[2];
+                    d.entry[k] = c.count < 0 ? (uint32_t)c.ref * (uint32_t)sizeof(DevWideNode)
+                               : c.count > 0 ? gpt_wide_leaf_entry(c.ref, c.count) : GPT_WIDE_NONE;
                 }
+            }
             ctx->wide_ok = true;
             ctx->wide_depth = depth;
             ctx->n_wide = n_wide;
@@ -608,13 +612,18 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
             gpt_set_error("gpt_set_traversal_order: the scene has no wide tree (empty scene, or deeper than %d wide levels)", (GPT_WIDE_STACK_MAX - 1) / 3);
             return GPT_ERR_UNSUPPORTED;
         }
-        if (!ctx->P.wide_stack) {          // spill space of the per-ray stacks: one slice per ray group of every wave that can be resident
+        if (!ctx->P.wide_stack) {          // spill space of the per-ray stacks: one slice per wave that can be resident
+            int bpc = 1;
+            for (int w = 0; w < 2; ++w)
+                for (int c = 0; c < 2; ++c) bpc = std::max(bpc, ctx->blocks_per_cu_wide[w][c]);
+            const size_t blocks = (size_t)std::max(ctx->n_cus, 1) * (size_t)bpc;
             void *p = nullptr;
-            const size_t n = (size_t)ctx->n_cus * 8 * 4 * 16 * (GPT_WIDE_STACK_MAX + 8);
+            const size_t n = blocks * 4 * 64 * (GPT_WIDE_STACK_MAX + 8);
             HIP_TRY(hipSetDevice(ctx->device));
             HIP_TRY(hipMalloc(&p, n * sizeof(uint32_t)));
             ctx->allocs.push_back(p);
             ctx->P.wide_stack = static_cast<uint32_t *>(p);
+            ctx->P.wide_stack_blocks = (uint32_t)blocks;
         }
     }
     ctx->P.traversal = order;
@@ -634,7 +643,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     }
     HIP_TRY(hipSetDevice(ctx->device));
     const bool count = ctx->count_next;
-    if (count) HIP_TRY(hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->counters, 0, 16 * sizeof(unsigned long long), ctx->stream));     // (probe builds count without the counting kernels)
     const uint32_t n_tiles = ctx->P.n_tiles, rank = ctx->P.rank, n_ranks = ctx->P.n_ranks;
     const uint32_t n_owned = (n_tiles > rank) ? (n_tiles - rank + n_ranks - 1) / n_ranks : 0u;
     // reset clears the accumulator of EVERY pixel (Output, pathtracer.cu:2521).  With tile ownership the

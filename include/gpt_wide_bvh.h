@@ -2,7 +2,8 @@
  * gpt_wide_bvh.h - the 4-wide BVH of GPT_TRAVERSAL_WIDE4 ("stage B"): its structure, how it is
  * derived from the reference's binary tree, and the order in which a ray walks it.  Shared by the host side of libgpt and
  * by the CPU oracle, like gpt_traversal.h: this file is the SPECIFICATION both follow; the walk itself is written twice
- * (oracle/pt_oracle.c: one ray at a time; csrc/pt_kernel.hip: four lanes per ray).
+ * (oracle/pt_oracle.c: one ray at a time; csrc/pt_kernel.hip: one lane per ray, all four boxes of a node tested by that lane,
+ * the ray's stack in an LDS slice of its lane).
  *
  * Why: the reference's tree (binned SAH, <= 4 primitives per leaf, src/bvh.cpp:38-173) is walked one 40-byte node per
  * dependent memory access, left child first (src/pathtracer.cu:214-255).  On scenes that do not fit LDS that chain of
@@ -31,8 +32,8 @@
  *   stack <- {}, current <- wide node 0
  *   wide node:  test the four boxes against the ray's CURRENT interval; push the hit children so that they pop in order
  *               of increasing entry distance tn (gpt_wide_key: near-ties in slot order); pop
- *   leaf:       test its triangles four at a time, all four against the same interval; then tmax <- the smallest
- *               accepted distance; any more in the leaf: stay, else pop
+ *   leaf:       test its triangles in index order, each against the ray's CURRENT interval; an accepted distance that is
+ *               not NaN and nearer than the interval's end becomes the interval's end; then pop
  *   an accepted triangle replaces the best hit when it is nearer, or exactly as near with a larger primitive index.
  */
 #ifndef GPT_WIDE_BVH_H
@@ -190,16 +191,15 @@ static inline int32_t gpt_wide_build(const gpt_bvh_node *nodes, int32_t n_nodes,
 }
 
 /* The order key of hit child `slot` (0..3) with entry distance tn: children pop in order of increasing key.  The key is the
- * distance mapped to an unsigned integer that sorts like the float (NaN counts as -inf), with its two lowest bits replaced
- * by the slot: keys of one node are all different, and distances that agree up to their two last mantissa bits pop in slot
- * order. */
+ * bit pattern of max(tn, +0) - every distance that is not positive (the ray starts inside the box; -0; NaN) counts as +0, and
+ * positive floats sort like their bit patterns - with its two lowest bits replaced by the slot: keys of one node are all
+ * different, and distances that agree up to their two last mantissa bits pop in slot order.  (On the GPU: one v_max_f32
+ * against +0, which returns +0 for a NaN and for -0, and one v_and_or_b32.) */
 static inline uint32_t gpt_wide_key(float tn, int slot)
 {
-    uint32_t u;
-    if (!(tn == tn)) tn = -__builtin_inff();
-    __builtin_memcpy(&u, &tn, 4);
-    const uint32_t m = u ^ (((uint32_t)((int32_t)u >> 31)) | 0x80000000u);
-    return (m & ~3u) | (uint32_t)slot;
+    uint32_t u = 0;
+    if (tn > 0.0f) __builtin_memcpy(&u, &tn, 4);
+    return (u & ~3u) | (uint32_t)slot;
 }
 
 #endif /* GPT_WIDE_BVH_H */

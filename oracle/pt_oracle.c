@@ -385,8 +385,8 @@ static inline void push_children(const scene_t *sc, const gpt_bvh_node *node, in
 
 /* ---- GPT_TRAVERSAL_WIDE4: the walk of include/gpt_wide_bvh.h ------------------------------------------------------
  * Same box arithmetic (bbox.h:77-96, with the box's entry distance kept as the order key) and the same triangle test
- * (mesh.h:45-67) as above; only the order of the tests is the wide tree's.  The GPU does this with four lanes per ray: the
- * four boxes of a node in one step, the triangles of a leaf four at a time against the same interval. */
+ * (mesh.h:45-67) as above; only the order of the tests is the wide tree's.  The GPU does this with one lane per ray: the
+ * four boxes of a node in one step, the triangles of a leaf one per step. */
 static inline int wide_box(const gpt_wide_child *c, const ray_t *r, f3 inv_dir, float ray_tmax, float *tn_out)
 {
     float t1 = (c->bmin[0] - r->o.x) * inv_dir.x;
@@ -465,28 +465,20 @@ static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any
             cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
         } else {
             const int first = gpt_wide_entry_first(cur), count = gpt_wide_entry_count(cur);
-            const int m = count < 4 ? count : 4;
-            float nearest = INFINITY;
-            int accepted = 0;
-            for (int k = 0; k < m; ++k) {              /* all against the same interval */
+            for (int k = 0; k < count; ++k) {          /* in index order, each against the current interval */
                 float tt, b1, b2;
                 t_cnt.prim_tests++;
                 if (!tri_test(&sc->d->prims[first + k].triangle, ray, tmax, &tt, &b1, &b2)) continue;
-                accepted = 1;
-                if (tt < nearest) nearest = tt;
                 if (best_prim < 0 || tt < best_t || (tt == best_t && first + k > best_prim)) {
                     best_prim = first + k; best_t = tt; best_b1 = b1; best_b2 = b2;
                 }
-            }
-            if (accepted) {
-                if (nearest < tmax) tmax = nearest;
+                if (tt < tmax) tmax = tt;              /* (a NaN distance never becomes the interval's end) */
                 if (any_hit) {
                     ray->tmax = best_t; t_hit_prim = best_prim; t_hit_b1 = best_b1; t_hit_b2 = best_b2;
                     return 1;
                 }
             }
-            if (count > 4) cur = gpt_wide_leaf_entry(first + 4, count - 4);
-            else cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
+            cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
         }
     }
     if (best_prim < 0) return 0;

@@ -25,7 +25,7 @@ print(f"per sample: closest-hit rays {c['closest_rays']/s:.2f}, shadow rays {c['
 rays = c['closest_rays'] + c['shadow_rays']
 print(f"per ray: node visits {c['node_visits']/rays:.1f}, triangle tests {c['prim_tests']/rays:.1f}")
 if near == "wide":
-    print(f"wide: trips per 64 samples {c['w_trip']*64/s:.1f}, busy groups per trip {c['l_trip']/max(1,c['w_trip']):.2f} of 16, trips with a node block {c['w_node']/max(1,c['w_trip']):.2f}, with a leaf block {c['w_prim']/max(1,c['w_trip']):.2f}")
+    print(f"wide: trips per 64 samples {c['w_trip']*64/s:.1f}, busy lanes per trip {c['l_trip']/max(1,c['w_trip']):.2f} of 64, lanes per node block {c['node_visits']/max(1,c['w_node']):.1f}, per triangle block {c['prim_tests']/max(1,c['w_prim']):.1f}, trips with a node block {c['w_node']/max(1,c['w_trip']):.2f}, with a leaf block {c['w_prim']/max(1,c['w_trip']):.2f}")
 elif c["w_node"]:
     print(f"wave trips per sample-lane: node {c['w_node']*64/s:.1f} (lanes active {c['node_visits']/c['w_node']:.1f} of 64), "
           f"triangle {c['w_prim']*64/s:.1f} (lanes active {c['prim_tests']/max(1,c['w_prim']):.1f} of 64)")
