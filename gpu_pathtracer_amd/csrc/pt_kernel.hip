@@ -1150,6 +1150,12 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 #ifndef PT_WIDE_ASM
 #define PT_WIDE_ASM 1
 #endif
+#ifndef PT_WIDE_EARLY
+#define PT_WIDE_EARLY 0          // (measured: -5 %, the extra vector-memory instructions cost more than the overlap gains) a lane that descends into a wide node fetches that record before the trip's triangle block
+#endif
+#ifndef PT_WIDE_EXTRA_LOADS
+#define PT_WIDE_EXTRA_LOADS        // experiment hook: redundant fetches per trip (how much does a vector-memory instruction cost?)
+#endif
 #ifndef PT_WIDE_PROBE
 #define PT_WIDE_PROBE 0          // 1: the loop counts its trips, node / triangle blocks and the lanes in them (probe builds)
 #endif
@@ -1182,6 +1188,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_mov_b32 s76, 0x322bcc77\n"
         "s_mov_b32 s77, 0x71800000\n"
         "s_mov_b64 s[64:65], 0\n"
+        "s_mov_b64 s[82:83], 0\n"
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
         "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
         "v_lshl_add_u32 v18, v33, 2, %[stack]\n"
@@ -1238,7 +1245,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "global_load_dwordx4 v[28:31], v53, %[tris] offset:16\n"
         "global_load_dword v32, v53, %[tris] offset:32\n"
         "global_load_dwordx4 v[24:27], v53, %[tris]\n"
-        "s_mov_b64 exec, s[62:63]\n"
+        "s_andn2_b64 exec, s[62:63], s[82:83]\n"           /* (the lanes that descended last trip fetched their record then) */
         "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
         "global_load_dwordx4 v[36:39], v12, %[nodes] offset:48\n"
         "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
@@ -1246,7 +1253,10 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "global_load_dwordx4 v[32:35], v12, %[nodes] offset:32\n"
         "global_load_dwordx4 v[44:47], v12, %[nodes] offset:80\n"
         "global_load_dwordx4 v[48:51], v12, %[nodes] offset:96\n"
+        PT_WIDE_EXTRA_LOADS
         "s_mov_b64 s[78:79], 0\n"
+        "s_mov_b64 s[82:83], 0\n"
+        "s_mov_b64 exec, s[62:63]\n"
         "s_cbranch_execz TW_LEAF_%=\n"
         "s_waitcnt vmcnt(0)\n"
         /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
@@ -1417,11 +1427,27 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e64 v13, v13, v56, s[80:81]\n"
         "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
         "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
+#if PT_WIDE_EARLY
+        /* a lane that descends into a wide node fetches that record NOW: the fetch overlaps the triangle block, the pops and
+           the loop overhead (nothing below touches v[24:64] of these lanes) */
+        "v_cmp_lt_i32_e32 vcc, -1, v50\n"
+        "s_and_b64 s[82:83], vcc, s[80:81]\n"
+        "s_mov_b64 exec, s[82:83]\n"
+        "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
+        "global_load_dwordx4 v[36:39], v12, %[nodes] offset:48\n"
+        "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
+        "global_load_dwordx4 v[40:43], v12, %[nodes] offset:64\n"
+        "global_load_dwordx4 v[32:35], v12, %[nodes] offset:32\n"
+        "global_load_dwordx4 v[44:47], v12, %[nodes] offset:80\n"
+        "global_load_dwordx4 v[48:51], v12, %[nodes] offset:96\n"
+#endif
         /* ---------------------------------------------------------------- leaf: one triangle (exec = s[60:61]) */
-        "TW_LEAF_%=:\n"
+        "s_branch TW_LEAF_GO_%=\n"
+        "TW_LEAF_%=:\n"                                     /* no lane at a wide node: the triangle fetches have not been waited for */
+        "s_waitcnt vmcnt(0)\n"
+        "TW_LEAF_GO_%=:\n"
         "s_mov_b64 exec, s[60:61]\n"
         "s_cbranch_execz TW_POP_%=\n"
-        "s_waitcnt vmcnt(0)\n"
         "v_mul_f32_e32 v33, v5, v32\n"
         "v_mul_f32_e32 v42, v6, v31\n"
         "v_sub_f32_e32 v33, v33, v42\n"
@@ -1612,14 +1638,15 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cmp_gt_u32 s71, %[maxbusy]\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
         "s_not_b64 s[66:67], s[64:65]\n"
-        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
-        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
-        "v_add_u32_e32 v33, s70, v33\n"
-        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
+        "v_mbcnt_lo_u32_b32 v65, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v65, s67, v65\n"
+        "v_add_u32_e32 v65, s70, v65\n"
+        "v_cmp_gt_i32_e32 vcc, %[rays], v65\n"
         "s_and_b64 s[66:67], vcc, s[66:67]\n"
         "s_sub_i32 s71, 64, s71\n"
         "s_add_i32 s70, s70, s71\n"
         "s_mov_b64 exec, s[66:67]\n"
+        "v_mov_b32_e32 v33, v65\n"
         PT_FETCH_ORDERED
         "ds_read_b128 v[4:7], v15\n"
         "ds_read_b128 v[8:11], v15 offset:16\n"
@@ -1648,6 +1675,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cmp_gt_u32 s71, %[tstop]\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
         "TW_DONE_%=:\n"
+        "s_waitcnt vmcnt(0)\n"                             /* (an early fetch must not land after the registers have been handed back) */
         "ds_write_b128 v17, v[12:15]\n"
         "ds_write_b128 v17, v[20:23] offset:16\n"
         "s_waitcnt lgkmcnt(0)\n"
@@ -1662,11 +1690,11 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
           [tstop] "n"(PT_WIDE_STOP_T), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
-          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81",
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
           "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64");
+          "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
@@ -3524,7 +3552,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
             } else if (WIDE) {
-                if (COUNT || !PT_WIDE_ASM)          // the counting build runs the C++ twin (it has the counters)
+                if ((COUNT && !PT_ASM_IN_COUNT) || !PT_WIDE_ASM)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
                 else
                     trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0, wprobe);

@@ -1,4 +1,4 @@
-"""Time kernel variants (build/variants/libgpt_*.so) on the headline workload and check that every one
+"""Time kernel variants (var/libgpt_*.so) on the headline workload and check that every one
 produces the same film as the first (bit-exact).  Usage: python tools/bench_variants.py name1 name2 ..."""
 import hashlib, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +21,7 @@ print(json.dumps({"hash8spp": h, "ms64": best, "msamples": W*H*64/best/1e3}))
 ''' % (ROOT, ROOT)
 ref = None
 for name in sys.argv[1:]:
-    env = dict(os.environ, GPT_LIB_PATH=os.path.join(ROOT, "build", "variants", f"libgpt_{name}.so"), GPT_ALLOW_OLD_LIB="1")
+    env = dict(os.environ, GPT_LIB_PATH=os.path.join(ROOT, "var", f"libgpt_{name}.so"), GPT_ALLOW_OLD_LIB="1")
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]
     try:

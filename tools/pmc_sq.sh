@@ -1,8 +1,8 @@
 #!/bin/bash
 # SQ-level counters of the path kernel (own passes, --kernel-trace only): lane utilisation, VALU busy, waits.
-# usage: bash tools/pmc_sq.sh <tag> [variant-name]   (variant = build/variants/libgpt_<name>.so)
+# usage: bash tools/pmc_sq.sh <tag> [variant-name]   (variant = var/libgpt_<name>.so)
 TAG=${1:-sq}
-if [ -n "$2" ]; then export GPT_LIB_PATH=$PWD/build/variants/libgpt_$2.so; fi
+if [ -n "$2" ]; then export GPT_LIB_PATH=$PWD/var/libgpt_$2.so; fi
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
