@@ -21,6 +21,11 @@ What the JSON line carries besides the contract's fields (rank 0, N = 1):
                 fraction of the 8 TB/s peak.
   cpu_baseline  the oracle (CPU restatement) on one host core, bounded sample; host CPU model and core count.
   parity        GPU film against the pinned (glibc) oracle at 256x256 / 1024 spp / depth 8: per-channel relative RMS.
+  config.other_configs   BASELINE.json configs 3 - 5 on their SURVEY.md 8(d) stand-ins (tests/standins.py, built from
+                tests/golden/meshes.npz through the product loader), one full-size launch per traversal order: Msamples/s from the
+                library's HIP events, and for the faster order the VALU-issue fraction, active lanes and HBM-side GB/s of one extra
+                rocprofv3 pass set.  Parity-test cases, not the headline: they are here so that their numbers are driver-witnessed.
+`python bench.py --gpus N` without a torch.distributed.run environment launches itself under it (one rank per GPU).
 Nothing here reads /root/reference.
 """
 import argparse
@@ -122,25 +127,57 @@ def parity_check(api):
 
 # ---- counters measured in this run -------------------------------------------------------------------------------------------
 
-def counter_child():
-    """Run under rocprofv3 by live_counters(): two launches of the headline kernel (64 iterations at 1080p each)."""
+STANDINS = {"c3": ("config 3 stand-in: 3 x sphere.obj + cube-subdiv.obj, shaderball camera / light / metals, glass, substrate, checker; 1920x1080, depth 10", 32),
+            "c4": ("config 4 stand-in: config-5 geometry under a procedural 1024x512 sky, no area light; 1920x1080, depth 7", 32),
+            "c5": ("config 5 stand-in: Cornell walls + dragon + bunny2 + teapot + 9 spheres (248 574 triangles); 3840x2160, depth 16", 8)}
+
+
+def load_standin(which):
+    """The stand-in's scene directory is written, loaded through the product loader and removed.  The loader reports its progress
+    on stdout like the reference's (parsescene.cpp): that goes to stderr here - stdout carries the one JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import standins
+    from gpu_pathtracer_amd import api
+    d = tempfile.mkdtemp(prefix="gpt_standin_")
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return api.LoadedScene(standins.write_standin_scene(d, which))      # (the loader copies everything it reads)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def counter_child(which="c2", mode="reference"):
+    """Run under rocprofv3 by live_counters(): two launches of the kernel to be counted (c2: 64 iterations at 1080p each)."""
     from gpu_pathtracer_amd import api, host
-    scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
-    cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
-    with api.Renderer(scene.desc, WIDTH, HEIGHT, EPS) as r:
-        r.render(cam, 1, SPP_PER_STEP, reset=True)
-        r.render(cam, SPP_PER_STEP + 1, SPP_PER_STEP, reset=False)
+    if which == "c2":
+        scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
+        cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
+        with api.Renderer(scene.desc, WIDTH, HEIGHT, EPS) as r:
+            r.render(cam, 1, SPP_PER_STEP, reset=True)
+            r.render(cam, SPP_PER_STEP + 1, SPP_PER_STEP, reset=False)
+            r.synchronize()
+        return
+    ls = load_standin(which)
+    spp = STANDINS[which][1]
+    with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
+        r.set_traversal_order(mode)
+        r.render(ls.camera, 1, spp, reset=True)
+        r.render(ls.camera, spp + 1, spp, reset=False)
         r.synchronize()
 
 
-def rocprof_pass(counters, workdir, tag):
+def rocprof_pass(counters, workdir, tag, child=("c2", "reference")):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     out = os.path.join(workdir, tag)
     env = dict(os.environ, TMPDIR=workdir)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", tag, "--",
-                                                          sys.executable, os.path.abspath(__file__), "--counter-child"]
+                                                          sys.executable, os.path.abspath(__file__), "--counter-child", child[0], child[1]]
     p = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=150)     # a pass takes ~6 s; a hang must not cost the bench line
     vals = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -149,7 +186,9 @@ def rocprof_pass(counters, workdir, tag):
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     if not vals:
         raise RuntimeError(f"rocprofv3 pass {tag} produced no counters (rc {p.returncode}): {p.stderr[-300:]}")
-    return {k: sum(v) / len(v) for k, v in vals.items()}, max(len(v) for v in vals.values())
+    # the launches to be counted are the large ones (a stand-in child may also run small ones: keep the two largest per counter)
+    big = {k: sorted(v)[-2:] for k, v in vals.items()}
+    return {k: sum(v) / len(v) for k, v in big.items()}, max(len(v) for v in big.values())
 
 
 def live_counters():
@@ -171,6 +210,64 @@ def live_counters():
     return sq
 
 
+def standin_leg(api, which, counters=True):
+    """One BASELINE stand-in at full size: a launch per traversal order timed with the library's HIP events; counters of the faster
+    order from one extra rocprofv3 pass set (SQ, FETCH_SIZE, WRITE_SIZE: each in its own pass)."""
+    label, spp = STANDINS[which]
+    ls = load_standin(which)
+    out = {"workload": label, "triangles": int(ls.desc.n_prims), "bvh_nodes": int(ls.desc.n_nodes), "iterations_per_launch": spp, "orders": {}}
+    n_samples = ls.width * ls.height * spp
+    sha, film = {}, {}
+    with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
+        for mode in ("reference", "wide"):
+            r.set_traversal_order(mode)
+            r.render(ls.camera, 1, spp, reset=True)             # same call as the timed one: the sample planes exist afterwards
+            r.synchronize()
+            best = None
+            for _ in range(2):
+                r.kernel_time_reset()
+                r.render(ls.camera, 1, spp, reset=True)
+                r.synchronize()
+                n, ms = r.kernel_time()
+                best = ms / max(1, n) if best is None else min(best, ms / max(1, n))
+            film[mode] = r.read_accum()
+            sha[mode] = hashlib.sha1(film[mode].tobytes()).hexdigest()[:16]
+            out["orders"][mode] = {"value": n_samples / best / 1e3, "unit": "Msamples/s", "launch_ms": best}
+    # the wide order against the reference order: equal films except where two hits tie within rounding (include/gpt_wide_bvh.h)
+    import numpy as np
+    a, b = film["wide"].reshape(-1, 3).astype(np.float64), film["reference"].reshape(-1, 3).astype(np.float64)
+    out["wide_vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film["wide"] != film["reference"])), "floats": int(film["wide"].size),
+                                      "rel_rms": [float(x) for x in np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))], "tolerance": 1e-4}
+    out["accumulator_sha1"] = sha
+    fast = max(out["orders"], key=lambda m: out["orders"][m]["value"])
+    out["faster_order"] = fast
+    if counters:
+        work = tempfile.mkdtemp(prefix="gpt_pmc_")
+        try:
+            sq, _ = rocprof_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
+                                 work, "sq", (which, fast))
+            fetch, _ = rocprof_pass(["FETCH_SIZE"], work, "fetch", (which, fast))
+            write, _ = rocprof_pass(["WRITE_SIZE"], work, "write", (which, fast))
+            ms = out["orders"][fast]["launch_ms"]
+            peak_issue = N_SIMD * CLOCK_HZ / VALU_CYCLES
+            traffic = (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0
+            out["roofline"] = {"order": fast, "bound": "valu_issue + memory latency (DESIGN.md section 4)",
+                               "valu_issue_frac": sq["SQ_INSTS_VALU"] / (ms * 1e-3) / peak_issue,
+                               "valu_insts_per_sample_lane": sq["SQ_INSTS_VALU"] / n_samples * 64,
+                               "active_lanes_of_64": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+                               "wait_any_over_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                               "hbm_GBps": traffic / (ms * 1e-3) / 1e9, "hbm_frac_of_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "fetch_KiB_raw_per_launch": fetch["FETCH_SIZE"], "write_KiB_per_launch": write["WRITE_SIZE"],
+                               "compulsory_bytes_per_launch": 16.0 * n_samples,
+                               "counters": "rocprofv3 --pmc on launches of the same size of this libgpt.so, inside this run"}
+        except Exception as e:
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    ls.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,10 +278,11 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-square", action="store_true", help="skip the square-frame figure and the counting render (a rocprofv3 --stats run then sees "
                                                              "only the headline kernel's full-size launches)")
-    ap.add_argument("--counter-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the stand-ins of BASELINE.json configs 3 - 5 (config.other_configs)")
+    ap.add_argument("--counter-child", nargs=2, metavar=("WHICH", "ORDER"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.counter_child:
-        return counter_child()
+        return counter_child(*args.counter_child)
 
     import numpy as np
     import torch
@@ -195,6 +293,12 @@ def main():
     local_rank = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # called as `python bench.py --gpus N`: launch the N ranks (one per GPU) the way the driver does
+            port = 29500 + os.getpid() % 2000
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -298,14 +402,18 @@ def main():
             # cost one traversal each.  The same scene at 1080 x 1080 (every pixel sees the box), same kernel:
             sq_cam = host.camera_from_meta(meta, 1088, 1080)
             with api.Renderer(scene.desc, 1088, 1080, EPS, device=local_rank) as rs:
-                rs.render(sq_cam, 1, 64, reset=True)
+                rs.render(sq_cam, 1, 256, reset=True)            # the same call as the timed one: the sample planes exist afterwards
                 rs.synchronize()
                 rs.kernel_time_reset()
                 ts = time.perf_counter()
                 rs.render(sq_cam, 1, 256, reset=True)
                 rs.synchronize()
+                wall = time.perf_counter() - ts
+                n_sq, ms_sq = rs.kernel_time()
                 square = {"frame": "1088x1080 (square framing: every primary ray enters the box)", "spp": 256,
-                          "value": 1088 * 1080 * 256 / (time.perf_counter() - ts) / 1e6, "unit": "Msamples/s"}
+                          "value": 1088 * 1080 * 256 / (ms_sq * 1e-3) / 1e6, "unit": "Msamples/s",
+                          "timed": "path-kernel launches, HIP events of the library (gpt_kernel_time)", "launches": n_sq,
+                          "wall_clock_value": 1088 * 1080 * 256 / wall / 1e6}
 
         live, live_err = None, None
         if single and not args.no_counters:
@@ -349,6 +457,14 @@ def main():
                         "fetch_KiB_raw_per_launch": per_sample["FETCH_SIZE"] * samples_per_launch,
                         "write_KiB_per_launch": per_sample["WRITE_SIZE"] * samples_per_launch})
         roof["hbm"] = hbm
+        others = None
+        if single and not args.no_other_configs:
+            others = {}
+            for which in ("c3", "c4", "c5"):
+                try:
+                    others[which] = standin_leg(api, which, counters=not args.no_counters and which != "c4")
+                except Exception as e:
+                    others[which] = {"error": f"{type(e).__name__}: {e}"[:300]}
         par = None
         if single and not args.no_parity:
             par = parity_check(api)
@@ -368,7 +484,7 @@ def main():
                        "renderer_options": options, "options_set": dict(r.options_set),
                        "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND", "GPT_BENCH_TRY_NATIVE") if os.environ.get(k)}),
                        "reduce": (comm.kind if comm is not None else None),
-                       "square_frame": square,
+                       "square_frame": square, "other_configs": others,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": roof,
         }

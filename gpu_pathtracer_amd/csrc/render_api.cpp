@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,8 @@ struct gpt_ctx {
     float *samples = nullptr;             // per-iteration sample planes, grown on demand
     size_t sample_bytes = 0;              // bytes allocated for them
     uint32_t last_batch_cap = 0;          // iterations per launch the last gpt_render used
+    uint32_t batch_cap_limit = 0;         // a larger plane allocation failed (0: none did): not retried until the tile ownership changes
+    uint32_t batch_limit_owned = 0;       // ... the owned-tile count that limit was found for
     double last_trace_ms = 0.0;           // kernel time of the last gpt_debug_trace (HIP events)
     uint32_t max_batch = 256;             // "max_batch": iterations per path-kernel launch; also capped by the memory budget
     bool max_batch_set = false;           // ... as set by the caller (else: 256 x the number of ranks sharing the frame)
@@ -88,6 +91,7 @@ struct gpt_ctx {
     // multi-GPU film reduce (gpt_comm_init / gpt_reduce_film)
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
     int wide_depth = 0, n_wide = 0;
+    std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
@@ -397,7 +401,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     DevParams &P = ctx->P;
     if ((rc = dev_upload(ctx, nodes.data(), nodes.size(), &P.nodes)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, tris.data(), tris.size(), &P.tris)) != GPT_OK) return fail(rc);
-    if ((rc = dev_upload(ctx, wide_dev.data(), wide_dev.size(), &P.wide)) != GPT_OK) return fail(rc);
+    ctx->wide_host.swap(wide_dev);          // (128 B per wide node: uploaded only if the wide walk is ever selected)
     if ((rc = dev_upload(ctx, shade.data(), shade.size(), &P.shade)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, scene->materials, (size_t)scene->n_materials, &P.materials)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, lights.data(), lights.size(), &P.lights)) != GPT_OK) return fail(rc);
@@ -612,6 +616,12 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
             gpt_set_error("gpt_set_traversal_order: the scene has no wide tree (empty scene, or deeper than %d wide levels)", (GPT_WIDE_STACK_MAX - 1) / 3);
             return GPT_ERR_UNSUPPORTED;
         }
+        if (!ctx->P.wide) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            int rc = dev_upload(ctx, ctx->wide_host.data(), ctx->wide_host.size(), &ctx->P.wide);
+            if (rc != GPT_OK) return rc;
+            std::vector<DevWideNode>().swap(ctx->wide_host);
+        }
         if (!ctx->P.wide_stack) {          // spill space of the per-ray stacks: one slice per wave that can be resident
             int bpc = 1;
             for (int w = 0; w < 2; ++w)
@@ -678,6 +688,8 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     const uint64_t wanted = ctx->max_batch_set ? (uint64_t)ctx->max_batch : (uint64_t)ctx->max_batch * n_ranks;
     const uint32_t max_batch = wanted < by_memory ? (uint32_t)wanted : by_memory;
     uint32_t batch_cap = iter_count < max_batch ? iter_count : max_batch;
+    if (ctx->batch_cap_limit && ctx->batch_limit_owned == n_owned && batch_cap > ctx->batch_cap_limit)
+        batch_cap = ctx->batch_cap_limit;     // a larger allocation failed before: do not free, fail and halve again every frame
     if (ctx->sample_bytes < plane_bytes * batch_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->samples) {
@@ -696,6 +708,8 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
                 return GPT_ERR_HIP;
             }
             batch_cap = (batch_cap + 1) / 2;
+            ctx->batch_cap_limit = batch_cap;
+            ctx->batch_limit_owned = n_owned;
         }
         ctx->allocs.push_back(ps);
         ctx->samples = static_cast<float *>(ps);
@@ -788,12 +802,14 @@ struct Rccl {
 Rccl *rccl()
 {
     static Rccl lib;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::string why;                 // why it could not be loaded (kept: dlerror() can be read once only)
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
             lib.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib.handle) break;
+            const char *e = dlerror();
+            why = e ? e : "dlopen failed";
         }
         if (lib.handle) {
             lib.GetUniqueId = reinterpret_cast<decltype(lib.GetUniqueId)>(dlsym(lib.handle, "ncclGetUniqueId"));
@@ -804,11 +820,12 @@ Rccl *rccl()
             if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommDestroy || !lib.Reduce || !lib.GetErrorString) {
                 dlclose(lib.handle);
                 lib.handle = nullptr;
+                why = "a symbol of the RCCL API is missing (ncclGetUniqueId / CommInitRank / CommDestroy / Reduce / GetErrorString)";
             }
         }
-    }
+    });
     if (!lib.handle) {
-        gpt_set_error("RCCL (librccl.so.1) cannot be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+        gpt_set_error("RCCL (librccl.so.1) cannot be loaded: %s", why.c_str());
         return nullptr;
     }
     return &lib;

@@ -640,6 +640,7 @@ void Scene::Init(Camera *cam, std::string file)   // scene.h:50-83
     std::printf("Bvh total nodes:%d\n", bvh.total_nodes);
     std::printf("Scene Bounds [%.3f, %.3f, %.3f]-[%.3f, %.3f, %.3f]\n", bvh.root_box.fmin.x, bvh.root_box.fmin.y,
                 bvh.root_box.fmin.z, bvh.root_box.fmax.x, bvh.root_box.fmax.y, bvh.root_box.fmax.z);
+    std::fflush(stdout);            // (a caller that redirects the progress lines gets all of them before the call returns)
     if (infinite.isvalid) {
         infinite.data = infinite_data.data();
         float box[6] = {bvh.root_box.fmin.x, bvh.root_box.fmin.y, bvh.root_box.fmin.z,

@@ -62,28 +62,35 @@ class FilmReducer:
         self.kind = "rccl ncclReduce issued by libgpt.so (gpt_reduce_film)" if native else f"torch.distributed {dist.get_backend()} reduce (all ranks share one GPU)"
         self.native_error = None
         if native:
-            # every rank must end up on the same path: agree on the outcome of the RCCL set-up before using it
-            ok = 1
+            # Every rank must end up on the same path, and ncclCommInitRank is itself a collective: a rank that cannot even load
+            # RCCL must not leave the others blocked in it.  So the agreement has two steps.
+            # Step 1 (no RCCL collective yet): can every rank load RCCL, and could rank 0 create the id?
+            import torch
+            ok, uid = 1, None
             try:
-                box = [None]
-                if rank == 0:
-                    try:
-                        box[0] = api.comm_unique_id()
-                    except Exception as e:            # RCCL cannot be loaded: tell the others through the broadcast
-                        self.native_error = str(e)
-                dist.broadcast_object_list(box, src=0)
-                if box[0] is None:
-                    raise RuntimeError(self.native_error or "rank 0 could not create an RCCL id")
-                renderer.comm_init(rank, world, box[0])
+                uid = api.comm_unique_id()        # loads librccl; the id itself is used from rank 0 only
             except Exception as e:
                 ok, self.native_error = 0, str(e)
-            import torch
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                renderer.comm_destroy()
                 self.native = native = False
-                self.kind = f"torch.distributed {dist.get_backend()} reduce (the library's RCCL path failed: {self.native_error})"
+                self.kind = (f"torch.distributed {dist.get_backend()} reduce (RCCL could not be loaded on every rank: "
+                             f"{self.native_error or 'another rank failed'})")
+            else:
+                # Step 2: everybody enters ncclCommInitRank with rank 0's id; its outcome is agreed on as well
+                box = [uid if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                try:
+                    renderer.comm_init(rank, world, box[0])
+                except Exception as e:
+                    ok, self.native_error = 0, str(e)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    renderer.comm_destroy()
+                    self.native = native = False
+                    self.kind = f"torch.distributed {dist.get_backend()} reduce (the library's RCCL path failed: {self.native_error or 'on another rank'})"
         if not native:
             import torch
             renderer.set_tile_owner(rank, world)

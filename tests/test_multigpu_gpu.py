@@ -64,7 +64,7 @@ def test_two_rank_bench_on_one_gpu_gives_the_one_rank_frame():
     ownership, per-rank sample planes, the reduce into a separate buffer and Output from the reduced frame.  The film's hash
     equals the single-rank run's.  (RCCL refuses two ranks on one device, so the reduce travels over gloo here; the library's
     own ncclReduce is covered by the test above.)"""
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-parity"]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-parity", "--no-other-configs", "--no-square"]
     one = run_bench({}, ["--gpus", "1"] + common)
     two = run_bench({"GPT_BENCH_SHARE_GPU": "1"}, ["--gpus", "2"] + common,
                     launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -79,4 +79,38 @@ def test_two_rank_bench_on_one_gpu_gives_the_one_rank_frame():
                              "--master-port", str(free_port())])
     assert "RCCL path failed" in fb["config"]["reduce"] and fb["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
     # each rank allocates sample planes for its own tiles only
+    assert two["config"]["renderer_options"]["sample_plane_bytes"] * 2 <= one["config"]["renderer_options"]["sample_plane_bytes"] + 64 * 16 * 128
+
+
+def test_bench_launches_its_own_ranks_when_called_plainly():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment around it (the shape of the driver's 1-GPU call)
+    starts the two ranks itself instead of refusing: same film as one rank."""
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-parity", "--no-other-configs", "--no-square"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GPT_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ol.ROOT, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ol.ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    two = json.loads(lines[0])
+    one = run_bench({}, ["--gpus", "1"] + common)
+    assert two["n_gpus"] == 2 and two["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
+
+
+def test_two_ranks_on_two_gpus_reduce_through_rccl():
+    """Where the box has two GPUs (the driver's multi-GPU node; a 1-GPU lease skips this): bench.py --gpus 2 natively, one rank
+    per GPU.  The reduce must be the library's own ncclReduce over the fabric, the film must equal the 1-rank film bit for bit
+    (disjoint supports: the sum adds zeros), and each rank's sample planes are half the size."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: the N > 1 RCCL path cannot run on a 1-GPU lease (RCCL refuses two ranks on one device)")
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-parity", "--no-other-configs", "--no-square"]
+    one = run_bench({}, ["--gpus", "1"] + common)
+    two = run_bench({}, ["--gpus", "2"] + common,
+                    launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(free_port())])
+    assert two["n_gpus"] == 2 and "ncclReduce" in two["config"]["reduce"], two["config"]["reduce"]
+    assert two["config"]["all_finite"]
+    assert two["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
     assert two["config"]["renderer_options"]["sample_plane_bytes"] * 2 <= one["config"]["renderer_options"]["sample_plane_bytes"] + 64 * 16 * 128
