@@ -2073,6 +2073,60 @@ API void oracle_math_batch(int fn, const float *x, const float *y, float *out, i
         }
     }
 }
+/* ---- the BSDF and light operators alone, for the analytic property tests (tier T4:
+ * tests/test_bsdf_properties.py).  Untextured materials only (the scene is not consulted). ---- */
+API void oracle_bsdf_sample_batch(const gpt_material *m, const float wo[3], const float nor[3], const float dpdu[3], const float *u3, int n,
+                                  float *wi_out, float *fr_out, float *pdf_out)
+{
+    scene_t sc;
+    memset(&sc, 0, sizeof(sc));
+    for (int i = 0; i < n; ++i) {
+        f3 out = mk3(0, 0, 0), fr = mk3(0, 0, 0);
+        float pdf = 0.f;
+        sample_bsdf(&sc, m, mk3(wo[0], wo[1], wo[2]), mk3(nor[0], nor[1], nor[2]), mk2(0.f, 0.f), mk3(dpdu[0], dpdu[1], dpdu[2]),
+                    mk3(u3[3 * i], u3[3 * i + 1], u3[3 * i + 2]), &out, &fr, &pdf);
+        wi_out[3 * i] = out.x; wi_out[3 * i + 1] = out.y; wi_out[3 * i + 2] = out.z;
+        fr_out[3 * i] = fr.x; fr_out[3 * i + 1] = fr.y; fr_out[3 * i + 2] = fr.z;
+        pdf_out[i] = pdf;
+    }
+}
+API void oracle_bsdf_eval_batch(const gpt_material *m, const float wo[3], const float nor[3], const float dpdu[3], const float *wi, int n,
+                                float *fr_out, float *pdf_out)
+{
+    scene_t sc;
+    memset(&sc, 0, sizeof(sc));
+    for (int i = 0; i < n; ++i) {
+        f3 fr = mk3(0, 0, 0);
+        float pdf = 0.f;
+        eval_bsdf(&sc, m, mk3(wo[0], wo[1], wo[2]), mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), mk3(nor[0], nor[1], nor[2]), mk2(0.f, 0.f),
+                  mk3(dpdu[0], dpdu[1], dpdu[2]), &fr, &pdf);
+        fr_out[3 * i] = fr.x; fr_out[3 * i + 1] = fr.y; fr_out[3 * i + 2] = fr.z;
+        pdf_out[i] = pdf;
+    }
+}
+/* Infinite::SampleLight and Infinite::Le (infinite.h:17-59) for n uniforms / n directions */
+API void oracle_infinite_sample_batch(const gpt_infinite *inf, const float pos[3], const float *u2, int n, float eps,
+                                      float *dir_out, float *rad_out, float *pdf_out, float *tmax_out)
+{
+    for (int i = 0; i < n; ++i) {
+        f3 rad, nor;
+        ray_t ray;
+        float pdf;
+        inf_sample_light(inf, mk3(pos[0], pos[1], pos[2]), mk2(u2[2 * i], u2[2 * i + 1]), &rad, &ray, &nor, &pdf, eps);
+        dir_out[3 * i] = ray.d.x; dir_out[3 * i + 1] = ray.d.y; dir_out[3 * i + 2] = ray.d.z;
+        rad_out[3 * i] = rad.x; rad_out[3 * i + 1] = rad.y; rad_out[3 * i + 2] = rad.z;
+        pdf_out[i] = pdf;
+        tmax_out[i] = ray.tmax;
+    }
+}
+API void oracle_infinite_le_batch(const gpt_infinite *inf, const float *dir, int n, float *rad_out)
+{
+    for (int i = 0; i < n; ++i) {
+        const f3 r = inf_lookup(inf, mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+        rad_out[3 * i] = r.x; rad_out[3 * i + 1] = r.y; rad_out[3 * i + 2] = r.z;
+    }
+}
+
 API int oracle_uses_softmath(void)
 {
 #ifdef ORACLE_SOFTMATH
