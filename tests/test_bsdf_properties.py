@@ -306,8 +306,7 @@ def test_infinite_light_sampling_and_lookup():
 def furnace_scene(mat_type, depth=8):
     """a convex, flat-shaded box floating in a constant environment of radiance 1: whatever leaves its surface has radiance
     albedo x 1, because no ray that leaves a convex body comes back to it"""
-    mats = scenes.material_table()
-    mats[0] = material(mat_type, diffuse=(1, 1, 1), specular=(1, 1, 1))[0]
+    mats = np.concatenate([material(mat_type, diffuse=(1, 1, 1), specular=(1, 1, 1)), material(st.MT_LAMBERTIAN, diffuse=(0, 0, 0))])
     box = scenes.box_mesh((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), 0)
     env = np.full((8, 16, 3), 1.0, np.float32)
     scene = ol.make_scene(box, mats, light_radiance=None, max_depth=depth, env=env, lib=ol.load("libm"))
@@ -355,9 +354,7 @@ def test_direct_light_on_a_floor_matches_lamberts_formula():
     Area::SampleLight / Pdf / Le (one-sided), the shadow ray's interval, the BSDF-sampled light ray and the power heuristic: the two
     MIS-weighted estimators have to add up to the closed form."""
     lib = ol.load("libm")
-    mats = scenes.material_table()
-    mats[0] = material(st.MT_LAMBERTIAN, diffuse=(0.5, 0.5, 0.5))[0]
-    mats[1] = material(st.MT_LAMBERTIAN, diffuse=(0, 0, 0))[0]
+    mats = np.concatenate([material(st.MT_LAMBERTIAN, diffuse=(0.5, 0.5, 0.5)), material(st.MT_LAMBERTIAN, diffuse=(0, 0, 0))])
     up, down = (0, 1, 0), (0, -1, 0)
     F = [np.float32(c) for c in ((-2, 0, -2), (-2, 0, 2), (2, 0, 2), (2, 0, -2))]
     L = [np.float32(c) for c in ((-0.25, 1, -0.25), (0.25, 1, -0.25), (0.25, 1, 0.25), (-0.25, 1, 0.25))]
