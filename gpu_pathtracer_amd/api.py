@@ -55,6 +55,8 @@ def load():
         "gpt_set_option": [vp, C.c_char_p, C.c_int64],
         "gpt_get_option": [vp, C.c_char_p, C.POINTER(C.c_int64)],
         "gpt_scene_load_cached": [C.c_char_p, C.c_int, C.POINTER(vp)],
+        "gpt_scene_load_ex": [C.c_char_p, C.c_int, C.POINTER(vp)],
+        "gpt_sbvh_build": [vp, i32, f32, vp, i32, C.POINTER(i32), vp, vp, i32, C.POINTER(i32), vp],
         "gpt_render": [vp, vp, u32, u32, C.c_int, vp],
         "gpt_tonemap": [vp, u32, C.c_int, vp],
         "gpt_tonemap_from": [vp, vp, u32, C.c_int, vp],
@@ -128,6 +130,21 @@ def bvh_build(prims):
     return out, nodes[: nn.value].copy(), box
 
 
+def sbvh_build(prims, alpha=1e-5, capacity=None):
+    """gpt_sbvh_build: the split BVH (object + spatial splits, duplicated references) -> (prims, nodes, box, origin index)"""
+    lib = load()
+    prims = np.ascontiguousarray(prims)
+    n = len(prims)
+    cap = int(capacity or 2 * n + 64)
+    out = np.zeros(cap, dtype=st.PRIMITIVE)
+    orig = np.zeros(cap, dtype=np.int32)
+    nodes = np.zeros(max(1, 2 * cap), dtype=st.BVH_NODE)
+    box = np.zeros(6, dtype=np.float32)
+    nn, npr = C.c_int32(0), C.c_int32(0)
+    check(lib.gpt_sbvh_build(st.ptr(prims), n, float(alpha), st.ptr(out), cap, C.byref(npr), st.ptr(orig), st.ptr(nodes), len(nodes), C.byref(nn), st.ptr(box)))
+    return out[: npr.value].copy(), nodes[: nn.value].copy(), box, orig[: npr.value].copy()
+
+
 def light_distribution(lights, infinite=None):
     lib = load()
     cdf = np.zeros(len(lights) + 2, dtype=np.float32)
@@ -149,10 +166,10 @@ def camera_init(position, lookat, up=(0, 1, 0), res=(512, 512), fov=60.0, apertu
 class LoadedScene:
     """gpt_scene_load: LoadScene + InitScene of the reference (src/parsescene.cpp:45, src/main.cpp:261-278)."""
 
-    def __init__(self, json_path, use_bvh_cache=False):
+    def __init__(self, json_path, use_bvh_cache=False, sbvh=False):
         self.lib = load()
         self.handle = C.c_void_p()
-        check(self.lib.gpt_scene_load_cached(os.fsencode(json_path), int(bool(use_bvh_cache)), C.byref(self.handle)))
+        check(self.lib.gpt_scene_load_ex(os.fsencode(json_path), (1 if use_bvh_cache else 0) | (2 if sbvh else 0), C.byref(self.handle)))
         self.desc = st.SceneDesc()
         check(self.lib.gpt_scene_get_desc(self.handle, C.byref(self.desc)))
         w, h, eps = C.c_int32(), C.c_int32(), C.c_float()

@@ -58,6 +58,9 @@ public:
     // reads <scene dir>/bvh.cache when it matches the primitives, else builds and writes it (src/bvh.cpp:189-218)
     void LoadOrBuildBVH(std::vector<Primitive> &primitives, std::string file);
     void Build(std::vector<Primitive> &primitives);
+    // gpt_sbvh_build instead (spatial splits; not in the reference, whose src/sbvh.h is empty)
+    void BuildSplit(std::vector<Primitive> &primitives, float alpha = 1e-5f);
+    std::vector<int> prim_origin;       // BuildSplit: input index of every (possibly duplicated) primitive
 };
 
 enum IntegratorType { IT_AO = 0, IT_PT, IT_VPT, IT_LT, IT_BDPT, IT_MLT, IT_SPPM, IT_IR };   // src/scene.h:15-24
@@ -86,6 +89,7 @@ public:
         int photonsPerIteration = 0;
     } integrator;
     bool use_bvh_cache = false;          // the reference always uses <scene dir>/bvh.cache; opt-in here
+    bool use_sbvh = false;               // GPT_LOAD_SBVH: spatial-split tree instead of the reference's builder
 
     Scene();
     void Init(Camera *cam, std::string file);

@@ -67,11 +67,17 @@ int gpt_scene_load(const char *json_path, gpt_scene **out) { return gpt_scene_lo
 
 int gpt_scene_load_cached(const char *json_path, int use_bvh_cache, gpt_scene **out)
 {
+    return gpt_scene_load_ex(json_path, use_bvh_cache ? GPT_LOAD_BVH_CACHE : 0, out);
+}
+
+int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out)
+{
     if (!json_path || !out) { gpt_set_error("gpt_scene_load: null argument"); return GPT_ERR_INVALID_ARG; }
     *out = nullptr;
     gpt_scene *s = new gpt_scene();
     // the reference always reads/writes <scene dir>/bvh.cache (src/bvh.cpp:189-218); here it is opt-in
-    s->scene.use_bvh_cache = use_bvh_cache != 0;
+    s->scene.use_bvh_cache = (flags & GPT_LOAD_BVH_CACHE) != 0;
+    s->scene.use_sbvh = (flags & GPT_LOAD_SBVH) != 0;
     if (!LoadScene(json_path, s->config, s->scene)) {
         delete s;
         return std::strstr(gpt_last_error(), "Parse scene error") ? GPT_ERR_PARSE : GPT_ERR_IO;

@@ -571,6 +571,34 @@ void BVH::Build(std::vector<Primitive> &primitives)
     primitives.clear();   // bvh.cpp:30
 }
 
+void BVH::BuildSplit(std::vector<Primitive> &primitives, float alpha)
+{
+    delete[] linear_root;
+    linear_root = nullptr;
+    total_nodes = 0;
+    const int n = (int)primitives.size();
+    prims.clear();
+    prim_origin.clear();
+    if (n == 0) return;
+    const int cap = 2 * n + 64;
+    prims.assign((size_t)cap, Primitive());
+    prim_origin.assign((size_t)cap, 0);
+    linear_root = new LinearBVHNode[(size_t)2 * cap];
+    float box[6];
+    int32_t nn = 0, np = 0;
+    if (gpt_sbvh_build(primitives.data(), n, alpha, prims.data(), cap, &np, prim_origin.data(), linear_root, 2 * cap, &nn, box) != GPT_OK) {
+        prims.clear();
+        prim_origin.clear();
+        return;
+    }
+    prims.resize((size_t)np);
+    prim_origin.resize((size_t)np);
+    total_nodes = nn;
+    root_box.fmin = gpt_float3{box[0], box[1], box[2]};
+    root_box.fmax = gpt_float3{box[3], box[4], box[5]};
+    primitives.clear();
+}
+
 // bvh.cache: int total_nodes, int nprims, float[3] min, float[3] max, Primitive[nprims], LinearBVHNode[total_nodes]
 // (src/bvh.cpp:189-218), followed here by an 8-byte FNV-1a hash of the INPUT primitives.  The reference keys
 // the cache by directory only and silently reuses a stale one; here a cache is used only when the primitive
@@ -635,7 +663,8 @@ Scene::Scene()
 void Scene::Init(Camera *cam, std::string file)   // scene.h:50-83
 {
     camera = cam;
-    if (use_bvh_cache) bvh.LoadOrBuildBVH(primitives, file);
+    if (use_sbvh) bvh.BuildSplit(primitives);
+    else if (use_bvh_cache) bvh.LoadOrBuildBVH(primitives, file);
     else bvh.Build(primitives);
     std::printf("Bvh total nodes:%d\n", bvh.total_nodes);
     std::printf("Scene Bounds [%.3f, %.3f, %.3f]-[%.3f, %.3f, %.3f]\n", bvh.root_box.fmin.x, bvh.root_box.fmin.y,

@@ -198,6 +198,16 @@ int gpt_debug_rng(int device, uint32_t pixel, uint32_t iter, uint32_t *seed_out,
 int gpt_bvh_build(const gpt_primitive *prims_in, int32_t n, gpt_primitive *prims_out,
                   gpt_bvh_node *nodes_out, int32_t *n_nodes_out, float root_box6[6]);
 
+/* The split BVH north_star names (src/sbvh.h is an empty class in the reference; Stich et al., HPG 2009): object splits like the
+ * builder above + spatial splits that DUPLICATE the primitives straddling the plane, in the same tree layout, so every
+ * traversal (reference order, near-first, 4-wide) and gpt_begin take it as they take the reference's tree.
+ * alpha: a spatial split is considered when the object split's children overlap by more than alpha x the root's surface area
+ * (the paper's 1e-5).  prims_out / orig_out hold prims_cap records (n .. 2n in practice; duplication stops when the capacity is
+ * used), orig_out[i] = input index of prims_out[i]; nodes_out holds nodes_cap (2 * prims_cap suffices). */
+int gpt_sbvh_build(const gpt_primitive *prims_in, int32_t n, float alpha, gpt_primitive *prims_out, int32_t prims_cap,
+                   int32_t *n_prims_out, int32_t *orig_out, gpt_bvh_node *nodes_out, int32_t nodes_cap, int32_t *n_nodes_out,
+                   float root_box6[6]);
+
 /* Scene::Init light power CDF (src/scene.h:65-82); cdf_out holds n_lights+2 floats */
 int gpt_light_distribution(const gpt_area *lights, int32_t n_lights, const gpt_infinite *infinite,
                            float *cdf_out, int32_t *n_out);
@@ -216,6 +226,11 @@ int gpt_scene_load(const char *json_path, gpt_scene **out);
 /* ... with BVH::LoadOrBuildBVH's cache file <scene dir>/bvh.cache (src/bvh.cpp:189-218) when use_bvh_cache != 0.  The
  * reference always uses it and silently reuses a stale one; here it is opt-in and carries a content hash. */
 int gpt_scene_load_cached(const char *json_path, int use_bvh_cache, gpt_scene **out);
+/* ... with flags: GPT_LOAD_BVH_CACHE as above; GPT_LOAD_SBVH builds the tree with gpt_sbvh_build (alpha 1e-5, at most 2x the
+ * primitives) instead of the reference's builder: same scene, same films up to exactly-equal-distance ties, fewer node visits. */
+#define GPT_LOAD_BVH_CACHE 1
+#define GPT_LOAD_SBVH 2
+int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out);
 int gpt_scene_get_desc(const gpt_scene *scene, gpt_scene_desc *desc_out);
 int gpt_scene_get_config(const gpt_scene *scene, int32_t *width, int32_t *height, float *epsilon,
                          gpt_camera *camera_out);

@@ -35,3 +35,11 @@ def gpt():
     from gpu_pathtracer_amd import api
     api.load()
     return api
+
+
+@pytest.fixture(scope="session")
+def gpt_host():
+    """The same library for its host-side entry points (scene preparation: no GPU needed)."""
+    from gpu_pathtracer_amd import api
+    api.load()
+    return api

@@ -1,0 +1,197 @@
+"""gpt_sbvh_build (csrc/sbvh_build.cpp): the split BVH north_star names - object splits + spatial splits with duplicated
+references - in the reference's tree layout.  The reference has no such builder (src/sbvh.h is an empty class), so what is
+checked is (1) the structure's invariants, (2) that every traversal gives the SAME hits on it as on the reference's tree
+(the oracle walks both), (3) that spatial splits pay where they should, and, on the GPU, (4) kernel == oracle bit for bit on the
+split tree in both traversal orders and the film against the reference tree's within north_star's tolerance."""
+import ctypes as C
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+import standins
+from gpu_pathtracer_amd import scene_types as st
+
+RMS_TOL = 1e-4
+
+
+def sticks(n, seed=7, length=1.2, width=0.01, mat=2):
+    """long thin triangles in random directions: the geometry object splits cannot separate"""
+    rng = np.random.default_rng(seed)
+    out = np.zeros(n, dtype=st.PRIMITIVE)
+    for i in range(n):
+        c = rng.uniform((-0.8, 0.2, -0.8), (0.8, 1.8, 0.8))
+        d = rng.standard_normal(3)
+        d /= np.linalg.norm(d)
+        s = np.cross(d, rng.standard_normal(3))
+        s /= np.linalg.norm(s)
+        a, b, e = c - d * length / 2, c + d * length / 2, c + s * width
+        nrm = np.cross(b - a, e - a)
+        nrm /= np.linalg.norm(nrm)
+        out[i] = scenes.make_tri(np.float32(a), np.float32(b), np.float32(e), nrm, nrm, nrm, mat=mat)
+    return out
+
+
+def sticks_scene(n_sticks=1500, n_soup=3000, max_depth=5):
+    prims, _, meta = scenes.cornell_raw()
+    allp = scenes.concat([prims, sticks(n_sticks), scenes.random_soup(n_soup, 3, size=0.03)])
+    scene = ol.make_scene(allp, scenes.material_table(), light_radiance=meta["light_radiance"], max_depth=max_depth,
+                          textures=[scenes.checker_texture()])
+    return scene, meta
+
+
+def with_tree(scene, prims, nodes):
+    """the same scene description on another tree (the arrays are kept alive by the returned object)"""
+    class Other:
+        pass
+    o = Other()
+    o.prims, o.nodes = np.ascontiguousarray(prims), np.ascontiguousarray(nodes)
+    o.desc = st.SceneDesc()
+    C.memmove(C.byref(o.desc), C.byref(scene.desc), C.sizeof(o.desc))
+    o.desc.prims, o.desc.n_prims = st.ptr(o.prims), len(o.prims)
+    o.desc.nodes, o.desc.n_nodes = st.ptr(o.nodes), len(o.nodes)
+    o.keep = scene
+    return o
+
+
+def boxes(nodes):
+    lo = np.stack([nodes["fmin"]["x"], nodes["fmin"]["y"], nodes["fmin"]["z"]], -1)
+    hi = np.stack([nodes["fmax"]["x"], nodes["fmax"]["y"], nodes["fmax"]["z"]], -1)
+    return lo, hi
+
+
+def tri_vertices(prims):
+    t = prims["triangle"]
+    return np.stack([np.stack([t[v]["v"]["x"], t[v]["v"]["y"], t[v]["v"]["z"]], -1) for v in ("v1", "v2", "v3")], 1)
+
+
+def test_split_tree_invariants(gpt_host):
+    """preorder layout, child boxes inside their parent's, every leaf of <= 4 primitives, every input primitive present, a
+    duplicate is a bit-for-bit copy, and every primitive of a leaf actually reaches into the leaf's box"""
+    scene, _ = sticks_scene()
+    prims = scene.prims
+    out, nodes, box, orig = gpt_host.sbvh_build(prims, 1e-5)
+    n = len(prims)
+    assert n < len(out) <= 2 * n + 64 and len(orig) == len(out)
+    assert set(orig.tolist()) == set(range(n))
+    assert out.tobytes() == prims[orig].tobytes()
+    lo, hi = boxes(nodes)
+    leaf = nodes["is_leaf"] != 0
+    inner = np.nonzero(~leaf)[0]
+    right = nodes["second_child_offset"][inner]
+    assert (right > inner + 1).all() and (right < len(nodes)).all()
+    for child in (inner + 1, right):
+        assert (lo[child] >= lo[inner]).all() and (hi[child] <= hi[inner]).all()
+    start, end = nodes["start"][leaf], nodes["end"][leaf]
+    assert (start >= 0).all() and (end - start + 1 <= 4).all()
+    # leaves tile the output array in preorder
+    assert start[0] == 0 and (start[1:] == end[:-1] + 1).all() and end[-1] == len(out) - 1
+    v = tri_vertices(out)
+    tlo, thi = v.min(1), v.max(1)
+    li = np.nonzero(leaf)[0]
+    for k in range(len(li)):
+        s, e = start[k], end[k] + 1
+        assert (tlo[s:e] <= hi[li[k]] + 1e-6).all() and (thi[s:e] >= lo[li[k]] - 1e-6).all()
+    assert np.allclose(box, np.concatenate([tlo.min(0), thi.max(0)]))
+    # no spatial split wanted: the object-split tree, no duplicates
+    out1, nodes1, _, orig1 = gpt_host.sbvh_build(prims, 1.0)
+    assert len(out1) == n and sorted(orig1.tolist()) == list(range(n))
+    # capacity: duplication stops at the capacity it is given
+    out2, _, _, _ = gpt_host.sbvh_build(prims, 1e-5, capacity=n + 100)
+    assert n <= len(out2) <= n + 100
+    lib = gpt_host.load()
+    assert lib.gpt_sbvh_build(None, 3, C.c_float(1e-5), None, 3, C.byref(C.c_int32()), None, None, 6, C.byref(C.c_int32()), None) < 0
+    assert b"gpt_sbvh_build" in lib.gpt_last_error()
+
+
+def test_every_traversal_finds_the_same_hits_on_the_split_tree(gpt_host):
+    """60 000 rays (edge cases of tests/test_gpu_parity.py included) through the reference's tree and through the split tree, in
+    the reference order and on the 4-wide collapse: blocked / not blocked identical for any-hit rays, and the closest hit the
+    same TRIANGLE at the same (t, b1, b2), bit for bit - a duplicated reference is a copy - while the split tree needs far fewer
+    node visits (spatial splits pay on this geometry: >= 35 % fewer than its own object splits alone)."""
+    from test_gpu_parity import operator_rays
+    scene, meta = sticks_scene()
+    rays = operator_rays(60_000, 23)
+    proper = ~np.isnan(rays).any(axis=1) & (np.abs(rays[:, 3:6]).sum(axis=1) > 0)
+    rays = rays[proper]
+    out, nodes, _, orig = gpt_host.sbvh_build(scene.prims, 1e-5)
+    split = with_tree(scene, out, nodes)
+    out1, nodes1, _, orig1 = gpt_host.sbvh_build(scene.prims, 1.0)
+    nosplit = with_tree(scene, out1, nodes1)
+    # Two kinds of rays may legitimately differ between two trees over the same triangles, and are left out / counted:
+    #  - an axis-aligned ray whose origin lies exactly ON a box plane has 0 * inf = NaN in the reference's slab test
+    #    (bbox.h:77-96), and which planes exist depends on the tree;
+    #  - two DIFFERENT triangles hit at exactly the same distance (coplanar, overlapping): the later primitive wins, and the
+    #    primitive order is the tree's.  The distance itself is the same.
+    generic = ~(np.abs(rays[:, 3:6]) == 1).any(axis=1)
+    closest = (rays[:, 7] == 0) & generic
+    for order in (0, 2):
+        p_ref, t_ref = ol.trace_rays(scene, 0.001, rays, order)
+        p_new, t_new = ol.trace_rays(split, 0.001, rays, order)
+        assert np.array_equal((p_ref >= 0)[generic], (p_new >= 0)[generic])
+        hit = closest & (p_ref >= 0)
+        assert hit.sum() > 10_000
+        assert t_ref[hit, 0].tobytes() == t_new[hit, 0].tobytes()
+        same = (tri_vertices(scene.prims[p_ref[hit]]) == tri_vertices(out[p_new[hit]])).all(axis=(1, 2))
+        assert same.mean() > 0.999
+        assert t_ref[hit][same].tobytes() == t_new[hit][same].tobytes()
+    W = 96
+    cam = ol.cornell_camera(meta, W, W)
+    lib = ol.load("soft")
+    visits = {}
+    for name, sc in (("reference", scene), ("object", nosplit), ("split", split)):
+        acc, _ = ol.render(sc, cam, W, W, 0.001, 1, 2, kind="soft")
+        c = ol.counters("soft")
+        visits[name] = (c["node_visits"] / c["samples"], acc.copy())
+    assert visits["split"][0] < 0.65 * visits["object"][0], {k: v[0] for k, v in visits.items()}
+    assert visits["object"][0] < 1.1 * visits["reference"][0]
+    a, b = visits["split"][1].reshape(-1, 3).astype(np.float64), visits["reference"][1].reshape(-1, 3).astype(np.float64)
+    assert (np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0)) <= RMS_TOL).all()
+
+
+def test_loader_flag_builds_the_split_tree(gpt_host):
+    """GPT_LOAD_SBVH through gpt_scene_load_ex on the config-3 stand-in: the same scene on the other tree; here the gain is the
+    reference's rule that a box thinner than 1e-4 is ONE leaf (bvh.cpp:43: the floor, the cube's faces), which this builder does
+    not have - a thirtieth of the triangle tests - and the oracle's film is the reference tree's."""
+    path = standins.write_standin_scene(tempfile.mkdtemp(), "c3")
+    ref = gpt_host.LoadedScene(path)
+    new = gpt_host.LoadedScene(path, sbvh=True)
+    assert new.desc.n_prims >= ref.desc.n_prims and new.desc.n_materials == ref.desc.n_materials and new.desc.n_lights == ref.desc.n_lights
+    W, H = 96, 54
+    res = {}
+    for name, sc in (("ref", ref), ("new", new)):
+        cam = ol.make_camera((-0.3, 0.5, -0.5), (0.0, 0.075, 0.0), (0, 1, 0), (W, H), 37.0)          # the stand-in's camera at this size
+        acc, _ = ol.render(sc, cam, W, H, ref.epsilon, 1, 2, kind="soft")
+        c = ol.counters("soft")
+        res[name] = (acc.copy(), c["prim_tests"] / c["samples"])
+    assert res["new"][1] < 0.1 * res["ref"][1]
+    a, b = res["new"][0].reshape(-1, 3).astype(np.float64), res["ref"][0].reshape(-1, 3).astype(np.float64)
+    assert (np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0)) <= RMS_TOL).all()
+
+
+@pytest.mark.gpu
+def test_kernel_on_the_split_tree(gpt):
+    """the render kernel on the split tree (global-memory binary loop and the 4-wide walk): bit-identical to the oracle on the
+    same tree, and within north_star's tolerance of the film on the reference's tree"""
+    scene, meta = sticks_scene(n_sticks=800, n_soup=1500, max_depth=6)
+    out, nodes, _, orig = gpt.sbvh_build(scene.prims, 1e-5)
+    split = with_tree(scene, out, nodes)
+    W, H, spp = 160, 128, 4
+    cam = ol.cornell_camera(meta, W, H)
+    lib = ol.load("soft")
+    base, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
+    with gpt.Renderer(split.desc, W, H, 0.001) as r:
+        for order, name in ((0, "reference"), (2, "wide")):
+            assert lib.oracle_set_traversal(order) == 0
+            try:
+                want, _ = ol.render(split, cam, W, H, 0.001, 1, spp, kind="soft")
+            finally:
+                lib.oracle_set_traversal(0)
+            r.set_traversal_order(name)
+            r.render(cam, 1, spp, reset=True)
+            got = r.read_accum()
+            assert got.tobytes() == want.tobytes(), f"split tree, {name} order: {np.count_nonzero(got != want)} floats differ"
+            a, b = got.reshape(-1, 3).astype(np.float64), base.reshape(-1, 3).astype(np.float64)
+            assert (np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0)) <= RMS_TOL).all()
