@@ -463,7 +463,10 @@ constexpr int kWideSpillStride = GPT_WIDE_STACK_MAX + 8;
 #ifndef PT_WIDE_STOP_T
 #define PT_WIDE_STOP_T 24                                         // a dry pool with at most this many rays in flight ends the drain
 #endif
-static_assert(PT_WIDE_STOP_T < 64 - PT_WIDE_FETCH_T, "a resumed drain starts with a refill");
+#ifndef PT_WIDE_STOP_T_SMALL
+#define PT_WIDE_STOP_T_SMALL 12                                   // ... trees of fewer than 64k binary nodes
+#endif
+static_assert(PT_WIDE_STOP_T < 64 - PT_WIDE_FETCH_T && PT_WIDE_STOP_T_SMALL < 64 - PT_WIDE_FETCH_T, "a resumed drain starts with a refill");
 // A block of a trip costs the wave the same whether one lane or sixty-four take part.  Lanes at a leaf wait until
 // PT_WIDE_LEAF_MIN of them have gathered (or no lane is at a wide node), and the other way round with PT_WIDE_NODE_MIN.
 #ifndef PT_WIDE_LEAF_MIN
@@ -844,6 +847,37 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_branch TP_DIV_DONE2_%=\n" \
         "TP_T2X_%=:\n"
 
+// PT_LOOP_PROBE (probe builds): the binary loops count, per drain, their node / triangle trips, the lanes active in them, the
+// lanes that hold a ray at each trip, and the same for the trips after the pool ran dry (the drain's tail); the sums go to a
+// per-wave LDS record {node trips, node lanes, triangle trips, triangle lanes, busy lanes, dry trips, busy lanes in dry trips}.
+#ifndef PT_LOOP_PROBE
+#define PT_LOOP_PROBE 0
+#endif
+#if PT_LOOP_PROBE
+#define PT_PROBE_INIT "s_mov_b32 s78, 0\n" "s_mov_b32 s79, 0\n" "s_mov_b32 s80, 0\n" "s_mov_b32 s81, 0\n" "s_mov_b32 s82, 0\n" "s_mov_b32 s83, 0\n" "s_mov_b32 s84, 0\n"
+#define PT_PROBE_COMMON \
+        "s_bcnt1_i32_b64 s73, s[64:65]\n" "s_add_u32 s82, s82, s73\n" "s_cmp_ge_i32 s70, %[rays]\n" "s_cbranch_scc0 TP_PRB_%=\n" \
+        "s_add_u32 s83, s83, 1\n" "s_add_u32 s84, s84, s73\n"
+#define PT_PROBE_NODE PT_PROBE_COMMON "TP_PRB_%=:\n" "s_add_u32 s78, s78, 1\n" "s_bcnt1_i32_b64 s73, exec\n" "s_add_u32 s79, s79, s73\n"
+#define PT_PROBE_TRI "s_bcnt1_i32_b64 s73, s[64:65]\n" "s_add_u32 s82, s82, s73\n" "s_cmp_ge_i32 s70, %[rays]\n" "s_cbranch_scc0 TP_PRT_%=\n" \
+        "s_add_u32 s83, s83, 1\n" "s_add_u32 s84, s84, s73\n" "TP_PRT_%=:\n" "s_add_u32 s80, s80, 1\n" "s_bcnt1_i32_b64 s73, exec\n" "s_add_u32 s81, s81, s73\n"
+#define PT_PROBE_EXIT \
+        "s_mov_b64 exec, 1\n" "v_mov_b32_e32 v33, %[probe]\n" \
+        "v_mov_b32_e32 v34, s78\n" "ds_add_u32 v33, v34\n" "v_mov_b32_e32 v34, s79\n" "ds_add_u32 v33, v34 offset:4\n" \
+        "v_mov_b32_e32 v34, s80\n" "ds_add_u32 v33, v34 offset:8\n" "v_mov_b32_e32 v34, s81\n" "ds_add_u32 v33, v34 offset:12\n" \
+        "v_mov_b32_e32 v34, s82\n" "ds_add_u32 v33, v34 offset:16\n" "v_mov_b32_e32 v34, s83\n" "ds_add_u32 v33, v34 offset:20\n" \
+        "v_mov_b32_e32 v34, s84\n" "ds_add_u32 v33, v34 offset:24\n" "s_mov_b64 exec, -1\n"
+#define PT_PROBE_CLOBBERS "s73", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+#define PT_PROBE_OPERAND , [probe] "s"(s_probe)
+#else
+#define PT_PROBE_INIT
+#define PT_PROBE_NODE
+#define PT_PROBE_TRI
+#define PT_PROBE_EXIT
+#define PT_PROBE_CLOBBERS
+#define PT_PROBE_OPERAND
+#endif
+
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
 #define PT_TRACE_ASM(LD_NODE, NODE_W1, NODE_W0, NODE2, TRI2, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
@@ -852,6 +886,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_mov_b32 s76, 0x322bcc77\n" \
         "s_mov_b32 s77, 0x71800000\n" \
         "s_mov_b64 s[64:65], 0\n" \
+        PT_PROBE_INIT \
         ENTRY_STATE \
         "s_branch TP_FILL_%=\n" \
         PT_LOOP_ALIGN \
@@ -870,6 +905,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_cmp_ge_u32 s71, s72\n" \
         "s_cbranch_scc0 TP_TRI_%=\n" \
         "s_mov_b64 exec, s[62:63]\n" \
+        PT_PROBE_NODE \
         LD_NODE \
         NODE_W1 \
         "v_sub_f32_e32 v33, v24, v0\n" \
@@ -909,6 +945,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_branch TP_LOOP_%=\n" \
         "TP_TRI_%=:\n" \
         "s_mov_b64 exec, s[60:61]\n" \
+        PT_PROBE_TRI \
         LD_TRI \
         "v_add_u32_e32 v13, 48, v13\n" \
         WAIT_1 \
@@ -1058,17 +1095,18 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         DRY_POOL \
         "TP_DONE_%=:\n" \
         EXIT_EXTRA \
+        PT_PROBE_EXIT \
         "s_waitcnt lgkmcnt(0)\n" \
         "s_mov_b64 exec, -1\n" \
         : \
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias), \
-          [eps] "s"(s_eps), __VA_ARGS__, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
+          [eps] "s"(s_eps), __VA_ARGS__ PT_PROBE_OPERAND, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", \
-          "s72", "s76", "s77", MORE_CLOBBERS "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
+          "s72", "s76", "s77", PT_PROBE_CLOBBERS MORE_CLOBBERS "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
           "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
           "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
 
-__device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps)
+__device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps, unsigned loop_probe_lds = 0)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
@@ -1076,6 +1114,8 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
     const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
+    const unsigned s_probe = __builtin_amdgcn_readfirstlane(loop_probe_lds);
+    (void)s_probe;
     PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "", "",
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
@@ -1085,7 +1125,7 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
 
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
 // 32-bit VGPR-offset form.  (vmcnt also counts this wave's earlier sample stores; they are long gone.)
-__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop)
+__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop, unsigned loop_probe_lds = 0)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
@@ -1097,6 +1137,8 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
     const int s_tstop = __builtin_amdgcn_readfirstlane(mem.end - mem.first >= 65536 * 32 ? PT_STOP_T : PT_STOP_T_SMALL);
+    const unsigned s_probe = __builtin_amdgcn_readfirstlane(loop_probe_lds);
+    (void)s_probe;
 #if PT_NODE_LOOKAHEAD
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
                  "global_load_dwordx4 v[44:47], v12, %[nodes] offset:32\n" "global_load_dwordx4 v[48:51], v12, %[nodes] offset:48\n",
@@ -1181,6 +1223,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
     const unsigned s_stack = s_pool + kWideStackOff * 16 - 768;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
+    // expensive materials want fewer, fuller shading rounds; long rays in deep trees shorter tails (as in trace_pool_global_asm)
+    const int s_tstop = __builtin_amdgcn_readfirstlane(P.n_nodes >= 65536 ? PT_WIDE_STOP_T : PT_WIDE_STOP_T_SMALL);
     // this lane's column of the wave's spill slice, in bytes (level l at + 256 l)
     const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)(64 * kWideSpillStride) + lane) * 4u;
     asm volatile(
@@ -1687,7 +1731,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
 #endif
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [tris] "s"(s_tris), [spill] "s"(s_spill),
           [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [susp] "s"(s_susp), [allow] "s"(s_allow), [vspill] "v"(v_spill),
-          [tstop] "n"(PT_WIDE_STOP_T), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
+          [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
@@ -2512,7 +2556,14 @@ template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
 __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES)) pt_render_kernel(const DevParams P_in)
 {
     static_assert(!(WIDE && SMALL), "the wide tree is walked from global memory");
-    __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 : 1];
+    __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 - (PT_LOOP_PROBE ? 8 : 0) : 1];
+#if PT_LOOP_PROBE
+    __shared__ unsigned lds_loop_probe[4 * 8];
+    if ((threadIdx.x & 63u) < 8u) lds_loop_probe[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63u)] = 0u;
+    const unsigned loop_probe = lds_address(lds_loop_probe + (threadIdx.x >> 6) * 8);
+#else
+    const unsigned loop_probe = 0u;
+#endif
     DevParams P = P_in;
     if (SMALL) {
         // layout: nodes | triangles | shading records | lights | materials (all 16-byte multiples except the
@@ -3550,7 +3601,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 if (COUNT && !PT_ASM_IN_COUNT)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool<COUNT, false>(P, pool, L.n_rays, cnt, mem);
                 else
-                    trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
+                    trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps, loop_probe);
             } else if (WIDE) {
                 if ((COUNT && !PT_ASM_IN_COUNT) || !PT_WIDE_ASM)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
@@ -3567,7 +3618,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 if (COUNT && !PT_ASM_IN_COUNT)      // (the twin always drains to the end: nothing is ever suspended)
                     trace_pool<COUNT, true>(P, pool, n_new, cnt, mem);
                 else
-                    trace_pool_global_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0);
+                    trace_pool_global_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0, loop_probe);
             }
             if (COUNT) {
                 cyc_mark = __builtin_readcyclecounter();
@@ -3600,6 +3651,19 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         }
     }
 
+#if PT_LOOP_PROBE
+    if (!WIDE && !COUNT && lane == 0) {       // probe builds: what the hand-scheduled binary loop counted (per wave)
+        wave_lds_fence();
+        const unsigned *pr = lds_loop_probe + (threadIdx.x >> 6) * 8;
+        atomicAdd(&P.counters[6], (unsigned long long)pr[0]);      // node trips
+        atomicAdd(&P.counters[0], (unsigned long long)pr[1]);      // lanes in them
+        atomicAdd(&P.counters[7], (unsigned long long)pr[2]);      // triangle trips
+        atomicAdd(&P.counters[1], (unsigned long long)pr[3]);      // lanes in them
+        atomicAdd(&P.counters[9], (unsigned long long)pr[4]);      // lanes holding a ray, summed over the trips
+        atomicAdd(&P.counters[8], (unsigned long long)pr[5]);      // trips after the pool ran dry
+        atomicAdd(&P.counters[13], (unsigned long long)pr[6]);     // lanes holding a ray in those
+    }
+#endif
 #if PT_WIDE_PROBE
     if (WIDE && !COUNT && lane == 0) {      // probe builds: what the hand-scheduled wide loop counted (per wave)
         atomicAdd(&P.counters[0], (unsigned long long)wprobe.nlanes);
