@@ -67,7 +67,7 @@ while time.time() < t_end:
     else:
         cam = ol.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.2, 2.5)), float(rng.uniform(3, 8))), (0, 1, 0), (0, 1, 0), (W, H), float(rng.uniform(15, 70)))
     ao = bool(rng.random() < 0.2) and not vpt
-    order = int(rng.choice([0, 0, 1, 2, 2]))            # reference / nearer child first / 4-wide tree, four lanes per ray
+    order = int(rng.choice([0, 0, 1, 2, 2]))            # reference / nearer child first / 4-wide tree, one lane per ray
     near = order
     force_global = bool(rng.random() < 0.4)
     eps = float(rng.choice([0.001, 0.0005, 0.01]))
