@@ -453,10 +453,14 @@ __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int
 // The stack: kWideStackDepth entries per lane in LDS, level-major (level l of lane i at word 64 l + i: conflict-free for any
 // mix of levels); deeper entries go to the wave's slice of P.wide_stack in global memory, in the same arrangement
 // (3 * depth + 1 <= GPT_WIDE_STACK_MAX is checked by the host).
-constexpr int kWideStackDepth = 12;
-constexpr int kWideStackOff = kWaveCarryFloat4;                   // after the carry layout's regions
-constexpr int kWaveWideFloat4 = kWaveCarryFloat4 + 16 * kWideStackDepth;      // one level of 64 lanes = 16 float4
-constexpr int kWideSpillStride = GPT_WIDE_STACK_MAX + 8;
+#ifndef PT_WIDE_STACK_DEPTH
+#define PT_WIDE_STACK_DEPTH 9
+#endif
+constexpr int kWideStackDepth = PT_WIDE_STACK_DEPTH;
+constexpr int kWideStackOff = kSuspOff;                           // where the binary loops keep their suspend records: the wide walk's
+                                                                  // are in the wave's slice of P.wide_stack (read and written once per drain)
+constexpr int kWaveWideFloat4 = kSuspOff + 16 * kWideStackDepth;  // one level of 64 lanes = 16 float4; 9 levels: 10 112 B per wave, four workgroups per CU
+constexpr int kWideSpillStride = kWideSpillLevels;
 #ifndef PT_WIDE_FETCH_T
 #define PT_WIDE_FETCH_T 12                                        // idle lanes that trigger a refill
 #endif
@@ -489,7 +493,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
 {
     const unsigned lane = threadIdx.x & 63u;
     unsigned *stk = reinterpret_cast<unsigned *>(pool + kWideStackOff) + lane;
-    volatile unsigned *spill = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (64u * kWideSpillStride) + lane;
+    volatile unsigned *spill = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords + lane;
     const char *wnodes = reinterpret_cast<const char *>(P.wide);
     const char *tris = reinterpret_cast<const char *>(P.tris);
     const float tmin_ray = P.eps;
@@ -1192,6 +1196,15 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 #ifndef PT_WIDE_ASM
 #define PT_WIDE_ASM 1
 #endif
+// a lane's suspend record lives in the wave's slice of P.wide_stack (the hand-scheduled loop reads it when a drain starts and
+// writes it when the drain ends, both with sc0 sc1: the same wave reads what it wrote, past its L1); "no ray" at kernel start
+__device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, unsigned lane)
+{
+    volatile unsigned *rec = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords + 64u * (unsigned)kWideSpillStride + 8u * lane;
+    rec[0] = 0xffffffffu; rec[1] = 0u; rec[2] = 0u; rec[3] = 0xffffffffu;
+    rec[4] = 0xffffffffu; rec[5] = 0u; rec[6] = 0u; rec[7] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
 #ifndef PT_WIDE_EARLY
 #define PT_WIDE_EARLY 0          // (measured: -5 %, the extra vector-memory instructions cost more than the overlap gains) a lane that descends into a wide node fetches that record before the trip's triangle block
 #endif
@@ -1220,13 +1233,15 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
     const unsigned long long s_nodes = uniform64((unsigned long long)P.wide), s_tris = uniform64((unsigned long long)P.tris);
     const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
-    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16;
     const unsigned s_stack = s_pool + kWideStackOff * 16 - 768;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
     // expensive materials want fewer, fuller shading rounds; long rays in deep trees shorter tails (as in trace_pool_global_asm)
     const int s_tstop = __builtin_amdgcn_readfirstlane(P.n_nodes >= 65536 ? PT_WIDE_STOP_T : PT_WIDE_STOP_T_SMALL);
     // this lane's column of the wave's spill slice, in bytes (level l at + 256 l)
-    const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)(64 * kWideSpillStride) + lane) * 4u;
+    const unsigned wave_slice = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords;
+    const unsigned v_spill = (wave_slice + lane) * 4u;
+    const unsigned v_susp = (wave_slice + 64u * (unsigned)kWideSpillStride + 8u * lane) * 4u;      // this lane's suspend record
     asm volatile(
         "s_mov_b32 s70, 0\n"
         "s_mov_b32 s76, 0x322bcc77\n"
@@ -1236,13 +1251,13 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
         "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
         "v_lshl_add_u32 v18, v33, 2, %[stack]\n"
-        "v_lshl_add_u32 v17, v33, 5, %[susp]\n"
+        "v_mov_b32_e32 v17, %[vsusp]\n"
         "v_mov_b32_e32 v16, %[vspill]\n"
         /* every lane resumes the ray it was walking when the last drain stopped (its record: {entry, stack size, end of the
            interval, slot} {best hit}); direction and origin come back from the ray's slot */
-        "ds_read_b128 v[12:15], v17\n"
-        "ds_read_b128 v[20:23], v17 offset:16\n"
-        "s_waitcnt lgkmcnt(0)\n"
+        "global_load_dwordx4 v[12:15], v17, %[spill] sc0 sc1\n"
+        "global_load_dwordx4 v[20:23], v17, %[spill] offset:16 sc0 sc1\n"
+        "s_waitcnt vmcnt(0)\n"
         "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"
         "s_mov_b64 exec, s[64:65]\n"
         "ds_read_b128 v[4:7], v15\n"
@@ -1720,9 +1735,9 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cbranch_scc1 TW_TRIP_%=\n"
         "TW_DONE_%=:\n"
         "s_waitcnt vmcnt(0)\n"                             /* (an early fetch must not land after the registers have been handed back) */
-        "ds_write_b128 v17, v[12:15]\n"
-        "ds_write_b128 v17, v[20:23] offset:16\n"
-        "s_waitcnt lgkmcnt(0)\n"
+        "global_store_dwordx4 v17, v[12:15], %[spill] sc0 sc1\n"
+        "global_store_dwordx4 v17, v[20:23], %[spill] offset:16 sc0 sc1\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
 #if PT_WIDE_PROBE
         : [pr_trips] "+v"(pr.trips), [pr_nlanes] "+v"(pr.nlanes), [pr_tlanes] "+v"(pr.tlanes), [pr_nblk] "+v"(pr.nblk), [pr_tblk] "+v"(pr.tblk), [pr_busy] "+v"(pr.busy)
@@ -1730,7 +1745,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         :
 #endif
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [tris] "s"(s_tris), [spill] "s"(s_spill),
-          [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [susp] "s"(s_susp), [allow] "s"(s_allow), [vspill] "v"(v_spill),
+          [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [allow] "s"(s_allow), [vspill] "v"(v_spill), [vsusp] "v"(v_susp),
           [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
@@ -2549,7 +2564,7 @@ constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 #endif
 constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH;
 #ifndef PT_WIDE_WAVES
-#define PT_WIDE_WAVES 3                 // 168 registers and 52 KB of LDS per workgroup: the per-lane stacks and the 67-register loop fit without scratch
+#define PT_WIDE_WAVES 4
 #endif
 // WIDE: scenes in global memory walked on the 4-wide tree, one lane per ray (GPT_TRAVERSAL_WIDE4, trace_pool_wide<>)
 template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
@@ -2603,15 +2618,12 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     __shared__ float4 lds_pool[4 * kWaveFloat4];        // one private ray pool per wavefront
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
     const unsigned lane = threadIdx.x & 63u;
-    if (CARRY) {                                        // nothing pending, no suspended ray (an idle lane's cursors)
-        reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;
+    if (CARRY) reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;     // nothing pending
+    if (CARRY && !WIDE) {                               // no suspended ray (an idle lane's cursors)
         pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
-    if (WIDE) {                                         // trace_pool_wide_asm: a lane's record is {entry, stack size, interval end, slot} {best hit}: idle
-        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
-        pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-    }
+    if (WIDE) wide_init_suspend_record(P, lane);        // trace_pool_wide_asm: a lane's record {entry, stack size, interval end, slot} {best hit}: idle
     bool waiting = false;                               // carry: some of this path's rays are still being traced
     // Volpath: the medium the path ray travels in (-1 = none), the one the pending direct-light rays travel in, and
     // whether an occluded light sample poisons the sample (Tr = 0 times a non-finite factor is NaN, pathtracer.cu:1092,1150)
@@ -3793,15 +3805,12 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
     __shared__ float4 lds_pool[4 * kWaveFloat4];
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
     const unsigned lane = threadIdx.x & 63u;
-    if (CARRY) {
-        reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;
+    if (CARRY) reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;
+    if (CARRY && !WIDE) {
         pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
-    if (WIDE) {
-        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(-1), __int_as_float(0), 0.f, __int_as_float(-1));
-        pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-    }
+    if (WIDE) wide_init_suspend_record(P, lane);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)cnt;
     WideProbe wprobe = {0, 0, 0, 0, 0, 0};

@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include "../../include/gpt_types.h"
 #include "pt_vec.h"
+#include "../../include/gpt_wide_bvh.h"
 
 namespace pt {
 
@@ -59,6 +60,10 @@ struct alignas(16) DevWideNode {
     uint32_t pad[4];
 };
 static_assert(sizeof(DevWideNode) == 128, "DevWideNode");
+// A wave's slice of DevParams.wide_stack, in dwords: the overflow levels of its 64 per-lane stacks (level-major: level l of lane
+// i at 64 l + i) and, behind them, one 8-dword suspend record per lane (a ray that is still being walked when a drain stops)
+constexpr int kWideSpillLevels = GPT_WIDE_STACK_MAX + 8;
+constexpr int kWideWaveSliceDwords = 64 * kWideSpillLevels + 64 * 8;
 
 struct alignas(16) DevShade {
     float n1[3], n2[3], n3[3];   // vertex normals
@@ -150,7 +155,7 @@ struct DevParams {
     int32_t vpt_walk;                  // Volpath: density grids or material-less surfaces -> the one-ray-at-a-time kernel
     // GPT_TRAVERSAL_WIDE4 only (include/gpt_wide_bvh.h)
     const struct DevWideNode *wide;    // the 4-wide tree; node w at byte offset 128 * w
-    uint32_t *wide_stack;              // overflow of the per-ray LDS stacks: 64 * kWideSpillStride entries per wave of the widest grid
+    uint32_t *wide_stack;              // overflow of the per-ray LDS stacks and suspend records: kWideWaveSliceDwords per wave of the widest grid
     uint32_t wide_stack_blocks;        // workgroups that buffer was sized for (no wide kernel is launched with more)
 };
 

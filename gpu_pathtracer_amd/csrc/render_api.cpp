@@ -628,7 +628,7 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
                 for (int c = 0; c < 2; ++c) bpc = std::max(bpc, ctx->blocks_per_cu_wide[w][c]);
             const size_t blocks = (size_t)std::max(ctx->n_cus, 1) * (size_t)bpc;
             void *p = nullptr;
-            const size_t n = blocks * 4 * 64 * (GPT_WIDE_STACK_MAX + 8);
+            const size_t n = blocks * 4 * (size_t)kWideWaveSliceDwords;
             HIP_TRY(hipSetDevice(ctx->device));
             HIP_TRY(hipMalloc(&p, n * sizeof(uint32_t)));
             ctx->allocs.push_back(p);

@@ -7,9 +7,17 @@ import scenes
 from gpu_pathtracer_amd import api
 which = sys.argv[1] if len(sys.argv) > 1 else "c5"
 mode = sys.argv[2] if len(sys.argv) > 2 else "wide"
-ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which, 1920, 1080))
 W, H, spp = 1920, 1080, 8
+if which == "c2":
+    from gpu_pathtracer_amd import host
+    _scene, _meta = host.load_baked("tests/golden/cornell_pt.npz", 8)
+    class ls: pass
+    ls.desc, ls.camera, ls.epsilon = _scene.desc, host.camera_from_meta(_meta, W, H), 0.001
+else:
+    ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which, 1920, 1080))
 with api.Renderer(ls.desc, W, H, ls.epsilon) as r:
+    if which == "c2" and mode != "reference":
+        r.set_option("lds_scene", 0)
     r.set_traversal_order(mode)
     r.enable_counters(True)
     r.render(ls.camera, 1, 2, reset=True); r.synchronize(); r.kernel_time_reset()
