@@ -1224,7 +1224,12 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
 #else
 #define PT_WIDE_PROBE_TRIP
 #endif
-struct WideProbe { unsigned trips, nlanes, tlanes, nblk, tblk, busy; };
+#if PT_WIDE_PROBE
+#define PT_WIDE_PROBE_SLOW "v_add_u32_e32 %[pr_slow], 1, %[pr_slow]\n"
+#else
+#define PT_WIDE_PROBE_SLOW
+#endif
+struct WideProbe { unsigned trips, nlanes, tlanes, nblk, tblk, busy, slow; };
 
 __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop, WideProbe &pr)
 {
@@ -1635,6 +1640,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_branch TW_LOOP_%=\n"
         /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
         "TW_PUSH_SLOW_%=:\n"
+        PT_WIDE_PROBE_SLOW
         "v_add_u32_e32 v57, -3, v56\n"
         "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
         "s_and_b64 exec, s[72:73], vcc\n"
@@ -1740,7 +1746,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
 #if PT_WIDE_PROBE
-        : [pr_trips] "+v"(pr.trips), [pr_nlanes] "+v"(pr.nlanes), [pr_tlanes] "+v"(pr.tlanes), [pr_nblk] "+v"(pr.nblk), [pr_tblk] "+v"(pr.tblk), [pr_busy] "+v"(pr.busy)
+        : [pr_trips] "+v"(pr.trips), [pr_nlanes] "+v"(pr.nlanes), [pr_tlanes] "+v"(pr.tlanes), [pr_nblk] "+v"(pr.nblk), [pr_tblk] "+v"(pr.tblk), [pr_busy] "+v"(pr.busy), [pr_slow] "+v"(pr.slow)
 #else
         :
 #endif
@@ -2631,7 +2637,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     bool poison_occluded = false;
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    WideProbe wprobe = {0, 0, 0, 0, 0, 0};
+    WideProbe wprobe = {0, 0, 0, 0, 0, 0, 0};
     (void)wprobe;
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
     unsigned long long cyc_direct = 0, cyc_hit = 0, cyc_regen = 0, cyc_sub = 0;                                // ... split of cyc_shade
@@ -3684,6 +3690,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         atomicAdd(&P.counters[7], (unsigned long long)wprobe.tblk);
         atomicAdd(&P.counters[8], (unsigned long long)wprobe.trips);
         atomicAdd(&P.counters[9], (unsigned long long)wprobe.busy);
+        atomicAdd(&P.counters[13], (unsigned long long)wprobe.slow);
     }
 #endif
     if (COUNT) {
@@ -3813,7 +3820,7 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
     if (WIDE) wide_init_suspend_record(P, lane);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)cnt;
-    WideProbe wprobe = {0, 0, 0, 0, 0, 0};
+    WideProbe wprobe = {0, 0, 0, 0, 0, 0, 0};
     (void)wprobe;
     const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = (int)gridDim.x * 4;
     for (int base = wave * 64; base < n; base += n_waves * 64) {      // wave-uniform

@@ -17,4 +17,4 @@ s = W * H * spp
 t = max(1, c["w_trip"])
 print(f"PROBE {which} wide (asm): {W*H*spp/ms/1e3:.1f} Msamples/s; per 64 samples: {c['w_trip']*64/s:.1f} trips, {c['w_node']*64/s:.1f} node blocks "
       f"({c['node_visits']/max(1,c['w_node']):.1f} lanes), {c['w_prim']*64/s:.1f} triangle blocks ({c['prim_tests']/max(1,c['w_prim']):.1f} lanes); "
-      f"busy lanes per trip {c['l_trip']/t:.1f}; node visits / sample {c['node_visits']/s:.1f}, triangle tests / sample {c['prim_tests']/s:.1f}")
+      f"busy lanes per trip {c['l_trip']/t:.1f}; trips through the slow push {100*c['unused13']/t:.1f} %; node visits / sample {c['node_visits']/s:.1f}, triangle tests / sample {c['prim_tests']/s:.1f}")
