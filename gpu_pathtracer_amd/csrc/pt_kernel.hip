@@ -2543,7 +2543,16 @@ struct RayResults {    // this lane's own rays, read back from the pool
 // Scenes that fit kSmallSceneFloat4 (nodes 2 float4 each, triangles 3, shading records 5, lights 6, materials
 // 72 B) are staged in LDS once per workgroup; traversal and shading then read LDS instead of going through
 // the vector-memory pipe.
-constexpr int kSmallSceneFloat4 = 768;                  // 12 KB: with the ray pools exactly 4 workgroups per CU
+#ifndef PT_SMALL_FLOAT4
+#define PT_SMALL_FLOAT4 768
+#endif
+#ifndef PT_LDS_SHADE
+#define PT_LDS_SHADE 1          // 0 (experiment): shading records, lights and materials stay in global memory, only nodes and triangles are staged
+#endif
+#ifndef PT_SMALL_WAVES
+#define PT_SMALL_WAVES PT_MIN_WAVES
+#endif
+constexpr int kSmallSceneFloat4 = PT_SMALL_FLOAT4;      // 12 KB: with the ray pools exactly 4 workgroups per CU
 
 // INTEG: GPT_IT_PT = Path (pathtracer.cu:880-1021), GPT_IT_AO = Ao (:830-876: one cosine-weighted occlusion ray
 // of length maxDist per primary hit; the same pools, drain and sample planes), GPT_IT_VPT = Volpath (:1025-1242) for
@@ -2574,7 +2583,7 @@ constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBa
 #endif
 // WIDE: scenes in global memory walked on the 4-wide tree, one lane per ray (GPT_TRAVERSAL_WIDE4, trace_pool_wide<>)
 template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
-__global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES)) pt_render_kernel(const DevParams P_in)
+__global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : (SMALL ? PT_SMALL_WAVES : PT_MIN_WAVES))) pt_render_kernel(const DevParams P_in)
 {
     static_assert(!(WIDE && SMALL), "the wide tree is walked from global memory");
     __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 - (PT_LOOP_PROBE ? 8 : 0) : 1];
@@ -2610,6 +2619,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
             lds_scene[i] = v;
         }
         for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[o_tri + i] = gt[i];
+#if PT_LDS_SHADE
         for (int i = threadIdx.x; i < 5 * P.n_prims; i += 256) lds_scene[o_shade + i] = gs[i];
         for (int i = threadIdx.x; i < 6 * P.n_lights; i += 256) lds_scene[o_light + i] = gl[i];
         uint32_t *lm = reinterpret_cast<uint32_t *>(lds_scene + o_mat);
@@ -2618,6 +2628,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         P.shade = reinterpret_cast<const DevShade *>(lds_scene + o_shade);
         P.lights = reinterpret_cast<const DevLight *>(lds_scene + o_light);
         P.materials = reinterpret_cast<const gpt_material *>(lds_scene + o_mat);
+#else
+        (void)gs; (void)gl; (void)gm; (void)o_mat;
+        __syncthreads();
+#endif
     }
     constexpr bool CARRY = !SMALL;                      // scenes in global memory: fixed slots, drains may stop early
     constexpr int kWaveFloat4 = WIDE ? kWaveWideFloat4 : (CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4);
@@ -3951,7 +3965,7 @@ int render_kernel_blocks_per_cu(bool count, bool walk, bool wide)
 
 bool render_scene_fits_lds(const DevParams &P)
 {
-    return P.traversal == 0 && 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4;
+    return P.traversal == 0 && 2 * P.n_nodes + (PT_LDS_SHADE ? 8 : 3) * P.n_prims + (PT_LDS_SHADE ? 6 * P.n_lights + (18 * P.n_materials + 3) / 4 : 0) <= kSmallSceneFloat4;
 }
 
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream)
