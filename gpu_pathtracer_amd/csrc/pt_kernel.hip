@@ -151,6 +151,9 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #ifndef PT_NODE_LOOKAHEAD
 #define PT_NODE_LOOKAHEAD 1      // scenes in global memory fetch two consecutive nodes per node trip (PT_NODE2_LOOKAHEAD); 0: one
 #endif
+#ifndef PT_ORDER_BY_LANE
+#define PT_ORDER_BY_LANE 0      // 1 (experiment): fetch order by lane, then kind, instead of by kind (longest rays first), then lane
+#endif
 #ifndef PT_ASM_IN_COUNT
 #define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
 #endif
@@ -240,9 +243,18 @@ __device__ __forceinline__ int pool_deposit_fixed(float4 *pool, const RaySet &rs
         pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
         pend[lane] = (dp ? 1u : 0u) | (dm ? 2u : 0u) | (ds ? 4u : 0u);
     }
+#if PT_ORDER_BY_LANE
+    // (experiment) a lane's rays next to each other in the fetch order: they finish around the same time, so fewer LANES wait when a drain stops
+    const int base = lane_rank(m_p) + lane_rank(m_m) + lane_rank(m_s);
+    if (dp) { pool_put(pool, (int)lane, rs.dir_p, P_TMAX ? rs.tmax_s : __builtin_inff(), lane, false); order[base] = (unsigned short)lane; }
+    if (dm) { pool_put(pool, 64 + (int)lane, rs.dir_m, __builtin_inff(), lane, rs.mis_any); order[base + (dp ? 1 : 0)] = (unsigned short)(64u + lane); }
+    if (ds) { pool_put(pool, 128 + (int)lane, rs.dir_s, rs.tmax_s, lane, true); order[base + (dp ? 1 : 0) + (dm ? 1 : 0)] = (unsigned short)(128u + lane); }
+    (void)n_p; (void)n_m;
+#else
     if (dp) { pool_put(pool, (int)lane, rs.dir_p, P_TMAX ? rs.tmax_s : __builtin_inff(), lane, false); order[lane_rank(m_p)] = (unsigned short)lane; }
     if (dm) { pool_put(pool, 64 + (int)lane, rs.dir_m, __builtin_inff(), lane, rs.mis_any); order[n_p + lane_rank(m_m)] = (unsigned short)(64u + lane); }
     if (ds) { pool_put(pool, 128 + (int)lane, rs.dir_s, rs.tmax_s, lane, true); order[n_p + n_m + lane_rank(m_s)] = (unsigned short)(128u + lane); }
+#endif
     return n_p + n_m + popc(m_s);
 }
 
