@@ -22,7 +22,7 @@ What the JSON line carries besides the contract's fields (rank 0, N = 1):
   cpu_baseline  the oracle (CPU restatement) on one host core, bounded sample; host CPU model and core count.
   parity        GPU film against the pinned (glibc) oracle at 256x256 / 1024 spp / depth 8: per-channel relative RMS.
   config.other_configs   BASELINE.json configs 3 - 5 on their SURVEY.md 8(d) stand-ins (tests/standins.py, built from
-                tests/golden/meshes.npz through the product loader), one full-size launch per traversal order: Msamples/s from the
+                tests/golden/meshes.npz through the product loader), one full-size launch per traversal order (reference / nearer child first / 4-wide): Msamples/s from the
                 library's HIP events, and for the faster order the VALU-issue fraction, active lanes and HBM-side GB/s of one extra
                 rocprofv3 pass set.  Parity-test cases, not the headline: they are here so that their numbers are driver-witnessed.
 `python bench.py --gpus N` without a torch.distributed.run environment launches itself under it (one rank per GPU).
@@ -178,7 +178,13 @@ def rocprof_pass(counters, workdir, tag, child=("c2", "reference")):
         env.pop(k, None)
     cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", tag, "--",
                                                           sys.executable, os.path.abspath(__file__), "--counter-child", child[0], child[1]]
-    p = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=150)     # a pass takes ~6 s; a hang must not cost the bench line
+    if rocprof_pass.gave_up:
+        raise RuntimeError("an earlier rocprofv3 pass of this run hung: the remaining passes are skipped")
+    try:
+        p = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True, timeout=90)   # a pass takes 2 - 6 s; a hang must not cost the bench line
+    except subprocess.TimeoutExpired:
+        rocprof_pass.gave_up = True       # one hang: no further passes in this run (nine passes x the timeout would be a quarter of an hour)
+        raise
     vals = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -189,6 +195,9 @@ def rocprof_pass(counters, workdir, tag, child=("c2", "reference")):
     # the launches to be counted are the large ones (a stand-in child may also run small ones: keep the two largest per counter)
     big = {k: sorted(v)[-2:] for k, v in vals.items()}
     return {k: sum(v) / len(v) for k, v in big.items()}, max(len(v) for v in big.values())
+
+
+rocprof_pass.gave_up = False
 
 
 def live_counters():
@@ -219,7 +228,7 @@ def standin_leg(api, which, counters=True):
     n_samples = ls.width * ls.height * spp
     sha, film = {}, {}
     with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-        for mode in ("reference", "wide"):
+        for mode in ("reference", "near", "wide"):
             r.set_traversal_order(mode)
             r.render(ls.camera, 1, spp, reset=True)             # same call as the timed one: the sample planes exist afterwards
             r.synchronize()
@@ -233,11 +242,14 @@ def standin_leg(api, which, counters=True):
             film[mode] = r.read_accum()
             sha[mode] = hashlib.sha1(film[mode].tobytes()).hexdigest()[:16]
             out["orders"][mode] = {"value": n_samples / best / 1e3, "unit": "Msamples/s", "launch_ms": best}
-    # the wide order against the reference order: equal films except where two hits tie within rounding (include/gpt_wide_bvh.h)
+    # the other orders against the reference order: equal films except where two hits tie within rounding (include/gpt_traversal.h,
+    # include/gpt_wide_bvh.h)
     import numpy as np
-    a, b = film["wide"].reshape(-1, 3).astype(np.float64), film["reference"].reshape(-1, 3).astype(np.float64)
-    out["wide_vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film["wide"] != film["reference"])), "floats": int(film["wide"].size),
-                                      "rel_rms": [float(x) for x in np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))], "tolerance": 1e-4}
+    b = film["reference"].reshape(-1, 3).astype(np.float64)
+    for mode in ("near", "wide"):
+        a = film[mode].reshape(-1, 3).astype(np.float64)
+        out[mode + "_vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film[mode] != film["reference"])), "floats": int(film[mode].size),
+                                             "rel_rms": [float(x) for x in np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))], "tolerance": 1e-4}
     out["accumulator_sha1"] = sha
     fast = max(out["orders"], key=lambda m: out["orders"][m]["value"])
     out["faster_order"] = fast
@@ -266,6 +278,14 @@ def standin_leg(api, which, counters=True):
             shutil.rmtree(work, ignore_errors=True)
     ls.close()
     return out
+
+
+T0 = time.perf_counter()
+
+
+def note(what):
+    """progress to stderr (stdout carries the one JSON line): where the wall-clock time of a run goes"""
+    print(f"[bench {time.perf_counter() - T0:7.1f} s] {what}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -317,6 +337,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    note("imports done")
     scene, meta = host.load_baked(os.path.join(ROOT, "tests", "golden", "cornell_pt.npz"), MAX_DEPTH)
     cam = host.camera_from_meta(meta, WIDTH, HEIGHT)
     n_floats = WIDTH * HEIGHT * 3
@@ -366,6 +387,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     launches, kernel_ms = r.kernel_time()
+    note(f"timed region done: {dt:.3f} s for {args.steps} steps")
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -385,6 +407,7 @@ def main():
         single = world == 1
         if single and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+            note("cpu_baseline done")
             b_alg = cpu_baseline.b_alg      # algorithmic bytes of the reference algorithm on this workload
         # this rank's launches cover its own tiles: samples per launch on this rank
         samples_per_launch = samples / world / max(1, launches)
@@ -415,12 +438,14 @@ def main():
                           "timed": "path-kernel launches, HIP events of the library (gpt_kernel_time)", "launches": n_sq,
                           "wall_clock_value": 1088 * 1080 * 256 / wall / 1e6}
 
+        note("square frame and kernel ray counts done")
         live, live_err = None, None
         if single and not args.no_counters:
             try:
                 live = live_counters()
             except Exception as e:          # rocprofv3 missing or refused: say so, print nulls
                 live_err = f"{type(e).__name__}: {e}"[:300]
+        note("headline counters (3 rocprofv3 passes) done")
         per_sample = None
         if live:
             n_per_launch_samples = WIDTH * HEIGHT * live["iterations_per_launch"]
@@ -465,9 +490,11 @@ def main():
                     others[which] = standin_leg(api, which, counters=not args.no_counters and which != "c4")
                 except Exception as e:
                     others[which] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                note(f"other_configs {which} done")
         par = None
         if single and not args.no_parity:
             par = parity_check(api)
+            note("parity check done")
         line = {
             "metric": "Msamples/s at 1920x1080, 8-bounce PT",
             "value": samples / dt_max / 1e6,
