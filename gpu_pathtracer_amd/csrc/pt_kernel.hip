@@ -1202,7 +1202,8 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 //   v18 LDS address of the lane's stack column - 768 (level l at v18 + 768 + 256 l)
 //   v[20:23] best hit {triangle index or -1, t, b1, b2}
 //   lanes at a wide node: v[24:47] six planes of four boxes, v[48:51] the children's entries, v[52:55] their keys, v[56:64] temporaries
-//   lanes at a leaf:      v[24:32] the triangle record, v[33:43] temporaries (as in PT_TRACE_ASM), v52 the triangle's index, v53 its byte offset
+//   lanes at a leaf:      v[24:32] the triangle record, v[44:52] the record after it (PT_WIDE_TRI2), v[33:43] temporaries (as in PT_TRACE_ASM),
+//                         v54 the triangle's index, v55 its byte offset
 //   s[60:61] lanes at a leaf  s[62:63] lanes at a wide node  s[64:65] lanes with a ray / busy lanes  s[66:69],s[72:75] scratch masks
 //   s70 next ray  s71 s72 counts  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] node lanes with a hit child
 #ifndef PT_WIDE_ASM
@@ -1217,6 +1218,9 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
     rec[4] = 0xffffffffu; rec[5] = 0u; rec[6] = 0u; rec[7] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
+#ifndef PT_WIDE_TRI2
+#define PT_WIDE_TRI2 1           // a leaf lane tests the leaf's next triangle in the same trip (its record is fetched with the first one's)
+#endif
 #ifndef PT_WIDE_EARLY
 #define PT_WIDE_EARLY 0          // (measured: -5 %, the extra vector-memory instructions cost more than the overlap gains) a lane that descends into a wide node fetches that record before the trip's triangle block
 #endif
@@ -1315,12 +1319,17 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
            wait for everything) */
         "s_mov_b64 exec, s[60:61]\n"
-        "v_and_b32_e32 v52, 0x7ffffff, v12\n"              /* the leaf's first triangle */
-        "v_lshlrev_b32_e32 v53, 4, v52\n"
-        "v_lshl_add_u32 v53, v52, 5, v53\n"                /* * 48 */
-        "global_load_dwordx4 v[28:31], v53, %[tris] offset:16\n"
-        "global_load_dword v32, v53, %[tris] offset:32\n"
-        "global_load_dwordx4 v[24:27], v53, %[tris]\n"
+        "v_and_b32_e32 v54, 0x7ffffff, v12\n"              /* the leaf's first triangle */
+        "v_lshlrev_b32_e32 v55, 4, v54\n"
+        "v_lshl_add_u32 v55, v54, 5, v55\n"                /* * 48 */
+        "global_load_dwordx4 v[28:31], v55, %[tris] offset:16\n"
+        "global_load_dword v32, v55, %[tris] offset:32\n"
+        "global_load_dwordx4 v[24:27], v55, %[tris]\n"
+#if PT_WIDE_TRI2
+        "global_load_dwordx4 v[48:51], v55, %[tris] offset:64\n"      /* ... and the one after it (the array is padded by one record) */
+        "global_load_dword v52, v55, %[tris] offset:80\n"
+        "global_load_dwordx4 v[44:47], v55, %[tris] offset:48\n"
+#endif
         "s_andn2_b64 exec, s[62:63], s[82:83]\n"           /* (the lanes that descended last trip fetched their record then) */
         "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
         "global_load_dwordx4 v[36:39], v12, %[nodes] offset:48\n"
@@ -1598,7 +1607,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_lt_f32_e32 vcc, v39, v21\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_eq_f32_e32 vcc, v39, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v52, v20\n"
+        "v_cmp_gt_i32_e64 s[72:73], v54, v20\n"
         "s_and_b64 vcc, vcc, s[72:73]\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_lt_f32_e32 vcc, v39, v14\n"
@@ -1606,7 +1615,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
         "v_and_b32_e32 v42, 0x100, v11\n"
         "s_and_b64 exec, exec, s[68:69]\n"
-        "v_mov_b32_e32 v20, v52\n"
+        "v_mov_b32_e32 v20, v54\n"
         "v_mov_b32_e32 v21, v39\n"
         "v_mov_b32_e32 v22, v43\n"
         "v_mov_b32_e32 v23, v38\n"
@@ -1616,6 +1625,121 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
         "TW_TRI_END_%=:\n"
         "s_mov_b64 exec, s[60:61]\n"
+#if PT_WIDE_TRI2
+        /* a ray that goes on and whose leaf has another triangle tests it in the same trip (its record came with the first one's):
+           the order of the tests and the interval they see are those of two trips */
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
+        "v_bfe_u32 v42, v12, 27, 4\n"
+        "v_cmp_lt_u32_e64 s[66:67], 0, v42\n"
+        "s_nop 0\n"
+        "s_and_b64 s[84:85], s[66:67], vcc\n"             /* second test */
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"           /* the leaf is exhausted: pop */
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
+        "s_mov_b64 exec, s[84:85]\n"
+        "s_cbranch_execz TW_POP_%=\n"
+        "v_add_u32_e32 v54, 1, v54\n"
+        "v_mul_f32_e32 v33, v5, v52\n"
+        "v_mul_f32_e32 v42, v6, v51\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v6, v50\n"
+        "v_mul_f32_e32 v42, v4, v52\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v4, v51\n"
+        "v_mul_f32_e32 v42, v5, v50\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v36, v33, v47\n"
+        "v_mul_f32_e32 v42, v34, v48\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_mul_f32_e32 v42, v35, v49\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_rcp_f32_e32 v38, v36\n"
+        "v_sub_f32_e32 v44, v0, v44\n"
+        "v_sub_f32_e32 v45, v1, v45\n"
+        "v_sub_f32_e32 v46, v2, v46\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
+        "v_fma_f32 v41, -v36, v38, 1.0\n"
+        "v_fma_f32 v37, v41, v38, v38\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TW_DIV_IEEE2_%=\n"
+        "TW_DIV_DONE2_%=:\n"
+        "v_mul_f32_e32 v43, v44, v33\n"
+        "v_mul_f32_e32 v42, v45, v34\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v42, v46, v35\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v33, v45, v49\n"
+        "v_mul_f32_e32 v42, v46, v48\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v46, v47\n"
+        "v_mul_f32_e32 v42, v44, v49\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v44, v48\n"
+        "v_mul_f32_e32 v42, v45, v47\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v43, v43, v37\n"                    /* b1 */
+        "v_mul_f32_e32 v38, v4, v33\n"
+        "v_mul_f32_e32 v42, v5, v34\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v42, v6, v35\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v38, v38, v37\n"                    /* b2 */
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"
+        "v_add_f32_e32 v42, v43, v38\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TW_TRI2_END_%=\n"
+        "v_mul_f32_e32 v39, v50, v33\n"
+        "v_mul_f32_e32 v42, v51, v34\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v42, v52, v35\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v39, v39, v37\n"                    /* tt */
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v39, v14\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TW_TRI2_END_%=\n"
+        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
+           distance that is not NaN and nearer than the interval's end becomes the interval's end */
+        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
+        "v_cmp_lt_f32_e32 vcc, v39, v21\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_eq_f32_e32 vcc, v39, v21\n"
+        "v_cmp_gt_i32_e64 s[72:73], v54, v20\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_lt_f32_e32 vcc, v39, v14\n"
+        "s_mov_b64 s[72:73], exec\n"
+        "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
+        "v_and_b32_e32 v42, 0x100, v11\n"
+        "s_and_b64 exec, exec, s[68:69]\n"
+        "v_mov_b32_e32 v20, v54\n"
+        "v_mov_b32_e32 v21, v39\n"
+        "v_mov_b32_e32 v22, v43\n"
+        "v_mov_b32_e32 v23, v38\n"
+        "s_mov_b64 exec, s[72:73]\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v42\n"                   /* IntersectP: the first accepted triangle ends the ray */
+        "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
+        "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
+        "TW_TRI2_END_%=:\n"
+        "s_mov_b64 exec, s[84:85]\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
+        "v_bfe_u32 v42, v12, 27, 4\n"
+        "v_add_u32_e32 v41, 0xf0000002, v12\n"             /* first + 2, two triangles fewer */
+        "v_cmp_lt_u32_e64 s[66:67], 1, v42\n"
+        "s_nop 0\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v12, v41, s[66:67]\n"
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
+#else
         /* a ray that goes on: the leaf's next triangle if it has one, else pop */
         "v_cmp_ne_u32_e32 vcc, -1, v12\n"
         "v_bfe_u32 v42, v12, 27, 4\n"
@@ -1626,6 +1750,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
         "v_cndmask_b32_e64 v12, v12, v41, s[66:67]\n"
         "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
+#endif
         /* ---------------------------------------------------------------- pop (s[78:79]) */
         "TW_POP_%=:\n"
         "s_mov_b64 exec, s[78:79]\n"
@@ -1696,6 +1821,23 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_div_fmas_f32 v37, v37, v38, v40\n"
         "v_div_fixup_f32 v37, v37, v36, 1.0\n"
         "s_branch TW_DIV_DONE_%=\n"
+#if PT_WIDE_TRI2
+        "TW_DIV_IEEE2_%=:\n"
+        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
+        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
+        "v_rcp_f32_e32 v38, v37\n"
+        "s_nop 0\n"
+        "v_fma_f32 v41, -v37, v38, 1.0\n"
+        "v_fmac_f32_e32 v38, v41, v38\n"
+        "v_mul_f32_e32 v40, v39, v38\n"
+        "v_fma_f32 v41, -v37, v40, v39\n"
+        "v_fmac_f32_e32 v40, v41, v38\n"
+        "v_fma_f32 v37, -v37, v40, v39\n"
+        "v_div_fmas_f32 v37, v37, v38, v40\n"
+        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
+        "s_branch TW_DIV_DONE2_%=\n"
+#endif
+
         /* ---------------------------------------------------------------- finished rays (s[68:69]) */
         "TW_FIN_%=:\n"
         "s_mov_b64 exec, s[68:69]\n"
@@ -1767,7 +1909,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
           [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
-          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
           "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
