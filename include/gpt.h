@@ -74,12 +74,12 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
  *   GPT_TRAVERSAL_REFERENCE (0, default)  the reference's order; results are the reference's bit for bit.
  *   GPT_TRAVERSAL_NEAR_FIRST (1)          the same tree, nearer child first (include/gpt_traversal.h): fewer node visits on
  *                                         large scenes.
- *   GPT_TRAVERSAL_WIDE4 (2)               a 4-wide tree collapsed from the reference's, walked by four lanes per ray
+ *   GPT_TRAVERSAL_WIDE4 (2)               a 4-wide tree collapsed from the reference's, walked one lane per ray
  *                                         (include/gpt_wide_bvh.h): a quarter of the node visits, faster where leaves are
  *                                         large; GPT_ERR_UNSUPPORTED for an empty scene or a tree deeper than 21 wide levels.
  * Modes 1 and 2 change only the ORDER of the reference's box and triangle tests: each is bit-identical to the oracle in the
- * same mode and within 1e-4 relative RMS of the reference order (measured: mode 2 identical on every scene tried, mode 1
- * identical up to exactly-equal hits).  Both always traverse from global memory. */
+ * same mode and within 1e-4 relative RMS of the reference order (measured: identical films, or single pixels where two hits
+ * tie within rounding - relative RMS <= 2e-7).  Both always traverse from global memory. */
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
 
 /* Renderer options, by name; none of them changes a result.  Nothing in the library is steered by environment

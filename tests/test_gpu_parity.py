@@ -640,7 +640,7 @@ def test_config5_standin_near_first_and_small_frame(gpt, standin):
     assert (rel_rms(near, ref) <= RMS_TOL).all()
 
 
-# ---- GPT_TRAVERSAL_WIDE4: the 4-wide tree, four lanes per ray (include/gpt_wide_bvh.h) ------------------------------------
+# ---- GPT_TRAVERSAL_WIDE4: the 4-wide tree, one lane per ray (include/gpt_wide_bvh.h) ------------------------------------
 
 def wide_both(gpt, scene, cam, W, H, eps, spp, what, threads=None):
     """GPU and oracle in the wide mode: bit-identical; and the wide film against the reference-order film: north_star's bar"""
@@ -768,7 +768,7 @@ def chain_scene(n, max_depth=3):
 
 
 def test_wide_traversal_stack_spills_past_its_lds_entries(gpt):
-    """The wide walk keeps 24 stack entries per ray in LDS and spills deeper ones to global memory.  A 36-sheet chain makes every
+    """The wide walk keeps 9 stack entries per ray in LDS and spills deeper ones to global memory.  A 36-sheet chain makes every
     ray that looks down the stack hold more than 24 pending entries (the oracle reports the deepest stack it needed)."""
     scene = chain_scene(36)
     W, H, spp = 64, 48, 3
