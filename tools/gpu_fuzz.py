@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle soak: random triangle soups + Cornell parts, random materials, cameras, frame sizes,
 iteration batching, integrator (pt / ao / vpt with random homogeneous and density-grid media, material-less boxes and
-medium-filled meshes), traversal order and memory path; every film must match the oracle bit for bit.
+medium-filled meshes), traversal order, tree builder (the reference's or the split BVH) and memory path; every film must match the oracle bit for bit.
 usage: python tools/gpu_fuzz.py <seconds> [seed]      (run under `timeout`; each case is small)"""
 import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -79,6 +79,12 @@ while time.time() < t_end:
         scene.desc.set_integrator("vpt", depth)
         cam.medium = cam_medium
         force_walk = bool(rng.random() < 0.3)
+    split_tree = bool(rng.random() < 0.25) and len(scene.prims) > 0          # the split BVH (gpt_sbvh_build) instead of the reference builder's tree
+    if split_tree:
+        sb_prims, sb_nodes, _, _ = api.sbvh_build(scene.prims, float(rng.choice([1e-5, 1e-3, 1.0])))
+        scene.sb_keep = (sb_prims, sb_nodes)
+        scene.desc.prims, scene.desc.n_prims = st.ptr(sb_prims), len(sb_prims)
+        scene.desc.nodes, scene.desc.n_nodes = st.ptr(sb_nodes), len(sb_nodes)
     lib.oracle_set_traversal(order)
     if order == 2 and len(scene.nodes) == 0:
         order = near = 0
@@ -100,7 +106,7 @@ while time.time() < t_end:
             if k < spp: r.render(cam, k + 1, spp - k, reset=False)
         got = r.read_accum()
     bad = int(np.count_nonzero(got.view(np.uint32) != ref.view(np.uint32)))
-    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} order {order} global {force_global}"
+    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} order {order} global {force_global} split {split_tree}"
     if bad:
         n_bad += 1
         print("MISMATCH", bad, tag, flush=True)
