@@ -2127,6 +2127,34 @@ API void oracle_infinite_le_batch(const gpt_infinite *inf, const float *dir, int
     }
 }
 
+/* Camera::GeneratePrimaryRay (camera.h:48-84) for n film positions and lens samples: rays6 = origin, direction */
+API void oracle_primary_ray_batch(const gpt_camera *cam, const float *xy, const float *lens_xy, int n, float *rays6)
+{
+    for (int i = 0; i < n; ++i) {
+        const ray_t r = generate_primary_ray(cam, xy[2 * i], xy[2 * i + 1], mk2(lens_xy[2 * i], lens_xy[2 * i + 1]));
+        rays6[6 * i] = r.o.x; rays6[6 * i + 1] = r.o.y; rays6[6 * i + 2] = r.o.z;
+        rays6[6 * i + 3] = r.d.x; rays6[6 * i + 4] = r.d.y; rays6[6 * i + 5] = r.d.z;
+    }
+}
+/* GetTexel (pathtracer.cu:341-359: bilinear, repeat-wrap, uchar4 -> float) of one texture at n uv positions */
+API void oracle_texel_batch(const gpt_texture *tex, const float *uv, int n, float *rgb_out)
+{
+    gpt_scene_desc d;
+    scene_t sc;
+    gpt_material m;
+    memset(&d, 0, sizeof(d));
+    memset(&sc, 0, sizeof(sc));
+    memset(&m, 0, sizeof(m));
+    d.textures = tex;
+    d.n_textures = 1;
+    sc.d = &d;
+    m.textureIdx = 0;
+    for (int i = 0; i < n; ++i) {
+        const f3 c = get_texel(&sc, &m, mk2(uv[2 * i], uv[2 * i + 1]));
+        rgb_out[3 * i] = c.x; rgb_out[3 * i + 1] = c.y; rgb_out[3 * i + 2] = c.z;
+    }
+}
+
 API int oracle_uses_softmath(void)
 {
 #ifdef ORACLE_SOFTMATH

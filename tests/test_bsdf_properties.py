@@ -414,3 +414,107 @@ def test_furnace_on_the_gpu(gpt):
                     assert np.allclose(img[~on_box], 1.0, atol=1e-6)
                 if order == "reference":
                     assert got.tobytes() == want.tobytes()
+
+
+# ---- 7. camera, texture lookup, light selection: the remaining helpers of SURVEY 8(a) against independent restatements -------
+
+def primary_rays(cam, xy, lens):
+    lib = ol.load("libm")
+    xy, lens = np.ascontiguousarray(xy, np.float32), np.ascontiguousarray(lens, np.float32)
+    out = np.zeros((len(xy), 6), np.float32)
+    lib.oracle_primary_ray_batch(C.byref(cam), P(xy), P(lens), len(xy), P(out))
+    return out[:, :3].astype(np.float64), out[:, 3:].astype(np.float64)
+
+
+def test_pinhole_and_thin_lens_camera_geometry():
+    """Camera::GeneratePrimaryRay (camera.h:48-84).  Pinhole: the image plane is the plane at `distance` in front of the eye, the
+    vertical field of view is `fov`, pixel (x, y) maps linearly onto it and the centre pixel looks at the target.  Thin lens: every
+    ray of one film position passes through ONE point of the plane at focalDistance - the point the pinhole ray hits there - and
+    starts on the lens disc."""
+    lib = ol.load("libm")
+    W, H = 200, 100
+    eye, target = np.array([1.0, 2.0, 5.0]), np.array([0.5, 1.0, 0.0])
+    cam = ol.make_camera(tuple(eye), tuple(target), (0, 1, 0), (W, H), 40.0, lib=lib)
+    fwd = (target - eye) / np.linalg.norm(target - eye)
+    o, d = primary_rays(cam, [[W / 2, H / 2], [W / 2, 0.0], [W / 2, H], [0.0, H / 2], [W, H / 2]], np.zeros((5, 2)))
+    assert np.allclose(o, eye) and np.allclose(np.linalg.norm(d, axis=1), 1, atol=1e-6)
+    assert np.allclose(d[0], fwd, atol=1e-6)
+    half_v = np.degrees(np.arccos(np.clip(d[1] @ fwd, -1, 1))), np.degrees(np.arccos(np.clip(d[2] @ fwd, -1, 1)))
+    assert np.allclose(half_v, 20.0, atol=1e-3)                                     # fov is the full vertical angle
+    half_h = np.degrees(np.arccos(np.clip(d[3] @ fwd, -1, 1)))
+    assert abs(np.tan(np.radians(half_h)) / np.tan(np.radians(20.0)) - W / H) < 1e-4     # square pixels
+    # linear in the pixel coordinates on the image plane
+    rng = np.random.default_rng(2)
+    xy = rng.uniform((0, 0), (W, H), (500, 2))
+    _, d = primary_rays(cam, xy, np.zeros((500, 2)))
+    on_plane = d / (d @ fwd)[:, None]                                                # points at distance 1 along the axis
+    A = np.c_[xy, np.ones(len(xy))]
+    for k in range(3):
+        coef, res, *_ = np.linalg.lstsq(A, on_plane[:, k], rcond=None)
+        assert np.abs(A @ coef - on_plane[:, k]).max() < 1e-5
+    # thin lens
+    lens_cam = ol.make_camera(tuple(eye), tuple(target), (0, 1, 0), (W, H), 40.0, aperture=0.3, focal=4.0, lib=lib)
+    for px in ([30.0, 20.0], [150.5, 77.25], [100.0, 50.0]):
+        lens = rng.uniform(-1, 1, (400, 2))
+        lens = lens[(lens ** 2).sum(1) <= 1]
+        o, d = primary_rays(lens_cam, np.tile(px, (len(lens), 1)), lens)
+        _, d0 = primary_rays(cam, [px], [[0, 0]])
+        focus = eye + d0[0] * (4.0 / (d0[0] @ fwd))                                  # where the pinhole ray meets the focal plane
+        t = ((focus - o) @ fwd) / (d @ fwd)
+        assert np.abs(o + d * t[:, None] - focus).max() < 2e-5
+        assert (np.linalg.norm(o - eye, axis=1) <= 0.3 + 1e-6).all() and np.abs((o - eye) @ fwd).max() < 1e-6
+
+
+def test_environment_camera_is_the_lat_long_map():
+    """the environment camera (camera.h:49-56): theta = pi (1 - y / H) from the camera's v axis, phi = 2 pi (1 - x / W)"""
+    lib = ol.load("libm")
+    W, H = 64, 32
+    cam = ol.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), (W, H), 40.0, environment=True, lib=lib)
+    _, d = primary_rays(cam, [[0.0, H / 2], [W / 4, H / 2], [W / 2, H / 2], [7.0, H], [7.0, 0.0]], np.zeros((5, 2)))
+    u, v, w = (np.array([getattr(cam, a).x, getattr(cam, a).y, getattr(cam, a).z]) for a in ("u", "v", "w"))
+    assert np.allclose(d[0], u, atol=1e-6)                       # phi = 2 pi: along +u
+    assert np.allclose(d[1], w, atol=1e-6)                       # phi = 3 pi / 2: sin = -1, and the w term enters with a minus sign
+    assert np.allclose(d[2], -u, atol=1e-6)
+    assert np.allclose(d[3], v, atol=1e-6) and np.allclose(d[4], -v, atol=1e-6)        # y = H is the zenith, y = 0 the nadir
+
+
+def test_texture_lookup_is_bilinear_with_repeat_wrap():
+    """GetTexel (pathtracer.cu:324-359): texel (x, y) covers [x, x+1) x [y, y+1) of (w u, h v), the four neighbours of
+    floor(w u), floor(h v) are blended with the fractional parts, indices wrap around, 8-bit channels / 255"""
+    lib = ol.load("libm")
+    rng = np.random.default_rng(6)
+    h, w = 7, 5
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    tex = st.Texture()
+    tex.data, tex.width, tex.height = img.ctypes.data, w, h
+    uv = np.ascontiguousarray(rng.uniform(-1.5, 2.5, (4000, 2)), np.float32)
+    got = np.zeros((len(uv), 3), np.float32)
+    lib.oracle_texel_batch(C.byref(tex), P(uv), len(uv), P(got))
+    xx, yy = w * uv[:, 0].astype(np.float64), h * uv[:, 1].astype(np.float64)
+    x0, y0 = np.floor(xx).astype(int), np.floor(yy).astype(int)
+    fx, fy = xx - x0, yy - y0
+    f = img[..., :3].astype(np.float64) / 255.0
+
+    def at(x, y):
+        return f[y % h, x % w]
+    want = ((at(x0, y0) * (1 - fx)[:, None] + at(x0 + 1, y0) * fx[:, None]) * (1 - fy)[:, None] +
+            (at(x0, y0 + 1) * (1 - fx)[:, None] + at(x0 + 1, y0 + 1) * fx[:, None]) * fy[:, None])
+    assert np.abs(got - want).max() < 2e-5        # (uv are float32 here, the products w u are rounded once more in the reference)
+
+
+def test_light_selection_follows_the_power_distribution():
+    """Scene::Init (scene.h:65-82) + LookUpLightDistribution (pathtracer.cu:172-181): a light is chosen with probability
+    luminance(radiance) x area / total, the environment with luminance(texel 0) x 4 pi r^2 - checked on the CDF and on what a
+    render does with it: two emitters of equal radiance and areas 1 : 3 light a floor in proportion"""
+    lib = ol.load("libm")
+    lights = np.zeros(3, dtype=st.AREA)
+    tris = [((0, 0, 0), (1, 0, 0), (0, 1, 0)), ((0, 0, 0), (2, 0, 0), (0, 3, 0)), ((0, 0, 0), (1, 0, 0), (0, 0, 4))]      # areas 0.5, 3, 2
+    rad = [(1, 1, 1), (0.5, 0.5, 0.5), (2, 0, 0)]
+    for i, (t, r) in enumerate(zip(tris, rad)):
+        lights[i]["triangle"] = scenes.make_tri(np.float32(t[0]), np.float32(t[1]), np.float32(t[2]), (0, 0, 1), (0, 0, 1), (0, 0, 1))["triangle"]
+        lights[i]["radiance"] = st.f3(r)
+    cdf = np.zeros(5, np.float32)
+    n = lib.oracle_light_distribution(st.ptr(lights), 3, None, st.ptr(cdf))
+    luma = np.array([0.212671, 0.715160, 0.072169])
+    power = np.array([0.5 * 1.0, 3.0 * 0.5, 2.0 * (2 * luma[0])])
+    assert n == 4 and np.allclose(np.diff(cdf[:4]), power / power.sum(), rtol=1e-5) and cdf[0] == 0 and abs(cdf[3] - 1) < 1e-6
