@@ -2155,6 +2155,34 @@ API void oracle_texel_batch(const gpt_texture *tex, const float *uv, int n, floa
     }
 }
 
+/* Homogeneous::Sample (medium.h:19-50) for n uniforms: scatter distance, whether the medium was sampled, the weight;
+ * Medium::SamplePhase / Phase (medium.h:196-233) for n uniform pairs / n directions */
+API void oracle_medium_sample_batch(const gpt_medium *m, float ray_tmax, const float *u, int n, float *t_out, int32_t *sampled_out, float *weight_out)
+{
+    for (int i = 0; i < n; ++i) {
+        int sampled = 0;
+        float t = 0.f;
+        const f3 w = hom_sample(m, ray_tmax, u[i], &t, &sampled);
+        t_out[i] = t; sampled_out[i] = sampled;
+        weight_out[3 * i] = w.x; weight_out[3 * i + 1] = w.y; weight_out[3 * i + 2] = w.z;
+    }
+}
+API void oracle_phase_sample_batch(const gpt_medium *m, const float *u2, int n, float *dir_out, float *phase_out, float *pdf_out)
+{
+    for (int i = 0; i < n; ++i) {
+        f3 d = mk3(0, 0, 0);
+        float phase = 0.f, pdf = 0.f;
+        medium_sample_phase(m, u2[2 * i], u2[2 * i + 1], &d, &phase, &pdf);
+        dir_out[3 * i] = d.x; dir_out[3 * i + 1] = d.y; dir_out[3 * i + 2] = d.z;
+        phase_out[i] = phase; pdf_out[i] = pdf;
+    }
+}
+API void oracle_phase_eval_batch(const gpt_medium *m, const float in[3], const float *out, int n, float *phase_out)
+{
+    for (int i = 0; i < n; ++i)
+        medium_phase(m, mk3(in[0], in[1], in[2]), mk3(out[3 * i], out[3 * i + 1], out[3 * i + 2]), &phase_out[i]);
+}
+
 API int oracle_uses_softmath(void)
 {
 #ifdef ORACLE_SOFTMATH

@@ -518,3 +518,69 @@ def test_light_selection_follows_the_power_distribution():
     luma = np.array([0.212671, 0.715160, 0.072169])
     power = np.array([0.5 * 1.0, 3.0 * 0.5, 2.0 * (2 * luma[0])])
     assert n == 4 and np.allclose(np.diff(cdf[:4]), power / power.sum(), rtol=1e-5) and cdf[0] == 0 and abs(cdf[3] - 1) < 1e-6
+
+
+# ---- 8. Volpath's medium operators (src/medium.h): free-flight sampling and the Henyey-Greenstein phase function ---------------
+
+def test_homogeneous_free_flight_sampling_is_unbiased():
+    """Homogeneous::Sample (medium.h:19-50) draws the distance from the LUMINANCE-weighted extinction and weights per channel:
+    E[weight; scattered before tmax] = sigmaS / sigmaT (1 - exp(-sigmaT tmax)) and E[weight; reached the surface] = exp(-sigmaT tmax),
+    channel by channel - the two terms of the volume rendering equation; the distances are exponential with the mean extinction."""
+    lib = ol.load("libm")
+    m = np.array([st.make_medium((0.2, 0.5, 0.1), (0.9, 0.4, 1.3), 0.0)], dtype=st.MEDIUM)
+    sig_t = np.array([1.1, 0.9, 1.4])
+    sig_s = np.array([0.9, 0.4, 1.3])
+    sig_bar = sig_t @ np.array([0.212671, 0.715160, 0.072169])
+    rng = np.random.default_rng(8)
+    n = 2_000_000
+    u = np.ascontiguousarray(1.0 - rng.random(n), np.float32)             # (0, 1]
+    for tmax in (0.3, 1.5):
+        t, sampled, w = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 3), np.float32)
+        lib.oracle_medium_sample_batch(P(m), C.c_float(tmax), P(u), n, P(t), P(sampled), P(w))
+        hit = sampled != 0
+        assert abs(hit.mean() - (1 - np.exp(-sig_bar * tmax))) < 2e-3
+        for x in (0.1, 0.25, 1.0):
+            assert abs((t < x).mean() - (1 - np.exp(-sig_bar * x))) < 2e-3
+        w = w.astype(np.float64)
+        scattered = (w * hit[:, None]).mean(0)
+        through = (w * ~hit[:, None]).mean(0)
+        assert np.allclose(scattered, sig_s / sig_t * (1 - np.exp(-sig_t * tmax)), rtol=1e-2)
+        assert np.allclose(through, np.exp(-sig_t * tmax), rtol=1e-2)
+
+
+@pytest.mark.parametrize("g", [0.0, 0.0005, 0.5, -0.6])
+def test_henyey_greenstein_phase_function(g):
+    """Medium::Phase integrates to 1 over the sphere and has mean cosine g; Medium::SamplePhase returns directions whose polar
+    cosine has the density 2 pi x Phase and whose azimuth is uniform, with pdf = Phase.  One quirk of the reference (asserted by
+    construction: SamplePhase takes no direction): the sampled direction is used AS A WORLD DIRECTION (pathtracer.cu:1100,
+    polar axis = world +y), not relative to the ray - for g = 0 that is the same thing."""
+    lib = ol.load("libm")
+    m = np.array([st.make_medium((0.1, 0.1, 0.1), (1, 1, 1), g)], dtype=st.MEDIUM)
+    dirs, dw = sphere_grid(400, 800)
+    flat = np.ascontiguousarray(dirs.reshape(-1, 3), np.float32)
+    ph = np.zeros(len(flat), np.float32)
+    axis = np.float32([0, 1, 0])
+    lib.oracle_phase_eval_batch(P(m), P(axis), P(flat), len(flat), P(ph))
+    assert abs(ph.astype(np.float64).sum() * dw - 1) < 1e-3
+    assert abs((ph.astype(np.float64) * flat[:, 1]).sum() * dw - g) < 2e-3
+    rng = np.random.default_rng(12)
+    n = 1_000_000
+    u = np.ascontiguousarray(rng.random((n, 2)), np.float32)
+    d, phase, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib.oracle_phase_sample_batch(P(m), P(u), n, P(d), P(phase), P(pdf))
+    assert np.allclose(np.linalg.norm(d, axis=1), 1, atol=1e-5) and np.allclose(pdf, phase)
+    back = np.zeros(n, np.float32)
+    lib.oracle_phase_eval_batch(P(m), P(axis), P(d), n, P(back))
+    assert np.allclose(back, phase, rtol=2e-4)                          # the value it returns is Phase(axis, direction)
+    assert abs(d[:, 1].astype(np.float64).mean() - g) < 2e-3
+    nb = 40
+    observed = np.histogram(d[:, 1], bins=nb, range=(-1, 1))[0]
+    ct = (np.arange(nb * 50) + 0.5) / (nb * 50) * 2 - 1
+    cell = np.ascontiguousarray(np.stack([np.sqrt(1 - ct * ct), ct, np.zeros_like(ct)], -1), np.float32)
+    pc = np.zeros(len(cell), np.float32)
+    lib.oracle_phase_eval_batch(P(m), P(axis), P(cell), len(cell), P(pc))
+    expected = pc.astype(np.float64).reshape(nb, 50).sum(1) * (2.0 / (nb * 50)) * 2 * np.pi * n
+    z = (observed - expected) / np.sqrt(expected)
+    assert (z * z).mean() < 2.0
+    azimuth = np.arctan2(d[:, 2], d[:, 0])
+    assert np.abs(np.histogram(azimuth, bins=16, range=(-np.pi, np.pi))[0] / (n / 16) - 1).max() < 0.02
