@@ -314,6 +314,28 @@ def furnace_scene(mat_type, depth=8):
     return scene, cam
 
 
+def test_glass_furnace_conserves_radiance():
+    """A lossless dielectric box in a constant environment: every path refracts in (radiance x (1 / 1.5)^2, Q4), bounces inside (total
+    internal reflection included) and refracts out (x 1.5^2) or reflects; whatever the path, the radiance it returns is the
+    environment's, so the box is invisible in expectation: 1 everywhere, up to the paths maxDepth cuts (they only lose)."""
+    mats = np.concatenate([material(st.MT_DIELECTRIC), material(st.MT_LAMBERTIAN, diffuse=(0, 0, 0))])
+    box = scenes.box_mesh((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), 0)
+    env = np.full((8, 16, 3), 1.0, np.float32)
+    lib = ol.load("libm")
+    cam = ol.make_camera((1.6, 1.3, 2.1), (0, 0, 0), (0, 1, 0), (64, 64), 40.0, lib=lib)
+    means = {}
+    for depth in (8, 32):
+        scene = ol.make_scene(box, mats, light_radiance=None, max_depth=depth, env=env, lib=lib)
+        acc, _ = ol.render(scene, cam, 64, 64, 0.001, 1, 256, kind="libm")
+        img = acc.reshape(64, 64, 3) / 256
+        assert np.isfinite(img).all()
+        on_box = np.abs(img[..., 0] - 1) > 1e-6
+        assert 0.2 < on_box.mean() < 0.5 and np.allclose(img[~on_box], 1.0, atol=1e-6)
+        means[depth] = img[on_box].mean()
+    assert 0.996 < means[32] < 1.003, means
+    assert 0.98 < means[8] <= means[32] + 2e-3, means
+
+
 @pytest.mark.parametrize("mat", ["lambertian", "mirror"])
 def test_white_furnace_in_a_constant_environment(mat):
     """Path (pathtracer.cu:880-1021) end to end on the infinite light: camera ray, hit, light sample + BSDF sample with MIS against
