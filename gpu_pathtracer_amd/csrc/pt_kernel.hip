@@ -1201,7 +1201,8 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 //   v16 byte offset of the lane's column of the wave's spill slice   v17 LDS address of the lane's suspend record
 //   v18 LDS address of the lane's stack column - 768 (level l at v18 + 768 + 256 l)
 //   v[20:23] best hit {triangle index or -1, t, b1, b2}
-//   lanes at a wide node: v[24:47] six planes of four boxes, v[48:51] the children's entries, v[52:55] their keys, v[56:64] temporaries
+//   lanes at a wide node: v[24:47] six planes of four boxes (child k's key replaces its lo.x value, v24+k, once the child is tested), v[48:51] the
+//                         children's entries, v[52:60] temporaries
 //   lanes at a leaf:      v[24:32] the triangle record, v[44:52] the record after it (PT_WIDE_TRI2), v[33:43] temporaries (as in PT_TRACE_ASM),
 //                         v54 the triangle's index, v55 its byte offset
 //   s[60:61] lanes at a leaf  s[62:63] lanes at a wide node  s[64:65] lanes with a ray / busy lanes  s[66:69],s[72:75] scratch masks
@@ -1345,171 +1346,172 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cbranch_execz TW_LEAF_%=\n"
         "s_waitcnt vmcnt(0)\n"
         /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
-        "v_sub_f32_e32 v56, v24, v0\n"
-        "v_sub_f32_e32 v57, v36, v0\n"
-        "v_sub_f32_e32 v58, v28, v1\n"
-        "v_sub_f32_e32 v60, v32, v2\n"
-        "v_sub_f32_e32 v59, v40, v1\n"
-        "v_sub_f32_e32 v61, v44, v2\n"
-        "v_mul_f32_e32 v56, v8, v56\n"
-        "v_mul_f32_e32 v57, v8, v57\n"
-        "v_mul_f32_e32 v58, v9, v58\n"
-        "v_mul_f32_e32 v59, v9, v59\n"
-        "v_mul_f32_e32 v60, v10, v60\n"
-        "v_mul_f32_e32 v61, v10, v61\n"
-        "v_min_f32_e32 v62, v56, v57\n"
-        "v_min_f32_e32 v63, v58, v59\n"
-        "v_min_f32_e32 v64, v60, v61\n"
+        "v_sub_f32_e32 v52, v24, v0\n"
+        "v_sub_f32_e32 v53, v36, v0\n"
+        "v_sub_f32_e32 v54, v28, v1\n"
+        "v_sub_f32_e32 v56, v32, v2\n"
+        "v_sub_f32_e32 v55, v40, v1\n"
+        "v_sub_f32_e32 v57, v44, v2\n"
+        "v_mul_f32_e32 v52, v8, v52\n"
+        "v_mul_f32_e32 v53, v8, v53\n"
+        "v_mul_f32_e32 v54, v9, v54\n"
+        "v_mul_f32_e32 v55, v9, v55\n"
+        "v_mul_f32_e32 v56, v10, v56\n"
+        "v_mul_f32_e32 v57, v10, v57\n"
+        "v_min_f32_e32 v58, v52, v53\n"
+        "v_min_f32_e32 v59, v54, v55\n"
+        "v_min_f32_e32 v60, v56, v57\n"
+        "v_max_f32_e32 v52, v52, v53\n"
+        "v_max_f32_e32 v54, v54, v55\n"
         "v_max_f32_e32 v56, v56, v57\n"
-        "v_max_f32_e32 v58, v58, v59\n"
-        "v_max_f32_e32 v60, v60, v61\n"
-        "v_min3_f32 v56, v56, v58, v60\n"
-        "v_max3_f32 v62, v62, v63, v64\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
-        "v_min_f32_e32 v56, v56, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
-        "v_max_f32_e32 v62, 0, v62\n"
+        "v_min3_f32 v52, v52, v54, v56\n"
+        "v_max3_f32 v58, v58, v59, v60\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
+        "v_min_f32_e32 v52, v52, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
+        "v_max_f32_e32 v58, 0, v58\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v48\n"
-        "v_and_or_b32 v62, v62, -4, 0\n"
+        "v_and_or_b32 v58, v58, -4, 0\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v52, -1, v62, s[66:67]\n"
-        "v_sub_f32_e32 v56, v25, v0\n"
-        "v_sub_f32_e32 v57, v37, v0\n"
-        "v_sub_f32_e32 v58, v29, v1\n"
-        "v_sub_f32_e32 v60, v33, v2\n"
-        "v_sub_f32_e32 v59, v41, v1\n"
-        "v_sub_f32_e32 v61, v45, v2\n"
-        "v_mul_f32_e32 v56, v8, v56\n"
-        "v_mul_f32_e32 v57, v8, v57\n"
-        "v_mul_f32_e32 v58, v9, v58\n"
-        "v_mul_f32_e32 v59, v9, v59\n"
-        "v_mul_f32_e32 v60, v10, v60\n"
-        "v_mul_f32_e32 v61, v10, v61\n"
-        "v_min_f32_e32 v62, v56, v57\n"
-        "v_min_f32_e32 v63, v58, v59\n"
-        "v_min_f32_e32 v64, v60, v61\n"
+        "v_cndmask_b32_e64 v24, -1, v58, s[66:67]\n"
+        "v_sub_f32_e32 v52, v25, v0\n"
+        "v_sub_f32_e32 v53, v37, v0\n"
+        "v_sub_f32_e32 v54, v29, v1\n"
+        "v_sub_f32_e32 v56, v33, v2\n"
+        "v_sub_f32_e32 v55, v41, v1\n"
+        "v_sub_f32_e32 v57, v45, v2\n"
+        "v_mul_f32_e32 v52, v8, v52\n"
+        "v_mul_f32_e32 v53, v8, v53\n"
+        "v_mul_f32_e32 v54, v9, v54\n"
+        "v_mul_f32_e32 v55, v9, v55\n"
+        "v_mul_f32_e32 v56, v10, v56\n"
+        "v_mul_f32_e32 v57, v10, v57\n"
+        "v_min_f32_e32 v58, v52, v53\n"
+        "v_min_f32_e32 v59, v54, v55\n"
+        "v_min_f32_e32 v60, v56, v57\n"
+        "v_max_f32_e32 v52, v52, v53\n"
+        "v_max_f32_e32 v54, v54, v55\n"
         "v_max_f32_e32 v56, v56, v57\n"
-        "v_max_f32_e32 v58, v58, v59\n"
-        "v_max_f32_e32 v60, v60, v61\n"
-        "v_min3_f32 v56, v56, v58, v60\n"
-        "v_max3_f32 v62, v62, v63, v64\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
-        "v_min_f32_e32 v56, v56, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
-        "v_max_f32_e32 v62, 0, v62\n"
+        "v_min3_f32 v52, v52, v54, v56\n"
+        "v_max3_f32 v58, v58, v59, v60\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
+        "v_min_f32_e32 v52, v52, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
+        "v_max_f32_e32 v58, 0, v58\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v49\n"
-        "v_and_or_b32 v62, v62, -4, 1\n"
+        "v_and_or_b32 v58, v58, -4, 1\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v53, -1, v62, s[66:67]\n"
-        "v_sub_f32_e32 v56, v26, v0\n"
-        "v_sub_f32_e32 v57, v38, v0\n"
-        "v_sub_f32_e32 v58, v30, v1\n"
-        "v_sub_f32_e32 v60, v34, v2\n"
-        "v_sub_f32_e32 v59, v42, v1\n"
-        "v_sub_f32_e32 v61, v46, v2\n"
-        "v_mul_f32_e32 v56, v8, v56\n"
-        "v_mul_f32_e32 v57, v8, v57\n"
-        "v_mul_f32_e32 v58, v9, v58\n"
-        "v_mul_f32_e32 v59, v9, v59\n"
-        "v_mul_f32_e32 v60, v10, v60\n"
-        "v_mul_f32_e32 v61, v10, v61\n"
-        "v_min_f32_e32 v62, v56, v57\n"
-        "v_min_f32_e32 v63, v58, v59\n"
-        "v_min_f32_e32 v64, v60, v61\n"
+        "v_cndmask_b32_e64 v25, -1, v58, s[66:67]\n"
+        "v_sub_f32_e32 v52, v26, v0\n"
+        "v_sub_f32_e32 v53, v38, v0\n"
+        "v_sub_f32_e32 v54, v30, v1\n"
+        "v_sub_f32_e32 v56, v34, v2\n"
+        "v_sub_f32_e32 v55, v42, v1\n"
+        "v_sub_f32_e32 v57, v46, v2\n"
+        "v_mul_f32_e32 v52, v8, v52\n"
+        "v_mul_f32_e32 v53, v8, v53\n"
+        "v_mul_f32_e32 v54, v9, v54\n"
+        "v_mul_f32_e32 v55, v9, v55\n"
+        "v_mul_f32_e32 v56, v10, v56\n"
+        "v_mul_f32_e32 v57, v10, v57\n"
+        "v_min_f32_e32 v58, v52, v53\n"
+        "v_min_f32_e32 v59, v54, v55\n"
+        "v_min_f32_e32 v60, v56, v57\n"
+        "v_max_f32_e32 v52, v52, v53\n"
+        "v_max_f32_e32 v54, v54, v55\n"
         "v_max_f32_e32 v56, v56, v57\n"
-        "v_max_f32_e32 v58, v58, v59\n"
-        "v_max_f32_e32 v60, v60, v61\n"
-        "v_min3_f32 v56, v56, v58, v60\n"
-        "v_max3_f32 v62, v62, v63, v64\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
-        "v_min_f32_e32 v56, v56, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
-        "v_max_f32_e32 v62, 0, v62\n"
+        "v_min3_f32 v52, v52, v54, v56\n"
+        "v_max3_f32 v58, v58, v59, v60\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
+        "v_min_f32_e32 v52, v52, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
+        "v_max_f32_e32 v58, 0, v58\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v50\n"
-        "v_and_or_b32 v62, v62, -4, 2\n"
+        "v_and_or_b32 v58, v58, -4, 2\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v54, -1, v62, s[66:67]\n"
-        "v_sub_f32_e32 v56, v27, v0\n"
-        "v_sub_f32_e32 v57, v39, v0\n"
-        "v_sub_f32_e32 v58, v31, v1\n"
-        "v_sub_f32_e32 v60, v35, v2\n"
-        "v_sub_f32_e32 v59, v43, v1\n"
-        "v_sub_f32_e32 v61, v47, v2\n"
-        "v_mul_f32_e32 v56, v8, v56\n"
-        "v_mul_f32_e32 v57, v8, v57\n"
-        "v_mul_f32_e32 v58, v9, v58\n"
-        "v_mul_f32_e32 v59, v9, v59\n"
-        "v_mul_f32_e32 v60, v10, v60\n"
-        "v_mul_f32_e32 v61, v10, v61\n"
-        "v_min_f32_e32 v62, v56, v57\n"
-        "v_min_f32_e32 v63, v58, v59\n"
-        "v_min_f32_e32 v64, v60, v61\n"
+        "v_cndmask_b32_e64 v26, -1, v58, s[66:67]\n"
+        "v_sub_f32_e32 v52, v27, v0\n"
+        "v_sub_f32_e32 v53, v39, v0\n"
+        "v_sub_f32_e32 v54, v31, v1\n"
+        "v_sub_f32_e32 v56, v35, v2\n"
+        "v_sub_f32_e32 v55, v43, v1\n"
+        "v_sub_f32_e32 v57, v47, v2\n"
+        "v_mul_f32_e32 v52, v8, v52\n"
+        "v_mul_f32_e32 v53, v8, v53\n"
+        "v_mul_f32_e32 v54, v9, v54\n"
+        "v_mul_f32_e32 v55, v9, v55\n"
+        "v_mul_f32_e32 v56, v10, v56\n"
+        "v_mul_f32_e32 v57, v10, v57\n"
+        "v_min_f32_e32 v58, v52, v53\n"
+        "v_min_f32_e32 v59, v54, v55\n"
+        "v_min_f32_e32 v60, v56, v57\n"
+        "v_max_f32_e32 v52, v52, v53\n"
+        "v_max_f32_e32 v54, v54, v55\n"
         "v_max_f32_e32 v56, v56, v57\n"
-        "v_max_f32_e32 v58, v58, v59\n"
-        "v_max_f32_e32 v60, v60, v61\n"
-        "v_min3_f32 v56, v56, v58, v60\n"
-        "v_max3_f32 v62, v62, v63, v64\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v56\n"
-        "v_min_f32_e32 v56, v56, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v56, v62\n"
-        "v_max_f32_e32 v62, 0, v62\n"
+        "v_min3_f32 v52, v52, v54, v56\n"
+        "v_max3_f32 v58, v58, v59, v60\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
+        "v_min_f32_e32 v52, v52, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
+        "v_max_f32_e32 v58, 0, v58\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v51\n"
-        "v_and_or_b32 v62, v62, -4, 3\n"
+        "v_and_or_b32 v58, v58, -4, 3\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v55, -1, v62, s[66:67]\n"
-        /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange */
-        "v_cmp_lt_u32_e32 vcc, v53, v52\n"
-        "v_min_u32_e32 v56, v52, v53\n"
-        "v_max_u32_e32 v53, v52, v53\n"
-        "v_cndmask_b32_e32 v57, v48, v49, vcc\n"
+        "v_cndmask_b32_e64 v27, -1, v58, s[66:67]\n"
+        /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the
+           register its lo.x plane value came in) */
+        "v_cmp_lt_u32_e32 vcc, v25, v24\n"
+        "v_min_u32_e32 v52, v24, v25\n"
+        "v_max_u32_e32 v25, v24, v25\n"
+        "v_cndmask_b32_e32 v53, v48, v49, vcc\n"
         "v_cndmask_b32_e32 v49, v49, v48, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v55, v54\n"
-        "v_min_u32_e32 v52, v54, v55\n"
-        "v_max_u32_e32 v55, v54, v55\n"
+        "v_cmp_lt_u32_e32 vcc, v27, v26\n"
+        "v_min_u32_e32 v24, v26, v27\n"
+        "v_max_u32_e32 v27, v26, v27\n"
         "v_cndmask_b32_e32 v48, v50, v51, vcc\n"
         "v_cndmask_b32_e32 v51, v51, v50, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v52, v56\n"
-        "v_min_u32_e32 v54, v56, v52\n"
-        "v_max_u32_e32 v52, v56, v52\n"
-        "v_cndmask_b32_e32 v50, v57, v48, vcc\n"
-        "v_cndmask_b32_e32 v48, v48, v57, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v55, v53\n"
-        "v_min_u32_e32 v56, v53, v55\n"
-        "v_max_u32_e32 v55, v53, v55\n"
-        "v_cndmask_b32_e32 v57, v49, v51, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v24, v52\n"
+        "v_min_u32_e32 v26, v52, v24\n"
+        "v_max_u32_e32 v24, v52, v24\n"
+        "v_cndmask_b32_e32 v50, v53, v48, vcc\n"
+        "v_cndmask_b32_e32 v48, v48, v53, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v27, v25\n"
+        "v_min_u32_e32 v52, v25, v27\n"
+        "v_max_u32_e32 v27, v25, v27\n"
+        "v_cndmask_b32_e32 v53, v49, v51, vcc\n"
         "v_cndmask_b32_e32 v51, v51, v49, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v52, v56\n"
-        "v_min_u32_e32 v53, v56, v52\n"
-        "v_max_u32_e32 v52, v56, v52\n"
-        "v_cndmask_b32_e32 v49, v57, v48, vcc\n"
-        "v_cndmask_b32_e32 v48, v48, v57, vcc\n"
-        /* sorted: keys v54 <= v53 <= v52 <= v55, entries v50, v49, v48, v51 (a child that is not hit: key -1, sorts last) */
-        "v_cmp_ne_u32_e64 s[66:67], -1, v53\n"
-        "v_cmp_ne_u32_e64 s[68:69], -1, v52\n"
-        "v_cmp_ne_u32_e64 s[72:73], -1, v55\n"
-        "v_cmp_ne_u32_e64 s[80:81], -1, v54\n"             /* the node has a hit child */
+        "v_cmp_lt_u32_e32 vcc, v24, v52\n"
+        "v_min_u32_e32 v25, v52, v24\n"
+        "v_max_u32_e32 v24, v52, v24\n"
+        "v_cndmask_b32_e32 v49, v53, v48, vcc\n"
+        "v_cndmask_b32_e32 v48, v48, v53, vcc\n"
+        /* sorted: keys v26 <= v25 <= v24 <= v27, entries v50, v49, v48, v51 (a child that is not hit: key -1, sorts last) */
+        "v_cmp_ne_u32_e64 s[66:67], -1, v25\n"
+        "v_cmp_ne_u32_e64 s[68:69], -1, v24\n"
+        "v_cmp_ne_u32_e64 s[72:73], -1, v27\n"
+        "v_cmp_ne_u32_e64 s[80:81], -1, v26\n"             /* the node has a hit child */
         "s_nop 0\n"
-        "v_addc_co_u32_e64 v56, s[74:75], v13, 0, s[66:67]\n"
-        "v_addc_co_u32_e64 v56, s[74:75], v56, 0, s[68:69]\n"
-        "v_addc_co_u32_e64 v56, s[74:75], v56, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
+        "v_addc_co_u32_e64 v54, s[74:75], v13, 0, s[66:67]\n"
+        "v_addc_co_u32_e64 v54, s[74:75], v54, 0, s[68:69]\n"
+        "v_addc_co_u32_e64 v54, s[74:75], v54, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
         /* the others are pushed farthest first: sorted child j ends at level size' - j */
-        "v_cmp_lt_u32_e64 s[74:75], %[depth], v56\n"
-        "v_lshl_add_u32 v57, v56, 8, v18\n"                /* address of level size' - 3 */
+        "v_cmp_lt_u32_e64 s[74:75], %[depth], v54\n"
+        "v_lshl_add_u32 v55, v54, 8, v18\n"                /* address of level size' - 3 */
         "s_cmp_lg_u64 s[74:75], 0\n"
         "s_cbranch_scc1 TW_PUSH_SLOW_%=\n"
         "s_mov_b64 exec, s[72:73]\n"
-        "ds_write_b32 v57, v51\n"
+        "ds_write_b32 v55, v51\n"
         "s_mov_b64 exec, s[68:69]\n"
-        "ds_write_b32 v57, v48 offset:256\n"
+        "ds_write_b32 v55, v48 offset:256\n"
         "s_mov_b64 exec, s[66:67]\n"
-        "ds_write_b32 v57, v49 offset:512\n"
+        "ds_write_b32 v55, v49 offset:512\n"
         "TW_PUSHED_%=:\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_cndmask_b32_e64 v13, v13, v56, s[80:81]\n"
+        "v_cndmask_b32_e64 v13, v13, v54, s[80:81]\n"
         "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
         "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
 #if PT_WIDE_EARLY
@@ -1763,12 +1765,12 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
         "s_mov_b64 s[72:73], exec\n"
         "s_and_b64 exec, exec, vcc\n"
-        "v_lshl_add_u32 v56, v13, 8, v18\n"
-        "ds_read_b32 v12, v56 offset:768\n"
+        "v_lshl_add_u32 v54, v13, 8, v18\n"
+        "ds_read_b32 v12, v54 offset:768\n"
         "s_andn2_b64 exec, s[72:73], vcc\n"
         "s_cbranch_execz TW_POP_LDS_%=\n"
-        "v_lshl_add_u32 v56, v13, 8, v16\n"
-        "global_load_dword v12, v56, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v54, v13, 8, v16\n"
+        "global_load_dword v12, v54, %[spill] sc0 sc1\n"
         "s_waitcnt vmcnt(0)\n"
         "TW_POP_LDS_%=:\n"
         "s_waitcnt lgkmcnt(0)\n"
@@ -1778,32 +1780,32 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
         "TW_PUSH_SLOW_%=:\n"
         PT_WIDE_PROBE_SLOW
-        "v_add_u32_e32 v57, -3, v56\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
+        "v_add_u32_e32 v55, -3, v54\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v55\n"
         "s_and_b64 exec, s[72:73], vcc\n"
-        "v_lshl_add_u32 v58, v57, 8, v18\n"
-        "ds_write_b32 v58, v51 offset:768\n"
+        "v_lshl_add_u32 v56, v55, 8, v18\n"
+        "ds_write_b32 v56, v51 offset:768\n"
         "s_andn2_b64 exec, s[72:73], vcc\n"
-        "v_lshl_add_u32 v58, v57, 8, v16\n"
-        "global_store_dword v58, v51, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v56, v55, 8, v16\n"
+        "global_store_dword v56, v51, %[spill] sc0 sc1\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v57, -2, v56\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
+        "v_add_u32_e32 v55, -2, v54\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v55\n"
         "s_and_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v58, v57, 8, v18\n"
-        "ds_write_b32 v58, v48 offset:768\n"
+        "v_lshl_add_u32 v56, v55, 8, v18\n"
+        "ds_write_b32 v56, v48 offset:768\n"
         "s_andn2_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v58, v57, 8, v16\n"
-        "global_store_dword v58, v48, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v56, v55, 8, v16\n"
+        "global_store_dword v56, v48, %[spill] sc0 sc1\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v57, -1, v56\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v57\n"
+        "v_add_u32_e32 v55, -1, v54\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v55\n"
         "s_and_b64 exec, s[66:67], vcc\n"
-        "v_lshl_add_u32 v58, v57, 8, v18\n"
-        "ds_write_b32 v58, v49 offset:768\n"
+        "v_lshl_add_u32 v56, v55, 8, v18\n"
+        "ds_write_b32 v56, v49 offset:768\n"
         "s_andn2_b64 exec, s[66:67], vcc\n"
-        "v_lshl_add_u32 v58, v57, 8, v16\n"
-        "global_store_dword v58, v49, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v56, v55, 8, v16\n"
+        "global_store_dword v56, v49, %[spill] sc0 sc1\n"
         "s_waitcnt vmcnt(0)\n"
         "s_branch TW_PUSHED_%=\n"
         /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
@@ -1857,15 +1859,14 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cmp_gt_u32 s71, %[maxbusy]\n"
         "s_cbranch_scc1 TW_TRIP_%=\n"
         "s_not_b64 s[66:67], s[64:65]\n"
-        "v_mbcnt_lo_u32_b32 v65, s66, 0\n"
-        "v_mbcnt_hi_u32_b32 v65, s67, v65\n"
-        "v_add_u32_e32 v65, s70, v65\n"
-        "v_cmp_gt_i32_e32 vcc, %[rays], v65\n"
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"               /* v33: a temporary of the leaf block, dead between trips (v54 is not) */
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
+        "v_add_u32_e32 v33, s70, v33\n"
+        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
         "s_and_b64 s[66:67], vcc, s[66:67]\n"
         "s_sub_i32 s71, 64, s71\n"
         "s_add_i32 s70, s70, s71\n"
         "s_mov_b64 exec, s[66:67]\n"
-        "v_mov_b32_e32 v33, v65\n"
         PT_FETCH_ORDERED
         "ds_read_b128 v[4:7], v15\n"
         "ds_read_b128 v[8:11], v15 offset:16\n"
@@ -1913,7 +1914,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
           "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65");
+          "v56", "v57", "v58", "v59", "v60");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
