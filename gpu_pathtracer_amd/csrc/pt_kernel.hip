@@ -1201,10 +1201,10 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 //   v16 byte offset of the lane's column of the wave's spill slice   v17 LDS address of the lane's suspend record
 //   v18 LDS address of the lane's stack column - 768 (level l at v18 + 768 + 256 l)
 //   v[20:23] best hit {triangle index or -1, t, b1, b2}
-//   lanes at a wide node: v[24:47] six planes of four boxes (child k's key replaces its lo.x value, v24+k, once the child is tested), v[48:51] the
-//                         children's entries, v[52:60] temporaries
+//   lanes at a wide node: v[24:47] six planes of four boxes, worked on in place (child k: v24+k, v28+k, ... v44+k; its key ends in v24+k),
+//                         v[48:51] the children's entries, v52 v53 temporaries; after the sort v[28:30] (push addresses)
 //   lanes at a leaf:      v[24:32] the triangle record, v[44:52] the record after it (PT_WIDE_TRI2), v[33:43] temporaries (as in PT_TRACE_ASM),
-//                         v54 the triangle's index, v55 its byte offset
+//                         v53 the triangle's index, v54 its byte offset
 //   s[60:61] lanes at a leaf  s[62:63] lanes at a wide node  s[64:65] lanes with a ray / busy lanes  s[66:69],s[72:75] scratch masks
 //   s70 next ray  s71 s72 counts  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] node lanes with a hit child
 #ifndef PT_WIDE_ASM
@@ -1320,16 +1320,16 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
            wait for everything) */
         "s_mov_b64 exec, s[60:61]\n"
-        "v_and_b32_e32 v54, 0x7ffffff, v12\n"              /* the leaf's first triangle */
-        "v_lshlrev_b32_e32 v55, 4, v54\n"
-        "v_lshl_add_u32 v55, v54, 5, v55\n"                /* * 48 */
-        "global_load_dwordx4 v[28:31], v55, %[tris] offset:16\n"
-        "global_load_dword v32, v55, %[tris] offset:32\n"
-        "global_load_dwordx4 v[24:27], v55, %[tris]\n"
+        "v_and_b32_e32 v53, 0x7ffffff, v12\n"              /* the leaf's first triangle */
+        "v_lshlrev_b32_e32 v54, 4, v53\n"
+        "v_lshl_add_u32 v54, v53, 5, v54\n"                /* * 48 */
+        "global_load_dwordx4 v[28:31], v54, %[tris] offset:16\n"
+        "global_load_dword v32, v54, %[tris] offset:32\n"
+        "global_load_dwordx4 v[24:27], v54, %[tris]\n"
 #if PT_WIDE_TRI2
-        "global_load_dwordx4 v[48:51], v55, %[tris] offset:64\n"      /* ... and the one after it (the array is padded by one record) */
-        "global_load_dword v52, v55, %[tris] offset:80\n"
-        "global_load_dwordx4 v[44:47], v55, %[tris] offset:48\n"
+        "global_load_dwordx4 v[48:51], v54, %[tris] offset:64\n"      /* ... and the one after it (the array is padded by one record) */
+        "global_load_dword v52, v54, %[tris] offset:80\n"
+        "global_load_dwordx4 v[44:47], v54, %[tris] offset:48\n"
 #endif
         "s_andn2_b64 exec, s[62:63], s[82:83]\n"           /* (the lanes that descended last trip fetched their record then) */
         "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
@@ -1346,122 +1346,123 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cbranch_execz TW_LEAF_%=\n"
         "s_waitcnt vmcnt(0)\n"
         /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
-        "v_sub_f32_e32 v52, v24, v0\n"
-        "v_sub_f32_e32 v53, v36, v0\n"
-        "v_sub_f32_e32 v54, v28, v1\n"
-        "v_sub_f32_e32 v56, v32, v2\n"
-        "v_sub_f32_e32 v55, v40, v1\n"
-        "v_sub_f32_e32 v57, v44, v2\n"
-        "v_mul_f32_e32 v52, v8, v52\n"
-        "v_mul_f32_e32 v53, v8, v53\n"
-        "v_mul_f32_e32 v54, v9, v54\n"
-        "v_mul_f32_e32 v55, v9, v55\n"
-        "v_mul_f32_e32 v56, v10, v56\n"
-        "v_mul_f32_e32 v57, v10, v57\n"
-        "v_min_f32_e32 v58, v52, v53\n"
-        "v_min_f32_e32 v59, v54, v55\n"
-        "v_min_f32_e32 v60, v56, v57\n"
-        "v_max_f32_e32 v52, v52, v53\n"
-        "v_max_f32_e32 v54, v54, v55\n"
-        "v_max_f32_e32 v56, v56, v57\n"
-        "v_min3_f32 v52, v52, v54, v56\n"
-        "v_max3_f32 v58, v58, v59, v60\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
-        "v_min_f32_e32 v52, v52, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
-        "v_max_f32_e32 v58, 0, v58\n"
+        /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */
+        "v_sub_f32_e32 v24, v24, v0\n"
+        "v_sub_f32_e32 v36, v36, v0\n"
+        "v_sub_f32_e32 v28, v28, v1\n"
+        "v_sub_f32_e32 v32, v32, v2\n"
+        "v_sub_f32_e32 v40, v40, v1\n"
+        "v_sub_f32_e32 v44, v44, v2\n"
+        "v_mul_f32_e32 v24, v8, v24\n"
+        "v_mul_f32_e32 v36, v8, v36\n"
+        "v_mul_f32_e32 v28, v9, v28\n"
+        "v_mul_f32_e32 v40, v9, v40\n"
+        "v_mul_f32_e32 v32, v10, v32\n"
+        "v_mul_f32_e32 v44, v10, v44\n"
+        "v_min_f32_e32 v52, v24, v36\n"
+        "v_max_f32_e32 v24, v24, v36\n"
+        "v_min_f32_e32 v36, v28, v40\n"
+        "v_max_f32_e32 v28, v28, v40\n"
+        "v_min_f32_e32 v40, v32, v44\n"
+        "v_max_f32_e32 v32, v32, v44\n"
+        "v_min3_f32 v24, v24, v28, v32\n"
+        "v_max3_f32 v52, v52, v36, v40\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v24\n"
+        "v_min_f32_e32 v24, v24, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v24, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v48\n"
-        "v_and_or_b32 v58, v58, -4, 0\n"
+        "v_and_or_b32 v52, v52, -4, 0\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v24, -1, v58, s[66:67]\n"
-        "v_sub_f32_e32 v52, v25, v0\n"
-        "v_sub_f32_e32 v53, v37, v0\n"
-        "v_sub_f32_e32 v54, v29, v1\n"
-        "v_sub_f32_e32 v56, v33, v2\n"
-        "v_sub_f32_e32 v55, v41, v1\n"
-        "v_sub_f32_e32 v57, v45, v2\n"
-        "v_mul_f32_e32 v52, v8, v52\n"
-        "v_mul_f32_e32 v53, v8, v53\n"
-        "v_mul_f32_e32 v54, v9, v54\n"
-        "v_mul_f32_e32 v55, v9, v55\n"
-        "v_mul_f32_e32 v56, v10, v56\n"
-        "v_mul_f32_e32 v57, v10, v57\n"
-        "v_min_f32_e32 v58, v52, v53\n"
-        "v_min_f32_e32 v59, v54, v55\n"
-        "v_min_f32_e32 v60, v56, v57\n"
-        "v_max_f32_e32 v52, v52, v53\n"
-        "v_max_f32_e32 v54, v54, v55\n"
-        "v_max_f32_e32 v56, v56, v57\n"
-        "v_min3_f32 v52, v52, v54, v56\n"
-        "v_max3_f32 v58, v58, v59, v60\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
-        "v_min_f32_e32 v52, v52, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
-        "v_max_f32_e32 v58, 0, v58\n"
+        "v_cndmask_b32_e64 v24, -1, v52, s[66:67]\n"
+        "v_sub_f32_e32 v25, v25, v0\n"
+        "v_sub_f32_e32 v37, v37, v0\n"
+        "v_sub_f32_e32 v29, v29, v1\n"
+        "v_sub_f32_e32 v33, v33, v2\n"
+        "v_sub_f32_e32 v41, v41, v1\n"
+        "v_sub_f32_e32 v45, v45, v2\n"
+        "v_mul_f32_e32 v25, v8, v25\n"
+        "v_mul_f32_e32 v37, v8, v37\n"
+        "v_mul_f32_e32 v29, v9, v29\n"
+        "v_mul_f32_e32 v41, v9, v41\n"
+        "v_mul_f32_e32 v33, v10, v33\n"
+        "v_mul_f32_e32 v45, v10, v45\n"
+        "v_min_f32_e32 v52, v25, v37\n"
+        "v_max_f32_e32 v25, v25, v37\n"
+        "v_min_f32_e32 v37, v29, v41\n"
+        "v_max_f32_e32 v29, v29, v41\n"
+        "v_min_f32_e32 v41, v33, v45\n"
+        "v_max_f32_e32 v33, v33, v45\n"
+        "v_min3_f32 v25, v25, v29, v33\n"
+        "v_max3_f32 v52, v52, v37, v41\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v25\n"
+        "v_min_f32_e32 v25, v25, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v25, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v49\n"
-        "v_and_or_b32 v58, v58, -4, 1\n"
+        "v_and_or_b32 v52, v52, -4, 1\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v25, -1, v58, s[66:67]\n"
-        "v_sub_f32_e32 v52, v26, v0\n"
-        "v_sub_f32_e32 v53, v38, v0\n"
-        "v_sub_f32_e32 v54, v30, v1\n"
-        "v_sub_f32_e32 v56, v34, v2\n"
-        "v_sub_f32_e32 v55, v42, v1\n"
-        "v_sub_f32_e32 v57, v46, v2\n"
-        "v_mul_f32_e32 v52, v8, v52\n"
-        "v_mul_f32_e32 v53, v8, v53\n"
-        "v_mul_f32_e32 v54, v9, v54\n"
-        "v_mul_f32_e32 v55, v9, v55\n"
-        "v_mul_f32_e32 v56, v10, v56\n"
-        "v_mul_f32_e32 v57, v10, v57\n"
-        "v_min_f32_e32 v58, v52, v53\n"
-        "v_min_f32_e32 v59, v54, v55\n"
-        "v_min_f32_e32 v60, v56, v57\n"
-        "v_max_f32_e32 v52, v52, v53\n"
-        "v_max_f32_e32 v54, v54, v55\n"
-        "v_max_f32_e32 v56, v56, v57\n"
-        "v_min3_f32 v52, v52, v54, v56\n"
-        "v_max3_f32 v58, v58, v59, v60\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
-        "v_min_f32_e32 v52, v52, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
-        "v_max_f32_e32 v58, 0, v58\n"
+        "v_cndmask_b32_e64 v25, -1, v52, s[66:67]\n"
+        "v_sub_f32_e32 v26, v26, v0\n"
+        "v_sub_f32_e32 v38, v38, v0\n"
+        "v_sub_f32_e32 v30, v30, v1\n"
+        "v_sub_f32_e32 v34, v34, v2\n"
+        "v_sub_f32_e32 v42, v42, v1\n"
+        "v_sub_f32_e32 v46, v46, v2\n"
+        "v_mul_f32_e32 v26, v8, v26\n"
+        "v_mul_f32_e32 v38, v8, v38\n"
+        "v_mul_f32_e32 v30, v9, v30\n"
+        "v_mul_f32_e32 v42, v9, v42\n"
+        "v_mul_f32_e32 v34, v10, v34\n"
+        "v_mul_f32_e32 v46, v10, v46\n"
+        "v_min_f32_e32 v52, v26, v38\n"
+        "v_max_f32_e32 v26, v26, v38\n"
+        "v_min_f32_e32 v38, v30, v42\n"
+        "v_max_f32_e32 v30, v30, v42\n"
+        "v_min_f32_e32 v42, v34, v46\n"
+        "v_max_f32_e32 v34, v34, v46\n"
+        "v_min3_f32 v26, v26, v30, v34\n"
+        "v_max3_f32 v52, v52, v38, v42\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v26\n"
+        "v_min_f32_e32 v26, v26, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v26, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v50\n"
-        "v_and_or_b32 v58, v58, -4, 2\n"
+        "v_and_or_b32 v52, v52, -4, 2\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v26, -1, v58, s[66:67]\n"
-        "v_sub_f32_e32 v52, v27, v0\n"
-        "v_sub_f32_e32 v53, v39, v0\n"
-        "v_sub_f32_e32 v54, v31, v1\n"
-        "v_sub_f32_e32 v56, v35, v2\n"
-        "v_sub_f32_e32 v55, v43, v1\n"
-        "v_sub_f32_e32 v57, v47, v2\n"
-        "v_mul_f32_e32 v52, v8, v52\n"
-        "v_mul_f32_e32 v53, v8, v53\n"
-        "v_mul_f32_e32 v54, v9, v54\n"
-        "v_mul_f32_e32 v55, v9, v55\n"
-        "v_mul_f32_e32 v56, v10, v56\n"
-        "v_mul_f32_e32 v57, v10, v57\n"
-        "v_min_f32_e32 v58, v52, v53\n"
-        "v_min_f32_e32 v59, v54, v55\n"
-        "v_min_f32_e32 v60, v56, v57\n"
-        "v_max_f32_e32 v52, v52, v53\n"
-        "v_max_f32_e32 v54, v54, v55\n"
-        "v_max_f32_e32 v56, v56, v57\n"
-        "v_min3_f32 v52, v52, v54, v56\n"
-        "v_max3_f32 v58, v58, v59, v60\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v52\n"
-        "v_min_f32_e32 v52, v52, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v52, v58\n"
-        "v_max_f32_e32 v58, 0, v58\n"
+        "v_cndmask_b32_e64 v26, -1, v52, s[66:67]\n"
+        "v_sub_f32_e32 v27, v27, v0\n"
+        "v_sub_f32_e32 v39, v39, v0\n"
+        "v_sub_f32_e32 v31, v31, v1\n"
+        "v_sub_f32_e32 v35, v35, v2\n"
+        "v_sub_f32_e32 v43, v43, v1\n"
+        "v_sub_f32_e32 v47, v47, v2\n"
+        "v_mul_f32_e32 v27, v8, v27\n"
+        "v_mul_f32_e32 v39, v8, v39\n"
+        "v_mul_f32_e32 v31, v9, v31\n"
+        "v_mul_f32_e32 v43, v9, v43\n"
+        "v_mul_f32_e32 v35, v10, v35\n"
+        "v_mul_f32_e32 v47, v10, v47\n"
+        "v_min_f32_e32 v52, v27, v39\n"
+        "v_max_f32_e32 v27, v27, v39\n"
+        "v_min_f32_e32 v39, v31, v43\n"
+        "v_max_f32_e32 v31, v31, v43\n"
+        "v_min_f32_e32 v43, v35, v47\n"
+        "v_max_f32_e32 v35, v35, v47\n"
+        "v_min3_f32 v27, v27, v31, v35\n"
+        "v_max3_f32 v52, v52, v39, v43\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v27\n"
+        "v_min_f32_e32 v27, v27, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v27, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cmp_ne_u32_e32 vcc, -1, v51\n"
-        "v_and_or_b32 v58, v58, -4, 3\n"
+        "v_and_or_b32 v52, v52, -4, 3\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v27, -1, v58, s[66:67]\n"
+        "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
         /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the
            register its lo.x plane value came in) */
         "v_cmp_lt_u32_e32 vcc, v25, v24\n"
@@ -1495,23 +1496,23 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_ne_u32_e64 s[72:73], -1, v27\n"
         "v_cmp_ne_u32_e64 s[80:81], -1, v26\n"             /* the node has a hit child */
         "s_nop 0\n"
-        "v_addc_co_u32_e64 v54, s[74:75], v13, 0, s[66:67]\n"
-        "v_addc_co_u32_e64 v54, s[74:75], v54, 0, s[68:69]\n"
-        "v_addc_co_u32_e64 v54, s[74:75], v54, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
+        "v_addc_co_u32_e64 v28, s[74:75], v13, 0, s[66:67]\n"
+        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[68:69]\n"
+        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
         /* the others are pushed farthest first: sorted child j ends at level size' - j */
-        "v_cmp_lt_u32_e64 s[74:75], %[depth], v54\n"
-        "v_lshl_add_u32 v55, v54, 8, v18\n"                /* address of level size' - 3 */
+        "v_cmp_lt_u32_e64 s[74:75], %[depth], v28\n"
+        "v_lshl_add_u32 v29, v28, 8, v18\n"                /* address of level size' - 3 */
         "s_cmp_lg_u64 s[74:75], 0\n"
         "s_cbranch_scc1 TW_PUSH_SLOW_%=\n"
         "s_mov_b64 exec, s[72:73]\n"
-        "ds_write_b32 v55, v51\n"
+        "ds_write_b32 v29, v51\n"
         "s_mov_b64 exec, s[68:69]\n"
-        "ds_write_b32 v55, v48 offset:256\n"
+        "ds_write_b32 v29, v48 offset:256\n"
         "s_mov_b64 exec, s[66:67]\n"
-        "ds_write_b32 v55, v49 offset:512\n"
+        "ds_write_b32 v29, v49 offset:512\n"
         "TW_PUSHED_%=:\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_cndmask_b32_e64 v13, v13, v54, s[80:81]\n"
+        "v_cndmask_b32_e64 v13, v13, v28, s[80:81]\n"
         "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
         "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
 #if PT_WIDE_EARLY
@@ -1609,7 +1610,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_lt_f32_e32 vcc, v39, v21\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_eq_f32_e32 vcc, v39, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v54, v20\n"
+        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
         "s_and_b64 vcc, vcc, s[72:73]\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_lt_f32_e32 vcc, v39, v14\n"
@@ -1617,7 +1618,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
         "v_and_b32_e32 v42, 0x100, v11\n"
         "s_and_b64 exec, exec, s[68:69]\n"
-        "v_mov_b32_e32 v20, v54\n"
+        "v_mov_b32_e32 v20, v53\n"
         "v_mov_b32_e32 v21, v39\n"
         "v_mov_b32_e32 v22, v43\n"
         "v_mov_b32_e32 v23, v38\n"
@@ -1639,7 +1640,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
         "s_mov_b64 exec, s[84:85]\n"
         "s_cbranch_execz TW_POP_%=\n"
-        "v_add_u32_e32 v54, 1, v54\n"
+        "v_add_u32_e32 v53, 1, v53\n"
         "v_mul_f32_e32 v33, v5, v52\n"
         "v_mul_f32_e32 v42, v6, v51\n"
         "v_sub_f32_e32 v33, v33, v42\n"
@@ -1714,7 +1715,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_lt_f32_e32 vcc, v39, v21\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_eq_f32_e32 vcc, v39, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v54, v20\n"
+        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
         "s_and_b64 vcc, vcc, s[72:73]\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
         "v_cmp_lt_f32_e32 vcc, v39, v14\n"
@@ -1722,7 +1723,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
         "v_and_b32_e32 v42, 0x100, v11\n"
         "s_and_b64 exec, exec, s[68:69]\n"
-        "v_mov_b32_e32 v20, v54\n"
+        "v_mov_b32_e32 v20, v53\n"
         "v_mov_b32_e32 v21, v39\n"
         "v_mov_b32_e32 v22, v43\n"
         "v_mov_b32_e32 v23, v38\n"
@@ -1765,12 +1766,12 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
         "s_mov_b64 s[72:73], exec\n"
         "s_and_b64 exec, exec, vcc\n"
-        "v_lshl_add_u32 v54, v13, 8, v18\n"
-        "ds_read_b32 v12, v54 offset:768\n"
+        "v_lshl_add_u32 v33, v13, 8, v18\n"
+        "ds_read_b32 v12, v33 offset:768\n"
         "s_andn2_b64 exec, s[72:73], vcc\n"
         "s_cbranch_execz TW_POP_LDS_%=\n"
-        "v_lshl_add_u32 v54, v13, 8, v16\n"
-        "global_load_dword v12, v54, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v33, v13, 8, v16\n"
+        "global_load_dword v12, v33, %[spill] sc0 sc1\n"
         "s_waitcnt vmcnt(0)\n"
         "TW_POP_LDS_%=:\n"
         "s_waitcnt lgkmcnt(0)\n"
@@ -1780,32 +1781,32 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
         "TW_PUSH_SLOW_%=:\n"
         PT_WIDE_PROBE_SLOW
-        "v_add_u32_e32 v55, -3, v54\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v55\n"
+        "v_add_u32_e32 v29, -3, v28\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
         "s_and_b64 exec, s[72:73], vcc\n"
-        "v_lshl_add_u32 v56, v55, 8, v18\n"
-        "ds_write_b32 v56, v51 offset:768\n"
+        "v_lshl_add_u32 v30, v29, 8, v18\n"
+        "ds_write_b32 v30, v51 offset:768\n"
         "s_andn2_b64 exec, s[72:73], vcc\n"
-        "v_lshl_add_u32 v56, v55, 8, v16\n"
-        "global_store_dword v56, v51, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v30, v29, 8, v16\n"
+        "global_store_dword v30, v51, %[spill] sc0 sc1\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v55, -2, v54\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v55\n"
+        "v_add_u32_e32 v29, -2, v28\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
         "s_and_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v56, v55, 8, v18\n"
-        "ds_write_b32 v56, v48 offset:768\n"
+        "v_lshl_add_u32 v30, v29, 8, v18\n"
+        "ds_write_b32 v30, v48 offset:768\n"
         "s_andn2_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v56, v55, 8, v16\n"
-        "global_store_dword v56, v48, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v30, v29, 8, v16\n"
+        "global_store_dword v30, v48, %[spill] sc0 sc1\n"
         "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v55, -1, v54\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v55\n"
+        "v_add_u32_e32 v29, -1, v28\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
         "s_and_b64 exec, s[66:67], vcc\n"
-        "v_lshl_add_u32 v56, v55, 8, v18\n"
-        "ds_write_b32 v56, v49 offset:768\n"
+        "v_lshl_add_u32 v30, v29, 8, v18\n"
+        "ds_write_b32 v30, v49 offset:768\n"
         "s_andn2_b64 exec, s[66:67], vcc\n"
-        "v_lshl_add_u32 v56, v55, 8, v16\n"
-        "global_store_dword v56, v49, %[spill] sc0 sc1\n"
+        "v_lshl_add_u32 v30, v29, 8, v16\n"
+        "global_store_dword v30, v49, %[spill] sc0 sc1\n"
         "s_waitcnt vmcnt(0)\n"
         "s_branch TW_PUSHED_%=\n"
         /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
@@ -1913,8 +1914,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
           "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
-          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v56", "v57", "v58", "v59", "v60");
+          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 }
 
 // mesh.h:68-95 evaluated once for the final hit
