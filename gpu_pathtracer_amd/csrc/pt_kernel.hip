@@ -1210,6 +1210,12 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 #ifndef PT_WIDE_ASM
 #define PT_WIDE_ASM 1
 #endif
+// cache-policy bits of the loop's accesses to the wave's spill slice.  None: a wave reads only what the same wave wrote, which its CU's
+// write-through L1 keeps coherent, and the lines stay in L2 (" sc0 sc1" - system scope - wrote every suspend record through to HBM:
+// 24 GB per launch of the c5 stand-in against 1 GB of sample planes)
+#ifndef PT_WIDE_SC
+#define PT_WIDE_SC ""
+#endif
 // a lane's suspend record lives in the wave's slice of P.wide_stack (the hand-scheduled loop reads it when a drain starts and
 // writes it when the drain ends, both with sc0 sc1: the same wave reads what it wrote, past its L1); "no ray" at kernel start
 __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, unsigned lane)
@@ -1277,8 +1283,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_mov_b32_e32 v16, %[vspill]\n"
         /* every lane resumes the ray it was walking when the last drain stopped (its record: {entry, stack size, end of the
            interval, slot} {best hit}); direction and origin come back from the ray's slot */
-        "global_load_dwordx4 v[12:15], v17, %[spill] sc0 sc1\n"
-        "global_load_dwordx4 v[20:23], v17, %[spill] offset:16 sc0 sc1\n"
+        "global_load_dwordx4 v[12:15], v17, %[spill]" PT_WIDE_SC "\n"
+        "global_load_dwordx4 v[20:23], v17, %[spill] offset:16" PT_WIDE_SC "\n"
         "s_waitcnt vmcnt(0)\n"
         "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"
         "s_mov_b64 exec, s[64:65]\n"
@@ -1771,7 +1777,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_andn2_b64 exec, s[72:73], vcc\n"
         "s_cbranch_execz TW_POP_LDS_%=\n"
         "v_lshl_add_u32 v33, v13, 8, v16\n"
-        "global_load_dword v12, v33, %[spill] sc0 sc1\n"
+        "global_load_dword v12, v33, %[spill]" PT_WIDE_SC "\n"
         "s_waitcnt vmcnt(0)\n"
         "TW_POP_LDS_%=:\n"
         "s_waitcnt lgkmcnt(0)\n"
@@ -1788,7 +1794,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "ds_write_b32 v30, v51 offset:768\n"
         "s_andn2_b64 exec, s[72:73], vcc\n"
         "v_lshl_add_u32 v30, v29, 8, v16\n"
-        "global_store_dword v30, v51, %[spill] sc0 sc1\n"
+        "global_store_dword v30, v51, %[spill]" PT_WIDE_SC "\n"
         "s_mov_b64 exec, s[62:63]\n"
         "v_add_u32_e32 v29, -2, v28\n"
         "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
@@ -1797,7 +1803,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "ds_write_b32 v30, v48 offset:768\n"
         "s_andn2_b64 exec, s[68:69], vcc\n"
         "v_lshl_add_u32 v30, v29, 8, v16\n"
-        "global_store_dword v30, v48, %[spill] sc0 sc1\n"
+        "global_store_dword v30, v48, %[spill]" PT_WIDE_SC "\n"
         "s_mov_b64 exec, s[62:63]\n"
         "v_add_u32_e32 v29, -1, v28\n"
         "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
@@ -1806,7 +1812,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "ds_write_b32 v30, v49 offset:768\n"
         "s_andn2_b64 exec, s[66:67], vcc\n"
         "v_lshl_add_u32 v30, v29, 8, v16\n"
-        "global_store_dword v30, v49, %[spill] sc0 sc1\n"
+        "global_store_dword v30, v49, %[spill]" PT_WIDE_SC "\n"
         "s_waitcnt vmcnt(0)\n"
         "s_branch TW_PUSHED_%=\n"
         /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
@@ -1897,8 +1903,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cbranch_scc1 TW_TRIP_%=\n"
         "TW_DONE_%=:\n"
         "s_waitcnt vmcnt(0)\n"                             /* (an early fetch must not land after the registers have been handed back) */
-        "global_store_dwordx4 v17, v[12:15], %[spill] sc0 sc1\n"
-        "global_store_dwordx4 v17, v[20:23], %[spill] offset:16 sc0 sc1\n"
+        "global_store_dwordx4 v17, v[12:15], %[spill]" PT_WIDE_SC "\n"
+        "global_store_dwordx4 v17, v[20:23], %[spill] offset:16" PT_WIDE_SC "\n"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
 #if PT_WIDE_PROBE
