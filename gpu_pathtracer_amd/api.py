@@ -92,6 +92,9 @@ def load():
         "gpt_save_png": [C.c_char_p, i32, i32, vp],
         "gpt_save_pfm": [C.c_char_p, i32, i32, vp],
         "gpt_save_exr": [C.c_char_p, i32, i32, vp],
+        "gpt_decode_image8": [C.c_char_p, vp, vp, vp, vp, C.c_int64],
+        "gpt_load_texture": [C.c_char_p, vp, vp, vp, C.c_int64],
+        "gpt_load_exr": [C.c_char_p, vp, vp, vp, C.c_int64],
     }
     for name, args in sig.items():
         try:
@@ -209,6 +212,33 @@ def save_png(path, width, height, rgb):
 def save_exr(path, width, height, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     check(load().gpt_save_exr(os.fsencode(path), width, height, st.ptr(rgb)))
+
+
+def decode_image8(path):
+    """gpt_decode_image8: PNG / JPEG -> uint8 [H, W, components], row 0 = bottom (stb_image with flip-on-load)."""
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    check(load().gpt_decode_image8(os.fsencode(path), C.byref(w), C.byref(h), C.byref(c), None, 0))
+    out = np.empty((h.value, w.value, c.value), np.uint8)
+    check(load().gpt_decode_image8(os.fsencode(path), C.byref(w), C.byref(h), C.byref(c), st.ptr(out), out.size))
+    return out
+
+
+def load_texture(path):
+    """gpt_load_texture: the texels the kernel samples, uint8 [H, W, 4]."""
+    w, h = C.c_int32(), C.c_int32()
+    check(load().gpt_load_texture(os.fsencode(path), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    check(load().gpt_load_texture(os.fsencode(path), C.byref(w), C.byref(h), st.ptr(out), out.size // 4))
+    return out
+
+
+def load_exr(path):
+    """gpt_load_exr: float32 [H, W, 3], row 0 = top."""
+    w, h = C.c_int32(), C.c_int32()
+    check(load().gpt_load_exr(os.fsencode(path), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 3), np.float32)
+    check(load().gpt_load_exr(os.fsencode(path), C.byref(w), C.byref(h), st.ptr(out), out.size))
+    return out
 
 
 def save_pfm(path, width, height, rgb):

@@ -10,9 +10,8 @@
 // Here: a PNG writer (stored-deflate, no compression needed for a checker
 // output), a PNG reader (8-bit grey / grey+alpha / RGB / RGBA / palette,
 // non-interlaced) on a small inflate, and PFM (little- or big-endian float32)
-// for linear radiance and environment maps, an OpenEXR scanline reader (NONE / RLE / ZIPS / ZIP,
+// for linear radiance and environment maps, an OpenEXR scanline reader (NONE / RLE / ZIPS / ZIP / PIZ,
 // half / float) for the reference's environment maps, and a baseline + progressive JPEG reader for textures.
-// EXR PIZ is not implemented (DESIGN.md "Next").
 #include "imageio.h"
 
 #include <cmath>
@@ -327,15 +326,16 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
 }
 
 // ---- JPEG: baseline and progressive DCT (Huffman, 8-bit, 1 or 3 components, any h/v sampling, restart
-// intervals; spectral selection and successive approximation for SOF2 files).  Chroma is up-sampled by replication and the inverse DCT is evaluated in float; stb_image, which
-// the reference uses, has its own fixed-point IDCT and smooth chroma filter, so texel values can differ from
-// the reference's by a few 8-bit steps (parity of JPEG textures is unpinned — DESIGN.md).  Arithmetic-coded,
-// lossless and hierarchical files are refused.
+// intervals; spectral selection and successive approximation for SOF2 files).  The inverse DCT, the chroma up-sampling and the
+// YCbCr -> RGB conversion restate stb_image's integer arithmetic (the reference's reader), so the bytes are the reference's
+// bytes (tests/test_imageio_reference.py compares them with stb_image itself).  Arithmetic-coded, lossless, hierarchical
+// and four-component (CMYK / YCCK) files are refused.
 namespace {
 struct JpegHuff {
     unsigned char bits[17] = {0};
     unsigned char vals[256] = {0};
-    int mincode[17], maxcode[18], valptr[17];
+    int mincode[17] = {0}, maxcode[18], valptr[17] = {0};
+    JpegHuff() { for (int &m : maxcode) m = -1; }          // a table the file never defines decodes nothing
     void build()
     {
         int code = 0, k = 0;
@@ -391,29 +391,101 @@ struct JpegBits {
     void reset() { cnt = 0; eof = false; }
 };
 int jpeg_extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
-void jpeg_idct(const float in[64], unsigned char *out, int stride)
+// stb_image's inverse DCT (the reference's JPEG reader, include/stb/stb_image.h: a fixed-point factorisation with 12-bit
+// constants; columns keep 2 extra bits, rows round once at the end).  A texel of a JPEG texture is DEFINED by this
+// arithmetic for the reference, so it is restated here operation for operation, not approximated.
+inline int jfix(double x) { return (int)(x * 4096.0 + 0.5); }
+// (32-bit two's-complement arithmetic that wraps, written with unsigned operands: coefficients of a damaged file can overflow it)
+typedef uint32_t jw;
+struct JpegIdct1D { jw x0, x1, x2, x3, t0, t1, t2, t3; };
+inline JpegIdct1D jpeg_idct_1d(jw s0, jw s1, jw s2, jw s3, jw s4, jw s5, jw s6, jw s7)
 {
-    static float c[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int x = 0; x < 8; ++x)
-            for (int u = 0; u < 8; ++u) c[x][u] = (u == 0 ? 0.35355339059f : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
-        init = true;
+    static const jw c0541 = (jw)jfix(0.5411961f), cm1847 = (jw)jfix(-1.847759065f), c0765 = (jw)jfix(0.765366865f), c1175 = (jw)jfix(1.175875602f),
+                    c0298 = (jw)jfix(0.298631336f), c2053 = (jw)jfix(2.053119869f), c3072 = (jw)jfix(3.072711026f), c1501 = (jw)jfix(1.501321110f),
+                    cm0899 = (jw)jfix(-0.899976223f), cm2562 = (jw)jfix(-2.562915447f), cm1961 = (jw)jfix(-1.961570560f), cm0390 = (jw)jfix(-0.390180644f);
+    JpegIdct1D r;
+    jw p1 = (s2 + s6) * c0541;
+    const jw e2 = p1 + s6 * cm1847, e3 = p1 + s2 * c0765;
+    const jw e0 = (s0 + s4) * 4096u, e1 = (s0 - s4) * 4096u;
+    r.x0 = e0 + e3; r.x3 = e0 - e3; r.x1 = e1 + e2; r.x2 = e1 - e2;
+    jw t0 = s7, t1 = s5, t2 = s3, t3 = s1;
+    jw p3 = t0 + t2, p4 = t1 + t3, p2 = t1 + t2;
+    p1 = t0 + t3;
+    const jw p5 = (p3 + p4) * c1175;
+    t0 *= c0298; t1 *= c2053; t2 *= c3072; t3 *= c1501;
+    p1 = p5 + p1 * cm0899;
+    p2 = p5 + p2 * cm2562;
+    p3 *= cm1961;
+    p4 *= cm0390;
+    r.t3 = t3 + p1 + p4; r.t2 = t2 + p2 + p3; r.t1 = t1 + p2 + p4; r.t0 = t0 + p1 + p3;
+    return r;
+}
+inline unsigned char jclamp(int x) { return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline int jsar(jw x, int n) { return (int32_t)x >> n; }          // arithmetic shift of the signed value
+void jpeg_idct(const short in[64], unsigned char *out, int stride)
+{
+    jw v[64];
+    for (int i = 0; i < 8; ++i) {
+        const short *d = in + i;
+        if (!d[8] && !d[16] && !d[24] && !d[32] && !d[40] && !d[48] && !d[56]) {       // a column with only its DC term
+            const jw dc = (jw)(d[0] * 4);
+            for (int k = 0; k < 8; ++k) v[k * 8 + i] = dc;
+            continue;
+        }
+        JpegIdct1D r = jpeg_idct_1d((jw)d[0], (jw)d[8], (jw)d[16], (jw)d[24], (jw)d[32], (jw)d[40], (jw)d[48], (jw)d[56]);
+        r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
+        v[i] = (jw)jsar(r.x0 + r.t3, 10);       v[56 + i] = (jw)jsar(r.x0 - r.t3, 10);
+        v[8 + i] = (jw)jsar(r.x1 + r.t2, 10);   v[48 + i] = (jw)jsar(r.x1 - r.t2, 10);
+        v[16 + i] = (jw)jsar(r.x2 + r.t1, 10);  v[40 + i] = (jw)jsar(r.x2 - r.t1, 10);
+        v[24 + i] = (jw)jsar(r.x3 + r.t0, 10);  v[32 + i] = (jw)jsar(r.x3 - r.t0, 10);
     }
-    float tmp[64];
-    for (int y = 0; y < 8; ++y)
-        for (int x = 0; x < 8; ++x) {
-            float s = 0;
-            for (int u = 0; u < 8; ++u) s += c[x][u] * in[y * 8 + u];
-            tmp[y * 8 + x] = s;
+    for (int i = 0; i < 8; ++i) {
+        const jw *w = v + i * 8;
+        unsigned char *o = out + (size_t)i * stride;
+        JpegIdct1D r = jpeg_idct_1d(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+        const jw bias = 65536u + (128u << 17);      // rounding, and the level shift back to 0..255
+        r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
+        o[0] = jclamp(jsar(r.x0 + r.t3, 17)); o[7] = jclamp(jsar(r.x0 - r.t3, 17));
+        o[1] = jclamp(jsar(r.x1 + r.t2, 17)); o[6] = jclamp(jsar(r.x1 - r.t2, 17));
+        o[2] = jclamp(jsar(r.x2 + r.t1, 17)); o[5] = jclamp(jsar(r.x2 - r.t1, 17));
+        o[3] = jclamp(jsar(r.x3 + r.t0, 17)); o[4] = jclamp(jsar(r.x3 - r.t0, 17));
+    }
+}
+// stb_image's chroma up-sampling: one output row of `w` low-resolution samples widened by `hs`, from the nearer and the
+// farther of the two source rows around it (triangle filters for the factors 2; replication for anything else)
+void jpeg_upsample_row(unsigned char *out, const unsigned char *near_row, const unsigned char *far_row, int w, int hs, int vs)
+{
+    if (hs == 1 && vs == 1) { std::memcpy(out, near_row, (size_t)w); return; }
+    if (hs == 1 && vs == 2) { for (int i = 0; i < w; ++i) out[i] = (unsigned char)((3 * near_row[i] + far_row[i] + 2) >> 2); return; }
+    if (hs == 2 && vs == 1) {
+        const unsigned char *in = near_row;
+        if (w == 1) { out[0] = out[1] = in[0]; return; }
+        out[0] = in[0];
+        out[1] = (unsigned char)((in[0] * 3 + in[1] + 2) >> 2);
+        for (int i = 1; i < w - 1; ++i) {
+            const int n = 3 * in[i] + 2;
+            out[2 * i] = (unsigned char)((n + in[i - 1]) >> 2);
+            out[2 * i + 1] = (unsigned char)((n + in[i + 1]) >> 2);
         }
-    for (int x = 0; x < 8; ++x)
-        for (int y = 0; y < 8; ++y) {
-            float s = 0;
-            for (int v = 0; v < 8; ++v) s += c[y][v] * tmp[v * 8 + x];
-            int q = (int)std::floor(s + 128.5f);
-            out[y * stride + x] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        out[2 * (w - 1)] = (unsigned char)((in[w - 2] * 3 + in[w - 1] + 2) >> 2);
+        out[2 * (w - 1) + 1] = in[w - 1];
+        return;
+    }
+    if (hs == 2 && vs == 2) {
+        int t1 = 3 * near_row[0] + far_row[0];
+        if (w == 1) { out[0] = out[1] = (unsigned char)((t1 + 2) >> 2); return; }
+        out[0] = (unsigned char)((t1 + 2) >> 2);
+        for (int i = 1; i < w; ++i) {
+            const int t0 = t1;
+            t1 = 3 * near_row[i] + far_row[i];
+            out[2 * i - 1] = (unsigned char)((3 * t0 + t1 + 8) >> 4);
+            out[2 * i] = (unsigned char)((3 * t1 + t0 + 8) >> 4);
         }
+        out[2 * w - 1] = (unsigned char)((t1 + 2) >> 2);
+        return;
+    }
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < hs; ++j) out[i * hs + j] = near_row[i];
 }
 }  // namespace
 
@@ -423,7 +495,9 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
                                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
     std::vector<unsigned char> d;
     if (!read_file(path, d) || d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return false;
-    float qt[4][64] = {{0}};
+    uint16_t qt[4][64] = {{0}};
+    bool jfif = false;
+    int adobe_transform = -1;
     JpegHuff hdc[4], hac[4];
     // coefficients of every 8x8 block (natural order, not yet dequantised): a progressive file fills them in over
     // several scans (spectral selection Ss..Se, successive approximation Ah/Al), a baseline file in one
@@ -444,13 +518,15 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
         if (len < 2 || pos + len > d.size()) return false;
         const unsigned char *seg = &d[pos + 2];
         const size_t seglen = len - 2;
+        if (marker == 0xe0 && seglen >= 5 && !std::memcmp(seg, "JFIF\0", 5)) jfif = true;
+        else if (marker == 0xee && seglen >= 12 && !std::memcmp(seg, "Adobe\0", 6)) adobe_transform = seg[11];
         if (marker == 0xdb) {
             size_t q = 0;
             while (q < seglen) {
                 const int pq = seg[q] >> 4, tq = seg[q] & 15;
                 ++q;
                 if (tq > 3 || q + (pq ? 128u : 64u) > seglen) return false;
-                for (int i = 0; i < 64; ++i) { qt[tq][zigzag[i]] = pq ? (float)(seg[q] << 8 | seg[q + 1]) : (float)seg[q]; q += pq ? 2 : 1; }
+                for (int i = 0; i < 64; ++i) { qt[tq][zigzag[i]] = (uint16_t)(pq ? seg[q] << 8 | seg[q + 1] : seg[q]); q += pq ? 2 : 1; }
             }
         } else if (marker == 0xc4) {
             size_t q = 0;
@@ -656,33 +732,64 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
         pos += len;
     }
     if (!width || !have_scan) return false;
-    // dequantise + inverse DCT into 8-bit planes
+    // dequantise (16-bit products, as stb_image keeps them) + inverse DCT into 8-bit planes
     std::vector<unsigned char> plane[3];
     for (int i = 0; i < ncomp; ++i) {
         plane[i].assign((size_t)comp[i].pw * comp[i].ph, 0);
         for (int by = 0; by < comp[i].bh; ++by)
             for (int bx = 0; bx < comp[i].bw; ++bx) {
                 const short *cf = &comp[i].coef[((size_t)by * comp[i].bw + bx) * 64];
-                float blk[64];
-                for (int k = 0; k < 64; ++k) blk[k] = cf[k] * qt[comp[i].tq][k];
+                short blk[64];
+                for (int k = 0; k < 64; ++k) blk[k] = (short)(cf[k] * qt[comp[i].tq][k]);
                 jpeg_idct(blk, &plane[i][(size_t)(by * 8) * comp[i].pw + (size_t)bx * 8], comp[i].pw);
             }
     }
     components = ncomp;
     rgba.resize((size_t)width * height * 4);
-    for (int y = 0; y < height; ++y)
-        for (int x = 0; x < width; ++x) {
-            auto at = [&](int i) { return (float)plane[i][(size_t)(y * comp[i].v / vmax) * comp[i].pw + (size_t)(x * comp[i].h / hmax)]; };
-            unsigned char *o = &rgba[((size_t)y * width + x) * 4];
-            if (ncomp == 1) { o[0] = o[1] = o[2] = (unsigned char)at(0); }
-            else {
-                const float Y = at(0), cb = at(1) - 128.f, cr = at(2) - 128.f;
-                const float r = Y + 1.402f * cr, g = Y - 0.344136f * cb - 0.714136f * cr, b = Y + 1.772f * cb;
-                auto cl = [](float v) { int q = (int)std::floor(v + 0.5f); return (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q)); };
-                o[0] = cl(r); o[1] = cl(g); o[2] = cl(b);
+    // rows top to bottom; every component is widened to the full row by stb_image's filters, its two source rows stepping as
+    // stb_image steps them (the filter looks up on even output rows, down on odd ones; the last source row repeats)
+    struct Up { int hs, vs, ystep, w_lores, ypos, rows; const unsigned char *line0, *line1; std::vector<unsigned char> buf; } up[3];
+    for (int i = 0; i < ncomp; ++i) {
+        up[i].hs = hmax / comp[i].h;
+        up[i].vs = vmax / comp[i].v;
+        up[i].ystep = up[i].vs >> 1;
+        up[i].w_lores = (width + up[i].hs - 1) / up[i].hs;
+        up[i].ypos = 0;
+        up[i].rows = (height * comp[i].v + vmax - 1) / vmax;
+        up[i].line0 = up[i].line1 = plane[i].data();
+        up[i].buf.assign((size_t)(up[i].w_lores + 2) * up[i].hs + 8, 0);
+    }
+    // components that are R, G, B already: ids 'R','G','B', or an Adobe marker with transform 0 and no JFIF marker
+    const bool is_rgb = ncomp == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (adobe_transform == 0 && !jfif));
+    auto fixed = [](float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; };
+    const int k_cr_r = fixed(1.40200f), k_cr_g = -fixed(0.71414f), k_cb_g = -fixed(0.34414f), k_cb_b = fixed(1.77200f);
+    for (int y = 0; y < height; ++y) {
+        const unsigned char *row[3] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < ncomp; ++i) {
+            Up &u = up[i];
+            const bool lower = u.ystep >= (u.vs >> 1);
+            const unsigned char *nr = lower ? u.line1 : u.line0, *fr = lower ? u.line0 : u.line1;
+            if (u.hs == 1 && u.vs == 1) row[i] = nr;
+            else { jpeg_upsample_row(u.buf.data(), nr, fr, u.w_lores, u.hs, u.vs); row[i] = u.buf.data(); }
+            if (++u.ystep >= u.vs) {
+                u.ystep = 0;
+                u.line0 = u.line1;
+                if (++u.ypos < u.rows) u.line1 += comp[i].pw;
             }
-            o[3] = 255;
         }
+        unsigned char *o = &rgba[(size_t)y * width * 4];
+        for (int x = 0; x < width; ++x, o += 4) {
+            o[3] = 255;
+            if (ncomp == 1) { o[0] = o[1] = o[2] = row[0][x]; continue; }
+            if (is_rgb) { o[0] = row[0][x]; o[1] = row[1][x]; o[2] = row[2][x]; continue; }
+            // stb_image's YCbCr -> RGB: 20-bit fixed point, the Cb term of green cut to its upper 16 bits
+            const int yf = (row[0][x] << 20) + (1 << 19), cb = row[1][x] - 128, cr = row[2][x] - 128;
+            const int r = (yf + cr * k_cr_r) >> 20;
+            const int g = (int)((unsigned)(yf + cr * k_cr_g) + ((unsigned)(cb * k_cb_g) & 0xffff0000u)) >> 20;
+            const int b = (yf + cb * k_cb_b) >> 20;
+            o[0] = jclamp(r); o[1] = jclamp(g); o[2] = jclamp(b);
+        }
+    }
     return true;
 }
 
@@ -762,9 +869,9 @@ bool read_pfm_top_down(const char *path, int &width, int &height, std::vector<gp
 }
 
 // ---- OpenEXR, scanline images (what ImageIO::LoadExr hands the reference through tinyexr's LoadEXR:
-// float RGB, row 0 = top).  Supported: single-part scanline files, compression NONE / RLE / ZIPS / ZIP,
+// float RGB, row 0 = top).  Supported: single-part scanline files, compression NONE / RLE / ZIPS / ZIP / PIZ,
 // HALF / FLOAT / UINT channels named R,G,B (or a single luminance channel Y), sampling 1x1.  Not supported
-// (returns false): tiled or multi-part files, PIZ / PXR24 / B44 / DWA compression.
+// (returns false): tiled or multi-part files, PXR24 / B44 / DWA compression (tinyexr, the reference's reader, has none of those either).
 namespace {
 float half_to_float(uint16_t h)
 {
@@ -811,6 +918,230 @@ void exr_unpredict(std::vector<unsigned char> &buf, std::vector<unsigned char> &
         if (i < buf.size()) tmp[i++] = buf[b++];
     }
     buf.swap(tmp);
+}
+
+// ---- PIZ (OpenEXR's wavelet + Huffman scheme, as published in the OpenEXR sources' ImfPizCompressor / ImfHuf / ImfWav and
+// decoded by tinyexr for the reference).  A block of up to 32 scanlines is stored as: the range of 16-bit values in use
+// (a bitmap), then a Huffman-coded stream of 16-bit symbols holding, channel after channel, the 2-D Haar-like wavelet
+// transform of the block's values mapped through that bitmap.
+struct PizBits {                                    // most-significant-bit-first reader
+    const unsigned char *p, *end;
+    uint64_t acc = 0;
+    int n = 0;
+    bool need(int k) { while (n < k) { if (p >= end) return false; acc = acc << 8 | *p++; n += 8; } return true; }
+    uint32_t take(int k) { n -= k; return (uint32_t)(acc >> n) & ((1u << k) - 1u); }
+};
+constexpr int kHufEncSize = 65537, kHufDecBits = 14, kHufDecSize = 1 << kHufDecBits;
+struct HufDec { int len = 0; int lit = 0; std::vector<int> longs; };   // len > 0: short code of `lit`; else: the long codes under this prefix
+
+// code lengths im..iM (6 bits each, with zero runs) -> canonical codes: table[s] = length | code << 6
+bool huf_read_code_table(const unsigned char *src, size_t n, int im, int iM, std::vector<uint64_t> &table, size_t &used)
+{
+    PizBits b{src, src + n};
+    table.assign(kHufEncSize, 0);
+    for (int s = im; s <= iM; ++s) {
+        if (!b.need(6)) return false;
+        const uint32_t l = b.take(6);
+        if (l == 63) {                              // a long run of unused symbols
+            if (!b.need(8)) return false;
+            const int run = (int)b.take(8) + 6;
+            if (s + run > iM + 1) return false;
+            s += run - 1;
+        } else if (l >= 59) {                       // a short run
+            const int run = (int)l - 59 + 2;
+            if (s + run > iM + 1) return false;
+            s += run - 1;
+        } else table[(size_t)s] = l;
+    }
+    used = (size_t)(b.p - src);
+    uint64_t first[59] = {0}, c = 0;
+    for (int s = 0; s < kHufEncSize; ++s) first[table[(size_t)s]] += 1;
+    for (int l = 58; l > 0; --l) { const uint64_t next = (c + first[l]) >> 1; first[l] = c; c = next; }
+    for (int s = 0; s < kHufEncSize; ++s) {
+        const uint64_t l = table[(size_t)s];
+        if (l > 0) table[(size_t)s] = l | first[l]++ << 6;
+    }
+    return true;
+}
+
+bool huf_build_decoder(const std::vector<uint64_t> &table, int im, int iM, std::vector<HufDec> &dec)
+{
+    dec.assign(kHufDecSize, HufDec());
+    for (int s = im; s <= iM; ++s) {
+        const uint64_t c = table[(size_t)s] >> 6;
+        const int l = (int)(table[(size_t)s] & 63);
+        if (l == 0) continue;
+        if (c >> l) return false;
+        if (l > kHufDecBits) {
+            HufDec &d = dec[(size_t)(c >> (l - kHufDecBits))];
+            if (d.len) return false;
+            d.longs.push_back(s);
+        } else {
+            const size_t lo = (size_t)(c << (kHufDecBits - l)), cnt = (size_t)1 << (kHufDecBits - l);
+            for (size_t i = 0; i < cnt; ++i) {
+                HufDec &d = dec[lo + i];
+                if (d.len || !d.longs.empty()) return false;
+                d.len = l;
+                d.lit = s;
+            }
+        }
+    }
+    return true;
+}
+
+bool huf_decode(const std::vector<uint64_t> &table, const std::vector<HufDec> &dec, const unsigned char *src, size_t n_bits, int rlc,
+                std::vector<uint16_t> &out, size_t n_out)
+{
+    const unsigned char *in = src, *ie = src + (n_bits + 7) / 8;
+    uint64_t c = 0;
+    int lc = 0;
+    out.clear();
+    out.reserve(n_out);
+    auto emit = [&](int sym) -> bool {             // a symbol, or (the run-length symbol) a repeat of the last one
+        if (sym == rlc) {
+            if (lc < 8) { if (in >= ie) return false; c = c << 8 | *in++; lc += 8; }
+            lc -= 8;
+            const size_t cnt = (size_t)(c >> lc) & 0xff;
+            if (out.empty() || out.size() + cnt > n_out) return false;
+            out.insert(out.end(), cnt, out.back());
+        } else {
+            if (out.size() >= n_out) return false;
+            out.push_back((uint16_t)sym);
+        }
+        return true;
+    };
+    auto long_code = [&](const HufDec &d) -> bool {
+        for (int s : d.longs) {
+            const int l = (int)(table[(size_t)s] & 63);
+            while (lc < l && in < ie) { c = c << 8 | *in++; lc += 8; }
+            if (lc >= l && (table[(size_t)s] >> 6) == ((c >> (lc - l)) & (((uint64_t)1 << l) - 1))) { lc -= l; return emit(s); }
+        }
+        return false;
+    };
+    while (in < ie) {
+        c = c << 8 | *in++;
+        lc += 8;
+        while (lc >= kHufDecBits) {
+            const HufDec &d = dec[(size_t)(c >> (lc - kHufDecBits)) & (kHufDecSize - 1)];
+            if (d.len) { lc -= d.len; if (!emit(d.lit)) return false; }
+            else if (d.longs.empty() || !long_code(d)) return false;
+        }
+    }
+    const int pad = (int)((8 - n_bits) & 7);
+    c >>= pad;
+    lc -= pad;
+    while (lc > 0) {
+        const HufDec &d = dec[(size_t)(c << (kHufDecBits - lc)) & (kHufDecSize - 1)];
+        if (!d.len || d.len > lc) return false;
+        lc -= d.len;
+        if (!emit(d.lit)) return false;
+    }
+    return out.size() == n_out;
+}
+
+bool huf_uncompress(const unsigned char *src, size_t n, std::vector<uint16_t> &out, size_t n_out)
+{
+    if (n == 0) return n_out == 0;
+    if (n < 20) return false;
+    auto u32 = [&](size_t p) { return (uint32_t)src[p] | (uint32_t)src[p + 1] << 8 | (uint32_t)src[p + 2] << 16 | (uint32_t)src[p + 3] << 24; };
+    const uint32_t im = u32(0), iM = u32(4), n_bits = u32(12);
+    if (im >= (uint32_t)kHufEncSize || iM >= (uint32_t)kHufEncSize || im > iM) return false;
+    std::vector<uint64_t> table;
+    size_t used = 0;
+    if (!huf_read_code_table(src + 20, n - 20, (int)im, (int)iM, table, used)) return false;
+    if ((size_t)(n_bits + 7) / 8 > n - 20 - used) return false;
+    std::vector<HufDec> dec;
+    if (!huf_build_decoder(table, (int)im, (int)iM, dec)) return false;
+    return huf_decode(table, dec, src + 20 + used, n_bits, (int)iM, out, n_out);
+}
+
+// the inverse of the 2-D wavelet transform over an nx * ny grid of 16-bit values (strides ox, oy); mx: the largest value
+void wav_decode(uint16_t *v, int nx, int ox, int ny, int oy, uint16_t mx)
+{
+    const bool w14 = mx < (1 << 14);
+    auto undo = [w14](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+        if (w14) {                                  // 14-bit data: plain average / difference in 16-bit signed arithmetic
+            const int ls = (int16_t)l, hs = (int16_t)h;
+            const int ai = ls + (hs & 1) + (hs >> 1);
+            a = (uint16_t)(int16_t)ai;
+            b = (uint16_t)(int16_t)(ai - hs);
+        } else {                                    // full 16-bit data: modulo arithmetic
+            const int m = l, d = h;
+            const int bb = (m - (d >> 1)) & 0xffff;
+            b = (uint16_t)bb;
+            a = (uint16_t)((d + bb - 0x8000) & 0xffff);
+        }
+    };
+    const int n = nx > ny ? ny : nx;
+    int p = 1;
+    while (p <= n) p <<= 1;
+    p >>= 1;
+    int p2 = p;
+    p >>= 1;
+    for (; p >= 1; p2 = p, p >>= 1) {
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t *py = v, *const ey = v + (ptrdiff_t)oy * (ny - p2);
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py, *const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1, i00, i01, i10, i11;
+                undo(*px, *p10, i00, i10);
+                undo(*p01, *p11, i01, i11);
+                undo(i00, i01, *px, *p01);
+                undo(i10, i11, *p10, *p11);
+            }
+            if (nx & p) { uint16_t *p10 = px + oy1, i00; undo(*px, *p10, i00, *p10); *px = i00; }
+        }
+        if (ny & p) {
+            uint16_t *px = py, *const ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) { uint16_t *p01 = px + ox1, i00; undo(*px, *p01, i00, *p01); *px = i00; }
+        }
+    }
+}
+
+// one PIZ block -> `lines` scanlines in the uncompressed layout (per line: channel after channel).  words[c]: 16-bit words per
+// value of channel c (1 HALF, 2 FLOAT / UINT)
+bool exr_piz_decode(const unsigned char *src, size_t n, int width, int lines, const std::vector<int> &words, std::vector<unsigned char> &raw)
+{
+    if (n < 4) return false;
+    const int lo = src[0] | src[1] << 8, hi = src[2] | src[3] << 8;
+    std::vector<unsigned char> bitmap(8192, 0);
+    size_t pos = 4;
+    if (lo <= hi) {
+        if (hi >= 8192 || pos + (size_t)(hi - lo + 1) > n) return false;
+        std::memcpy(&bitmap[(size_t)lo], src + pos, (size_t)(hi - lo + 1));
+        pos += (size_t)(hi - lo + 1);
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    int k = 0;
+    for (int i = 0; i < 65536; ++i)
+        if (i == 0 || (bitmap[(size_t)i >> 3] & (1 << (i & 7)))) lut[(size_t)k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (pos + 4 > n) return false;
+    const uint32_t len = (uint32_t)src[pos] | (uint32_t)src[pos + 1] << 8 | (uint32_t)src[pos + 2] << 16 | (uint32_t)src[pos + 3] << 24;
+    pos += 4;
+    if (len > n - pos) return false;
+    size_t total = 0;
+    for (int wds : words) total += (size_t)width * lines * wds;
+    std::vector<uint16_t> v;
+    if (!huf_uncompress(src + pos, len, v, total)) return false;
+    size_t start = 0;
+    std::vector<size_t> chan_start(words.size());
+    for (size_t c = 0; c < words.size(); ++c) {
+        chan_start[c] = start;
+        for (int j = 0; j < words[c]; ++j) wav_decode(&v[start + (size_t)j], width, words[c], lines, width * words[c], max_value);
+        start += (size_t)width * lines * words[c];
+    }
+    for (uint16_t &x : v) x = lut[x];
+    raw.resize(total * 2);
+    unsigned char *o = raw.data();
+    for (int y = 0; y < lines; ++y)
+        for (size_t c = 0; c < words.size(); ++c) {
+            const size_t cnt = (size_t)width * words[c];
+            const uint16_t *q = &v[chan_start[c] + (size_t)y * cnt];
+            for (size_t i = 0; i < cnt; ++i) { *o++ = (unsigned char)(q[i] & 0xff); *o++ = (unsigned char)(q[i] >> 8); }
+        }
+    return true;
 }
 }  // namespace
 
@@ -860,11 +1191,13 @@ bool read_exr_rgb_top_down(const char *path, int &width, int &height, std::vecto
     if (w64 <= 0 || h64 <= 0 || w64 > (1 << 20) || h64 > (1 << 20) || w64 * h64 > ((int64_t)1 << 28)) return false;
     width = (int)w64;
     height = (int)h64;
-    if ( chans.empty() || compression < 0 || compression > 3) return false;
-    const int lines_per_block = compression == 3 ? 16 : 1;
+    if (chans.empty() || compression < 0 || compression > 4) return false;
+    const int lines_per_block = compression == 4 ? 32 : compression == 3 ? 16 : 1;
     const int n_blocks = (height + lines_per_block - 1) / lines_per_block;
     if (pos + (size_t)n_blocks * 8 > d.size()) return false;
     std::vector<size_t> choff(chans.size());
+    std::vector<int> words;
+    for (const Chan &c : chans) words.push_back(c.type == 1 ? 1 : 2);
     size_t line_bytes = 0;
     int ir = -1, ig = -1, ib = -1, iy = -1;
     for (size_t c = 0; c < chans.size(); ++c) {
@@ -902,6 +1235,8 @@ bool read_exr_rgb_top_down(const char *path, int &width, int &height, std::vecto
         else if (compression == 1) {
             if (!exr_rle_decode(src, csize, raw, expect)) return false;
             exr_unpredict(raw, tmp);
+        } else if (compression == 4) {
+            if (!exr_piz_decode(src, csize, width, lines, words, raw)) return false;
         } else {
             raw.clear();
             if (csize < 6 || !inflate_raw(src + 2, csize - 2, raw, expect)) return false;
@@ -1031,6 +1366,57 @@ int gpt_save_pfm(const char *path, int32_t width, int32_t height, const float *r
 {
     if (!path || !rgb || width <= 0 || height <= 0) { gpt_set_error("gpt_save_pfm: invalid argument"); return GPT_ERR_INVALID_ARG; }
     if (!imageio::write_pfm(path, width, height, rgb)) { gpt_set_error("gpt_save_pfm: cannot write %s", path); return GPT_ERR_IO; }
+    return GPT_OK;
+}
+
+// The decoders on their own (what the scene loader does per "diffuse": "<file>" / "infinite": "<file>").  A null buffer
+// asks for the size only; a buffer that is too small is refused.
+int gpt_decode_image8(const char *path, int32_t *width, int32_t *height, int32_t *components, unsigned char *pixels, int64_t capacity)
+{
+    if (!path || !width || !height || !components) { gpt_set_error("gpt_decode_image8: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    std::vector<unsigned char> rgba;
+    int w = 0, h = 0, comp = 0;
+    if (!imageio::read_png(path, w, h, comp, rgba) && !imageio::read_jpeg(path, w, h, comp, rgba)) {
+        gpt_set_error("gpt_decode_image8: cannot read %s as PNG or JPEG", path);
+        return GPT_ERR_IO;
+    }
+    *width = w; *height = h; *components = comp;
+    if (!pixels) return GPT_OK;
+    if (capacity < (int64_t)w * h * comp) { gpt_set_error("gpt_decode_image8: buffer too small"); return GPT_ERR_INVALID_ARG; }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const unsigned char *p = &rgba[((size_t)(h - 1 - y) * w + x) * 4];       // stbi_set_flip_vertically_on_load(true)
+            unsigned char *q = pixels + ((size_t)y * w + x) * comp;
+            if (comp == 1) q[0] = p[0];
+            else if (comp == 2) { q[0] = p[0]; q[1] = p[3]; }
+            else for (int c = 0; c < comp; ++c) q[c] = p[c];
+        }
+    return GPT_OK;
+}
+
+int gpt_load_texture(const char *path, int32_t *width, int32_t *height, gpt_uchar4 *texels, int64_t capacity)
+{
+    if (!path || !width || !height) { gpt_set_error("gpt_load_texture: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    std::vector<gpt_uchar4> t;
+    int w = 0, h = 0;
+    if (!imageio::load_texture(path, w, h, t)) { gpt_set_error("gpt_load_texture: cannot read %s as PNG or JPEG", path); return GPT_ERR_IO; }
+    *width = w; *height = h;
+    if (!texels) return GPT_OK;
+    if (capacity < (int64_t)w * h) { gpt_set_error("gpt_load_texture: buffer too small"); return GPT_ERR_INVALID_ARG; }
+    std::memcpy(texels, t.data(), t.size() * sizeof(gpt_uchar4));
+    return GPT_OK;
+}
+
+int gpt_load_exr(const char *path, int32_t *width, int32_t *height, float *rgb, int64_t capacity)
+{
+    if (!path || !width || !height) { gpt_set_error("gpt_load_exr: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    std::vector<gpt_float3> px;
+    int w = 0, h = 0;
+    if (!imageio::read_exr_rgb_top_down(path, w, h, px)) { gpt_set_error("gpt_load_exr: cannot read %s (scanline OpenEXR: NONE, RLE, ZIPS, ZIP, PIZ)", path); return GPT_ERR_IO; }
+    *width = w; *height = h;
+    if (!rgb) return GPT_OK;
+    if (capacity < (int64_t)w * h * 3) { gpt_set_error("gpt_load_exr: buffer too small"); return GPT_ERR_INVALID_ARG; }
+    for (size_t i = 0; i < px.size(); ++i) { rgb[3 * i] = px[i].x; rgb[3 * i + 1] = px[i].y; rgb[3 * i + 2] = px[i].z; }
     return GPT_OK;
 }
 

@@ -245,6 +245,17 @@ int gpt_save_exr(const char *path, int32_t width, int32_t height, const float *r
 /* linear radiance as PFM (little-endian float32, bottom-up) */
 int gpt_save_pfm(const char *path, int32_t width, int32_t height, const float *rgb);
 
+/* The file decoders by themselves (the loader calls them for "diffuse": "<file>" and "infinite": "<file>").  A null
+ * output buffer asks for the size only; `capacity` counts elements of the buffer's type.
+ * gpt_decode_image8: what stb_image hands ImageIO::LoadTexture (src/imageio.cpp:13-14: flip on load, 0 = the file's own
+ *                    channel count): PNG or JPEG -> `components` interleaved bytes per pixel, row 0 = bottom.
+ * gpt_load_texture:  ImageIO::LoadTexture + Texture::Texture (src/imageio.cpp:11-59, src/texture.h:15-27): the texels as
+ *                    the kernel samples them (1/255, powf(x, 2.2f) on r g b, truncated back to 8 bit).
+ * gpt_load_exr:      ImageIO::LoadExr (src/imageio.cpp:80-102): float R,G,B per pixel, row 0 = top. */
+int gpt_decode_image8(const char *path, int32_t *width, int32_t *height, int32_t *components, unsigned char *pixels, int64_t capacity);
+int gpt_load_texture(const char *path, int32_t *width, int32_t *height, gpt_uchar4 *texels, int64_t capacity);
+int gpt_load_exr(const char *path, int32_t *width, int32_t *height, float *rgb, int64_t capacity);
+
 #pragma GCC visibility pop
 
 #ifdef __cplusplus

@@ -1,0 +1,400 @@
+"""The image files either side of the path, against the REFERENCE'S OWN decoders.
+
+The reference reads textures with stb_image, environment maps with tinyexr and writes pictures with stb_image_write / tinyexr
+(src/imageio.cpp:1-9).  Those are vendored single-header libraries that compile with g++ on their own, so this part of the
+reference is built here where it lies (oracle/ref_imageio.cpp -> oracle/_ref/libref_imageio.so, see oracle/Makefile) and the
+product's decoders (gpu_pathtracer_amd/csrc/imageio.cpp, through the C ABI) must agree with it BIT FOR BIT: byte work.
+
+The few lines of src/imageio.cpp around those calls (1/255, powf(x, 2.2f), the flip of SavePng, Texture::Texture's truncation)
+are restated below, next to the call they follow.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpu_pathtracer_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libref_imageio.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(REF_LIB) and os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref/libref_imageio.so is not built and /root/reference is not here to build it from")
+    lib = C.CDLL(REF_LIB)
+    lib.ref_stbi_load_flipped.restype = C.c_void_p
+    lib.ref_stbi_load_flipped.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_free.argtypes = [C.c_void_p]
+    lib.ref_free.restype = None
+    lib.ref_stbi_write_png.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ref_load_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ref_save_exr.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    return lib
+
+
+def ref_decode8(ref, path):
+    """stbi_load as ImageIO::LoadTexture calls it (src/imageio.cpp:13-14) -> uint8 [H, W, components] or None"""
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    p = ref.ref_stbi_load_flipped(os.fsencode(str(path)), C.byref(w), C.byref(h), C.byref(c))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), (h.value, w.value, c.value)).copy()
+    ref.ref_free(p)
+    return out
+
+
+def ref_load_exr(ref, path):
+    """LoadEXR as ImageIO::LoadExr calls it (src/imageio.cpp:84) -> float32 [H, W, 4] (row 0 = top) or None"""
+    w, h, p = C.c_int(), C.c_int(), C.c_void_p()
+    if ref.ref_load_exr(os.fsencode(str(path)), C.byref(p), C.byref(w), C.byref(h)) != 0:
+        return None
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (h.value, w.value, 4)).copy()
+    ref.ref_free(p)
+    return out
+
+
+def ref_save_exr(ref, path, rgb_top_down, compression, half):
+    planes = [np.ascontiguousarray(rgb_top_down[..., c], dtype=np.float32) for c in range(3)]
+    h, w = planes[0].shape
+    rc = ref.ref_save_exr(os.fsencode(str(path)), w, h, planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data,
+                          compression, half)
+    assert rc == 0
+
+
+def radiance(rng, h, w, kind):
+    if kind == "smooth":                                    # few distinct 16-bit values: PIZ's 14-bit wavelet
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([x / max(w - 1, 1), y / max(h - 1, 1), (x + y) % 7 / 7.0], -1).astype(np.float32)
+        return (np.round(img * 40) / 8).astype(np.float32)
+    img = np.exp(rng.normal(0, 3, (h, w, 3))).astype(np.float32)     # sky-like dynamic range, every value different
+    img[rng.random((h, w)) < 0.05] = 0.0
+    return img
+
+
+NAMES = {0: "none", 1: "rle", 2: "zips", 3: "zip", 4: "piz"}
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3, 4], ids=lambda c: NAMES[c])
+@pytest.mark.parametrize("half", [1, 0], ids=["half", "float"])
+def test_exr_reader_equals_tinyexr(ref, tmp_path, compression, half):
+    """gpt_load_exr == the reference's LoadEXR on files written by the reference's own encoder: every compression tinyexr has,
+    HALF and FLOAT channels, sizes that leave partial blocks (ZIP: 16 lines, PIZ: 32), one-pixel rows and columns."""
+    rng = np.random.default_rng(compression * 2 + half)
+    for h, w, kind in ((1, 1, "noise"), (1, 9, "noise"), (9, 1, "smooth"), (37, 45, "smooth"), (37, 45, "noise"), (64, 32, "noise"),
+                       (33, 70, "noise"), (40, 700, "noise")):
+        img = radiance(rng, h, w, kind)
+        path = tmp_path / f"{NAMES[compression]}_{h}x{w}_{kind}.exr"
+        ref_save_exr(ref, path, img, compression, half)
+        want = ref_load_exr(ref, path)
+        assert want is not None and want.shape == (h, w, 4)
+        got = api.load_exr(str(path))
+        assert got.shape == (h, w, 3)
+        assert np.array_equal(got.view(np.uint32), want[..., :3].copy().view(np.uint32)), (h, w, kind)
+        if not half:
+            assert np.array_equal(got.view(np.uint32), img.view(np.uint32))          # FLOAT files are lossless
+
+
+def test_piz_takes_both_wavelet_paths(ref, tmp_path):
+    """PIZ's wavelet has a 14-bit and a 16-bit form, chosen by the number of distinct values in the block: make sure the files
+    above exercise both (so that the equality is not vacuous for one of them)."""
+    rng = np.random.default_rng(5)
+    for kind, h, w, wide in (("smooth", 37, 45, False), ("noise", 40, 700, True)):
+        img = radiance(rng, h, w, kind)
+        with np.errstate(over="ignore"):
+            block = img[:32].astype(np.float16).view(np.uint16)
+        assert (len(np.unique(block)) >= (1 << 14)) == wide
+
+
+def test_exr_writer_is_read_back_by_tinyexr(ref, tmp_path):
+    """gpt_save_exr (HALF B,G,R, rows top-down from the bottom-up film, ImageIO::SaveExr src/imageio.cpp:104-161) through the
+    reference's reader: the same values the reference's own writer stores for that film, including its float -> half rounding."""
+    rng = np.random.default_rng(11)
+    film = radiance(rng, 23, 31, "noise")
+    film[0, :8] = np.array([1e-9, 6.0e-8, 6.1e-5, 65504.0, 65520.0, 1e9, 0.1, 1.0 / 3.0], np.float32)[:, None]
+    api.save_exr(str(tmp_path / "ours.exr"), 31, 23, film)
+    ref_save_exr(ref, tmp_path / "theirs.exr", film, 0, 1)        # the reference hands SaveExr its top-down copy: compare unflipped
+    ours = ref_load_exr(ref, tmp_path / "ours.exr")
+    theirs = ref_load_exr(ref, tmp_path / "theirs.exr")
+    assert ours is not None and theirs is not None
+    # gpt_save_exr takes the film as the kernel holds it (row 0 = bottom) and stores it top-down
+    assert np.array_equal(ours[::-1, :, :3].copy().view(np.uint32), theirs[..., :3].copy().view(np.uint32))
+
+
+def png_cases(rng, directory):
+    from PIL import Image
+    cases = []
+    h, w = 19, 27
+    grey = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    for name, im, kw in (("grey", Image.fromarray(grey, "L"), {}), ("grey_alpha", Image.fromarray(rgba[..., :2].copy(), "LA"), {}),
+                         ("rgb", Image.fromarray(rgb, "RGB"), {}), ("rgba", Image.fromarray(rgba, "RGBA"), {}),
+                         ("rgb_fast", Image.fromarray(rgb, "RGB"), {"compress_level": 1}),
+                         ("rgb_stored", Image.fromarray(rgb, "RGB"), {"compress_level": 0}),
+                         ("palette", Image.fromarray(rgb, "RGB").quantize(17), {}),
+                         ("palette_transparent", Image.fromarray(rgb, "RGB").quantize(17), {"transparency": 3}),
+                         ("smooth", Image.fromarray((np.add.outer(np.arange(64), np.arange(80)) % 256).astype(np.uint8), "L").convert("RGB"), {"optimize": True})):
+        path = os.path.join(directory, name + ".png")
+        im.save(path, **kw)
+        cases.append(path)
+    return cases
+
+
+def test_png_reader_equals_stb_image(ref, tmp_path):
+    """gpt_decode_image8 == stbi_load(flip) for every 8-bit PNG colour type (and channel count reported the same way)."""
+    rng = np.random.default_rng(3)
+    for path in png_cases(rng, str(tmp_path)):
+        want = ref_decode8(ref, path)
+        got = api.decode_image8(path)
+        assert want is not None and got.shape == want.shape, path
+        assert np.array_equal(got, want), path
+
+
+def texels_like_the_reference(ref, path):
+    """ImageIO::LoadTexture (src/imageio.cpp:11-59) on stb_image's bytes, then Texture::Texture (src/texture.h:15-27)."""
+    px = ref_decode8(ref, path)
+    libm = C.CDLL("libm.so.6")
+    libm.powf.restype = C.c_float
+    libm.powf.argtypes = [C.c_float, C.c_float]
+    inv = np.float32(1.0) / np.float32(255.0)
+    unit = (np.arange(256, dtype=np.float32) * inv).astype(np.float32)
+    lin = np.array([libm.powf(float(v), 2.2) for v in unit], np.float32)           # powf(texel, 2.2f)
+    to8 = lambda v: (v * np.float32(255.0)).astype(np.uint8)                        # unsigned char(x * 255)
+    h, w, comp = px.shape
+    out = np.empty((h, w, 4), np.uint8)
+    if comp == 1:
+        out[..., :3] = to8(lin[px[..., 0]])[..., None]
+        out[..., 3] = 255
+    else:
+        out[..., :3] = to8(lin[px[..., :3]])
+        out[..., 3] = to8(unit[px[..., 3]]) if comp == 4 else 255
+    return out
+
+
+def test_texture_texels_equal_loadtexture_on_stb_bytes(ref, tmp_path):
+    rng = np.random.default_rng(4)
+    for path in png_cases(rng, str(tmp_path)):
+        if ref_decode8(ref, path).shape[2] == 2:
+            continue        # LoadTexture leaves a two-channel texel uninitialised (src/imageio.cpp:25-41): nothing to compare with
+        assert np.array_equal(api.load_texture(path), texels_like_the_reference(ref, path)), path
+
+
+def test_png_writer_equals_savepng_through_stb(ref, tmp_path):
+    """gpt_save_png vs ImageIO::SavePng (src/imageio.cpp:61-78: flip, clamp, truncate, stbi_write_png): the two files decode to
+    the same pixels (the deflate streams differ: stb compresses, the product stores)."""
+    rng = np.random.default_rng(8)
+    h, w = 21, 34
+    film = rng.uniform(-0.2, 1.3, (h, w, 3)).astype(np.float32)
+    film[0, :4] = [[0, 0, 0], [1, 1, 1], [0.999999, 0.5, 1.0 / 255], [np.float32(1.0) - np.float32(6e-8)] * 3]
+    api.save_png(str(tmp_path / "ours.png"), w, h, film)
+    clamped = np.clip(film, np.float32(0), np.float32(1))
+    bytes_top_down = np.ascontiguousarray((clamped[::-1] * np.float32(255.0)).astype(np.uint32).astype(np.uint8))
+    assert ref.ref_stbi_write_png(os.fsencode(str(tmp_path / "theirs.png")), w, h, bytes_top_down.ctypes.data) != 0
+    ours, theirs = ref_decode8(ref, tmp_path / "ours.png"), ref_decode8(ref, tmp_path / "theirs.png")
+    assert ours is not None and np.array_equal(ours, theirs)
+    assert np.array_equal(api.decode_image8(str(tmp_path / "theirs.png")), theirs)       # and the product reads stb's file
+
+
+def jpeg_cases(rng, directory):
+    from PIL import Image
+    y, x = np.mgrid[0:83, 0:117]
+    img = np.stack([127 + 120 * np.sin(x / 9.0), 127 + 120 * np.cos(y / 7.0), (3 * x + 2 * y) % 256], -1)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    cases = []
+    for name, kw in (("444_q90", dict(quality=90, subsampling=0)), ("422_q75", dict(quality=75, subsampling=1)),
+                     ("420_q60", dict(quality=60, subsampling=2)), ("420_q95_progressive", dict(quality=95, subsampling=2, progressive=True)),
+                     ("444_q30_progressive", dict(quality=30, subsampling=0, progressive=True)),
+                     ("420_restart", dict(quality=80, subsampling=2, restart_marker_blocks=3)),
+                     ("422_q100", dict(quality=100, subsampling=1)), ("420_q5", dict(quality=5, subsampling=2))):
+        path = os.path.join(directory, name + ".jpg")
+        Image.fromarray(img).save(path, **kw)
+        cases.append(path)
+    for name, kw in (("grey_q70", dict(quality=70)), ("grey_progressive", dict(quality=85, progressive=True))):
+        path = os.path.join(directory, name + ".jpg")
+        Image.fromarray(img[..., 0].copy(), "L").save(path, **kw)
+        cases.append(path)
+    for name, size in (("tiny_1x1", (1, 1)), ("odd_17x9", (9, 17)), ("odd_8x33", (33, 8))):
+        path = os.path.join(directory, name + ".jpg")
+        Image.fromarray(img[:size[0], :size[1]].copy()).save(path, quality=85, subsampling=2)
+        cases.append(path)
+    return cases
+
+
+def test_jpeg_reader_equals_stb_image(ref, tmp_path):
+    """gpt_decode_image8 == stbi_load(flip) on JPEG files: stb_image's fixed-point inverse DCT, its (3,1)-tap chroma filters
+    and its fixed-point YCbCr -> RGB are part of what a texel IS for the reference, so the product's reader restates them."""
+    rng = np.random.default_rng(6)
+    for path in jpeg_cases(rng, str(tmp_path)):
+        want = ref_decode8(ref, path)
+        got = api.decode_image8(path)
+        assert want is not None and got.shape == want.shape, path
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert diff.max() == 0, (os.path.basename(path), int(diff.max()), float((diff > 0).mean()))
+        assert np.array_equal(api.load_texture(path), texels_like_the_reference(ref, path)), path
+
+
+def encode_baseline_jpeg(img, sampling, quality_scale=2):
+    """A minimal baseline JPEG writer for the sampling factors PIL cannot produce (chroma 1x2, 4x1, 4x2 ...): float DCT,
+    one flat-ish quantisation table, the Huffman tables of a PIL file (Annex K).  sampling: (h, v) of the luma component;
+    both chroma components are 1x1, i.e. sub-sampled by h horizontally and v vertically."""
+    import io
+    from PIL import Image
+    probe = io.BytesIO()
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(probe, "JPEG", quality=75, subsampling=0)
+    d = probe.getvalue()
+    tables, pos, dht_segments = {}, 2, b""
+    while pos < len(d):
+        marker, length = d[pos + 1], int.from_bytes(d[pos + 2:pos + 4], "big")
+        if marker == 0xc4:
+            dht_segments += d[pos:pos + 2 + length]
+            q = pos + 4
+            while q < pos + 2 + length:
+                tc_th, bits = d[q], d[q + 1:q + 17]
+                vals = d[q + 17:q + 17 + sum(bits)]
+                code, k, table = 0, 0, {}
+                for l in range(1, 17):
+                    for _ in range(bits[l - 1]):
+                        table[vals[k]] = (code, l)
+                        code += 1
+                        k += 1
+                    code <<= 1
+                tables[tc_th] = table
+                q += 17 + sum(bits)
+        if marker == 0xda:
+            break
+        pos += 2 + length
+    zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    qt = np.clip((1 + np.add.outer(np.arange(8), np.arange(8))) * quality_scale, 1, 255).astype(np.int32)
+    H, W = img.shape[:2]
+    h, v = sampling
+    f = img.astype(np.float64)
+    ycc = np.stack([0.299 * f[..., 0] + 0.587 * f[..., 1] + 0.114 * f[..., 2],
+                    128 - 0.168736 * f[..., 0] - 0.331264 * f[..., 1] + 0.5 * f[..., 2],
+                    128 + 0.5 * f[..., 0] - 0.418688 * f[..., 1] - 0.081312 * f[..., 2]], -1)
+    mw, mh = 8 * h, 8 * v
+    PW, PH = -(-W // mw) * mw, -(-H // mh) * mh
+    ycc = np.pad(ycc, ((0, PH - H), (0, PW - W), (0, 0)), mode="edge")
+    planes = [ycc[..., 0], ycc[::v, ::h, 1], ycc[::v, ::h, 2]]          # chroma by point sampling: any choice is a valid file
+    k = np.arange(8)
+    basis = np.cos((2 * k[None, :] + 1) * k[:, None] * np.pi / 16) * np.where(k == 0, np.sqrt(1 / 8), 0.5)[:, None]
+    bits = []
+
+    def put(code, length):
+        bits.append((code, length))
+
+    def magnitude(x):
+        s = 0 if x == 0 else int(abs(x)).bit_length()
+        return s, (x if x >= 0 else x + (1 << s) - 1)
+    pred = [0, 0, 0]
+
+    def block(c, by, bx):
+        px = planes[c][by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] - 128.0
+        coef = np.rint(basis @ px @ basis.T / qt).astype(int).reshape(64)
+        dc_t, ac_t = tables[0 if c == 0 else 1], tables[0x10 if c == 0 else 0x11]
+        s, m = magnitude(coef[0] - pred[c])
+        pred[c] = coef[0]
+        put(*dc_t[s])
+        if s:
+            put(m, s)
+        run = 0
+        last = max([i for i in range(1, 64) if coef[zz[i]] != 0], default=0)
+        for i in range(1, last + 1):
+            x = coef[zz[i]]
+            if x == 0:
+                run += 1
+                continue
+            while run > 15:
+                put(*ac_t[0xf0])
+                run -= 16
+            s, m = magnitude(x)
+            put(*ac_t[run << 4 | s])
+            put(m, s)
+            run = 0
+        if last < 63:
+            put(*ac_t[0])
+    for my in range(PH // mh):
+        for mx in range(PW // mw):
+            for yy in range(v):
+                for xx in range(h):
+                    block(0, my * v + yy, mx * h + xx)
+            block(1, my, mx)
+            block(2, my, mx)
+    acc, n, body = 0, 0, bytearray()
+    for code, length in bits:
+        acc = acc << length | code
+        n += length
+        while n >= 8:
+            n -= 8
+            byte = acc >> n & 0xff
+            body.append(byte)
+            if byte == 0xff:
+                body.append(0)
+    if n:
+        byte = (acc << (8 - n) | (1 << (8 - n)) - 1) & 0xff
+        body.append(byte)
+        if byte == 0xff:
+            body.append(0)
+    seg = lambda marker, payload: bytes([0xff, marker]) + (len(payload) + 2).to_bytes(2, "big") + payload
+    out = b"\xff\xd8" + seg(0xe0, b"JFIF\0\1\1\0\0\1\0\1\0\0")
+    out += seg(0xdb, bytes([0]) + bytes(int(qt.reshape(64)[zz[i]]) for i in range(64)))
+    out += seg(0xc0, bytes([8]) + H.to_bytes(2, "big") + W.to_bytes(2, "big") + bytes([3, 1, h << 4 | v, 0, 2, 0x11, 0, 3, 0x11, 0]))
+    out += dht_segments
+    out += seg(0xda, bytes([3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0])) + bytes(body) + b"\xff\xd9"
+    return out
+
+
+@pytest.mark.parametrize("sampling", [(1, 2), (4, 1), (4, 2), (2, 4), (1, 1), (2, 2), (2, 1)], ids=lambda s: "%dx%d" % s)
+def test_jpeg_unusual_chroma_sampling_equals_stb_image(ref, tmp_path, sampling):
+    """The sampling factors PIL cannot write: vertical-only halving (stb_image's 3:1 vertical filter), factors of 4 (replication),
+    and the usual ones again through this file's own encoder as a check of the encoder."""
+    rng = np.random.default_rng(sampling[0] * 8 + sampling[1])
+    for h, w in ((50, 70), (16, 32), (1, 1), (9, 5), (33, 3)):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 5.0 + y / 11.0), 127 + 120 * np.cos(y / 4.0), (5 * x + 3 * y) % 256], -1)
+        img = np.clip(img + rng.normal(0, 10, img.shape), 0, 255).astype(np.uint8)
+        path = tmp_path / f"s{sampling[0]}{sampling[1]}_{h}x{w}.jpg"
+        path.write_bytes(encode_baseline_jpeg(img, sampling))
+        want = ref_decode8(ref, path)
+        assert want is not None and want.shape == (h, w, 3), path
+        assert np.abs(want[::-1].astype(int) - img.astype(int)).mean() < 40      # (the file really holds the picture)
+        got = api.decode_image8(str(path))
+        assert got.shape == want.shape and np.array_equal(got, want), path
+
+
+def test_damaged_files_are_refused_or_decoded_never_overrun(ref, tmp_path):
+    """Random damage to PIZ and JPEG files (the formats with the most pointer arithmetic in the reader): every call returns -
+    an error or some picture of the declared size.  (The same mutations ran under AddressSanitizer while the readers were
+    written; this keeps a short version of that in the suite.)"""
+    rng = np.random.default_rng(12)
+    seeds = []
+    for i, (h, w, kind, half) in enumerate(((37, 45, "smooth", 1), (40, 300, "noise", 1), (33, 20, "noise", 0))):
+        path = tmp_path / f"seed{i}.exr"
+        ref_save_exr(ref, path, radiance(rng, h, w, kind), 4, half)
+        seeds.append((path.read_bytes(), api.load_exr))
+    for path in jpeg_cases(rng, str(tmp_path))[:6]:
+        seeds.append((open(path, "rb").read(), api.decode_image8))
+    decoded = refused = 0
+    target = str(tmp_path / "damaged.bin")
+    for data, reader in seeds:
+        for _ in range(120):
+            m = bytearray(data)
+            for _ in range(int(rng.integers(1, 5))):
+                p = int(rng.integers(0, len(m)))
+                m[p] = (int(rng.integers(0, 256)), m[p] ^ (1 << int(rng.integers(0, 8))), 0xff, 0)[int(rng.integers(0, 4))]
+            if rng.random() < 0.1:
+                del m[int(rng.integers(1, len(m))):]
+            open(target, "wb").write(m)
+            try:
+                out = reader(target)
+                assert out.size > 0
+                decoded += 1
+            except RuntimeError:
+                refused += 1
+    assert decoded > 100 and refused > 100
