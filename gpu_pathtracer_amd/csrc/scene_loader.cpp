@@ -204,30 +204,35 @@ M4 transpose(const M4 &m)
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.c[i][j] = m.c[j][i];
     return r;
 }
-M4 inverse(const M4 &m)   // cofactor expansion (glm::inverse computes the same adjugate / determinant)
+// glm::inverse(mat4) of the glm the reference vendors (0.9.7, glm/detail/type_mat4x4.inl compute_inverse): adjugate over determinant,
+// with glm's grouping of the float operations so that the result is glm's to the last bit (oracle/ref_transform.cpp holds glm itself;
+// tests/test_transform_reference.py).  c[j][k] = column j, row k, as in glm.
+M4 inverse(const M4 &m)
 {
-    const float *a = &m.c[0][0];
-    float inv[16];
-    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
-    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
-    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
-    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
-    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
-    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
-    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
-    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
-    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
-    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
-    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
-    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
-    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
-    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
-    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
-    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
-    float det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
-    float id = 1.0f / det;
+    // 2x2 minors of the columns (j1, j2) in {(2,3), (1,3), (1,2)} over every pair of rows p < q
+    auto minor2 = [&](int j1, int j2, int p, int q) { return m.c[j1][p] * m.c[j2][q] - m.c[j2][p] * m.c[j1][q]; };
+    float fac[4][4][4];                                  // fac[p][q][k]: the minor that element k of an adjugate column multiplies
+    for (int p = 0; p < 4; ++p)
+        for (int q = p + 1; q < 4; ++q) {
+            fac[p][q][0] = fac[p][q][1] = minor2(2, 3, p, q);
+            fac[p][q][2] = minor2(1, 3, p, q);
+            fac[p][q][3] = minor2(1, 2, p, q);
+        }
+    M4 adj;
+    for (int r = 0; r < 4; ++r) {                        // column r of the adjugate: expand along the three other rows a < b < e
+        int o[3], n = 0;
+        for (int k = 0; k < 4; ++k) if (k != r) o[n++] = k;
+        const int a = o[0], b = o[1], e = o[2];
+        for (int k = 0; k < 4; ++k) {
+            const int col = k == 0 ? 1 : 0;              // glm's Vec*: (m[1][row], m[0][row], m[0][row], m[0][row])
+            const float v = (m.c[col][a] * fac[b][e][k] - m.c[col][b] * fac[a][e][k]) + m.c[col][e] * fac[a][b][k];
+            adj.c[r][k] = ((r + k) & 1) ? v * -1.0f : v * 1.0f;
+        }
+    }
+    const float det = (m.c[0][0] * adj.c[0][0] + m.c[0][1] * adj.c[1][0]) + (m.c[0][2] * adj.c[2][0] + m.c[0][3] * adj.c[3][0]);
+    const float inv_det = 1.0f / det;
     M4 r;
-    for (int i = 0; i < 16; ++i) (&r.c[0][0])[i] = inv[i] * id;
+    for (int j = 0; j < 4; ++j) for (int k = 0; k < 4; ++k) r.c[j][k] = adj.c[j][k] * inv_det;
     return r;
 }
 float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
