@@ -54,85 +54,237 @@ struct Json {
     double number(double dflt) const { return kind == Num ? num : dflt; }
 };
 
+// The reader follows rapidjson's (the reference parses its scene files with Document::Parse and the default flags,
+// src/parsescene.cpp:60-61; rapidjson is vendored under include/rapidjson):
+//   * the grammar it accepts and refuses: RFC 8259 values at the root, blanks = space / tab / CR / LF only, no comments, no
+//     trailing commas, no NaN / Infinity, escapes \" \\ \/ \b \f \n \r \t \uXXXX (surrogate pairs joined, UTF-8 out), raw
+//     bytes below 0x20 refused, anything after the root value refused, the text ends at its first NUL;
+//   * its NUMBER ARITHMETIC (reader.h ParseNumber + internal/strtod.h StrtodNormalPrecision, the default "normal precision"
+//     mode): the digits are gathered into an integer significand (at most 2^53 before the fraction digits stop being
+//     taken exactly, 17 significant digits in all), and the value is that significand times or divided by a power of ten —
+//     two roundings, not the correctly rounded strtod.  A scene value is a float made from that double, so the double is
+//     reproduced exactly (oracle/ref_json.cpp holds rapidjson itself; tests/test_json_reference.py).
 struct JsonParser {
     const char *p, *end;
     std::string err;
-    void ws()
-    {
-        for (;;) {
-            while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
-            if (p + 1 < end && p[0] == '/' && p[1] == '/') { while (p < end && *p != '\n') ++p; continue; }
-            break;
-        }
-    }
+    int peek() const { return p < end ? (unsigned char)*p : 0; }
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
     bool fail(const char *m) { if (err.empty()) err = m; return false; }
-    bool parse(Json &j)
+    static double pow10(int n)                          // 1e0 .. 1e308, each the double nearest to the power
     {
-        ws();
-        if (p >= end) return fail("unexpected end");
-        char c = *p;
-        if (c == '{') {
-            ++p; j.kind = Json::Obj;
-            ws();
-            if (p < end && *p == '}') { ++p; return true; }
-            for (;;) {
-                ws();
-                Json k;
-                if (p >= end || *p != '"' || !parse(k)) return fail("expected key");
-                ws();
-                if (p >= end || *p != ':') return fail("expected ':'");
-                ++p;
-                Json v;
-                if (!parse(v)) return false;
-                j.obj.emplace_back(k.str, std::move(v));
-                ws();
-                if (p < end && *p == ',') { ++p; continue; }
-                if (p < end && *p == '}') { ++p; return true; }
-                return fail("expected ',' or '}'");
-            }
+        static double table[309];
+        static bool ready = false;
+        if (!ready) {
+            char text[16];
+            for (int i = 0; i <= 308; ++i) { std::snprintf(text, sizeof(text), "1e%d", i); table[i] = std::strtod(text, nullptr); }
+            ready = true;
         }
-        if (c == '[') {
-            ++p; j.kind = Json::Arr;
-            ws();
-            if (p < end && *p == ']') { ++p; return true; }
-            for (;;) {
-                Json v;
-                if (!parse(v)) return false;
-                j.arr.push_back(std::move(v));
-                ws();
-                if (p < end && *p == ',') { ++p; continue; }
-                if (p < end && *p == ']') { ++p; return true; }
-                return fail("expected ',' or ']'");
+        return table[n];
+    }
+    static double scale10(double d, int e) { return e < -308 ? 0.0 : (e >= 0 ? d * pow10(e) : d / pow10(-e)); }
+    bool digit() const { return p < end && *p >= '0' && *p <= '9'; }
+    bool parse_number(Json &j)
+    {
+        bool minus = false;
+        if (peek() == '-') { minus = true; ++p; }
+        uint64_t sig = 0;                                // the significand while it is exact
+        bool is_double = false;
+        double d = 0.0;
+        int digits = 0;                                  // significant digits counted so far (the first integer digit is not)
+        if (peek() == '0') ++p;
+        else if (peek() >= '1' && peek() <= '9') {
+            sig = (uint64_t)(*p++ - '0');
+            // integers stay exact up to the 64-bit range rapidjson reports them in (a minus sign: up to 2^63)
+            const uint64_t tenth = minus ? 0x0CCCCCCCCCCCCCCCull : 0x1999999999999999ull;
+            const char last = minus ? '8' : '5';
+            while (digit()) {
+                if (sig >= tenth && (sig != tenth || *p > last)) { d = (double)sig; is_double = true; break; }
+                sig = sig * 10 + (uint64_t)(*p++ - '0');
+                ++digits;
             }
-        }
-        if (c == '"') {
-            ++p; j.kind = Json::Str;
-            while (p < end && *p != '"') {
-                if (*p == '\\' && p + 1 < end) {
-                    ++p;
-                    switch (*p) {
-                    case 'n': j.str += '\n'; break;
-                    case 't': j.str += '\t'; break;
-                    case 'r': j.str += '\r'; break;
-                    case 'u': j.str += '?'; p += (end - p > 4) ? 4 : 0; break;
-                    default: j.str += *p; break;
-                    }
-                    ++p;
-                } else j.str += *p++;
-            }
-            if (p >= end) return fail("unterminated string");
+            if (is_double)
+                while (digit()) {
+                    if (d >= 1.7976931348623157e307) return fail("number too big");
+                    d = d * 10 + (*p++ - '0');
+                }
+        } else return fail("invalid value");
+        bool integral = !is_double;
+        int exp_frac = 0;
+        if (peek() == '.') {
             ++p;
+            if (!digit()) return fail("missing fraction");
+            if (!is_double) {
+                while (digit()) {
+                    if (sig > 0x1FFFFFFFFFFFFFull) break;       // 2^53 - 1: beyond it the digits go through the double
+                    sig = sig * 10 + (uint64_t)(*p++ - '0');
+                    --exp_frac;
+                    if (sig != 0) ++digits;
+                }
+                d = (double)sig;
+                is_double = true;
+            }
+            while (digit()) {
+                if (digits < 17) {
+                    d = d * 10.0 + (*p++ - '0');
+                    --exp_frac;
+                    if (d > 0.0) ++digits;
+                } else ++p;
+            }
+            integral = false;
+        }
+        int exp = 0;
+        if (peek() == 'e' || peek() == 'E') {
+            if (!is_double) { d = (double)sig; is_double = true; }
+            integral = false;
+            ++p;
+            bool exp_minus = false;
+            if (peek() == '+') ++p;
+            else if (peek() == '-') { ++p; exp_minus = true; }
+            if (!digit()) return fail("missing exponent");
+            exp = *p++ - '0';
+            if (exp_minus) {
+                while (digit()) {
+                    exp = exp * 10 + (*p++ - '0');
+                    if (exp >= 214748364) while (digit()) ++p;
+                }
+                exp = -exp;
+            } else {
+                const int max_exp = 308 - exp_frac;
+                while (digit()) {
+                    exp = exp * 10 + (*p++ - '0');
+                    if (exp > max_exp) return fail("number too big");
+                }
+            }
+        }
+        j.kind = Json::Num;
+        if (integral) {
+            // an integer token: GetDouble() converts the 32- or 64-bit integer (two's complement for a minus sign)
+            j.num = minus ? (double)(int64_t)(~sig + 1) : (double)sig;
             return true;
         }
-        if (!std::strncmp(p, "true", 4)) { p += 4; j.kind = Json::Bool; j.b = true; return true; }
-        if (!std::strncmp(p, "false", 5)) { p += 5; j.kind = Json::Bool; j.b = false; return true; }
-        if (!std::strncmp(p, "null", 4)) { p += 4; j.kind = Json::Null; return true; }
-        char *e = nullptr;
-        double v = std::strtod(p, &e);
-        if (e == p) return fail("unexpected character");
-        p = e;
-        j.kind = Json::Num;
-        j.num = v;
+        const int e10 = exp + exp_frac;
+        d = e10 < -308 ? scale10(scale10(d, -308), e10 + 308) : scale10(d, e10);
+        j.num = minus ? -d : d;
+        return true;
+    }
+    bool hex4(unsigned &cp)
+    {
+        cp = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int c = peek();
+            cp <<= 4;
+            if (c >= '0' && c <= '9') cp += (unsigned)(c - '0');
+            else if (c >= 'A' && c <= 'F') cp += (unsigned)(c - 'A' + 10);
+            else if (c >= 'a' && c <= 'f') cp += (unsigned)(c - 'a' + 10);
+            else return fail("incorrect hex digit after \\u escape");
+            ++p;
+        }
+        return true;
+    }
+    bool parse_string(std::string &out)
+    {
+        ++p;                                             // the opening quote
+        for (;;) {
+            const int c = peek();
+            if (c == '\\') {
+                ++p;
+                const int e = peek();
+                ++p;
+                switch (e) {
+                case '"': out += '"'; break;
+                case '\\': out += '\\'; break;
+                case '/': out += '/'; break;
+                case 'b': out += '\b'; break;
+                case 'f': out += '\f'; break;
+                case 'n': out += '\n'; break;
+                case 'r': out += '\r'; break;
+                case 't': out += '\t'; break;
+                case 'u': {
+                    unsigned cp = 0;
+                    if (!hex4(cp)) return false;
+                    if (cp >= 0xD800 && cp <= 0xDBFF) {
+                        if (peek() != '\\') return fail("invalid surrogate pair");
+                        ++p;
+                        if (peek() != 'u') return fail("invalid surrogate pair");
+                        ++p;
+                        unsigned lo = 0;
+                        if (!hex4(lo)) return false;
+                        if (lo < 0xDC00 || lo > 0xDFFF) return fail("invalid surrogate pair");
+                        cp = (((cp - 0xD800) << 10) | (lo - 0xDC00)) + 0x10000;
+                    }
+                    if (cp <= 0x7F) out += (char)cp;
+                    else if (cp <= 0x7FF) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                    else if (cp <= 0xFFFF) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                    else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                    break;
+                }
+                default: return fail("invalid escape character in string");
+                }
+            } else if (c == '"') { ++p; return true; }
+            else if (c == 0) return fail("missing a closing quotation mark in string");
+            else if (c < 0x20) return fail("invalid character in string");
+            else { out += (char)c; ++p; }
+        }
+    }
+    bool literal(const char *word, size_t n)
+    {
+        if ((size_t)(end - p) < n || std::strncmp(p, word, n)) return fail("invalid value");
+        p += n;
+        return true;
+    }
+    bool parse_value(Json &j)
+    {
+        switch (peek()) {
+        case 'n': j.kind = Json::Null; return literal("null", 4);
+        case 't': j.kind = Json::Bool; j.b = true; return literal("true", 4);
+        case 'f': j.kind = Json::Bool; j.b = false; return literal("false", 5);
+        case '"': j.kind = Json::Str; return parse_string(j.str);
+        case '{':
+            ++p; j.kind = Json::Obj;
+            ws();
+            if (peek() == '}') { ++p; return true; }
+            for (;;) {
+                if (peek() != '"') return fail("missing a name for object member");
+                std::string key;
+                if (!parse_string(key)) return false;
+                ws();
+                if (peek() != ':') return fail("missing a colon after a name of object member");
+                ++p;
+                ws();
+                Json v;
+                if (!parse_value(v)) return false;
+                j.obj.emplace_back(std::move(key), std::move(v));
+                ws();
+                if (peek() == ',') { ++p; ws(); continue; }
+                if (peek() == '}') { ++p; return true; }
+                return fail("missing a comma or '}' after an object member");
+            }
+        case '[':
+            ++p; j.kind = Json::Arr;
+            ws();
+            if (peek() == ']') { ++p; return true; }
+            for (;;) {
+                Json v;
+                if (!parse_value(v)) return false;
+                j.arr.push_back(std::move(v));
+                ws();
+                if (peek() == ',') { ++p; ws(); continue; }
+                if (peek() == ']') { ++p; return true; }
+                return fail("missing a comma or ']' after an array element");
+            }
+        default: return parse_number(j);
+        }
+    }
+    // a whole document: one value, blanks around it, nothing else (the text ends at its first NUL, as the reference's buffer does)
+    bool parse(Json &j)
+    {
+        const char *nul = (const char *)std::memchr(p, 0, (size_t)(end - p));
+        if (nul) end = nul;
+        ws();
+        if (p >= end) return fail("the document is empty");
+        if (!parse_value(j)) return false;
+        ws();
+        if (p < end) return fail("the document root must not be followed by other values");
         return true;
     }
 };
@@ -1068,3 +1220,22 @@ bool LoadScene(const char *filename, GlobalConfig &config, Scene &scene)
     }
     return true;
 }
+
+// Test hook: the scene-file reader on its own.  text: a JSON document (NUL-terminated).  Returns -1 when the reader refuses
+// it; otherwise, for an array of numbers, how many there are (their values in out[0..cap)), and 0 for any other document.
+extern "C" __attribute__((visibility("default"))) int gpt_debug_json_numbers(const char *text, double *out, int cap)
+{
+    if (!text) return -1;
+    Json doc;
+    JsonParser jp{text, text + std::strlen(text), ""};
+    if (!jp.parse(doc)) return -1;
+    if (doc.kind != Json::Arr) return 0;
+    int n = 0;
+    for (const Json &v : doc.arr) {
+        if (v.kind != Json::Num) return 0;
+        if (out && n < cap) out[n] = v.num;
+        ++n;
+    }
+    return n;
+}
+

@@ -190,6 +190,9 @@ int gpt_debug_math(int device, int fn, const float *x, const float *y, float *ou
 int gpt_debug_trace(gpt_ctx *ctx, const float *rays8, int n, int32_t *prim_out, float *tb_out);
 /* first n uniform draws of the (pixel, iter) stream, evaluated on the device */
 int gpt_debug_rng(int device, uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n);
+/* the scene-file reader on its own (tests: against the rapidjson the reference vendors): -1 when the reader refuses the
+ * document; for an array of numbers their count, the values (as the reader's doubles) in out[0..cap); 0 for other documents */
+int gpt_debug_json_numbers(const char *text, double *out, int cap);
 
 /* ---- host-side scene preparation (CPU; no GPU needed) ---------------------- */
 

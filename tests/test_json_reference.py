@@ -1,0 +1,140 @@
+"""The scene-file reader against the rapidjson the reference vendors.
+
+src/parsescene.cpp:60-61 parses a scene with rapidjson's Document::Parse (default flags) and reads numbers with GetDouble();
+rapidjson is header-only under the reference's include/ and compiles with g++ where it lies (oracle/ref_json.cpp ->
+oracle/_ref/libref_json.so).  The product's reader (gpu_pathtracer_amd/csrc/scene_loader.cpp) must (1) accept and refuse the
+same documents — a scene the reference rejects must not load here, and the other way round — and (2) turn every number into the
+same double: rapidjson's default number conversion is NOT the correctly rounded one (two roundings: significand, then a multiply
+or divide by a power of ten), and a scene value is a float made from that double.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpu_pathtracer_amd import api
+
+REF_LIB = os.path.join(ol.ROOT, "oracle", "_ref", "libref_json.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(REF_LIB) and os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ol.ROOT, "oracle"), "ref"], check=True)
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref/libref_json.so is not built and /root/reference is not here to build it from")
+    lib = C.CDLL(REF_LIB)
+    lib.ref_json_numbers.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    lib.ref_json_accepts.argtypes = [C.c_char_p]
+    return lib
+
+
+def ours(text, cap=0):
+    lib = api.load()
+    lib.gpt_debug_json_numbers.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    out = np.zeros(max(cap, 1), np.float64)
+    n = lib.gpt_debug_json_numbers(text.encode() if isinstance(text, str) else text, out.ctypes.data, cap)
+    return n, out[:max(n, 0)]
+
+
+def theirs(ref, text, cap=0):
+    out = np.zeros(max(cap, 1), np.float64)
+    n = ref.ref_json_numbers(text.encode() if isinstance(text, str) else text, out.ctypes.data, cap)
+    return n, out[:max(n, 0)]
+
+
+def number_strings(rng):
+    s = ["0", "-0", "0.0", "-0.0", "1", "-1", "0.1", "0.08", "-0.35", "1e-3", "1E+2", "1e0", "0e5", "0.0005", "19.5", "2.2", "1.5", "37.0",
+         "4294967295", "4294967296", "-2147483648", "-2147483649", "9223372036854775807", "9223372036854775808", "-9223372036854775808",
+         "-9223372036854775809", "18446744073709551615", "18446744073709551616", "123456789012345678901234567890", "0.30000001192092896",
+         "0.1000000000000000055511151231257827", "9007199254740993", "9007199254740992.5", "0.9007199254740993", "1.7976931348623157e308",
+         "2e308", "1e308", "4.9e-324", "2.2250738585072014e-308", "1e-400", "123e-330", "0.000000000000000000000000000000000000001e40",
+         "1.00000000000000011102230246251565404236316680908203125", "8.5", "1e22", "1e23", "9.5367431640625e-07", "3.4028234663852886e+38",
+         "100000", "1000", "60", "5", "0.001", "0.01", "0.025", "0.5"]
+    for _ in range(3000):                      # plain decimals, 1 .. 25 digits
+        n_int, n_frac = int(rng.integers(1, 12)), int(rng.integers(0, 15))
+        t = str(int(rng.integers(1, 10))) + "".join(str(int(d)) for d in rng.integers(0, 10, n_int - 1)) if rng.random() < 0.7 else "0"
+        if n_frac:
+            t += "." + "".join(str(int(d)) for d in rng.integers(0, 10, n_frac))
+        if rng.random() < 0.3:
+            t += "e%+d" % int(rng.integers(-40, 40))
+        s.append(("-" if rng.random() < 0.3 else "") + t)
+    f32 = rng.normal(0, 1, 3000).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 6, 3000).astype(np.float32)
+    s += [repr(float(v)) for v in f32]                                  # what json.dump writes for a float32 scene value (17 digits)
+    s += [repr(float(np.float64(v))) for v in rng.normal(0, 1, 2000) * 10.0 ** rng.integers(-30, 30, 2000)]
+    s += ["%.9g" % v for v in f32[:1000]] + ["%.6f" % v for v in f32[:1000]] + ["%.3e" % v for v in f32[:1000]]
+    return s
+
+
+def test_numbers_become_the_same_doubles(ref):
+    rng = np.random.default_rng(17)
+    strings = number_strings(rng)
+    text = "[" + ",".join(strings) + "]"
+    n_ref, want = theirs(ref, text, len(strings))
+    n_got, got = ours(text, len(strings))
+    assert n_ref == n_got == len(strings)
+    differ = np.nonzero(want.view(np.uint64) != got.view(np.uint64))[0]
+    assert len(differ) == 0, [(strings[i], want[i].hex(), got[i].hex()) for i in differ[:5]]
+    # and the conversion really is not strtod's: some of these strings land one ulp off the correctly rounded value
+    exact = np.array([float(t) for t in strings])
+    with np.errstate(invalid="ignore"):
+        assert 0 < np.count_nonzero(exact != want) < len(strings) // 5
+    # ... which never changes the FLOAT a scene value becomes, for these strings (shown, not assumed) - except that the integer
+    # token "-0" is +0.0 for rapidjson (an int 0 converted), -0.0 for strtod
+    with np.errstate(over="ignore"):
+        as_float, exact_float = want.astype(np.float32), exact.astype(np.float32)
+    other = np.nonzero(as_float.view(np.uint32) != exact_float.view(np.uint32))[0]
+    assert len(other) > 0 and all(strings[i] == "-0" for i in other)
+    assert all(want[i] == 0.0 and not np.signbit(want[i]) for i in other)
+
+
+BORDERLINE = [
+    '{}', '[]', '  [1, 2 ]\n', '1', '"text"', 'null', 'true', '', '   ', '[1,]', '{"a":1,}', '[,1]', '[1 2]', '{"a" 1}', '{"a":}', '{a:1}',
+    "{'a':1}", '[1] x', '[1] [2]', '[1]//c', '//c\n[1]', '/*c*/[1]', '[1 /*c*/]', '[01]', '[-01]', '[1.]', '[.5]', '[+1]', '[1e]', '[1e+]', '[-]',
+    '[1.e3]', '[0x10]', '[1e5]', '[1E-5]', '[-0]', '[0.0e0]', '[NaN]', '[nan]', '[Infinity]', '[-Infinity]', '[inf]', '[tru]', '[True]', '[nul]',
+    '[truex]', '[nullnull]', '[1e400]', '[1e309]', '[-1e400]', '[1e-400]', '[0e999]', '[123456789012345678901234567890]', '[1' + '0' * 400 + ']',
+    '[0.' + '0' * 400 + '1]', '[1' + '0' * 307 + ']', '[1' + '0' * 308 + ']', '[1' + '0' * 309 + ']', '[9e307]', '[17e307]', '[18e307]', '[1.8e308]',
+    '["\\n\\t\\r\\b\\f\\/\\\\\\""]', '["\\q"]', '["\\u00e9"]', '["\\u00E9"]', '["\\u12"]', '["\\u12g4"]', '["\\ud83d\\ude00"]', '["\\ud83d"]', '["\\ud83dx"]', '["\\ud83d\\u0041"]', '["\\ude00"]', '["a\\u0000b"]',
+    r'["\ud83dA"]', r'["\ude00"]', '["a\tb"]', '["a\nb"]', '["a\x01b"]', '["a\x7fb"]', '["\xc3\xa9"]', '["\xff\xfe"]', '["abc]', '["abc\\"]',
+    '\xef\xbb\xbf[1]', '[1]\x00[2]', '[1\x00]', '{"a":1,"a":2}', '{"":1}', '[[[[[[[[[[[[[[[[[[[[1]]]]]]]]]]]]]]]]]]]]', '[[[[1]]]', '[1]]', '{"a":{"b":[1,{"c":null}]}}',
+    '[1,\n2,\r\n3,\t4]', '[1,\x0b2]', '[1,\x0c2]', '[1,\xa02]', '[ 1 , 2 ]', '{ "a" : 1 }', '[1;2]', '{"a"=1}', '[1,2', '{"a":1', '{"a"', '{"a":1 "b":2}',
+]
+
+
+def test_the_same_documents_are_accepted_and_refused(ref):
+    for doc in BORDERLINE:
+        raw = doc.encode("latin-1")
+        want = ref.ref_json_accepts(raw)
+        got = ours(raw)[0] >= 0
+        assert bool(want) == got, (doc[:60], "rapidjson accepts" if want else "rapidjson refuses")
+    accepted = sum(ref.ref_json_accepts(d.encode("latin-1")) for d in BORDERLINE)
+    assert 30 < accepted < len(BORDERLINE) - 40             # the list probes both sides
+
+
+def test_numbers_in_borderline_documents_agree(ref):
+    for doc in BORDERLINE:
+        raw = doc.encode("latin-1")
+        n_ref, want = theirs(ref, raw, 64)
+        if n_ref > 0:
+            n_got, got = ours(raw, 64)
+            assert n_got == n_ref and np.array_equal(got.view(np.uint64), want.view(np.uint64)), doc[:60]
+
+
+def test_a_scene_the_reference_refuses_does_not_load(tmp_path):
+    """End to end through gpt_scene_load: comments, a trailing comma, a bare NaN - each a parse error for the reference
+    (LoadScene returns false, src/parsescene.cpp:62-66) - are GPT_ERR_PARSE here."""
+    import shutil
+    src = os.path.join(ol.ROOT, "scenes", "cornell_pt")
+    text = open(os.path.join(src, "scene.json")).read()
+    assert api.LoadedScene(os.path.join(src, "scene.json")).desc.n_prims > 0
+    last_brace = text.rstrip().rfind("}")
+    for i, broken in enumerate(("// a comment\n" + text, text[:last_brace] + ",}" , text.replace('"maxDepth"', '"x": NaN, "maxDepth"', 1) if '"maxDepth"' in text else text + "x",
+                                text + "\n{}", "﻿" + text)):
+        d = tmp_path / f"case{i}"
+        shutil.copytree(src, d)
+        open(d / "scene.json", "w", encoding="utf-8").write(broken)
+        with pytest.raises(api.GptError, match="Parse scene error"):
+            api.LoadedScene(str(d / "scene.json"))
