@@ -1231,6 +1231,9 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
 #ifndef PT_WIDE_EARLY
 #define PT_WIDE_EARLY 0          // (measured: -5 %, the extra vector-memory instructions cost more than the overlap gains) a lane that descends into a wide node fetches that record before the trip's triangle block
 #endif
+#ifndef PT_WIDE_EXTRA_NODE
+#define PT_WIDE_EXTRA_NODE         // experiment hook: extra VALU instructions in the node block (what would fewer of them be worth?)
+#endif
 #ifndef PT_WIDE_EXTRA_LOADS
 #define PT_WIDE_EXTRA_LOADS        // experiment hook: redundant fetches per trip (how much does a vector-memory instruction cost?)
 #endif
@@ -1353,6 +1356,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_waitcnt vmcnt(0)\n"
         /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
         /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */
+        PT_WIDE_EXTRA_NODE
         "v_sub_f32_e32 v24, v24, v0\n"
         "v_sub_f32_e32 v36, v36, v0\n"
         "v_sub_f32_e32 v28, v28, v1\n"
