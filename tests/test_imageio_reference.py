@@ -398,3 +398,28 @@ def test_damaged_files_are_refused_or_decoded_never_overrun(ref, tmp_path):
             except RuntimeError:
                 refused += 1
     assert decoded > 100 and refused > 100
+
+
+def test_decoder_entry_points_report_errors_and_sizes(tmp_path):
+    """The C ABI of the decoders: size-only calls, buffers that are too small, files that are not pictures (no reference needed)."""
+    import ctypes as C
+    from PIL import Image
+    lib = api.load()
+    png = str(tmp_path / "a.png")
+    Image.fromarray(np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)).save(png)
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.gpt_decode_image8(os.fsencode(png), C.byref(w), C.byref(h), C.byref(c), None, 0) == 0
+    assert (w.value, h.value, c.value) == (7, 5, 3)
+    small = np.zeros(10, np.uint8)
+    assert lib.gpt_decode_image8(os.fsencode(png), C.byref(w), C.byref(h), C.byref(c), small.ctypes.data, small.size) == -1
+    assert lib.gpt_load_texture(os.fsencode(png), C.byref(w), C.byref(h), small.ctypes.data, 2) == -1
+    assert lib.gpt_decode_image8(None, C.byref(w), C.byref(h), C.byref(c), None, 0) == -1
+    junk = tmp_path / "junk.bin"
+    junk.write_bytes(b"not a picture at all" * 10)
+    for reader in (api.decode_image8, api.load_texture, api.load_exr):
+        with pytest.raises(api.GptError):
+            reader(str(junk))
+        with pytest.raises(api.GptError):
+            reader(str(tmp_path / "missing.file"))
+    assert api.decode_image8(png).shape == (5, 7, 3) and api.load_texture(png).shape == (5, 7, 4)
+
