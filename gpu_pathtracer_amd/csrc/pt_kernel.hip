@@ -157,6 +157,9 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #ifndef PT_ASM_IN_COUNT
 #define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
 #endif
+#ifndef PT_LANEPROBE
+#define PT_LANEPROBE 0            // 1 (with PT_ASM_IN_COUNT, without PT_SUBPROBES): lanes in the shading rounds (counters 6..9)
+#endif
 #ifndef PT_SUBPROBES
 #define PT_SUBPROBES 0            // 1 (with PT_ASM_IN_COUNT): finer time split of the hit-shading block
 #endif
@@ -3440,6 +3443,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                         const gpt_material material = P.materials[isect.matIdx];
                         q.has_s = q.has_m = q.has_p = false;
                         PT_MARK(1)
+#if PT_LANEPROBE
+                        if (COUNT) { const int h_ = popc(ballot(true)); if (first_active_lane()) { cnt.w_shade++; cnt.l_shade += (uint32_t)h_; } }
+#endif
 
                         // Volpath (pathtracer.cu:1062-1070): the medium decides whether the ray gets as far as the surface
                         bool scattered = false;
@@ -3790,6 +3796,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 c0 = __builtin_readcyclecounter();
                 if (lane == 0) cyc_shade += c0 - cyc_mark;
             }
+#if PT_LANEPROBE
+            if (COUNT) { const int a_ = popc(ballot(alive && !waiting)); if (lane == 0) { cnt.w_nee++; cnt.l_nee += (uint32_t)a_; } }
+#endif
             if (SMALL) {
                 LdsScene mem;
                 mem.first = (int)lds_address(lds_scene);
@@ -3883,6 +3892,12 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         atomicAdd(&P.counters[7], (unsigned long long)cnt.w_prim);
         atomicAdd(&P.counters[8], (unsigned long long)cnt.w_trip);
         atomicAdd(&P.counters[9], (unsigned long long)cnt.l_trip);
+#if PT_LANEPROBE
+        atomicAdd(&P.counters[6], (unsigned long long)cnt.w_shade);     // rounds in which some lane shades a hit
+        atomicAdd(&P.counters[7], (unsigned long long)cnt.l_shade);     // ... lanes that do
+        atomicAdd(&P.counters[8], (unsigned long long)cnt.w_nee);       // drains (one per round)
+        atomicAdd(&P.counters[9], (unsigned long long)cnt.l_nee);       // lanes with a path that is not waiting for a suspended ray, when a drain starts
+#endif
 #if PT_SUBPROBES
         if (lane == 0) {
             atomicAdd(&P.counters[6], probe[2]);    // make_hit + material      (reuses w_node..l_trip, unused with the asm loop)

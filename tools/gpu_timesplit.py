@@ -37,3 +37,9 @@ if "subprobe" in os.environ.get("GPT_LIB_PATH", ""):
     names = ["between rounds (incl. drain)", "make_hit + material", "light sample + BSDF eval", "MIS sample + emitter pre-test", "continuation sample + roulette"]
     hs = sum(sub[1:])
     print("SUB   " + "; ".join(f"{n} {100*v/max(1,hs):.1f} %" for n, v in zip(names[1:], sub[1:])) + f"  (of the hit-shading block; block = {hs*64/s:.0f} cycles per 64 samples)")
+if "laneprobe" in os.environ.get("GPT_LIB_PATH", ""):
+    # PT_LANEPROBE build: counters 6..9 = rounds with a hit-shading block, lanes in it, drains, lanes that deposited rays for a drain
+    print(f"LANES {which} {mode}: rounds per 64 samples {c['w_trip']*64/s:.2f}; lanes whose path takes part in a round {c['l_trip']/max(1,c['w_trip']):.1f}; "
+          f"rounds with hit shading {100*c['w_node']/max(1,c['w_trip']):.0f} %, lanes in the hit-shading block {c['w_prim']/max(1,c['w_node']):.1f} of 64; "
+          f"hit-shading lane-rounds per sample {c['w_prim']/s:.2f}")
+
