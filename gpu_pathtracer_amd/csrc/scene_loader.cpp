@@ -232,8 +232,12 @@ struct JsonParser {
         p += n;
         return true;
     }
+    int depth = 0;                                      // nesting: bounded (rapidjson recurses until the stack runs out; a scene file is 3 deep)
+    struct Nest { int &d; explicit Nest(int &x) : d(x) { ++d; } ~Nest() { --d; } };
     bool parse_value(Json &j)
     {
+        Nest nest(depth);
+        if (depth > 512) return fail("nested too deeply");
         switch (peek()) {
         case 'n': j.kind = Json::Null; return literal("null", 4);
         case 't': j.kind = Json::Bool; j.b = true; return literal("true", 4);

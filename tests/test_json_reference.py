@@ -138,3 +138,13 @@ def test_a_scene_the_reference_refuses_does_not_load(tmp_path):
         open(d / "scene.json", "w", encoding="utf-8").write(broken)
         with pytest.raises(api.GptError, match="Parse scene error"):
             api.LoadedScene(str(d / "scene.json"))
+
+
+def test_absurd_nesting_is_refused_not_crashed(ref):
+    """rapidjson's recursive reader has no depth limit (it runs out of stack); the product's stops at 512 levels with a parse error."""
+    ok = "[" * 400 + "1" + "]" * 400
+    assert ref.ref_json_accepts(ok.encode()) == 1 and ours(ok)[0] >= 0
+    assert ours("[" * 200000)[0] == -1
+    assert ours("[" * 200000 + "1" + "]" * 200000)[0] == -1
+    assert ours('{"a":' * 100000 + "1" + "}" * 100000)[0] == -1
+
