@@ -8,8 +8,8 @@
 //   ImageIO::LoadExr     src/imageio.cpp:80-102  lat-long environment map
 //
 // Here: a PNG writer (stored-deflate, no compression needed for a checker
-// output), a PNG reader (8-bit grey / grey+alpha / RGB / RGBA / palette,
-// non-interlaced) on a small inflate, and PFM (little- or big-endian float32)
+// output), a PNG reader (every colour type and bit depth, Adam7 interlacing,
+// colour keys) on a small inflate, and PFM (little- or big-endian float32)
 // for linear radiance and environment maps, an OpenEXR scanline reader (NONE / RLE / ZIPS / ZIP / PIZ,
 // half / float) for the reference's environment maps, and a baseline + progressive JPEG reader for textures.
 #include "imageio.h"
@@ -260,7 +260,11 @@ bool write_png_rgb8(const char *path, int width, int height, const unsigned char
     return w == out.size();
 }
 
-// 8-bit PNG -> RGBA8, rows top-down.  components = channels in the file (1, 2, 3 or 4; palette -> 3/4)
+// PNG -> RGBA8, rows top-down: every colour type and bit depth of the format (1 / 2 / 4 / 8 / 16 bits; grey, RGB, palette, with
+// alpha), Adam7 interlacing, tRNS colour keys.  The choices the format leaves to a reader follow stb_image, the reference's
+// (tests/test_imageio_reference.py compares with stb_image itself): 16-bit samples keep their HIGH byte, 1 / 2 / 4-bit grey is
+// scaled by 255 / 85 / 17, a colour key is compared at full sample precision and adds an alpha channel.
+// components = what stb_image reports for the file: 1, 2, 3 or 4 (palette -> 3, with tRNS 4; grey / RGB with a key -> 2 / 4)
 bool read_png(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
 {
     std::vector<unsigned char> d;
@@ -268,57 +272,111 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
     size_t pos = 8;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<unsigned char> idat, plte, trns;
+    bool have_trns = false;
     width = height = 0;
     while (pos + 12 <= d.size()) {
         uint32_t len = be32(&d[pos]);
         const unsigned char *type = &d[pos + 4];
-        if (pos + 12 + len > d.size()) return false;
+        if (len > d.size() || pos + 12 + len > d.size()) return false;
         const unsigned char *body = &d[pos + 8];
         if (!std::memcmp(type, "IHDR", 4)) {
-            if (len != 13) return false;
+            if (len != 13 || width) return false;
             width = (int)be32(body); height = (int)be32(body + 4);
             depth = body[8]; ctype = body[9]; interlace = body[12];
+            if (body[10] != 0 || body[11] != 0) return false;                  // compression / filter method
         } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
-        else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!std::memcmp(type, "tRNS", 4)) { trns.assign(body, body + len); have_trns = true; }
         else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!std::memcmp(type, "IEND", 4)) break;
         pos += 12 + len;
     }
-    if (width <= 0 || height <= 0 || depth != 8 || interlace != 0 || idat.size() < 6) return false;
-    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!ch) return false;
+    if (width <= 0 || height <= 0 || width > (1 << 24) || height > (1 << 24) || interlace > 1 || idat.size() < 6) return false;
     if ((uint64_t)width * (uint64_t)height > ((uint64_t)1 << 28)) return false;
-    std::vector<unsigned char> raw;
-    const size_t stride = (size_t)width * ch;
-    if (!inflate_raw(idat.data() + 2, idat.size() - 2, raw, (stride + 1) * (size_t)height)) return false;
-    if (raw.size() < (stride + 1) * (size_t)height) return false;
-    std::vector<unsigned char> img(stride * (size_t)height);
-    for (int y = 0; y < height; ++y) {
-        const unsigned char *in = &raw[(stride + 1) * (size_t)y];
-        unsigned char *cur = &img[stride * (size_t)y];
-        const unsigned char *up = y ? &img[stride * (size_t)(y - 1)] : nullptr;
-        int ft = in[0];
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= (size_t)ch ? cur[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
-            int x = in[i + 1];
-            int v = ft == 0 ? x : ft == 1 ? x + a : ft == 2 ? x + b : ft == 3 ? x + ((a + b) >> 1) : ft == 4 ? x + paeth(a, b, c) : -1;
-            if (v < 0) return false;
-            cur[i] = (unsigned char)v;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) return false;
+    const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+    if (!depth_ok) return false;
+    if (ctype == 3 && (plte.empty() || plte.size() > 768)) return false;
+    // the sub-images the data holds: the whole picture, or the seven Adam7 passes
+    struct Pass { int x0, y0, dx, dy, w, h; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back(Pass{0, 0, 1, 1, width, height});
+    else {
+        static const int x0[7] = {0, 4, 0, 2, 0, 1, 0}, y0[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int k = 0; k < 7; ++k) {
+            const int w = (width - x0[k] + dx[k] - 1) / dx[k], h = (height - y0[k] + dy[k] - 1) / dy[k];
+            if (w > 0 && h > 0) passes.push_back(Pass{x0[k], y0[k], dx[k], dy[k], w, h});
         }
     }
-    components = ctype == 3 ? (trns.empty() ? 3 : 4) : ch;
+    auto row_bytes = [&](int w) { return ((size_t)w * (size_t)ch * (size_t)depth + 7) >> 3; };
+    size_t expect = 0;
+    for (const Pass &ps : passes) expect += (row_bytes(ps.w) + 1) * (size_t)ps.h;
+    std::vector<unsigned char> raw;
+    if (!inflate_raw(idat.data() + 2, idat.size() - 2, raw, expect) || raw.size() < expect) return false;
+    const size_t bpp = (size_t)(ch * depth >= 8 ? ch * depth / 8 : 1);         // the filters' "corresponding byte of the pixel to the left"
+    std::vector<uint16_t> samp((size_t)width * height * ch);                   // every sample at its own precision
+    std::vector<unsigned char> cur_row, up_row;
+    size_t at = 0;
+    for (const Pass &ps : passes) {
+        const size_t rb = row_bytes(ps.w);
+        up_row.assign(rb, 0);
+        cur_row.assign(rb, 0);
+        for (int j = 0; j < ps.h; ++j) {
+            const unsigned char *in = &raw[at];
+            at += rb + 1;
+            const int ft = in[0];
+            if (ft > 4) return false;
+            for (size_t i = 0; i < rb; ++i) {
+                const int a = i >= bpp ? cur_row[i - bpp] : 0, b = up_row[i], c = i >= bpp ? up_row[i - bpp] : 0, x = in[i + 1];
+                cur_row[i] = (unsigned char)(ft == 0 ? x : ft == 1 ? x + a : ft == 2 ? x + b : ft == 3 ? x + ((a + b) >> 1) : x + paeth(a, b, c));
+            }
+            const size_t y = (size_t)ps.y0 + (size_t)j * ps.dy;
+            for (int i = 0; i < ps.w; ++i) {
+                uint16_t *o = &samp[(y * width + (size_t)ps.x0 + (size_t)i * ps.dx) * ch];
+                for (int c = 0; c < ch; ++c) {
+                    const size_t k = (size_t)i * ch + c;                       // sample number in the row
+                    if (depth == 16) o[c] = (uint16_t)(cur_row[2 * k] << 8 | cur_row[2 * k + 1]);
+                    else if (depth == 8) o[c] = cur_row[k];
+                    else {
+                        const size_t bit = k * (size_t)depth;
+                        o[c] = (uint16_t)((cur_row[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1 << depth) - 1));
+                    }
+                }
+            }
+            cur_row.swap(up_row);
+        }
+    }
+    const int scale = depth == 1 ? 0xff : depth == 2 ? 0x55 : depth == 4 ? 0x11 : 1;
+    auto to8 = [&](uint16_t v) { return (unsigned char)(depth == 16 ? v >> 8 : v * scale); };
+    // a colour key (tRNS of a grey or RGB file): 16-bit files compare the whole sample, the others the 8-bit value
+    uint16_t key[3] = {0, 0, 0};
+    const bool keyed = have_trns && (ctype == 0 || ctype == 2);
+    if (keyed) {
+        if (trns.size() < (size_t)(2 * ch)) return false;
+        for (int c = 0; c < ch; ++c) {
+            const uint16_t v = (uint16_t)(trns[2 * c] << 8 | trns[2 * c + 1]);
+            key[c] = depth == 16 ? v : (uint16_t)((v & 255) * scale);
+        }
+    }
+    components = ctype == 3 ? (have_trns ? 4 : 3) : ch + (keyed ? 1 : 0);
     rgba.resize((size_t)width * height * 4);
     for (size_t i = 0; i < (size_t)width * height; ++i) {
+        const uint16_t *v = &samp[i * ch];
         unsigned char r, g, b, a = 255;
-        if (ctype == 0) { r = g = b = img[i]; }
-        else if (ctype == 4) { r = g = b = img[2 * i]; a = img[2 * i + 1]; }
-        else if (ctype == 2) { r = img[3 * i]; g = img[3 * i + 1]; b = img[3 * i + 2]; }
-        else if (ctype == 6) { r = img[4 * i]; g = img[4 * i + 1]; b = img[4 * i + 2]; a = img[4 * i + 3]; }
-        else {
-            size_t k = img[i];
+        if (ctype == 3) {
+            const size_t k = v[0];
             if (3 * k + 2 >= plte.size()) return false;
             r = plte[3 * k]; g = plte[3 * k + 1]; b = plte[3 * k + 2];
             if (k < trns.size()) a = trns[k];
+        } else if (ctype == 0 || ctype == 4) {
+            r = g = b = to8(v[0]);
+            if (ctype == 4) a = to8(v[1]);
+            else if (keyed && (depth == 16 ? v[0] : (uint16_t)r) == key[0]) a = 0;
+        } else {
+            r = to8(v[0]); g = to8(v[1]); b = to8(v[2]);
+            if (ctype == 6) a = to8(v[3]);
+            else if (keyed && (depth == 16 ? (v[0] == key[0] && v[1] == key[1] && v[2] == key[2]) : (r == key[0] && g == key[1] && b == key[2]))) a = 0;
         }
         rgba[4 * i] = r; rgba[4 * i + 1] = g; rgba[4 * i + 2] = b; rgba[4 * i + 3] = a;
     }

@@ -369,7 +369,7 @@ def test_jpeg_unusual_chroma_sampling_equals_stb_image(ref, tmp_path, sampling):
 
 
 def test_damaged_files_are_refused_or_decoded_never_overrun(ref, tmp_path):
-    """Random damage to PIZ and JPEG files (the formats with the most pointer arithmetic in the reader): every call returns -
+    """Random damage to PIZ, JPEG and PNG files (the formats with the most pointer arithmetic in the reader): every call returns -
     an error or some picture of the declared size.  (The same mutations ran under AddressSanitizer while the readers were
     written; this keeps a short version of that in the suite.)"""
     rng = np.random.default_rng(12)
@@ -380,6 +380,9 @@ def test_damaged_files_are_refused_or_decoded_never_overrun(ref, tmp_path):
         seeds.append((path.read_bytes(), api.load_exr))
     for path in jpeg_cases(rng, str(tmp_path))[:6]:
         seeds.append((open(path, "rb").read(), api.decode_image8))
+    for depth, ctype, lace, ch in ((16, 2, True, 3), (4, 3, True, 1), (1, 0, False, 1), (8, 6, False, 4)):
+        plte = rng.integers(0, 256, 48).tolist() if ctype == 3 else None
+        seeds.append((encode_png(rng.integers(0, 1 << depth, (13, 21, ch)), depth, ctype, lace, plte, None, rng), api.decode_image8))
     decoded = refused = 0
     target = str(tmp_path / "damaged.bin")
     for data, reader in seeds:
@@ -422,4 +425,105 @@ def test_decoder_entry_points_report_errors_and_sizes(tmp_path):
         with pytest.raises(api.GptError):
             reader(str(tmp_path / "missing.file"))
     assert api.decode_image8(png).shape == (5, 7, 3) and api.load_texture(png).shape == (5, 7, 4)
+
+
+def encode_png(samples, depth, ctype, interlace=False, plte=None, trns=None, rng=None):
+    """A PNG writer for the corners of the format PIL does not write (Adam7, 16-bit RGB(A), 1 / 2 / 4-bit grey and palettes,
+    colour keys): samples [H, W, channels] of unsigned ints below 2**depth; every scanline gets a random filter type."""
+    import struct
+    import zlib
+    H, W, ch = samples.shape
+    rng = rng or np.random.default_rng(0)
+
+    def pack_row(row):                                   # [w, ch] -> bytes at this bit depth
+        flat = row.reshape(-1).astype(np.uint32)
+        if depth == 16:
+            return b"".join(struct.pack(">H", int(v)) for v in flat)
+        if depth == 8:
+            return bytes(int(v) for v in flat)
+        bits = "".join(format(int(v), "0%db" % depth) for v in flat)
+        bits += "0" * (-len(bits) % 8)
+        return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def filtered(rows):                                  # list of byte rows of one pass -> filter byte + filtered bytes each
+        bpp = max(1, ch * depth // 8)
+        out, prev = b"", None
+        for cur in rows:
+            ft = int(rng.integers(0, 5))
+            up = prev if prev is not None else bytes(len(cur))
+            line = bytearray()
+            for i, x in enumerate(cur):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = up[i]
+                c = up[i - bpp] if i >= bpp else 0
+                pred = (0, a, b, (a + b) >> 1, paeth(a, b, c))[ft]
+                line.append((x - pred) & 255)
+            out += bytes([ft]) + bytes(line)
+            prev = cur
+        return out
+    if interlace:
+        data = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                data += filtered([pack_row(r) for r in sub])
+    else:
+        data = filtered([pack_row(r) for r in samples])
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+    z = zlib.compress(data, 6)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        out += chunk(b"PLTE", bytes(plte))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    half = len(z) // 2                                    # two IDAT chunks: the stream continues across them
+    return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+def test_png_every_colour_type_depth_and_interlace_equals_stb_image(ref, tmp_path):
+    """The whole PNG matrix: colour types 0 / 2 / 3 / 4 / 6 at every legal bit depth, plain and Adam7, with and without a
+    tRNS chunk (a colour key for grey / RGB - compared at 16 bits in 16-bit files -, alpha per entry for palettes), sizes that leave
+    empty Adam7 passes.  stb_image decides what a reader may decide (16 -> 8 bits by the high byte, 1 / 2 / 4-bit grey scaled
+    by 255 / 85 / 17, a key adds a channel); the product's reader has to agree byte for byte and channel count for channel count."""
+    import struct
+    rng = np.random.default_rng(9)
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}
+    depths = {0: (1, 2, 4, 8, 16), 2: (8, 16), 3: (1, 2, 4, 8), 4: (8, 16), 6: (8, 16)}
+    n = 0
+    for ctype in (0, 2, 3, 4, 6):
+        for depth in depths[ctype]:
+            for interlace in (False, True):
+                for with_trns in ((False, True) if ctype in (0, 2, 3) else (False,)):
+                    for h, w in ((13, 21), (1, 1), (3, 2), (9, 5)):
+                        ch = channels[ctype]
+                        samples = rng.integers(0, 1 << depth, (h, w, ch))
+                        plte = trns = None
+                        if ctype == 3:
+                            n_entries = 1 << depth
+                            plte = rng.integers(0, 256, 3 * n_entries).tolist()
+                            if with_trns:
+                                trns = rng.integers(0, 256, max(1, n_entries // 2)).tolist()      # shorter than the palette: the rest is opaque
+                        elif with_trns:
+                            key = samples[h // 2, w // 2]                                       # a key that does occur
+                            if depth == 16:
+                                samples[0, 0] = key ^ 1 if ch == 1 else key                     # same high byte, different sample
+                                if ch == 1:
+                                    samples[0, 0] = (int(key[0]) & 0xff00) | ((int(key[0]) + 1) & 0xff)
+                            trns = b"".join(struct.pack(">H", int(v)) for v in key)
+                        path = tmp_path / f"t{ctype}_d{depth}_{'i' if interlace else 'p'}_{'k' if with_trns else 'n'}_{h}x{w}.png"
+                        path.write_bytes(encode_png(samples, depth, ctype, interlace, plte, trns, rng))
+                        want = ref_decode8(ref, path)
+                        assert want is not None, path.name
+                        got = api.decode_image8(str(path))
+                        assert got.shape == want.shape, (path.name, got.shape, want.shape)
+                        assert np.array_equal(got, want), path.name
+                        n += 1
+    assert n == 4 * (2 * 2 * 5 + 2 * 2 * 2 + 2 * 2 * 4 + 2 * 2 + 2 * 2)
 
