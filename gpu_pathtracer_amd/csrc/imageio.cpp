@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <initializer_list>
 #include <string>
 
@@ -607,6 +608,7 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
             width = seg[3] << 8 | seg[4];
             ncomp = seg[5];
             if ((ncomp != 1 && ncomp != 3) || seglen < 6 + 3 * (size_t)ncomp || width <= 0 || height <= 0) return false;
+            if ((uint64_t)width * (uint64_t)height > ((uint64_t)1 << 27)) return false;      // (the coefficient store is 2 bytes per sample)
             for (int i = 0; i < ncomp; ++i) {
                 comp[i].id = seg[6 + 3 * i];
                 comp[i].h = seg[7 + 3 * i] >> 4;
@@ -851,13 +853,260 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
     return true;
 }
 
+// ---- BMP and TGA: the two other texture formats of stb_image (the reference's reader) that scenes in the wild use.  Both readers
+// follow stb_image 2.19's reading of the formats where the formats leave room (tests/test_imageio_reference.py compares with stb_image
+// itself): which headers and bit fields are understood, how 5-bit channels are widened, what a missing alpha channel becomes, which
+// files are refused.  A read past the end of the file yields zeros, as stb_image's does.
+namespace {
+struct ByteReader {
+    const std::vector<unsigned char> &d;
+    size_t pos = 0;
+    explicit ByteReader(const std::vector<unsigned char> &v) : d(v) {}
+    int u8() { return pos < d.size() ? d[pos++] : (++pos, 0); }
+    int u16() { const int lo = u8(); return lo | u8() << 8; }
+    uint32_t u32() { const uint32_t lo = (uint32_t)u16(); return lo | (uint32_t)u16() << 16; }
+    void skip(long n) { if (n > 0) pos += (size_t)n; }              // (stb_image ignores negative skips too)
+};
+int high_bit(uint32_t z) { int n = -1; while (z) { ++n; z >>= 1; } return n; }
+int bit_count(uint32_t z) { int n = 0; for (; z; z &= z - 1) ++n; return n; }
+// a channel of `bits` bits under a mask, moved to bit 7 and widened to 8 bits by replicating it (stb_image's table: x * 0xff, 0x55,
+// 0x49 >> 1, 0x11, 0x21 >> 2, 0x41 >> 4, 0x81 >> 6, 1)
+int widen_channel(uint32_t v, int shift, int bits)
+{
+    static const unsigned mul[9] = {0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01}, shr[9] = {0, 0, 0, 1, 0, 2, 4, 6, 0};
+    if (bits < 0 || bits > 8) return 0;
+    uint32_t x = shift < 0 ? v << -shift : v >> shift;
+    x = (x & 255u) >> (8 - bits);
+    return (int)((x * mul[bits]) >> shr[bits]);
+}
+}  // namespace
+
+bool read_bmp(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
+{
+    std::vector<unsigned char> d;
+    if (!read_file(path, d) || d.size() < 26 || d[0] != 'B' || d[1] != 'M') return false;
+    ByteReader in(d);
+    in.skip(10);
+    const long offset = (long)in.u32();
+    const long hsz = (long)in.u32();
+    if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) return false;
+    int64_t w, h;
+    if (hsz == 12) { w = in.u16(); h = in.u16(); }
+    else { w = (int32_t)in.u32(); h = (int32_t)in.u32(); }
+    if (in.u16() != 1) return false;                                 // planes
+    const int bpp = in.u16();
+    uint32_t mr = 0, mg = 0, mb = 0, ma = 0, all_a = 255;
+    if (hsz != 12) {
+        const uint32_t compress = in.u32();
+        if (compress == 1 || compress == 2) return false;            // RLE
+        in.skip(20);
+        if (hsz == 40 || hsz == 56) {
+            if (hsz == 56) in.skip(16);
+            if (bpp == 16 || bpp == 32) {
+                if (compress == 0) {
+                    if (bpp == 32) { mr = 0xffu << 16; mg = 0xffu << 8; mb = 0xffu; ma = 0xffu << 24; all_a = 0; }
+                    else { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+                } else if (compress == 3) {
+                    mr = in.u32(); mg = in.u32(); mb = in.u32();
+                    if (mr == mg && mg == mb) return false;
+                } else return false;
+            }
+        } else {
+            mr = in.u32(); mg = in.u32(); mb = in.u32(); ma = in.u32();
+            in.skip(4 + 48);
+            if (hsz == 124) in.skip(16);
+        }
+    }
+    const bool bottom_up = h > 0;
+    if (h < 0) h = -h;
+    if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || w * h > ((int64_t)1 << 28)) return false;
+    if ((uint64_t)w * (uint64_t)h * (uint64_t)bpp / 8 > (uint64_t)d.size()) return false;      // more pixels than the file holds
+    width = (int)w;
+    height = (int)h;
+    long psize = 0;
+    if (hsz == 12) { if (bpp < 24) psize = (offset - 14 - 24) / 3; }
+    else if (bpp < 16) psize = (offset - 14 - hsz) >> 2;
+    components = ma ? 4 : 3;
+    rgba.assign((size_t)width * height * 4, 255);
+    auto row_of = [&](int j) { return &rgba[(size_t)(bottom_up ? height - 1 - j : j) * width * 4]; };
+    if (bpp < 16) {
+        if (psize <= 0 || psize > 256) return false;
+        unsigned char pal[256][3] = {{0}};
+        for (long i = 0; i < psize; ++i) {
+            pal[i][2] = (unsigned char)in.u8(); pal[i][1] = (unsigned char)in.u8(); pal[i][0] = (unsigned char)in.u8();
+            if (hsz != 12) in.u8();
+        }
+        in.skip(offset - 14 - hsz - psize * (hsz == 12 ? 3 : 4));
+        if (bpp != 1 && bpp != 4 && bpp != 8) return false;
+        const int row_bytes = bpp == 1 ? (width + 7) >> 3 : bpp == 4 ? (width + 1) >> 1 : width;
+        const int pad = (-row_bytes) & 3;
+        for (int j = 0; j < height; ++j) {
+            unsigned char *o = row_of(j);
+            int v = 0;
+            for (int i = 0; i < width; ++i) {
+                int k;
+                if (bpp == 8) k = in.u8();
+                else if (bpp == 4) { if (!(i & 1)) v = in.u8(); k = (i & 1) ? v & 15 : v >> 4; }
+                else { if (!(i & 7)) v = in.u8(); k = (v >> (7 - (i & 7))) & 1; }
+                o[4 * i] = pal[k][0]; o[4 * i + 1] = pal[k][1]; o[4 * i + 2] = pal[k][2];
+            }
+            if (bpp == 1 && !(width & 7)) in.u8();                  // (stb_image fetches the next byte after every eighth pixel, also the last)
+            in.skip(pad);
+        }
+    } else {
+        in.skip(offset - 14 - hsz);
+        const int row_bytes = bpp == 24 ? 3 * width : bpp == 16 ? 2 * width : 0;
+        const int pad = (-row_bytes) & 3;
+        int easy = 0;
+        if (bpp == 24) easy = 1;
+        else if (bpp == 32 && mb == 0xffu && mg == 0xff00u && mr == 0x00ff0000u && ma == 0xff000000u) easy = 2;
+        else if (bpp != 16 && bpp != 32) return false;
+        int rs = 0, gs = 0, bs = 0, as = 0, rc = 0, gc = 0, bc = 0, ac = 0;
+        if (!easy) {
+            if (!mr || !mg || !mb) return false;
+            rs = high_bit(mr) - 7; rc = bit_count(mr);
+            gs = high_bit(mg) - 7; gc = bit_count(mg);
+            bs = high_bit(mb) - 7; bc = bit_count(mb);
+            as = high_bit(ma) - 7; ac = bit_count(ma);
+        }
+        for (int j = 0; j < height; ++j) {
+            unsigned char *o = row_of(j);
+            for (int i = 0; i < width; ++i, o += 4) {
+                unsigned a;
+                if (easy) {
+                    o[2] = (unsigned char)in.u8(); o[1] = (unsigned char)in.u8(); o[0] = (unsigned char)in.u8();
+                    a = easy == 2 ? (unsigned)in.u8() : 255u;
+                } else {
+                    const uint32_t v = bpp == 16 ? (uint32_t)in.u16() : in.u32();
+                    o[0] = (unsigned char)widen_channel(v & mr, rs, rc);
+                    o[1] = (unsigned char)widen_channel(v & mg, gs, gc);
+                    o[2] = (unsigned char)widen_channel(v & mb, bs, bc);
+                    a = ma ? (unsigned)widen_channel(v & ma, as, ac) : 255u;
+                }
+                all_a |= a;
+                o[3] = (unsigned char)a;
+            }
+            in.skip(pad);
+        }
+    }
+    if (components == 4 && all_a == 0)                               // an alpha channel that is zero everywhere is not one
+        for (size_t i = 3; i < rgba.size(); i += 4) rgba[i] = 255;
+    if (components == 3)
+        for (size_t i = 3; i < rgba.size(); i += 4) rgba[i] = 255;
+    return true;
+}
+
+bool read_tga(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
+{
+    std::vector<unsigned char> d;
+    if (!read_file(path, d) || d.size() < 18) return false;
+    ByteReader in(d);
+    const int id_len = in.u8(), colour_map = in.u8();
+    int type = in.u8();
+    const int pal_start = in.u16(), pal_len = in.u16(), pal_bits = in.u8();
+    in.skip(4);                                                     // x, y origin
+    const int w = in.u16(), h = in.u16(), bpp = in.u8(), descriptor = in.u8();
+    // what stb_image recognises as a TGA at all (the format has no signature)
+    if (colour_map > 1) return false;
+    if (colour_map == 1) {
+        if (type != 1 && type != 9) return false;
+        if (pal_bits != 8 && pal_bits != 15 && pal_bits != 16 && pal_bits != 24 && pal_bits != 32) return false;
+        if (bpp != 8 && bpp != 16) return false;
+    } else if (type != 2 && type != 3 && type != 10 && type != 11) return false;
+    if (w < 1 || h < 1) return false;
+    if (bpp != 8 && bpp != 15 && bpp != 16 && bpp != 24 && bpp != 32) return false;
+    const bool rle = type >= 8;
+    if (rle) type -= 8;
+    const bool top_down = (descriptor >> 5) & 1;
+    // channels: from the palette entries of a colour-mapped file, else from the pixel size; 15 / 16 bits are 5-5-5 colour
+    // unless the file is grey (then 16 bits are grey + alpha)
+    auto channels = [](int bits, bool grey, bool &rgb16) {
+        rgb16 = false;
+        switch (bits) {
+        case 8: return 1;
+        case 16: if (grey) return 2;  /* fall through */
+        case 15: rgb16 = true; return 3;
+        case 24: return 3;
+        case 32: return 4;
+        default: return 0;
+        }
+    };
+    bool rgb16 = false;
+    const int comp = colour_map ? channels(pal_bits, false, rgb16) : channels(bpp, type == 3, rgb16);
+    if (!comp) return false;
+    if ((int64_t)w * h > ((int64_t)1 << 28)) return false;
+    // a header must not claim more pixels than the file can hold (a run-length packet yields at most 128 pixels from 2 bytes):
+    // stb_image hands back uninitialised rows for such files, here they are refused
+    const uint64_t px_bytes = (uint64_t)((bpp + 7) / 8);
+    if (rle ? (uint64_t)w * h > 128u * (uint64_t)d.size() : (uint64_t)w * h * px_bytes > (uint64_t)d.size()) return false;
+    width = w; height = h; components = comp;
+    in.skip(id_len);
+    auto read555 = [&](unsigned char *o) {
+        const int px = in.u16();
+        o[0] = (unsigned char)((((px >> 10) & 31) * 255) / 31);
+        o[1] = (unsigned char)((((px >> 5) & 31) * 255) / 31);
+        o[2] = (unsigned char)(((px & 31) * 255) / 31);
+    };
+    std::vector<unsigned char> palette;
+    if (colour_map) {
+        if (pal_len == 0) return false;                             // (stb_image reads entry 0 of an empty table)
+        in.skip(pal_start);
+        palette.assign((size_t)pal_len * comp, 0);
+        if (rgb16) for (int i = 0; i < pal_len; ++i) read555(&palette[(size_t)i * comp]);
+        else {
+            if (in.pos + palette.size() > d.size()) return false;    // "bad palette"
+            for (unsigned char &b : palette) b = (unsigned char)in.u8();
+        }
+    }
+    std::vector<unsigned char> px((size_t)w * h * comp);
+    unsigned char raw[4] = {0, 0, 0, 0};
+    int run = 0;
+    bool repeating = false;
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        bool fetch = true;
+        if (rle) {
+            if (run == 0) { const int cmd = in.u8(); run = 1 + (cmd & 127); repeating = cmd >> 7; }
+            else if (repeating) fetch = false;
+        }
+        if (fetch) {
+            if (colour_map) {
+                int k = bpp == 8 ? in.u8() : in.u16();
+                if (k >= pal_len) k = 0;
+                for (int j = 0; j < comp; ++j) raw[j] = palette[(size_t)k * comp + j];
+            } else if (rgb16) read555(raw);
+            else for (int j = 0; j < comp; ++j) raw[j] = (unsigned char)in.u8();
+        }
+        for (int j = 0; j < comp; ++j) px[i * comp + j] = raw[j];
+        --run;
+    }
+    rgba.resize((size_t)w * h * 4);
+    for (int y = 0; y < h; ++y) {
+        const unsigned char *src = &px[(size_t)(top_down ? y : h - 1 - y) * w * comp];
+        unsigned char *o = &rgba[(size_t)y * w * 4];
+        for (int x = 0; x < w; ++x, src += comp, o += 4) {
+            if (comp == 1) { o[0] = o[1] = o[2] = src[0]; o[3] = 255; }
+            else if (comp == 2) { o[0] = o[1] = o[2] = src[0]; o[3] = src[1]; }
+            else if (rgb16) { o[0] = src[0]; o[1] = src[1]; o[2] = src[2]; o[3] = 255; }
+            else { o[0] = src[2]; o[1] = src[1]; o[2] = src[0]; o[3] = comp == 4 ? src[3] : 255; }     // stored B, G, R
+        }
+    }
+    return true;
+}
+
+// the formats in the order stb_image tries them (TGA last: it has no signature)
+bool read_any8(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
+{
+    return read_jpeg(path, width, height, components, rgba) || read_png(path, width, height, components, rgba) ||
+           read_bmp(path, width, height, components, rgba) || read_tga(path, width, height, components, rgba);
+}
+
 // ImageIO::LoadTexture + Texture::Texture (src/imageio.cpp:11-59, src/texture.h:15-27):
 // flip vertically, 1/255, sRGB -> linear by powf(x, 2.2f) on r,g,b, then truncate x*255 back to uchar.
 bool load_texture(const char *path, int &width, int &height, std::vector<gpt_uchar4> &texels)
 {
     std::vector<unsigned char> rgba;
     int comp = 0;
-    if (!read_png(path, width, height, comp, rgba) && !read_jpeg(path, width, height, comp, rgba)) return false;
+    if (!read_any8(path, width, height, comp, rgba)) return false;
     texels.resize((size_t)width * height);
     const float inv = 1.f / 255.f;
     for (int y = 0; y < height; ++y) {
@@ -1431,51 +1680,66 @@ int gpt_save_pfm(const char *path, int32_t width, int32_t height, const float *r
 // asks for the size only; a buffer that is too small is refused.
 int gpt_decode_image8(const char *path, int32_t *width, int32_t *height, int32_t *components, unsigned char *pixels, int64_t capacity)
 {
-    if (!path || !width || !height || !components) { gpt_set_error("gpt_decode_image8: invalid argument"); return GPT_ERR_INVALID_ARG; }
-    std::vector<unsigned char> rgba;
-    int w = 0, h = 0, comp = 0;
-    if (!imageio::read_png(path, w, h, comp, rgba) && !imageio::read_jpeg(path, w, h, comp, rgba)) {
-        gpt_set_error("gpt_decode_image8: cannot read %s as PNG or JPEG", path);
+    try {
+        if (!path || !width || !height || !components) { gpt_set_error("gpt_decode_image8: invalid argument"); return GPT_ERR_INVALID_ARG; }
+        std::vector<unsigned char> rgba;
+        int w = 0, h = 0, comp = 0;
+        if (!imageio::read_any8(path, w, h, comp, rgba)) {
+            gpt_set_error("gpt_decode_image8: cannot read %s as PNG, JPEG, BMP or TGA", path);
+            return GPT_ERR_IO;
+        }
+        *width = w; *height = h; *components = comp;
+        if (!pixels) return GPT_OK;
+        if (capacity < (int64_t)w * h * comp) { gpt_set_error("gpt_decode_image8: buffer too small"); return GPT_ERR_INVALID_ARG; }
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const unsigned char *p = &rgba[((size_t)(h - 1 - y) * w + x) * 4];       // stbi_set_flip_vertically_on_load(true)
+                unsigned char *q = pixels + ((size_t)y * w + x) * comp;
+                if (comp == 1) q[0] = p[0];
+                else if (comp == 2) { q[0] = p[0]; q[1] = p[3]; }
+                else for (int c = 0; c < comp; ++c) q[c] = p[c];
+            }
+        return GPT_OK;
+    } catch (const std::exception &e) {
+        gpt_set_error("gpt_decode_image8: %s", e.what());
         return GPT_ERR_IO;
     }
-    *width = w; *height = h; *components = comp;
-    if (!pixels) return GPT_OK;
-    if (capacity < (int64_t)w * h * comp) { gpt_set_error("gpt_decode_image8: buffer too small"); return GPT_ERR_INVALID_ARG; }
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x) {
-            const unsigned char *p = &rgba[((size_t)(h - 1 - y) * w + x) * 4];       // stbi_set_flip_vertically_on_load(true)
-            unsigned char *q = pixels + ((size_t)y * w + x) * comp;
-            if (comp == 1) q[0] = p[0];
-            else if (comp == 2) { q[0] = p[0]; q[1] = p[3]; }
-            else for (int c = 0; c < comp; ++c) q[c] = p[c];
-        }
-    return GPT_OK;
 }
 
 int gpt_load_texture(const char *path, int32_t *width, int32_t *height, gpt_uchar4 *texels, int64_t capacity)
 {
-    if (!path || !width || !height) { gpt_set_error("gpt_load_texture: invalid argument"); return GPT_ERR_INVALID_ARG; }
-    std::vector<gpt_uchar4> t;
-    int w = 0, h = 0;
-    if (!imageio::load_texture(path, w, h, t)) { gpt_set_error("gpt_load_texture: cannot read %s as PNG or JPEG", path); return GPT_ERR_IO; }
-    *width = w; *height = h;
-    if (!texels) return GPT_OK;
-    if (capacity < (int64_t)w * h) { gpt_set_error("gpt_load_texture: buffer too small"); return GPT_ERR_INVALID_ARG; }
-    std::memcpy(texels, t.data(), t.size() * sizeof(gpt_uchar4));
-    return GPT_OK;
+    try {
+        if (!path || !width || !height) { gpt_set_error("gpt_load_texture: invalid argument"); return GPT_ERR_INVALID_ARG; }
+        std::vector<gpt_uchar4> t;
+        int w = 0, h = 0;
+        if (!imageio::load_texture(path, w, h, t)) { gpt_set_error("gpt_load_texture: cannot read %s as PNG, JPEG, BMP or TGA", path); return GPT_ERR_IO; }
+        *width = w; *height = h;
+        if (!texels) return GPT_OK;
+        if (capacity < (int64_t)w * h) { gpt_set_error("gpt_load_texture: buffer too small"); return GPT_ERR_INVALID_ARG; }
+        std::memcpy(texels, t.data(), t.size() * sizeof(gpt_uchar4));
+        return GPT_OK;
+    } catch (const std::exception &e) {
+        gpt_set_error("gpt_load_texture: %s", e.what());
+        return GPT_ERR_IO;
+    }
 }
 
 int gpt_load_exr(const char *path, int32_t *width, int32_t *height, float *rgb, int64_t capacity)
 {
-    if (!path || !width || !height) { gpt_set_error("gpt_load_exr: invalid argument"); return GPT_ERR_INVALID_ARG; }
-    std::vector<gpt_float3> px;
-    int w = 0, h = 0;
-    if (!imageio::read_exr_rgb_top_down(path, w, h, px)) { gpt_set_error("gpt_load_exr: cannot read %s (scanline OpenEXR: NONE, RLE, ZIPS, ZIP, PIZ)", path); return GPT_ERR_IO; }
-    *width = w; *height = h;
-    if (!rgb) return GPT_OK;
-    if (capacity < (int64_t)w * h * 3) { gpt_set_error("gpt_load_exr: buffer too small"); return GPT_ERR_INVALID_ARG; }
-    for (size_t i = 0; i < px.size(); ++i) { rgb[3 * i] = px[i].x; rgb[3 * i + 1] = px[i].y; rgb[3 * i + 2] = px[i].z; }
-    return GPT_OK;
+    try {
+        if (!path || !width || !height) { gpt_set_error("gpt_load_exr: invalid argument"); return GPT_ERR_INVALID_ARG; }
+        std::vector<gpt_float3> px;
+        int w = 0, h = 0;
+        if (!imageio::read_exr_rgb_top_down(path, w, h, px)) { gpt_set_error("gpt_load_exr: cannot read %s (scanline OpenEXR: NONE, RLE, ZIPS, ZIP, PIZ)", path); return GPT_ERR_IO; }
+        *width = w; *height = h;
+        if (!rgb) return GPT_OK;
+        if (capacity < (int64_t)w * h * 3) { gpt_set_error("gpt_load_exr: buffer too small"); return GPT_ERR_INVALID_ARG; }
+        for (size_t i = 0; i < px.size(); ++i) { rgb[3 * i] = px[i].x; rgb[3 * i + 1] = px[i].y; rgb[3 * i + 2] = px[i].z; }
+        return GPT_OK;
+    } catch (const std::exception &e) {
+        gpt_set_error("gpt_load_exr: %s", e.what());
+        return GPT_ERR_IO;
+    }
 }
 
 }  // extern "C"

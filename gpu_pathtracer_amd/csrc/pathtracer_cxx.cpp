@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 
 #include "host_util.h"
 #include "pathtracer.h"
@@ -78,18 +79,24 @@ int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out)
     // the reference always reads/writes <scene dir>/bvh.cache (src/bvh.cpp:189-218); here it is opt-in
     s->scene.use_bvh_cache = (flags & GPT_LOAD_BVH_CACHE) != 0;
     s->scene.use_sbvh = (flags & GPT_LOAD_SBVH) != 0;
-    if (!LoadScene(json_path, s->config, s->scene)) {
+    try {                                            // (no exception crosses the C ABI: a file that asks for more memory than there is)
+        if (!LoadScene(json_path, s->config, s->scene)) {
+            delete s;
+            return std::strstr(gpt_last_error(), "Parse scene error") ? GPT_ERR_PARSE : GPT_ERR_IO;
+        }
+        // InitScene, src/main.cpp:267-272: distance is the literal 0.1f
+        const Camera &c = s->config.camera;
+        gpt_float2 res;
+        res.x = (float)s->config.width;
+        res.y = (float)s->config.height;
+        s->camera = new Camera(c.position, c.u, c.v, c.w, res, 0.1f, c.fov, c.apertureRadius, c.focalDistance, c.filmic != 0, c.medium);
+        s->camera->environment = c.environment;
+        s->scene.Init(s->camera, json_path);
+    } catch (const std::exception &e) {
+        gpt_set_error("gpt_scene_load: %s while loading %s", e.what(), json_path);
         delete s;
-        return std::strstr(gpt_last_error(), "Parse scene error") ? GPT_ERR_PARSE : GPT_ERR_IO;
+        return GPT_ERR_IO;
     }
-    // InitScene, src/main.cpp:267-272: distance is the literal 0.1f
-    const Camera &c = s->config.camera;
-    gpt_float2 res;
-    res.x = (float)s->config.width;
-    res.y = (float)s->config.height;
-    s->camera = new Camera(c.position, c.u, c.v, c.w, res, 0.1f, c.fov, c.apertureRadius, c.focalDistance, c.filmic != 0, c.medium);
-    s->camera->environment = c.environment;
-    s->scene.Init(s->camera, json_path);
     *out = s;
     return GPT_OK;
 }
