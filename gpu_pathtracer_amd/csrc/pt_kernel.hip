@@ -1142,6 +1142,37 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
                  PT_ENTRY_IDLE, PT_FETCH_COMPACT, PT_CURSOR_FIRST, "", "%[end]", "", PT_DRY_DRAIN, "", , [unused] "n"(0))
 }
 
+// Experiment (PT_SMALL_CARRY=1; see kernel_variants.log): the LDS-resident scene with the carry machinery of the global-memory loop - fixed slots,
+// pending masks, a drain that may stop with rays in flight - so that the headline kernel's tail (60 % of its trips come after the
+// pool ran dry) can be traded against emptier shading rounds.  Cursors are LDS addresses: [first] + offset, v3 = one past the nodes.
+#ifndef PT_SMALL_CARRY
+#define PT_SMALL_CARRY 0
+#endif
+#ifndef PT_STOP_T_LDS
+#define PT_STOP_T_LDS 12
+#endif
+__device__ __forceinline__ void trace_pool_lds_carry_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps, bool may_stop, unsigned loop_probe_lds = 0)
+{
+    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
+    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
+    const int s_end = __builtin_amdgcn_readfirstlane(mem.end - mem.first);      // bytes of the node array
+    const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
+    const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
+    const int s_vstride = 0;
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
+    const int s_tstop = PT_STOP_T_LDS;
+    const unsigned s_probe = __builtin_amdgcn_readfirstlane(loop_probe_lds);
+    (void)s_probe;
+    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "", "",
+                 "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
+                 "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
+                 "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
+                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,
+                 [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp), [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
+}
+
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
 // 32-bit VGPR-offset form.  (vmcnt also counts this wave's earlier sample stores; they are long gone.)
 __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop, unsigned loop_probe_lds = 0)
@@ -2801,14 +2832,14 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         __syncthreads();
 #endif
     }
-    constexpr bool CARRY = !SMALL;                      // scenes in global memory: fixed slots, drains may stop early
+    constexpr bool CARRY = !SMALL || PT_SMALL_CARRY;    // scenes in global memory: fixed slots, drains may stop early
     constexpr int kWaveFloat4 = WIDE ? kWaveWideFloat4 : (CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4);
     __shared__ float4 lds_pool[4 * kWaveFloat4];        // one private ray pool per wavefront
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
     const unsigned lane = threadIdx.x & 63u;
     if (CARRY) reinterpret_cast<unsigned *>(pool + kPendOff)[lane] = 0u;     // nothing pending
     if (CARRY && !WIDE) {                               // no suspended ray (an idle lane's cursors)
-        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
+        pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(SMALL ? (int)lds_address(lds_scene) + 32 * P.n_nodes : 32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
     if (WIDE) wide_init_suspend_record(P, lane);        // trace_pool_wide_asm: a lane's record {entry, stack size, interval end, slot} {best hit}: idle
@@ -3804,10 +3835,14 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 mem.first = (int)lds_address(lds_scene);
                 mem.end = mem.first + 32 * P.n_nodes;
                 mem.tri_bias = mem.end;
+#if PT_SMALL_CARRY
+                trace_pool_lds_carry_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0, loop_probe);
+#else
                 if (COUNT && !PT_ASM_IN_COUNT)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool<COUNT, false>(P, pool, L.n_rays, cnt, mem);
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps, loop_probe);
+#endif
             } else if (WIDE) {
                 if ((COUNT && !PT_ASM_IN_COUNT) || !PT_WIDE_ASM)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
