@@ -1093,11 +1093,50 @@ bool read_tga(const char *path, int &width, int &height, int &components, std::v
     return true;
 }
 
+// binary PGM / PPM (P5 / P6) as stb_image reads them: 8-bit samples taken as they are (not scaled by the maximum value), '#' comments
+// between the header fields, the pixels starting right after the single character that ends the maximum value
+bool read_pnm(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
+{
+    std::vector<unsigned char> d;
+    if (!read_file(path, d) || d.size() < 3 || d[0] != 'P' || (d[1] != '5' && d[1] != '6')) return false;
+    ByteReader in(d);
+    in.skip(2);
+    const int comp = d[1] == '6' ? 3 : 1;
+    int c = in.u8();
+    auto at_end = [&]() { return in.pos >= d.size(); };
+    auto blanks = [&]() {
+        for (;;) {
+            while (!at_end() && (c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r')) c = in.u8();
+            if (at_end() || c != '#') break;
+            while (!at_end() && c != '\n' && c != '\r') c = in.u8();
+        }
+    };
+    auto number = [&]() { int64_t v = 0; while (!at_end() && c >= '0' && c <= '9') { v = v * 10 + (c - '0'); if (v > (1 << 28)) v = 1 << 28; c = in.u8(); } return (int)v; };
+    blanks();
+    const int w = number();
+    blanks();
+    const int h = number();
+    blanks();
+    const int maxv = number();
+    if (maxv > 255 || w <= 0 || h <= 0) return false;
+    if ((uint64_t)w * (uint64_t)h * (uint64_t)comp > (uint64_t)d.size()) return false;      // more pixels than the file holds
+    width = w; height = h; components = comp;
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        unsigned char *o = &rgba[4 * i];
+        if (comp == 1) o[0] = o[1] = o[2] = (unsigned char)in.u8();
+        else { o[0] = (unsigned char)in.u8(); o[1] = (unsigned char)in.u8(); o[2] = (unsigned char)in.u8(); }
+        o[3] = 255;
+    }
+    return true;
+}
+
 // the formats in the order stb_image tries them (TGA last: it has no signature)
 bool read_any8(const char *path, int &width, int &height, int &components, std::vector<unsigned char> &rgba)
 {
     return read_jpeg(path, width, height, components, rgba) || read_png(path, width, height, components, rgba) ||
-           read_bmp(path, width, height, components, rgba) || read_tga(path, width, height, components, rgba);
+           read_bmp(path, width, height, components, rgba) || read_pnm(path, width, height, components, rgba) ||
+           read_tga(path, width, height, components, rgba);
 }
 
 // ImageIO::LoadTexture + Texture::Texture (src/imageio.cpp:11-59, src/texture.h:15-27):
@@ -1685,7 +1724,7 @@ int gpt_decode_image8(const char *path, int32_t *width, int32_t *height, int32_t
         std::vector<unsigned char> rgba;
         int w = 0, h = 0, comp = 0;
         if (!imageio::read_any8(path, w, h, comp, rgba)) {
-            gpt_set_error("gpt_decode_image8: cannot read %s as PNG, JPEG, BMP or TGA", path);
+            gpt_set_error("gpt_decode_image8: cannot read %s as PNG, JPEG, BMP, PNM or TGA", path);
             return GPT_ERR_IO;
         }
         *width = w; *height = h; *components = comp;
@@ -1712,7 +1751,7 @@ int gpt_load_texture(const char *path, int32_t *width, int32_t *height, gpt_ucha
         if (!path || !width || !height) { gpt_set_error("gpt_load_texture: invalid argument"); return GPT_ERR_INVALID_ARG; }
         std::vector<gpt_uchar4> t;
         int w = 0, h = 0;
-        if (!imageio::load_texture(path, w, h, t)) { gpt_set_error("gpt_load_texture: cannot read %s as PNG, JPEG, BMP or TGA", path); return GPT_ERR_IO; }
+        if (!imageio::load_texture(path, w, h, t)) { gpt_set_error("gpt_load_texture: cannot read %s as PNG, JPEG, BMP, PNM or TGA", path); return GPT_ERR_IO; }
         *width = w; *height = h;
         if (!texels) return GPT_OK;
         if (capacity < (int64_t)w * h) { gpt_set_error("gpt_load_texture: buffer too small"); return GPT_ERR_INVALID_ARG; }

@@ -251,7 +251,7 @@ int gpt_save_pfm(const char *path, int32_t width, int32_t height, const float *r
 /* The file decoders by themselves (the loader calls them for "diffuse": "<file>" and "infinite": "<file>").  A null
  * output buffer asks for the size only; `capacity` counts elements of the buffer's type.
  * gpt_decode_image8: what stb_image hands ImageIO::LoadTexture (src/imageio.cpp:13-14: flip on load, 0 = the file's own
- *                    channel count): PNG, JPEG, BMP or TGA -> `components` interleaved bytes per pixel, row 0 = bottom.
+ *                    channel count): PNG, JPEG, BMP, binary PNM or TGA -> `components` interleaved bytes per pixel, row 0 = bottom.
  * gpt_load_texture:  ImageIO::LoadTexture + Texture::Texture (src/imageio.cpp:11-59, src/texture.h:15-27): the texels as
  *                    the kernel samples them (1/255, powf(x, 2.2f) on r g b, truncated back to 8 bit).
  * gpt_load_exr:      ImageIO::LoadExr (src/imageio.cpp:80-102): float R,G,B per pixel, row 0 = top. */

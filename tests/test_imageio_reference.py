@@ -701,3 +701,25 @@ def test_tga_reader_equals_stb_image(ref, tmp_path):
             assert np.array_equal(api.load_texture(str(path)), texels_like_the_reference(ref, path)), path.name
     assert len(files) > 130
 
+
+def test_pnm_reader_equals_stb_image(ref, tmp_path):
+    """Binary PGM / PPM as stb_image reads them (8-bit, samples unscaled, comments in the header)."""
+    from PIL import Image
+    rng = np.random.default_rng(16)
+    rgb = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "pil.ppm")
+    Image.fromarray(rgb[..., 0].copy(), "L").save(tmp_path / "pil.pgm")
+    (tmp_path / "comments.ppm").write_bytes(b"P6 # a comment\n# another\n9\t7 # size\r\n255\n" + rgb.tobytes())
+    (tmp_path / "max100.pgm").write_bytes(b"P5\n9 7\n100\n" + (rgb[..., 0] % 101).tobytes())
+    (tmp_path / "one.pgm").write_bytes(b"P5 1 1 255 " + bytes([77]))
+    for name in ("pil.ppm", "pil.pgm", "comments.ppm", "max100.pgm", "one.pgm"):
+        want = ref_decode8(ref, tmp_path / name)
+        got = api.decode_image8(str(tmp_path / name))
+        assert want is not None and got.shape == want.shape and np.array_equal(got, want), name
+    (tmp_path / "deep.pgm").write_bytes(b"P5\n2 2\n65535\n" + bytes(8))
+    (tmp_path / "ascii.pgm").write_bytes(b"P2\n2 2\n255\n1 2 3 4\n")
+    for name in ("deep.pgm", "ascii.pgm"):
+        assert ref_decode8(ref, tmp_path / name) is None
+        with pytest.raises(api.GptError):
+            api.decode_image8(str(tmp_path / name))
+
