@@ -475,7 +475,6 @@ constexpr int kWideStackDepth = PT_WIDE_STACK_DEPTH;
 constexpr int kWideStackOff = kSuspOff;                           // where the binary loops keep their suspend records: the wide walk's
                                                                   // are in the wave's slice of P.wide_stack (read and written once per drain)
 constexpr int kWaveWideFloat4 = kSuspOff + 16 * kWideStackDepth;  // one level of 64 lanes = 16 float4; 9 levels: 10 112 B per wave, four workgroups per CU
-constexpr int kWideSpillStride = kWideSpillLevels;
 #ifndef PT_WIDE_FETCH_T
 #define PT_WIDE_FETCH_T 12                                        // idle lanes that trigger a refill
 #endif
@@ -508,7 +507,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
 {
     const unsigned lane = threadIdx.x & 63u;
     unsigned *stk = reinterpret_cast<unsigned *>(pool + kWideStackOff) + lane;
-    volatile unsigned *spill = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords + lane;
+    volatile unsigned *spill = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords + 512u + lane;
     const char *wnodes = reinterpret_cast<const char *>(P.wide);
     const char *tris = reinterpret_cast<const char *>(P.tris);
     const float tmin_ray = P.eps;
@@ -1254,7 +1253,7 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 // writes it when the drain ends, both with sc0 sc1: the same wave reads what it wrote, past its L1); "no ray" at kernel start
 __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, unsigned lane)
 {
-    volatile unsigned *rec = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords + 64u * (unsigned)kWideSpillStride + 8u * lane;
+    volatile unsigned *rec = P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords + 8u * lane;
     rec[0] = 0xffffffffu; rec[1] = 0u; rec[2] = 0u; rec[3] = 0xffffffffu;
     rec[4] = 0xffffffffu; rec[5] = 0u; rec[6] = 0u; rec[7] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1305,8 +1304,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
     const int s_tstop = __builtin_amdgcn_readfirstlane(P.n_nodes >= 65536 ? PT_WIDE_STOP_T : PT_WIDE_STOP_T_SMALL);
     // this lane's column of the wave's spill slice, in bytes (level l at + 256 l)
     const unsigned wave_slice = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords;
-    const unsigned v_spill = (wave_slice + lane) * 4u;
-    const unsigned v_susp = (wave_slice + 64u * (unsigned)kWideSpillStride + 8u * lane) * 4u;      // this lane's suspend record
+    const unsigned v_spill = (wave_slice + 512u + lane) * 4u;
+    const unsigned v_susp = (wave_slice + 8u * lane) * 4u;      // this lane's suspend record (the records lead the slice: they are its hot part)
     asm volatile(
         "s_mov_b32 s70, 0\n"
         "s_mov_b32 s76, 0x322bcc77\n"

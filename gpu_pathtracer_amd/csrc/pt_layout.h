@@ -60,8 +60,9 @@ struct alignas(16) DevWideNode {
     uint32_t pad[4];
 };
 static_assert(sizeof(DevWideNode) == 128, "DevWideNode");
-// A wave's slice of DevParams.wide_stack, in dwords: the overflow levels of its 64 per-lane stacks (level-major: level l of lane
-// i at 64 l + i) and, behind them, one 8-dword suspend record per lane (a ray that is still being walked when a drain stops)
+// A wave's slice of DevParams.wide_stack, in dwords: first one 8-dword suspend record per lane (a ray that is still being walked when
+// a drain stops; read and written once per drain: the hot 2 KB), then the overflow levels of its 64 per-lane stacks (level-major:
+// level l of lane i at 512 + 64 l + i)
 constexpr int kWideSpillLevels = GPT_WIDE_STACK_MAX + 8;
 constexpr int kWideWaveSliceDwords = 64 * kWideSpillLevels + 64 * 8;
 

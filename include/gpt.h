@@ -76,7 +76,7 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
  *                                         large scenes.
  *   GPT_TRAVERSAL_WIDE4 (2)               a 4-wide tree collapsed from the reference's, walked one lane per ray
  *                                         (include/gpt_wide_bvh.h): a quarter of the node visits, faster where leaves are
- *                                         large; GPT_ERR_UNSUPPORTED for an empty scene or a tree deeper than 21 wide levels.
+ *                                         large; GPT_ERR_UNSUPPORTED for an empty scene or a tree deeper than 85 wide levels (the reference's own 64-entry stack ends at binary depth 64).
  * Modes 1 and 2 change only the ORDER of the reference's box and triangle tests: each is bit-identical to the oracle in the
  * same mode and within 1e-4 relative RMS of the reference order (measured: identical films, or single pixels where two hits
  * tie within rounding - relative RMS <= 2e-7).  Both always traverse from global memory. */

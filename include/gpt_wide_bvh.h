@@ -43,7 +43,7 @@
 
 #define GPT_TRAVERSAL_WIDE4 2
 #define GPT_WIDE_LEAF_MAX 16
-#define GPT_WIDE_STACK_MAX 64     /* deepest stack the walk may need: 3 * depth + 1 must not exceed it */
+#define GPT_WIDE_STACK_MAX 256    /* deepest stack the walk may need: 3 * depth + 1 must not exceed it (wide depth <= 85) */
 
 typedef struct {
     float bmin[3], bmax[3];

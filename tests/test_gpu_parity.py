@@ -783,12 +783,29 @@ def test_wide_traversal_stack_spills_past_its_lds_entries(gpt):
     finally:
         lib.oracle_set_traversal(0)
     assert deepest > 24, deepest
-    too_deep = chain_scene(71)                          # 3 * depth + 1 > 64: the wide mode is refused, the other orders still render
+    # a chain deeper than the reference's own 64-entry stack could take: the wide walk still agrees with its oracle (stack entries
+    # past the ninth live in the wave's slice of the spill buffer, 3 * depth + 1 <= 256 of them)
+    deep = chain_scene(71)
+    far_cam = ol.make_camera((0.05, 0.1, 7.5), (0.0, 0.1, 0.0), (0, 1, 0), (W, H), 35.0)
+    assert lib.oracle_set_traversal(2) == 0
+    try:
+        want, _ = ol.render(deep, far_cam, W, H, 0.001, 1, 2, kind="soft")      # (only the wide oracle: the reference-order one has the reference's stack)
+        assert lib.oracle_wide_stack_max() > 64
+    finally:
+        lib.oracle_set_traversal(0)
+    with gpt.Renderer(deep.desc, W, H, 0.001) as r:
+        r.set_traversal_order("wide")
+        r.render(far_cam, 1, 2, reset=True)
+        assert_bit_exact(r.read_accum(), want, "deep chain (wide)")
+        r.set_traversal_order("reference")
+        r.render(far_cam, 1, 2, reset=True)
+        assert (rel_rms(want, r.read_accum()) <= RMS_TOL).all()
+    too_deep = chain_scene(300)                         # 3 * depth + 1 > 256: the wide mode is refused, the other orders still render
     with gpt.Renderer(too_deep.desc, W, H, 0.001) as r:
         with pytest.raises(gpt.GptError):
             r.set_traversal_order("wide")
-        far_cam = ol.make_camera((0.05, 0.1, 7.5), (0.0, 0.1, 0.0), (0, 1, 0), (W, H), 35.0)
-        r.render(far_cam, 1, 2, reset=True)         # (stackless on the GPU; the reference's own 64-entry stack would overflow here)
+        very_far = ol.make_camera((0.05, 0.1, 30.5), (0.0, 0.1, 0.0), (0, 1, 0), (W, H), 35.0)
+        r.render(very_far, 1, 2, reset=True)        # (stackless on the GPU; the reference's own 64-entry stack would overflow here)
         got = r.read_accum()
         assert np.isfinite(got).all() and got.max() > 0
 
