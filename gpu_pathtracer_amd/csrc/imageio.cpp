@@ -387,8 +387,8 @@ bool read_png(const char *path, int &width, int &height, int &components, std::v
 // ---- JPEG: baseline and progressive DCT (Huffman, 8-bit, 1 or 3 components, any h/v sampling, restart
 // intervals; spectral selection and successive approximation for SOF2 files).  The inverse DCT, the chroma up-sampling and the
 // YCbCr -> RGB conversion restate stb_image's integer arithmetic (the reference's reader), so the bytes are the reference's
-// bytes (tests/test_imageio_reference.py compares them with stb_image itself).  Arithmetic-coded, lossless, hierarchical
-// and four-component (CMYK / YCCK) files are refused.
+// bytes (tests/test_imageio_reference.py compares them with stb_image itself).  Four-component files (Adobe CMYK / YCCK) come out as RGB the way stb_image converts them.
+// Arithmetic-coded, lossless and hierarchical files are refused.
 namespace {
 struct JpegHuff {
     unsigned char bits[17] = {0};
@@ -560,7 +560,7 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
     JpegHuff hdc[4], hac[4];
     // coefficients of every 8x8 block (natural order, not yet dequantised): a progressive file fills them in over
     // several scans (spectral selection Ss..Se, successive approximation Ah/Al), a baseline file in one
-    struct Comp { int id, h, v, tq, td, ta, pred; std::vector<short> coef; int bw, bh, pw, ph; } comp[3];
+    struct Comp { int id, h, v, tq, td, ta, pred; std::vector<short> coef; int bw, bh, pw, ph; } comp[4];
     int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
     bool progressive = false, have_scan = false;
     int mcux = 0, mcuy = 0;
@@ -607,7 +607,7 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
             height = seg[1] << 8 | seg[2];
             width = seg[3] << 8 | seg[4];
             ncomp = seg[5];
-            if ((ncomp != 1 && ncomp != 3) || seglen < 6 + 3 * (size_t)ncomp || width <= 0 || height <= 0) return false;
+            if ((ncomp != 1 && ncomp != 3 && ncomp != 4) || seglen < 6 + 3 * (size_t)ncomp || width <= 0 || height <= 0) return false;
             if ((uint64_t)width * (uint64_t)height > ((uint64_t)1 << 27)) return false;      // (the coefficient store is 2 bytes per sample)
             for (int i = 0; i < ncomp; ++i) {
                 comp[i].id = seg[6 + 3 * i];
@@ -638,7 +638,7 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
             if (!width || seglen < 1) return false;
             const int ns = seg[0];
             if (ns < 1 || ns > ncomp || seglen < 1 + 2 * (size_t)ns + 3) return false;
-            int order[3];
+            int order[4];
             for (int i = 0; i < ns; ++i) {
                 const int cid = seg[1 + 2 * i];
                 int k = 0;
@@ -793,7 +793,7 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
     }
     if (!width || !have_scan) return false;
     // dequantise (16-bit products, as stb_image keeps them) + inverse DCT into 8-bit planes
-    std::vector<unsigned char> plane[3];
+    std::vector<unsigned char> plane[4];
     for (int i = 0; i < ncomp; ++i) {
         plane[i].assign((size_t)comp[i].pw * comp[i].ph, 0);
         for (int by = 0; by < comp[i].bh; ++by)
@@ -804,11 +804,11 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
                 jpeg_idct(blk, &plane[i][(size_t)(by * 8) * comp[i].pw + (size_t)bx * 8], comp[i].pw);
             }
     }
-    components = ncomp;
+    components = ncomp >= 3 ? 3 : 1;                  // (a four-component file - CMYK / YCCK - comes out as RGB)
     rgba.resize((size_t)width * height * 4);
     // rows top to bottom; every component is widened to the full row by stb_image's filters, its two source rows stepping as
     // stb_image steps them (the filter looks up on even output rows, down on odd ones; the last source row repeats)
-    struct Up { int hs, vs, ystep, w_lores, ypos, rows; const unsigned char *line0, *line1; std::vector<unsigned char> buf; } up[3];
+    struct Up { int hs, vs, ystep, w_lores, ypos, rows; const unsigned char *line0, *line1; std::vector<unsigned char> buf; } up[4];
     for (int i = 0; i < ncomp; ++i) {
         up[i].hs = hmax / comp[i].h;
         up[i].vs = vmax / comp[i].v;
@@ -822,9 +822,10 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
     // components that are R, G, B already: ids 'R','G','B', or an Adobe marker with transform 0 and no JFIF marker
     const bool is_rgb = ncomp == 3 && ((comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B') || (adobe_transform == 0 && !jfif));
     auto fixed = [](float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; };
+    auto mul255 = [](int a, int b) { const unsigned t = (unsigned)(a * b + 128); return (unsigned char)((t + (t >> 8)) >> 8); };      // a * b / 255, rounded
     const int k_cr_r = fixed(1.40200f), k_cr_g = -fixed(0.71414f), k_cb_g = -fixed(0.34414f), k_cb_b = fixed(1.77200f);
     for (int y = 0; y < height; ++y) {
-        const unsigned char *row[3] = {nullptr, nullptr, nullptr};
+        const unsigned char *row[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int i = 0; i < ncomp; ++i) {
             Up &u = up[i];
             const bool lower = u.ystep >= (u.vs >> 1);
@@ -842,12 +843,19 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
             o[3] = 255;
             if (ncomp == 1) { o[0] = o[1] = o[2] = row[0][x]; continue; }
             if (is_rgb) { o[0] = row[0][x]; o[1] = row[1][x]; o[2] = row[2][x]; continue; }
+            if (ncomp == 4 && adobe_transform == 0) {            // CMYK as Adobe stores it (inverted): each channel scaled by K
+                o[0] = mul255(row[0][x], row[3][x]); o[1] = mul255(row[1][x], row[3][x]); o[2] = mul255(row[2][x], row[3][x]);
+                continue;
+            }
             // stb_image's YCbCr -> RGB: 20-bit fixed point, the Cb term of green cut to its upper 16 bits
             const int yf = (row[0][x] << 20) + (1 << 19), cb = row[1][x] - 128, cr = row[2][x] - 128;
             const int r = (yf + cr * k_cr_r) >> 20;
             const int g = (int)((unsigned)(yf + cr * k_cr_g) + ((unsigned)(cb * k_cb_g) & 0xffff0000u)) >> 20;
             const int b = (yf + cb * k_cb_b) >> 20;
             o[0] = jclamp(r); o[1] = jclamp(g); o[2] = jclamp(b);
+            if (ncomp == 4 && adobe_transform == 2) {            // YCCK: the converted colour is inverted and scaled by K
+                o[0] = mul255(255 - o[0], row[3][x]); o[1] = mul255(255 - o[1], row[3][x]); o[2] = mul255(255 - o[2], row[3][x]);
+            }                                                    // (four components without an Adobe marker: the fourth is ignored)
         }
     }
     return true;

@@ -723,3 +723,38 @@ def test_pnm_reader_equals_stb_image(ref, tmp_path):
         with pytest.raises(api.GptError):
             api.decode_image8(str(tmp_path / name))
 
+
+def test_cmyk_and_ycck_jpeg_equal_stb_image(ref, tmp_path):
+    """Four-component JPEG files: Adobe CMYK (transform 0), YCCK (transform 2), and four components without a recognised Adobe marker
+    (stb_image ignores the fourth) - all come out as three channels."""
+    from PIL import Image
+    rng = np.random.default_rng(19)
+    y, x = np.mgrid[0:45, 0:61]
+    img = np.stack([127 + 120 * np.sin(x / 6.0), 127 + 120 * np.cos(y / 5.0), (4 * x + 3 * y) % 256, 40 + (x * y) % 200], -1)
+    img = np.clip(img + rng.normal(0, 5, img.shape), 0, 255).astype(np.uint8)
+    n = 0
+    for name, kw in (("cmyk_444", dict(quality=90, subsampling=0)), ("cmyk_420", dict(quality=75, subsampling=2)),
+                     ("cmyk_progressive", dict(quality=80, subsampling=1, progressive=True))):
+        base = tmp_path / (name + ".jpg")
+        Image.fromarray(img, "CMYK").save(base, **kw)
+        data = bytearray(base.read_bytes())
+        at = data.find(b"Adobe")
+        assert at > 0 and data[at - 4:at - 2] == b"\xff\xee"
+        variants = {"": data}
+        for tag, value in (("_as_ycck", 2), ("_as_ycc_alpha", 1)):
+            v = bytearray(data)
+            v[at + 11] = value                                  # the colour-transform byte of the Adobe segment
+            variants[tag] = v
+        v = bytearray(data)
+        v[at:at + 5] = b"Adobf"                                 # not an Adobe marker any more
+        variants["_unmarked"] = v
+        for tag, blob in variants.items():
+            path = tmp_path / (name + tag + ".jpg")
+            path.write_bytes(bytes(blob))
+            want = ref_decode8(ref, path)
+            assert want is not None and want.shape == (45, 61, 3), path.name
+            got = api.decode_image8(str(path))
+            assert got.shape == want.shape and np.array_equal(got, want), path.name
+            n += 1
+    assert n == 12
+
