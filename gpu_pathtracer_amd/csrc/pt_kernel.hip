@@ -154,6 +154,15 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #ifndef PT_ORDER_BY_LANE
 #define PT_ORDER_BY_LANE 0      // 1 (experiment): fetch order by lane, then kind, instead of by kind (longest rays first), then lane
 #endif
+#ifndef PT_XCD_QUEUES
+#define PT_XCD_QUEUES 1          // 1 (scenes in global memory): one work queue per XCD (workgroup b runs on XCD b % 8), each a contiguous eighth of the items, so that
+#endif                           // an XCD's private L2 serves neighbouring tiles; a wave whose queue is empty takes from the next XCD's.  0: one queue
+#ifndef PT_XCD_BLOCK
+#define PT_XCD_BLOCK 0
+#endif
+#ifndef PT_TILE_STRIP
+#define PT_TILE_STRIP 16         // N > 0 (scenes in global memory): consecutive items walk down strips of N tiles instead of along whole tile rows (512 consecutive tiles = a compact block)
+#endif
 #ifndef PT_ASM_IN_COUNT
 #define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
 #endif
@@ -2885,6 +2894,12 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     // the end of the launch.  sample s -> pixel s % 64 of the tile, iteration chunk_first + s / 64.
     uint32_t tile_xy = 0, slot_base = 0, chunk_first = 0, n_item_samples = 0, next_sample = 0;     // wave-uniform
     bool more_items = true;
+    // Scenes in global memory: one queue per XCD (workgroup b runs on XCD b % 8), each a contiguous eighth of the items, and the
+    // items walk down strips of PT_TILE_STRIP tiles - what an XCD's private L2 serves at any time is one compact block of the
+    // frame.  A wave whose queue is empty takes from the next XCD's.  The LDS-resident scene has nothing to gain: one queue, tile rows.
+    constexpr bool XCD_QUEUES = PT_XCD_QUEUES && !SMALL;
+    constexpr uint32_t TILE_STRIP = SMALL ? 0u : (uint32_t)PT_TILE_STRIP;
+    uint32_t queues_done = 0;      // queues found empty so far: own XCD's first, then the others in turn
     uint32_t x = 0, y = 0, plane_slot = 0, iter = 0;      // plane_slot: where the sample goes in its iteration's plane
     {
         // ---- per-path state ---------------------------------------------------------
@@ -3741,14 +3756,48 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
             // ---- regenerate: pathtracer.cu:881-903 ---------------------------------------
             bool start = false;
             if (next_sample >= n_item_samples && more_items && !__all(alive)) {
-                uint32_t t = 0;
-                if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
-                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                if (t >= n_items) {
-                    more_items = false;
+                uint32_t t = n_items;
+                if constexpr (XCD_QUEUES) {
+                    while (queues_done < 8u) {
+                        const uint32_t qi = (blockIdx.x + queues_done) & 7u;
+                        uint32_t k = 0;
+                        if (lane == 0) k = atomicAdd(P.tile_counter + qi, 1u);
+                        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+#if PT_XCD_BLOCK      // (experiment) queue qi = blocks qi, qi + 8, ... of PT_XCD_BLOCK consecutive items: the XCDs advance through the frame together
+                        const uint32_t cand = ((k / (uint32_t)PT_XCD_BLOCK) * 8u + qi) * (uint32_t)PT_XCD_BLOCK + k % (uint32_t)PT_XCD_BLOCK;
+                        if (k < n_items && cand < n_items) {
+                            t = cand;
+                            break;
+                        }
+#else                 // queue qi = the qi-th eighth of the items
+                        const uint32_t lo = (uint32_t)(((uint64_t)n_items * qi) >> 3), hi = (uint32_t)(((uint64_t)n_items * (qi + 1u)) >> 3);
+                        if (k < hi - lo) {
+                            t = lo + k;
+                            break;
+                        }
+#endif
+                        queues_done++;
+                    }
+                    more_items = queues_done < 8u;
                 } else {
+                    if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                    more_items = t < n_items;
+                }
+                if (more_items) {
                     const uint32_t chunk = t / n_owned;
-                    const uint32_t tile_local = t - chunk * n_owned;
+                    uint32_t tile_local = t - chunk * n_owned;
+                    if constexpr (TILE_STRIP != 0u) {   // a bijection of [0, n_owned): the owned tiles seen as a grid of gw columns (exact when tiles_x % n_ranks == 0), strip by strip
+                        const uint32_t gw = (P.tiles_x + P.n_ranks - 1u) / P.n_ranks, gh = n_owned / gw;
+                        if (tile_local < gw * gh) {
+                            const uint32_t strip_items = TILE_STRIP * gh;
+                            const uint32_t strip = tile_local / strip_items, r = tile_local - strip * strip_items;
+                            const uint32_t left = gw - strip * TILE_STRIP;
+                            const uint32_t w = left < TILE_STRIP ? left : TILE_STRIP;
+                            const uint32_t ty = r / w;
+                            tile_local = ty * gw + strip * TILE_STRIP + (r - ty * w);
+                        }
+                    }
                     const uint32_t tile = P.rank + tile_local * P.n_ranks;
                     tile_xy = (tile % P.tiles_x) | ((tile / P.tiles_x) << 16);      // (one SGPR: the kernel is at the SGPR limit)
                     slot_base = tile_local * 64u;          // planes are tile-major over this rank's tiles

@@ -147,7 +147,7 @@ struct DevParams {
     // scheduler: independent work items w = (chunk, tile), chunk = w / n_owned
     uint32_t chunk_iters;        // iterations per work item
     uint32_t n_chunks;           // ceil(iter_count / chunk_iters)
-    uint32_t *tile_counter;      // work queue head (zeroed before every launch)
+    uint32_t *tile_counter;      // work queue heads, one per XCD (8 words, zeroed before every launch)
     unsigned long long *counters;  // work counters (counting build only)
     int32_t traversal;           // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_NEAR_FIRST (nodes holds 9 threaded variants)
     // Volpath only (new fields go at the END: the kernarg layout steers the register allocation of the headline kernel)
