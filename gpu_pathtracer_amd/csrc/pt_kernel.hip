@@ -1273,6 +1273,9 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
 #ifndef PT_WIDE_EARLY
 #define PT_WIDE_EARLY 0          // (measured: -5 %, the extra vector-memory instructions cost more than the overlap gains) a lane that descends into a wide node fetches that record before the trip's triangle block
 #endif
+#if PT_WIDE_EARLY
+#error "PT_WIDE_EARLY went with the separate node / triangle fetches (see git history): the loop now fetches for both kinds with one set of instructions"
+#endif
 #ifndef PT_WIDE_EXTRA_NODE
 #define PT_WIDE_EXTRA_NODE         // experiment hook: extra VALU instructions in the node block (what would fewer of them be worth?)
 #endif
@@ -1304,7 +1307,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
-    const unsigned long long s_nodes = uniform64((unsigned long long)P.wide), s_tris = uniform64((unsigned long long)P.tris);
+    const unsigned long long s_nodes = uniform64((unsigned long long)P.wide);
+    const unsigned s_trioff = __builtin_amdgcn_readfirstlane(P.wide_tris_off);
     const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16;
     const unsigned s_stack = s_pool + kWideStackOff * 16 - 768;
@@ -1370,26 +1374,24 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         PT_WIDE_PROBE_TRIP
         /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
            wait for everything) */
+        /* one set of fetches serves both kinds: a lane's offset from the base of the wide nodes is its node's, or that of its
+           triangle in the copy behind the nodes; a node lane gets its 112-byte record, a leaf lane its triangle in v[24:32] and the
+           one after it in v[36:44] (the rest of what it reads is not used) */
         "s_mov_b64 exec, s[60:61]\n"
         "v_and_b32_e32 v53, 0x7ffffff, v12\n"              /* the leaf's first triangle */
         "v_lshlrev_b32_e32 v54, 4, v53\n"
         "v_lshl_add_u32 v54, v53, 5, v54\n"                /* * 48 */
-        "global_load_dwordx4 v[28:31], v54, %[tris] offset:16\n"
-        "global_load_dword v32, v54, %[tris] offset:32\n"
-        "global_load_dwordx4 v[24:27], v54, %[tris]\n"
-#if PT_WIDE_TRI2
-        "global_load_dwordx4 v[48:51], v54, %[tris] offset:64\n"      /* ... and the one after it (the array is padded by one record) */
-        "global_load_dword v52, v54, %[tris] offset:80\n"
-        "global_load_dwordx4 v[44:47], v54, %[tris] offset:48\n"
-#endif
-        "s_andn2_b64 exec, s[62:63], s[82:83]\n"           /* (the lanes that descended last trip fetched their record then) */
-        "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
-        "global_load_dwordx4 v[36:39], v12, %[nodes] offset:48\n"
-        "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
-        "global_load_dwordx4 v[40:43], v12, %[nodes] offset:64\n"
-        "global_load_dwordx4 v[32:35], v12, %[nodes] offset:32\n"
-        "global_load_dwordx4 v[44:47], v12, %[nodes] offset:80\n"
-        "global_load_dwordx4 v[48:51], v12, %[nodes] offset:96\n"
+        "v_add_u32_e32 v54, %[trioff], v54\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_mov_b32_e32 v54, v12\n"
+        "s_or_b64 exec, s[60:61], s[62:63]\n"
+        "global_load_dwordx4 v[24:27], v54, %[nodes]\n"
+        "global_load_dwordx4 v[36:39], v54, %[nodes] offset:48\n"
+        "global_load_dwordx4 v[28:31], v54, %[nodes] offset:16\n"
+        "global_load_dwordx4 v[40:43], v54, %[nodes] offset:64\n"
+        "global_load_dwordx4 v[32:35], v54, %[nodes] offset:32\n"
+        "global_load_dwordx4 v[44:47], v54, %[nodes] offset:80\n"
+        "global_load_dwordx4 v[48:51], v54, %[nodes] offset:96\n"
         PT_WIDE_EXTRA_LOADS
         "s_mov_b64 s[78:79], 0\n"
         "s_mov_b64 s[82:83], 0\n"
@@ -1589,93 +1591,93 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_mov_b64 exec, s[60:61]\n"
         "s_cbranch_execz TW_POP_%=\n"
         "v_mul_f32_e32 v33, v5, v32\n"
-        "v_mul_f32_e32 v42, v6, v31\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v50, v6, v31\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
         "v_mul_f32_e32 v34, v6, v30\n"
-        "v_mul_f32_e32 v42, v4, v32\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v50, v4, v32\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
         "v_mul_f32_e32 v35, v4, v31\n"
-        "v_mul_f32_e32 v42, v5, v30\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v36, v33, v27\n"
-        "v_mul_f32_e32 v42, v34, v28\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_mul_f32_e32 v42, v35, v29\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_rcp_f32_e32 v38, v36\n"
+        "v_mul_f32_e32 v50, v5, v30\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v45, v33, v27\n"
+        "v_mul_f32_e32 v50, v34, v28\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_mul_f32_e32 v50, v35, v29\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_rcp_f32_e32 v47, v45\n"
         "v_sub_f32_e32 v24, v0, v24\n"
         "v_sub_f32_e32 v25, v1, v25\n"
         "v_sub_f32_e32 v26, v2, v26\n"
-        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
-        "v_fma_f32 v41, -v36, v38, 1.0\n"
-        "v_fma_f32 v37, v41, v38, v38\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n"
+        "v_fma_f32 v49, -v45, v47, 1.0\n"
+        "v_fma_f32 v46, v49, v47, v47\n"
         "s_cmp_lg_u64 s[66:67], 0\n"
         "s_cbranch_scc1 TW_DIV_IEEE_%=\n"
         "TW_DIV_DONE_%=:\n"
-        "v_mul_f32_e32 v43, v24, v33\n"
-        "v_mul_f32_e32 v42, v25, v34\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v42, v26, v35\n"
-        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v51, v24, v33\n"
+        "v_mul_f32_e32 v50, v25, v34\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v50, v26, v35\n"
+        "v_add_f32_e32 v51, v51, v50\n"
         "v_mul_f32_e32 v33, v25, v29\n"
-        "v_mul_f32_e32 v42, v26, v28\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v50, v26, v28\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
         "v_mul_f32_e32 v34, v26, v27\n"
-        "v_mul_f32_e32 v42, v24, v29\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v50, v24, v29\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
         "v_mul_f32_e32 v35, v24, v28\n"
-        "v_mul_f32_e32 v42, v25, v27\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v43, v43, v37\n"                    /* b1 */
-        "v_mul_f32_e32 v38, v4, v33\n"
-        "v_mul_f32_e32 v42, v5, v34\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v42, v6, v35\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v38, v38, v37\n"                    /* b2 */
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
+        "v_mul_f32_e32 v50, v25, v27\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */
+        "v_mul_f32_e32 v47, v4, v33\n"
+        "v_mul_f32_e32 v50, v5, v34\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v50, v6, v35\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v51\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"
-        "v_add_f32_e32 v42, v43, v38\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v47\n"
+        "v_add_f32_e32 v50, v51, v47\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_and_b64 exec, exec, s[66:67]\n"
         "s_cbranch_scc0 TW_TRI_END_%=\n"
-        "v_mul_f32_e32 v39, v30, v33\n"
-        "v_mul_f32_e32 v42, v31, v34\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v42, v32, v35\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v39, v39, v37\n"                    /* tt */
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
-        "v_cmp_ngt_f32_e64 s[66:67], v39, v14\n"
+        "v_mul_f32_e32 v48, v30, v33\n"
+        "v_mul_f32_e32 v50, v31, v34\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v50, v32, v35\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_and_b64 exec, exec, s[66:67]\n"
         "s_cbranch_scc0 TW_TRI_END_%=\n"
         /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
            distance that is not NaN and nearer than the interval's end becomes the interval's end */
         "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
-        "v_cmp_lt_f32_e32 vcc, v39, v21\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v21\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_eq_f32_e32 vcc, v39, v21\n"
+        "v_cmp_eq_f32_e32 vcc, v48, v21\n"
         "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
         "s_and_b64 vcc, vcc, s[72:73]\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_lt_f32_e32 vcc, v39, v14\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v14\n"
         "s_mov_b64 s[72:73], exec\n"
-        "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
-        "v_and_b32_e32 v42, 0x100, v11\n"
+        "v_cndmask_b32_e32 v14, v14, v48, vcc\n"
+        "v_and_b32_e32 v50, 0x100, v11\n"
         "s_and_b64 exec, exec, s[68:69]\n"
         "v_mov_b32_e32 v20, v53\n"
-        "v_mov_b32_e32 v21, v39\n"
-        "v_mov_b32_e32 v22, v43\n"
-        "v_mov_b32_e32 v23, v38\n"
+        "v_mov_b32_e32 v21, v48\n"
+        "v_mov_b32_e32 v22, v51\n"
+        "v_mov_b32_e32 v23, v47\n"
         "s_mov_b64 exec, s[72:73]\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v42\n"                   /* IntersectP: the first accepted triangle ends the ray */
+        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */
         "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
         "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
         "TW_TRI_END_%=:\n"
@@ -1684,8 +1686,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* a ray that goes on and whose leaf has another triangle tests it in the same trip (its record came with the first one's):
            the order of the tests and the interval they see are those of two trips */
         "v_cmp_ne_u32_e32 vcc, -1, v12\n"
-        "v_bfe_u32 v42, v12, 27, 4\n"
-        "v_cmp_lt_u32_e64 s[66:67], 0, v42\n"
+        "v_bfe_u32 v50, v12, 27, 4\n"
+        "v_cmp_lt_u32_e64 s[66:67], 0, v50\n"
         "s_nop 0\n"
         "s_and_b64 s[84:85], s[66:67], vcc\n"             /* second test */
         "s_andn2_b64 s[68:69], vcc, s[66:67]\n"           /* the leaf is exhausted: pop */
@@ -1693,117 +1695,117 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_mov_b64 exec, s[84:85]\n"
         "s_cbranch_execz TW_POP_%=\n"
         "v_add_u32_e32 v53, 1, v53\n"
-        "v_mul_f32_e32 v33, v5, v52\n"
-        "v_mul_f32_e32 v42, v6, v51\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v6, v50\n"
-        "v_mul_f32_e32 v42, v4, v52\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v4, v51\n"
-        "v_mul_f32_e32 v42, v5, v50\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v36, v33, v47\n"
-        "v_mul_f32_e32 v42, v34, v48\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_mul_f32_e32 v42, v35, v49\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_rcp_f32_e32 v38, v36\n"
-        "v_sub_f32_e32 v44, v0, v44\n"
-        "v_sub_f32_e32 v45, v1, v45\n"
-        "v_sub_f32_e32 v46, v2, v46\n"
-        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
-        "v_fma_f32 v41, -v36, v38, 1.0\n"
-        "v_fma_f32 v37, v41, v38, v38\n"
+        "v_mul_f32_e32 v33, v5, v44\n"
+        "v_mul_f32_e32 v50, v6, v43\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
+        "v_mul_f32_e32 v34, v6, v42\n"
+        "v_mul_f32_e32 v50, v4, v44\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
+        "v_mul_f32_e32 v35, v4, v43\n"
+        "v_mul_f32_e32 v50, v5, v42\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v45, v33, v39\n"
+        "v_mul_f32_e32 v50, v34, v40\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_mul_f32_e32 v50, v35, v41\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_rcp_f32_e32 v47, v45\n"
+        "v_sub_f32_e32 v36, v0, v36\n"
+        "v_sub_f32_e32 v37, v1, v37\n"
+        "v_sub_f32_e32 v38, v2, v38\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n"
+        "v_fma_f32 v49, -v45, v47, 1.0\n"
+        "v_fma_f32 v46, v49, v47, v47\n"
         "s_cmp_lg_u64 s[66:67], 0\n"
         "s_cbranch_scc1 TW_DIV_IEEE2_%=\n"
         "TW_DIV_DONE2_%=:\n"
-        "v_mul_f32_e32 v43, v44, v33\n"
-        "v_mul_f32_e32 v42, v45, v34\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v42, v46, v35\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v33, v45, v49\n"
-        "v_mul_f32_e32 v42, v46, v48\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v46, v47\n"
-        "v_mul_f32_e32 v42, v44, v49\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v44, v48\n"
-        "v_mul_f32_e32 v42, v45, v47\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v43, v43, v37\n"                    /* b1 */
-        "v_mul_f32_e32 v38, v4, v33\n"
-        "v_mul_f32_e32 v42, v5, v34\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v42, v6, v35\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v38, v38, v37\n"                    /* b2 */
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
+        "v_mul_f32_e32 v51, v36, v33\n"
+        "v_mul_f32_e32 v50, v37, v34\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v50, v38, v35\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v33, v37, v41\n"
+        "v_mul_f32_e32 v50, v38, v40\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
+        "v_mul_f32_e32 v34, v38, v39\n"
+        "v_mul_f32_e32 v50, v36, v41\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
+        "v_mul_f32_e32 v35, v36, v40\n"
+        "v_mul_f32_e32 v50, v37, v39\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */
+        "v_mul_f32_e32 v47, v4, v33\n"
+        "v_mul_f32_e32 v50, v5, v34\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v50, v6, v35\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v51\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"
-        "v_add_f32_e32 v42, v43, v38\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v47\n"
+        "v_add_f32_e32 v50, v51, v47\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_and_b64 exec, exec, s[66:67]\n"
         "s_cbranch_scc0 TW_TRI2_END_%=\n"
-        "v_mul_f32_e32 v39, v50, v33\n"
-        "v_mul_f32_e32 v42, v51, v34\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v42, v52, v35\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v39, v39, v37\n"                    /* tt */
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
-        "v_cmp_ngt_f32_e64 s[66:67], v39, v14\n"
+        "v_mul_f32_e32 v48, v42, v33\n"
+        "v_mul_f32_e32 v50, v43, v34\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v50, v44, v35\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_and_b64 exec, exec, s[66:67]\n"
         "s_cbranch_scc0 TW_TRI2_END_%=\n"
         /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
            distance that is not NaN and nearer than the interval's end becomes the interval's end */
         "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
-        "v_cmp_lt_f32_e32 vcc, v39, v21\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v21\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_eq_f32_e32 vcc, v39, v21\n"
+        "v_cmp_eq_f32_e32 vcc, v48, v21\n"
         "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
         "s_and_b64 vcc, vcc, s[72:73]\n"
         "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_lt_f32_e32 vcc, v39, v14\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v14\n"
         "s_mov_b64 s[72:73], exec\n"
-        "v_cndmask_b32_e32 v14, v14, v39, vcc\n"
-        "v_and_b32_e32 v42, 0x100, v11\n"
+        "v_cndmask_b32_e32 v14, v14, v48, vcc\n"
+        "v_and_b32_e32 v50, 0x100, v11\n"
         "s_and_b64 exec, exec, s[68:69]\n"
         "v_mov_b32_e32 v20, v53\n"
-        "v_mov_b32_e32 v21, v39\n"
-        "v_mov_b32_e32 v22, v43\n"
-        "v_mov_b32_e32 v23, v38\n"
+        "v_mov_b32_e32 v21, v48\n"
+        "v_mov_b32_e32 v22, v51\n"
+        "v_mov_b32_e32 v23, v47\n"
         "s_mov_b64 exec, s[72:73]\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v42\n"                   /* IntersectP: the first accepted triangle ends the ray */
+        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */
         "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
         "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
         "TW_TRI2_END_%=:\n"
         "s_mov_b64 exec, s[84:85]\n"
         "v_cmp_ne_u32_e32 vcc, -1, v12\n"
-        "v_bfe_u32 v42, v12, 27, 4\n"
-        "v_add_u32_e32 v41, 0xf0000002, v12\n"             /* first + 2, two triangles fewer */
-        "v_cmp_lt_u32_e64 s[66:67], 1, v42\n"
+        "v_bfe_u32 v50, v12, 27, 4\n"
+        "v_add_u32_e32 v49, 0xf0000002, v12\n"             /* first + 2, two triangles fewer */
+        "v_cmp_lt_u32_e64 s[66:67], 1, v50\n"
         "s_nop 0\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v12, v41, s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n"
         "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
 #else
         /* a ray that goes on: the leaf's next triangle if it has one, else pop */
         "v_cmp_ne_u32_e32 vcc, -1, v12\n"
-        "v_bfe_u32 v42, v12, 27, 4\n"
-        "v_add_u32_e32 v41, 0xf8000001, v12\n"             /* first + 1, one triangle fewer */
-        "v_cmp_lt_u32_e64 s[66:67], 0, v42\n"
+        "v_bfe_u32 v50, v12, 27, 4\n"
+        "v_add_u32_e32 v49, 0xf8000001, v12\n"             /* first + 1, one triangle fewer */
+        "v_cmp_lt_u32_e64 s[66:67], 0, v50\n"
         "s_nop 0\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v12, v41, s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n"
         "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
 #endif
         /* ---------------------------------------------------------------- pop (s[78:79]) */
@@ -1863,33 +1865,33 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_branch TW_PUSHED_%=\n"
         /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
         "TW_DIV_IEEE_%=:\n"
-        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
-        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
-        "v_rcp_f32_e32 v38, v37\n"
+        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
+        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
+        "v_rcp_f32_e32 v47, v46\n"
         "s_nop 0\n"
-        "v_fma_f32 v41, -v37, v38, 1.0\n"
-        "v_fmac_f32_e32 v38, v41, v38\n"
-        "v_mul_f32_e32 v40, v39, v38\n"
-        "v_fma_f32 v41, -v37, v40, v39\n"
-        "v_fmac_f32_e32 v40, v41, v38\n"
-        "v_fma_f32 v37, -v37, v40, v39\n"
-        "v_div_fmas_f32 v37, v37, v38, v40\n"
-        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
+        "v_fma_f32 v49, -v46, v47, 1.0\n"
+        "v_fmac_f32_e32 v47, v49, v47\n"
+        "v_mul_f32_e32 v52, v48, v47\n"
+        "v_fma_f32 v49, -v46, v52, v48\n"
+        "v_fmac_f32_e32 v52, v49, v47\n"
+        "v_fma_f32 v46, -v46, v52, v48\n"
+        "v_div_fmas_f32 v46, v46, v47, v52\n"
+        "v_div_fixup_f32 v46, v46, v45, 1.0\n"
         "s_branch TW_DIV_DONE_%=\n"
 #if PT_WIDE_TRI2
         "TW_DIV_IEEE2_%=:\n"
-        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
-        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
-        "v_rcp_f32_e32 v38, v37\n"
+        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
+        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
+        "v_rcp_f32_e32 v47, v46\n"
         "s_nop 0\n"
-        "v_fma_f32 v41, -v37, v38, 1.0\n"
-        "v_fmac_f32_e32 v38, v41, v38\n"
-        "v_mul_f32_e32 v40, v39, v38\n"
-        "v_fma_f32 v41, -v37, v40, v39\n"
-        "v_fmac_f32_e32 v40, v41, v38\n"
-        "v_fma_f32 v37, -v37, v40, v39\n"
-        "v_div_fmas_f32 v37, v37, v38, v40\n"
-        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
+        "v_fma_f32 v49, -v46, v47, 1.0\n"
+        "v_fmac_f32_e32 v47, v49, v47\n"
+        "v_mul_f32_e32 v52, v48, v47\n"
+        "v_fma_f32 v49, -v46, v52, v48\n"
+        "v_fmac_f32_e32 v52, v49, v47\n"
+        "v_fma_f32 v46, -v46, v52, v48\n"
+        "v_div_fmas_f32 v46, v46, v47, v52\n"
+        "v_div_fixup_f32 v46, v46, v45, 1.0\n"
         "s_branch TW_DIV_DONE2_%=\n"
 #endif
 
@@ -1958,7 +1960,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
 #else
         :
 #endif
-        : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [tris] "s"(s_tris), [spill] "s"(s_spill),
+        : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill),
           [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [allow] "s"(s_allow), [vspill] "v"(v_spill), [vsusp] "v"(v_susp),
           [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)

@@ -158,6 +158,7 @@ struct DevParams {
     const struct DevWideNode *wide;    // the 4-wide tree; node w at byte offset 128 * w
     uint32_t *wide_stack;              // overflow of the per-ray LDS stacks and suspend records: kWideWaveSliceDwords per wave of the widest grid
     uint32_t wide_stack_blocks;        // workgroups that buffer was sized for (no wide kernel is launched with more)
+    uint32_t wide_tris_off;            // byte offset from `wide` of the copy of `tris` that the hand-scheduled wide loop fetches from
 };
 
 }  // namespace pt

@@ -618,8 +618,23 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
         }
         if (!ctx->P.wide) {
             HIP_TRY(hipSetDevice(ctx->device));
-            int rc = dev_upload(ctx, ctx->wide_host.data(), ctx->wide_host.size(), &ctx->P.wide);
-            if (rc != GPT_OK) return rc;
+            // ONE allocation holds the wide nodes and, behind them, a copy of the triangle records: a trip of the wide loop fetches
+            // for its node lanes and its leaf lanes with the same seven instructions, a 32-bit offset per lane from one base
+            // (a leaf lane reads 112 bytes from its triangle on: the copy is padded by two records)
+            const size_t wide_bytes = ctx->wide_host.size() * sizeof(DevWideNode);
+            const size_t tri_bytes = (size_t)ctx->P.n_prims * sizeof(DevTri);
+            if (wide_bytes + tri_bytes + 3 * sizeof(DevTri) > (size_t)UINT32_MAX) {
+                gpt_set_error("gpt_set_traversal_order: the wide tree and its triangles exceed 4 GB");
+                return GPT_ERR_UNSUPPORTED;
+            }
+            void *p = nullptr;
+            HIP_TRY(hipMalloc(&p, wide_bytes + tri_bytes + 3 * sizeof(DevTri)));
+            ctx->allocs.push_back(p);
+            HIP_TRY(hipMemset(static_cast<char *>(p) + wide_bytes + tri_bytes, 0, 3 * sizeof(DevTri)));
+            HIP_TRY(hipMemcpy(p, ctx->wide_host.data(), wide_bytes, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(static_cast<char *>(p) + wide_bytes, ctx->P.tris, tri_bytes, hipMemcpyDeviceToDevice));
+            ctx->P.wide = static_cast<const DevWideNode *>(p);
+            ctx->P.wide_tris_off = (uint32_t)wide_bytes;
             std::vector<DevWideNode>().swap(ctx->wide_host);
         }
         if (!ctx->P.wide_stack) {          // spill space of the per-ray stacks: one slice per wave that can be resident
