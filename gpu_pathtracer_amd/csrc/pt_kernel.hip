@@ -1276,6 +1276,9 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
 #if PT_WIDE_EARLY
 #error "PT_WIDE_EARLY went with the separate node / triangle fetches (see git history): the loop now fetches for both kinds with one set of instructions"
 #endif
+#ifndef PT_WIDE_PK
+#define PT_WIDE_PK 0             // (measured: -2 %, packed fp32 issues no faster than two plain instructions here) 1: the node block forms (plane - origin) * inverse direction with v_pk_add_f32 / v_pk_mul_f32, two children at a time (24 VALU instructions fewer per node trip)
+#endif
 #ifndef PT_WIDE_EXTRA_NODE
 #define PT_WIDE_EXTRA_NODE         // experiment hook: extra VALU instructions in the node block (what would fewer of them be worth?)
 #endif
@@ -1401,6 +1404,102 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
         /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */
         PT_WIDE_EXTRA_NODE
+#if PT_WIDE_PK
+        /* children 0 and 1: (plane - origin) * inverse direction, two at a time (the same roundings as v_sub_f32 / v_mul_f32) */
+        "v_pk_add_f32 v[24:25], v[24:25], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[36:37], v[36:37], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[28:29], v[28:29], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[32:33], v[32:33], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[40:41], v[40:41], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[44:45], v[44:45], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_mul_f32 v[24:25], v[8:9], v[24:25] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[36:37], v[8:9], v[36:37] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[28:29], v[8:9], v[28:29] op_sel:[1,0] op_sel_hi:[1,1]\n"
+        "v_pk_mul_f32 v[40:41], v[8:9], v[40:41] op_sel:[1,0] op_sel_hi:[1,1]\n"
+        "v_pk_mul_f32 v[32:33], v[10:11], v[32:33] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[44:45], v[10:11], v[44:45] op_sel_hi:[0,1]\n"
+        "v_min_f32_e32 v52, v24, v36\n"
+        "v_max_f32_e32 v24, v24, v36\n"
+        "v_min_f32_e32 v36, v28, v40\n"
+        "v_max_f32_e32 v28, v28, v40\n"
+        "v_min_f32_e32 v40, v32, v44\n"
+        "v_max_f32_e32 v32, v32, v44\n"
+        "v_min3_f32 v24, v24, v28, v32\n"
+        "v_max3_f32 v52, v52, v36, v40\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v24\n"
+        "v_min_f32_e32 v24, v24, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v24, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v48\n"
+        "v_and_or_b32 v52, v52, -4, 0\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v24, -1, v52, s[66:67]\n"
+        "v_min_f32_e32 v52, v25, v37\n"
+        "v_max_f32_e32 v25, v25, v37\n"
+        "v_min_f32_e32 v37, v29, v41\n"
+        "v_max_f32_e32 v29, v29, v41\n"
+        "v_min_f32_e32 v41, v33, v45\n"
+        "v_max_f32_e32 v33, v33, v45\n"
+        "v_min3_f32 v25, v25, v29, v33\n"
+        "v_max3_f32 v52, v52, v37, v41\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v25\n"
+        "v_min_f32_e32 v25, v25, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v25, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v49\n"
+        "v_and_or_b32 v52, v52, -4, 1\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v25, -1, v52, s[66:67]\n"
+        /* children 2 and 3: (plane - origin) * inverse direction, two at a time (the same roundings as v_sub_f32 / v_mul_f32) */
+        "v_pk_add_f32 v[26:27], v[26:27], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[38:39], v[38:39], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[30:31], v[30:31], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[34:35], v[34:35], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[42:43], v[42:43], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 v[46:47], v[46:47], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+        "v_pk_mul_f32 v[26:27], v[8:9], v[26:27] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[38:39], v[8:9], v[38:39] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[30:31], v[8:9], v[30:31] op_sel:[1,0] op_sel_hi:[1,1]\n"
+        "v_pk_mul_f32 v[42:43], v[8:9], v[42:43] op_sel:[1,0] op_sel_hi:[1,1]\n"
+        "v_pk_mul_f32 v[34:35], v[10:11], v[34:35] op_sel_hi:[0,1]\n"
+        "v_pk_mul_f32 v[46:47], v[10:11], v[46:47] op_sel_hi:[0,1]\n"
+        "v_min_f32_e32 v52, v26, v38\n"
+        "v_max_f32_e32 v26, v26, v38\n"
+        "v_min_f32_e32 v38, v30, v42\n"
+        "v_max_f32_e32 v30, v30, v42\n"
+        "v_min_f32_e32 v42, v34, v46\n"
+        "v_max_f32_e32 v34, v34, v46\n"
+        "v_min3_f32 v26, v26, v30, v34\n"
+        "v_max3_f32 v52, v52, v38, v42\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v26\n"
+        "v_min_f32_e32 v26, v26, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v26, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v50\n"
+        "v_and_or_b32 v52, v52, -4, 2\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v26, -1, v52, s[66:67]\n"
+        "v_min_f32_e32 v52, v27, v39\n"
+        "v_max_f32_e32 v27, v27, v39\n"
+        "v_min_f32_e32 v39, v31, v43\n"
+        "v_max_f32_e32 v31, v31, v43\n"
+        "v_min_f32_e32 v43, v35, v47\n"
+        "v_max_f32_e32 v35, v35, v47\n"
+        "v_min3_f32 v27, v27, v31, v35\n"
+        "v_max3_f32 v52, v52, v39, v43\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v27\n"
+        "v_min_f32_e32 v27, v27, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v27, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v51\n"
+        "v_and_or_b32 v52, v52, -4, 3\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
+#else
         "v_sub_f32_e32 v24, v24, v0\n"
         "v_sub_f32_e32 v36, v36, v0\n"
         "v_sub_f32_e32 v28, v28, v1\n"
@@ -1517,6 +1616,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_and_or_b32 v52, v52, -4, 3\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
+#endif
         /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the
            register its lo.x plane value came in) */
         "v_cmp_lt_u32_e32 vcc, v25, v24\n"
