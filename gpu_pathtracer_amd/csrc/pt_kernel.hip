@@ -1276,6 +1276,9 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
 #if PT_WIDE_EARLY
 #error "PT_WIDE_EARLY went with the separate node / triangle fetches (see git history): the loop now fetches for both kinds with one set of instructions"
 #endif
+#ifndef PT_WIDE_EARLY_POP
+#define PT_WIDE_EARLY_POP 0      // (measured: +-0) 1: the entry a lane would pop is read from its LDS stack when the trip's fetches go out, not when it pops
+#endif
 #ifndef PT_WIDE_PK
 #define PT_WIDE_PK 0             // (measured: -2 %, packed fp32 issues no faster than two plain instructions here) 1: the node block forms (plane - origin) * inverse direction with v_pk_add_f32 / v_pk_mul_f32, two children at a time (24 VALU instructions fewer per node trip)
 #endif
@@ -1395,6 +1398,13 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "global_load_dwordx4 v[32:35], v54, %[nodes] offset:32\n"
         "global_load_dwordx4 v[44:47], v54, %[nodes] offset:80\n"
         "global_load_dwordx4 v[48:51], v54, %[nodes] offset:96\n"
+#if PT_WIDE_EARLY_POP
+        /* the top of the lane's stack, read now (v54 is free once the fetches are issued): a lane that pops at the end of this trip
+           has pushed nothing in it, so this is the entry it pops - and the LDS round trip hides behind the fetches */
+        "v_add_u32_e32 v54, -1, v13\n"
+        "v_lshl_add_u32 v54, v54, 8, v18\n"
+        "ds_read_b32 v54, v54 offset:768\n"
+#endif
         PT_WIDE_EXTRA_LOADS
         "s_mov_b64 s[78:79], 0\n"
         "s_mov_b64 s[82:83], 0\n"
@@ -1920,8 +1930,13 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
         "s_mov_b64 s[72:73], exec\n"
         "s_and_b64 exec, exec, vcc\n"
+#if PT_WIDE_EARLY_POP
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_mov_b32_e32 v12, v54\n"
+#else
         "v_lshl_add_u32 v33, v13, 8, v18\n"
         "ds_read_b32 v12, v33 offset:768\n"
+#endif
         "s_andn2_b64 exec, s[72:73], vcc\n"
         "s_cbranch_execz TW_POP_LDS_%=\n"
         "v_lshl_add_u32 v33, v13, 8, v16\n"
@@ -3858,8 +3873,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
             // ---- regenerate: pathtracer.cu:881-903 ---------------------------------------
             bool start = false;
             if (next_sample >= n_item_samples && more_items && !__all(alive)) {
-                uint32_t t = n_items;
+                uint32_t t = 0;
                 if constexpr (XCD_QUEUES) {
+                    t = n_items;
                     while (queues_done < 8u) {
                         const uint32_t qi = (blockIdx.x + queues_done) & 7u;
                         uint32_t k = 0;
@@ -3880,13 +3896,13 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
 #endif
                         queues_done++;
                     }
-                    more_items = queues_done < 8u;
                 } else {
                     if (lane == 0) t = atomicAdd(P.tile_counter, 1u);
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                    more_items = t < n_items;
                 }
-                if (more_items) {
+                if (t >= n_items) {
+                    more_items = false;
+                } else {
                     const uint32_t chunk = t / n_owned;
                     uint32_t tile_local = t - chunk * n_owned;
                     if constexpr (TILE_STRIP != 0u) {   // a bijection of [0, n_owned): the owned tiles seen as a grid of gw columns (exact when tiles_x % n_ranks == 0), strip by strip

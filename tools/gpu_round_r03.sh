@@ -15,6 +15,7 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python bench.py --no-cpu-baseline --no-counters --no-parity --no-square --no-other-configs > $OUT/bench_under_rocprof.json 2> $OUT/prof_stats.err
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; head -6 $f; done
 for w in c3 c4 c5; do n=32; [ $w = c5 ] && n=8; for m in reference near wide; do for t in "" sbvh; do python tools/gpu_standin.py $w $m $n 3 $t 2>/dev/null | grep STANDIN; done; done; done > $OUT/configs.log; cat $OUT/configs.log
+for w in c3 c5; do n=32; [ $w = c5 ] && n=8; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o stats -- python tools/gpu_standin.py $w wide $n 3 > /dev/null 2>&1; for f in $(find $OUT/prof_$w -name "*kernel_stats.csv"); do cp $f $OUT/${w}_wide_kernel_stats.csv; head -3 $f; done; done
 for w in c3 c5; do for m in reference wide; do bash tools/gpu_pmc_standin.sh $TAG $w $m $( [ $w = c5 ] && echo 8 || echo 32 ) > /dev/null 2>&1; cat $OUT/${w}_${m}_pmc_summary.txt; done; done > $OUT/standin_pmc.txt; cat $OUT/standin_pmc.txt
 if [ -f var/libgpt_probe.so ]; then
   for w in c3 c4 c5; do GPT_LIB_PATH=$PWD/var/libgpt_probe.so GPT_ALLOW_OLD_LIB=1 python tools/gpu_wide_probe.py $w 2>/dev/null | grep PROBE; done > $OUT/probes.txt
