@@ -79,7 +79,9 @@ int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth,
  *                                         large; GPT_ERR_UNSUPPORTED for an empty scene or a tree deeper than 85 wide levels (the reference's own 64-entry stack ends at binary depth 64).
  * Modes 1 and 2 change only the ORDER of the reference's box and triangle tests: each is bit-identical to the oracle in the
  * same mode and within 1e-4 relative RMS of the reference order (measured: identical films, or single pixels where two hits
- * tie within rounding - relative RMS <= 2e-7).  Both always traverse from global memory. */
+ * tie within rounding - relative RMS <= 2e-7).  Both always traverse from global memory.  The first selection of mode 2 uploads
+ * the wide tree with a copy of the triangle records behind it (128 B per wide node + 48 B per triangle, one allocation below
+ * 4 GB - GPT_ERR_UNSUPPORTED beyond) and the per-wave stack spill space. */
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
 
 /* Renderer options, by name; none of them changes a result.  Nothing in the library is steered by environment
