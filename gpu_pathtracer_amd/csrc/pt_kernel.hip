@@ -1225,6 +1225,289 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 #endif
 }
 
+// Experiment (off): the global-memory loop with BOTH kinds of lanes served in every trip (PT_GLOBAL_BOTH=1): the registers, the arithmetic and every ray's own
+// sequence of visits are those of PT_TRACE_ASM (so the film is the same bit for bit), but a trip is no longer voted to be a node trip or
+// a triangle trip.  Nodes and triangles share one allocation (gpt_begin), a lane's 32-bit offset from the base of the nodes is its node
+// cursor or its triangle cursor + [trioff], and ONE set of fetches goes out under exec = node lanes | triangle lanes: a node lane
+// receives its node in v[24:31] and the next one in memory in v[32:35], v[44:47] (the lookahead), a triangle lane its triangle in
+// v[24:32] and the one after it in v[44:52] (two more fetches, triangle lanes only).  Then the node block runs under the node lanes and
+// the triangle block under the triangle lanes - lanes at a triangle wait until PT_BOTH_LEAF_MIN have gathered or nobody is at a node.
+// The node block's temporaries moved from v33-v41 to v36-v43, v48 (the second node's first half now lands in v32-v35).
+#ifndef PT_GLOBAL_BOTH
+#define PT_GLOBAL_BOTH 0          // measured: -5 % on the config 3 - 5 stand-ins in the reference order (kernel_variants.log): the voted loop stays
+#endif
+#ifndef PT_BOTH_LEAF_MIN
+#define PT_BOTH_LEAF_MIN 8
+#endif
+#define PT_NODE2_LOOKAHEAD_B \
+        "s_andn2_b64 s[66:67], s[66:67], vcc\n" "s_mov_b64 exec, s[66:67]\n" "s_cbranch_execz TP_N2B_%=\n" "s_waitcnt vmcnt(0)\n" \
+        "v_sub_f32_e32 v36, v32, v0\n" "v_sub_f32_e32 v37, v35, v0\n" "v_sub_f32_e32 v38, v33, v1\n" "v_sub_f32_e32 v40, v34, v2\n" \
+        "v_sub_f32_e32 v39, v44, v1\n" "v_sub_f32_e32 v41, v45, v2\n" \
+        "v_mul_f32_e32 v36, v8, v36\n" "v_mul_f32_e32 v37, v8, v37\n" "v_mul_f32_e32 v38, v9, v38\n" "v_mul_f32_e32 v39, v9, v39\n" \
+        "v_mul_f32_e32 v40, v10, v40\n" "v_mul_f32_e32 v41, v10, v41\n" \
+        "v_min_f32_e32 v42, v36, v37\n" "v_min_f32_e32 v43, v38, v39\n" "v_min_f32_e32 v48, v40, v41\n" \
+        "v_max_f32_e32 v36, v36, v37\n" "v_max_f32_e32 v38, v38, v39\n" "v_max_f32_e32 v40, v40, v41\n" \
+        "v_min3_f32 v36, v36, v38, v40\n" "v_max3_f32 v42, v42, v43, v48\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v36\n" "v_min_f32_e32 v36, v36, v21\n" "v_cmp_nlt_f32_e64 s[66:67], v36, v42\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" "v_cmp_lt_i32_e32 vcc, -1, v47\n" "v_add_u32_e32 v36, 32, v12\n" \
+        "s_or_b64 s[68:69], vcc, s[66:67]\n" "s_and_b64 vcc, vcc, s[66:67]\n" \
+        "v_cndmask_b32_e64 v12, v46, v36, s[68:69]\n" "v_cndmask_b32_e32 v14, v14, v47, vcc\n" "v_cndmask_b32_e32 v13, v13, v46, vcc\n" \
+        "TP_N2B_%=:\n"
+
+__device__ __forceinline__ void trace_pool_global_both_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop)
+{
+    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
+    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
+    const int s_end = __builtin_amdgcn_readfirstlane(mem.end - mem.first);      // bytes of one node array
+    const int s_vstride = __builtin_amdgcn_readfirstlane(mem.near_stride);
+    const int s_first = s_vstride, s_bias = 0;                                   // variant 0, or variant 1 + octant
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
+    const unsigned long long s_nodes = uniform64((unsigned long long)mem.nodes);
+    const unsigned s_trioff = __builtin_amdgcn_readfirstlane((unsigned)(mem.tris - mem.nodes));     // one allocation, triangles behind the nodes
+    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
+    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
+    const int s_tstop = __builtin_amdgcn_readfirstlane(mem.end - mem.first >= 65536 * 32 ? PT_STOP_T : PT_STOP_T_SMALL);
+    asm volatile(
+        "s_mov_b32 s70, 0\n"
+        "s_mov_b32 s76, 0x322bcc77\n"
+        "s_mov_b32 s77, 0x71800000\n"
+        "s_mov_b64 s[64:65], 0\n"
+        PT_ENTRY_RESUME
+        "s_branch TP_FILL_%=\n"
+        PT_LOOP_ALIGN
+        "TP_LOOP_%=:\n"
+        "v_cmp_le_i32_e64 s[60:61], v13, v14\n"
+        "v_cmp_gt_i32_e64 s[62:63], v3, v12\n"
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"
+        "s_or_b64 s[66:67], s[60:61], s[62:63]\n"
+        "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n"
+        "s_cbranch_scc1 TP_FIN_%=\n"
+        "TP_VOTE_%=:\n"
+        "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n"
+        "s_bcnt1_i32_b64 s71, s[62:63]\n"
+        "s_bcnt1_i32_b64 s72, s[60:61]\n"
+        /* too few lanes at a triangle: they wait (unless nobody is at a node) */
+        "s_cmp_ge_u32 s72, %[leafmin]\n"
+        "s_cbranch_scc1 TP_VOTED_%=\n"
+        "s_cmp_eq_u32 s71, 0\n"
+        "s_cbranch_scc1 TP_VOTED_%=\n"
+        "s_mov_b64 s[60:61], 0\n"
+        "TP_VOTED_%=:\n"
+        /* ---- one set of fetches (v33 is the offset: the fetch that overwrites it goes last) */
+        "s_mov_b64 exec, s[60:61]\n"
+        "v_add_u32_e32 v33, %[trioff], v13\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_mov_b32_e32 v33, v12\n"
+        "s_or_b64 exec, s[60:61], s[62:63]\n"
+        "global_load_dwordx4 v[24:27], v33, %[nodes]\n"
+        "global_load_dwordx4 v[28:31], v33, %[nodes] offset:16\n"
+        "global_load_dwordx4 v[44:47], v33, %[nodes] offset:48\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        "global_load_dwordx4 v[48:51], v33, %[nodes] offset:64\n"
+        "global_load_dword v52, v33, %[nodes] offset:80\n"
+        "s_or_b64 exec, s[60:61], s[62:63]\n"
+        "global_load_dwordx4 v[32:35], v33, %[nodes] offset:32\n"
+        /* ---- node block (exec = s[62:63]) */
+        "s_mov_b64 exec, s[62:63]\n"
+        "s_cbranch_execz TP_TRI_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_sub_f32_e32 v36, v24, v0\n"
+        "v_sub_f32_e32 v37, v27, v0\n"
+        "v_sub_f32_e32 v38, v25, v1\n"
+        "v_sub_f32_e32 v40, v26, v2\n"
+        "v_sub_f32_e32 v39, v28, v1\n"
+        "v_sub_f32_e32 v41, v29, v2\n"
+        "v_mul_f32_e32 v36, v8, v36\n"
+        "v_mul_f32_e32 v37, v8, v37\n"
+        "v_mul_f32_e32 v38, v9, v38\n"
+        "v_mul_f32_e32 v39, v9, v39\n"
+        "v_mul_f32_e32 v40, v10, v40\n"
+        "v_mul_f32_e32 v41, v10, v41\n"
+        "v_min_f32_e32 v42, v36, v37\n"
+        "v_min_f32_e32 v43, v38, v39\n"
+        "v_min_f32_e32 v48, v40, v41\n"
+        "v_max_f32_e32 v36, v36, v37\n"
+        "v_max_f32_e32 v38, v38, v39\n"
+        "v_max_f32_e32 v40, v40, v41\n"
+        "v_min3_f32 v36, v36, v38, v40\n"
+        "v_max3_f32 v42, v42, v43, v48\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v36\n"
+        "v_min_f32_e32 v36, v36, v21\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v36, v42\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_lt_i32_e32 vcc, -1, v31\n"
+        "v_add_u32_e32 v36, 32, v12\n"
+        "s_or_b64 s[68:69], vcc, s[66:67]\n"
+        "s_and_b64 vcc, vcc, s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v30, v36, s[68:69]\n"
+        "v_cndmask_b32_e32 v14, v14, v31, vcc\n"
+        "v_cndmask_b32_e32 v13, v13, v30, vcc\n"
+        PT_NODE2_LOOKAHEAD_B
+        /* ---- triangle block (exec = s[60:61]) */
+        "TP_TRI_%=:\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        "s_cbranch_execz TP_BACK_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_add_u32_e32 v13, 48, v13\n"
+        "v_mul_f32_e32 v33, v5, v32\n"
+        "v_mul_f32_e32 v42, v6, v31\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v6, v30\n"
+        "v_mul_f32_e32 v42, v4, v32\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v4, v31\n"
+        "v_mul_f32_e32 v42, v5, v30\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v36, v33, v27\n"
+        "v_mul_f32_e32 v42, v34, v28\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_mul_f32_e32 v42, v35, v29\n"
+        "v_add_f32_e32 v36, v36, v42\n"
+        "v_rcp_f32_e32 v38, v36\n"
+        "v_sub_f32_e32 v24, v0, v24\n"
+        "v_sub_f32_e32 v25, v1, v25\n"
+        "v_sub_f32_e32 v26, v2, v26\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
+        "v_fma_f32 v41, -v36, v38, 1.0\n"
+        "v_fma_f32 v37, v41, v38, v38\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TP_DIV_IEEE_%=\n"
+        "TP_DIV_DONE_%=:\n"
+        "v_mul_f32_e32 v43, v24, v33\n"
+        "v_mul_f32_e32 v42, v25, v34\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v42, v26, v35\n"
+        "v_add_f32_e32 v43, v43, v42\n"
+        "v_mul_f32_e32 v33, v25, v29\n"
+        "v_mul_f32_e32 v42, v26, v28\n"
+        "v_sub_f32_e32 v33, v33, v42\n"
+        "v_mul_f32_e32 v34, v26, v27\n"
+        "v_mul_f32_e32 v42, v24, v29\n"
+        "v_sub_f32_e32 v34, v34, v42\n"
+        "v_mul_f32_e32 v35, v24, v28\n"
+        "v_mul_f32_e32 v42, v25, v27\n"
+        "v_sub_f32_e32 v35, v35, v42\n"
+        "v_mul_f32_e32 v43, v43, v37\n"
+        "v_mul_f32_e32 v38, v4, v33\n"
+        "v_mul_f32_e32 v42, v5, v34\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v42, v6, v35\n"
+        "v_add_f32_e32 v38, v38, v42\n"
+        "v_mul_f32_e32 v38, v38, v37\n"
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"
+        "v_add_f32_e32 v42, v43, v38\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TP_TRI_END_%=\n"
+        "v_mul_f32_e32 v39, v30, v33\n"
+        "v_mul_f32_e32 v42, v31, v34\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v42, v32, v35\n"
+        "v_add_f32_e32 v39, v39, v42\n"
+        "v_mul_f32_e32 v39, v39, v37\n"
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v39, v21\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TP_TRI_END_%=\n"
+        "v_and_b32_e32 v42, 0x100, v11\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v42\n"
+        "v_mov_b32_e32 v24, v3\n"
+        "v_mov_b32_e32 v21, v39\n"
+        "v_subrev_u32_e32 v20, 48, v13\n"
+        "v_mov_b32_e32 v22, v43\n"
+        "v_mov_b32_e32 v23, v38\n"
+        "v_cndmask_b32_e32 v12, v12, v24, vcc\n"
+        "v_cndmask_b32_e64 v14, v14, -1, vcc\n"
+        "TP_TRI_END_%=:\n"
+        PT_TRI2_LOOKAHEAD("v3")
+        "TP_BACK_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TP_LOOP_%=\n"
+        "TP_DIV_IEEE_%=:\n"
+        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
+        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
+        "v_rcp_f32_e32 v38, v37\n"
+        "s_nop 0\n"
+        "v_fma_f32 v41, -v37, v38, 1.0\n"
+        "v_fmac_f32_e32 v38, v41, v38\n"
+        "v_mul_f32_e32 v40, v39, v38\n"
+        "v_fma_f32 v41, -v37, v40, v39\n"
+        "v_fmac_f32_e32 v40, v41, v38\n"
+        "v_fma_f32 v37, -v37, v40, v39\n"
+        "v_div_fmas_f32 v37, v37, v38, v40\n"
+        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
+        "s_branch TP_DIV_DONE_%=\n"
+        "TP_FIN_%=:\n"
+        "s_mov_b64 exec, s[68:69]\n"
+        "s_mov_b32 s72, 0xaaaaaaab\n"
+        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
+        "v_subrev_u32_e32 v33, %[bias], v20\n"
+        "v_mul_hi_u32 v33, v33, s72\n"
+        "v_lshrrev_b32_e32 v33, 5, v33\n"
+        "v_cndmask_b32_e64 v20, v33, -1, vcc\n"
+        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"
+        "ds_write_b128 v15, v[20:23] offset:16\n"
+        PT_FINISH_PENDING
+        "v_mov_b32_e32 v15, -1\n"
+        "s_mov_b64 exec, -1\n"
+        "TP_FILL_%=:\n"
+        "s_cmp_ge_i32 s70, %[rays]\n"
+        "s_cbranch_scc1 TP_EMPTY_%=\n"
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
+        "s_cmp_gt_u32 s71, %[maxbusy]\n"
+        "s_cbranch_scc1 TP_VOTE_%=\n"
+        "s_not_b64 s[66:67], s[64:65]\n"
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
+        "v_add_u32_e32 v33, s70, v33\n"
+        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
+        "s_and_b64 s[66:67], vcc, s[66:67]\n"
+        "s_sub_i32 s71, 64, s71\n"
+        "s_add_i32 s70, s70, s71\n"
+        "s_mov_b64 exec, s[66:67]\n"
+        PT_FETCH_ORDERED
+        "ds_read_b128 v[4:7], v15\n"
+        "ds_read_b128 v[8:11], v15 offset:16\n"
+        "v_mov_b32_e32 v13, 0\n"
+        "v_mov_b32_e32 v14, -1\n"
+        "v_mov_b32_e32 v20, -1\n"
+        "v_mov_b32_e32 v22, 0\n"
+        "v_mov_b32_e32 v23, 0\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        PT_CURSOR_VARIANT
+        "v_and_b32_e32 v33, 0xff, v11\n"
+        "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
+        "ds_read_b96 v[0:2], v33 offset:%[org]\n"
+        "v_mov_b32_e32 v21, v7\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TP_LOOP_%=\n"
+        "TP_EMPTY_%=:\n"
+        PT_DRY_MAY_STOP
+        "TP_DONE_%=:\n"
+        PT_EXIT_SUSPEND
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        :
+        : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias),
+          [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
+          [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop), [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16),
+          [leafmin] "n"(PT_BOTH_LEAF_MIN)
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
+          "s72", "s76", "s77", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14",
+          "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32",
+          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52");
+}
+
+
 
 // ---- trace_pool_wide<>, hand-scheduled -------------------------------------------------------------------------------------
 // The instruction-for-instruction twin of trace_pool_wide<> above (which stays the specification and runs in the counting
@@ -4025,7 +4308,11 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 if (COUNT && !PT_ASM_IN_COUNT)      // (the twin always drains to the end: nothing is ever suspended)
                     trace_pool<COUNT, true>(P, pool, n_new, cnt, mem);
                 else
+#if PT_GLOBAL_BOTH && !PT_LOOP_PROBE
+                    trace_pool_global_both_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0);
+#else
                     trace_pool_global_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0, loop_probe);
+#endif
             }
             if (COUNT) {
                 cyc_mark = __builtin_readcyclecounter();
@@ -4264,7 +4551,11 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
                     mem.end = 32 * P.n_nodes;
                     mem.tri_bias = 0;
                     mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
+#if PT_GLOBAL_BOTH && !PT_LOOP_PROBE
+                    trace_pool_global_both_asm(lds_address(pool), fresh, mem, P.eps, fresh > 0);
+#else
                     trace_pool_global_asm(lds_address(pool), fresh, mem, P.eps, fresh > 0);
+#endif
                 }
                 wave_lds_fence();
                 const bool pending = valid && reinterpret_cast<const volatile unsigned *>(pool + kPendOff)[lane] != 0u;

@@ -399,8 +399,25 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     }
 
     DevParams &P = ctx->P;
-    if ((rc = dev_upload(ctx, nodes.data(), nodes.size(), &P.nodes)) != GPT_OK) return fail(rc);
-    if ((rc = dev_upload(ctx, tris.data(), tris.size(), &P.tris)) != GPT_OK) return fail(rc);
+    {
+        // nodes and triangles share ONE allocation, triangles behind the nodes: the global-memory loop fetches for its node lanes and
+        // its triangle lanes with the same instructions, a 32-bit offset per lane from the base of the nodes
+        const size_t node_bytes = nodes.size() * sizeof(nodes[0]), tri_bytes = tris.size() * sizeof(DevTri);
+        if (node_bytes + tri_bytes > (size_t)UINT32_MAX) {
+            gpt_set_error("gpt_begin: node arrays and triangles exceed 4 GB");
+            return fail(GPT_ERR_UNSUPPORTED);
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, node_bytes + tri_bytes) != hipSuccess) { gpt_set_error("gpt_begin: hipMalloc(nodes + triangles) failed"); return fail(GPT_ERR_HIP); }
+        ctx->allocs.push_back(p);
+        if (hipMemcpy(p, nodes.data(), node_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(static_cast<char *>(p) + node_bytes, tris.data(), tri_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            gpt_set_error("gpt_begin: upload of nodes / triangles failed");
+            return fail(GPT_ERR_HIP);
+        }
+        P.nodes = static_cast<const DevNode *>(p);
+        P.tris = reinterpret_cast<const DevTri *>(static_cast<const char *>(p) + node_bytes);
+    }
     ctx->wide_host.swap(wide_dev);          // (128 B per wide node: uploaded only if the wide walk is ever selected)
     if ((rc = dev_upload(ctx, shade.data(), shade.size(), &P.shade)) != GPT_OK) return fail(rc);
     if ((rc = dev_upload(ctx, scene->materials, (size_t)scene->n_materials, &P.materials)) != GPT_OK) return fail(rc);
