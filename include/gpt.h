@@ -53,7 +53,9 @@ const char *gpt_version(void);
  * (kernel_acc_image) and last-sample (kernel_color) planes, both zeroed.
  * `device` is the HIP device ordinal.  The caller keeps ownership of `scene`:
  * every array it points at (density grids of heterogeneous media included) is
- * read before gpt_begin returns and never afterwards. */
+ * read before gpt_begin returns and never afterwards.  Node arrays and triangle
+ * records share one device allocation addressed with 32-bit offsets: a scene whose
+ * two together exceed 4 GB (about 50 M triangles) is refused, GPT_ERR_UNSUPPORTED. */
 int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, float epsilon,
               int device, gpt_ctx **out);
 
