@@ -37,75 +37,11 @@
 //
 // Draw order inside argument lists is left to right.
 
-#include <hip/hip_runtime.h>
-#include <cstdlib>
-#include "pt_layout.h"
+#include "pt_device.h"
+#include "pt_shade.h"
 #include "../../include/gpt_wide_bvh.h"
 
 namespace pt {
-
-// ---------------------------------------------------------------- RNG --------
-struct Rng {
-    uint32_t x;
-};
-__device__ __forceinline__ uint32_t wang_hash(uint32_t seed)
-{
-    seed = (seed ^ 61u) ^ (seed >> 16);
-    seed = seed + (seed << 3);
-    seed = seed ^ (seed >> 4);
-    seed = seed * 0x27d4eb2du;
-    seed = seed ^ (seed >> 15);
-    return seed;
-}
-__device__ __forceinline__ void rng_seed(Rng &r, uint32_t s)
-{
-    uint32_t x = s % 2147483647u;     // minstd_rand::seed
-    r.x = x == 0 ? 1u : x;
-}
-// x <- x * 48271 mod (2^31 - 1) without a 64-bit division: for p < 2^47,
-// p mod (2^31-1) = (p & m) + (p >> 31), minus m once if that reaches m.
-__device__ __forceinline__ float rng_uniform(Rng &r)
-{
-    uint64_t p = (uint64_t)r.x * 48271ull;
-    uint32_t s = (uint32_t)(p & 0x7fffffffu) + (uint32_t)(p >> 31);
-    if (s >= 2147483647u) s -= 2147483647u;
-    r.x = s;
-    // uniform_real_distribution<float>(0,1): float(x - 1) / 2^31 (exact scaling)
-    return (float)(s - 1u) * 4.656612873077392578125e-10f;
-}
-
-// -------------------------------------------------------------- records ------
-struct Ray {
-    V3 o, d;
-    float tmin, tmax;
-};
-struct Hit {
-    V3 pos, nor;
-    V2 uv;
-    V3 dpdu;
-    int matIdx, lightIdx;
-};
-struct Counters {
-    uint32_t node_visits, prim_tests, bounce_iters, shadow_rays, closest_rays, samples;
-    // utilisation probes (counting build): wave-level trips, incremented by one lane per wave per trip
-    uint32_t w_node, w_prim, w_trip, l_trip, w_shade, l_shade, w_nee, l_nee;
-};
-// Wave votes.  The builtin takes the i1 directly (HIP's __ballot(int) widens the predicate to a VGPR and
-// compares it again: two VALU instructions per vote in the traversal loop), and counting the halves
-// separately keeps every comparison of counts on the scalar unit (a 64-bit ctpop is compared as u64 on VALU).
-__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ int popc(unsigned long long m)
-{
-    return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
-}
-__device__ __forceinline__ bool first_active_lane()
-{
-    const unsigned long long m = ballot(true);
-    return (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m);
-}
-
-__device__ __forceinline__ V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
-__device__ __forceinline__ V3 rcp3(V3 d) { return V3{1.f / d.x, 1.f / d.y, 1.f / d.z}; }
 
 // ------------------------------------------------------------ traversal ------
 // Rays live in an LDS pool that belongs to ONE wavefront (no workgroup barrier
@@ -204,17 +140,6 @@ struct RayResult {
     float t, b1, b2;
 };
 
-__device__ __forceinline__ int lane_rank(unsigned long long mask)   // number of set bits below this lane
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-__device__ __forceinline__ void wave_lds_fence()
-{
-    // LDS operations of one wave execute in issue order; this only stops the compiler from
-    // moving LDS accesses across the hand-off between lanes.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // slot = { dir.xyz, tmax } { 1/dir.xyz, bits(owner lane | any_hit << 8) }; the result replaces the second half
 __device__ __forceinline__ void pool_put(float4 *pool, int slot, V3 dir, float tmax, unsigned owner, bool any_hit)
@@ -319,16 +244,6 @@ struct LdsScene {
     float tri1(int) const { return 0.f; }
 #endif
 };
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)      // wave-uniform value -> SGPR pair
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned lds_address(const void *p)      // LDS byte address of a __shared__ object
-{
-    return (unsigned)(unsigned long long)p;                          // low half of the flat (shared aperture) address
-}
 
 template <bool COUNT, bool FIXED, class Mem>
 __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, const Mem mem)
@@ -2369,772 +2284,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 }
 
-// mesh.h:68-95 evaluated once for the final hit
-__device__ __forceinline__ Hit make_hit(const DevParams &P, const Ray &ray, float tt, int prim, float b1, float b2)
-{
-    const float4 *__restrict__ sp = reinterpret_cast<const float4 *>(P.shade) + 5 * prim;
-    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-    const V3 n1 = V3{s0.x, s0.y, s0.z}, n2 = V3{s0.w, s1.x, s1.y}, n3 = V3{s1.z, s1.w, s2.x};
-    const V2 uv1 = V2{s2.y, s2.z}, uv2 = V2{s2.w, s3.x}, uv3 = V2{s3.y, s3.z};
-    const V3 ndpdv = V3{s3.w, s4.x, s4.y};
-    Hit h;
-    h.pos = ray.o + tt * ray.d;
-    h.nor = normalize(n1 * (1.f - b1 - b2) + n2 * b1 + n3 * b2);
-    h.uv = uv1 * (1.f - b1 - b2) + uv2 * b1 + uv3 * b2;
-    h.matIdx = __float_as_int(s4.z);
-    h.lightIdx = __float_as_int(s4.w);
-    h.dpdu = normalize(cross(h.nor, ndpdv));
-    return h;
-}
-
-// ------------------------------------------------------------- samplers ------
-__device__ __forceinline__ V3 to_world(V3 dir, V3 u, V3 v, V3 w) { return dir.x * u + dir.y * v + dir.z * w; }
-
-__device__ __forceinline__ V3 cosine_hemisphere(float u1, float u2, float &pdf)   // wrap.h:51-62
-{
-    float sintheta = sqrt_rn(u1);
-    float costheta = sqrt_rn(1.f - u1);
-    float phi = TWOPI * u2;
-    float cosphi = gpt_cosf(phi);
-    float sinphi = gpt_sinf(phi);
-    pdf = costheta * ONE_OVER_PI;
-    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-}
-__device__ __forceinline__ V3 uniform_sphere(float u1, float u2, float &pdf)      // wrap.h:26-36
-{
-    float costheta = 1.f - 2.f * u1;
-    float sintheta = sqrt_rn(1.f - costheta * costheta);
-    float phi = TWOPI * u2;
-    float cosphi = gpt_cosf(phi);
-    float sinphi = gpt_sinf(phi);
-    pdf = ONE_OVER_FOUR_PI;
-    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-}
-
-// --------------------------------------------------------------- camera ------
-// `du1, du2` are the two draws of UniformDisk (pathtracer.cu:895, wrap.h:78-85).  The reference always
-// evaluates the disk sample; only the thin-lens branch reads it, so its sin/cos is evaluated there.
-__device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y, float du1, float du2)   // camera.h:48-84
-{
-    const V3 cu = V3{c.u.x, c.u.y, c.u.z}, cv = V3{c.v.x, c.v.y, c.v.z}, cw = V3{c.w.x, c.w.y, c.w.z};
-    Ray ray;
-    ray.tmin = 0.001f;
-    ray.tmax = __builtin_inff();
-    V3 orig = V3{c.position.x, c.position.y, c.position.z};
-    if (c.environment) {
-        float theta = PI * (1.f - y / c.resolution.y);
-        float phi = TWOPI * (1.f - x / c.resolution.x);
-        V3 dir = v3(gpt_sinf(theta) * gpt_cosf(phi), gpt_cosf(theta), gpt_sinf(theta) * gpt_sinf(phi));
-        dir = dir.x * cu + dir.y * cv - dir.z * cw;
-        ray.o = orig;
-        ray.d = dir;
-        return ray;
-    }
-    float xx = x * c.pixel2screen.x - c.width;
-    float yy = y * c.pixel2screen.y - c.height;
-    V3 dir;
-    if (c.apertureRadius > 0.00001f) {
-        float rr = sqrt_rn(du1);                  // UniformDisk
-        float phi = TWOPI * du2;
-        V2 xy = v2(rr * gpt_cosf(phi), rr * gpt_sinf(phi));
-        V2 aperture_xy = xy * c.apertureRadius;
-        float focal_x = c.ratio * xx;
-        float focal_y = c.ratio * yy;
-        V3 aperture = v3(aperture_xy.x, aperture_xy.y, 0);
-        V3 focal = v3(focal_x, focal_y, -c.focalDistance);
-        dir = focal - aperture;
-        dir = dir.x * cu + dir.y * cv + dir.z * cw;
-        orig += (aperture.x * cu + aperture.y * cv);
-    } else {
-        dir = xx * cu + yy * cv + -c.distance * cw;
-    }
-    dir = normalize(dir);
-    ray.o = orig;
-    ray.d = dir;
-    return ray;
-}
-
-// ------------------------------------------------------------- textures ------
-__device__ __forceinline__ V4 texel_int(const DevTexture &t, int w, int h, int x, int y)   // pathtracer.cu:324-339
-{
-    float inv = 1.f / 255.f;
-    float rx = x - (x / w) * w;
-    float ry = y - (y / h) * h;
-    x = (rx < 0) ? rx + w : rx;
-    y = (ry < 0) ? ry + h : ry;
-    if (x < 0) x = 0;
-    if (x > w - 1) x = w - 1;
-    if (y < 0) y = 0;
-    if (y > h - 1) y = h - 1;
-    gpt_uchar4 c = t.data[y * w + x];
-    return v4(c.x * inv, c.y * inv, c.z * inv, c.w * inv);
-}
-__device__ __forceinline__ V3 get_texel(const DevParams &P, const gpt_material &m, V2 uv)   // pathtracer.cu:341-359
-{
-    if (m.textureIdx == -1)
-        return V3{m.diffuse.x, m.diffuse.y, m.diffuse.z};
-#ifdef PT_ANALYSIS_LAMBERT
-    return V3{0.f, 0.f, 0.f};
-#endif
-    const DevTexture t = P.textures[m.textureIdx];
-    int w = t.width, h = t.height;
-    float xx = w * uv.x;
-    float yy = h * uv.y;
-    int x = (int)__builtin_floorf(xx);
-    int y = (int)__builtin_floorf(yy);
-    float dx = fabs_(xx - x);
-    float dy = fabs_(yy - y);
-    V4 c00 = texel_int(t, w, h, x, y);
-    V4 c10 = texel_int(t, w, h, x + 1, y);
-    V4 c01 = texel_int(t, w, h, x, y + 1);
-    V4 c11 = texel_int(t, w, h, x + 1, y + 1);
-    V4 r = (1 - dy) * ((1 - dx) * c00 + dx * c10) + dy * ((1 - dx) * c01 + dx * c11);
-    return V3{r.x, r.y, r.z};
-}
-
-// --------------------------------------------------------- BSDF helpers ------
-__device__ __forceinline__ float dielectric_fresnel(float cosi, float cost, float etai, float etat)   // :51-56
-{
-    float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
-    float Rperp = (etai * cosi - etat * cost) / (etai * cosi + etat * cost);
-    return (Rparl * Rparl + Rperp * Rperp) * 0.5f;
-}
-__device__ __forceinline__ V3 conduct_fresnel(float cosi, V3 eta, V3 k)                              // :58-66
-{
-    V3 tmp = (eta * eta + k * k) * cosi * cosi;
-    V3 Rparl2 = (tmp - eta * cosi * 2.f + 1.f) / (tmp + eta * cosi * 2.f + 1.f);
-    V3 tmp_f = (eta * eta + k * k);
-    V3 Rperp2 = (tmp_f - eta * cosi * 2.f + cosi * cosi) / (tmp_f + eta * cosi * 2.f + cosi * cosi);
-    return (Rparl2 + Rperp2) * 0.5f;
-}
-__device__ __forceinline__ float ggx_d(V3 wh, V3 normal, V3 dpdu, float alphaU, float alphaV)        // :68-84
-{
-    float costheta = dot(wh, normal);
-    if (costheta <= 0.f) return 0.f;
-    costheta = clamp(costheta, 0.f, 1.f);
-    float costheta2 = costheta * costheta;
-    float sintheta2 = 1.f - costheta2;
-    float costheta4 = costheta2 * costheta2;
-    float tantheta2 = sintheta2 / costheta2;
-    V3 uu = dpdu;
-    V3 dir = normalize(wh - costheta * normal);
-    float cosphi = dot(dir, uu);
-    float cosphi2 = cosphi * cosphi;
-    float sinphi2 = 1.f - cosphi2;
-    float sqrD = 1.f + tantheta2 * (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
-    return 1.f / (PI * alphaU * alphaV * costheta4 * sqrD * sqrD);
-}
-__device__ __forceinline__ float smith_g(V3 w, V3 normal, V3 wh, V3 dpdu, float alphaU, float alphaV)  // :86-101
-{
-    float wdn = dot(w, normal);
-    if (wdn * dot(w, wh) < 0.f) return 0.f;
-    float sintheta = sqrt_rn(clamp(1.f - wdn * wdn, 0.f, 1.f));
-    float tantheta = sintheta / wdn;
-    if (gpt_isinff(tantheta)) return 0.f;
-    V3 uu = dpdu;
-    V3 dir = normalize(w - wdn * normal);
-    float cosphi = dot(dir, uu);
-    float cosphi2 = cosphi * cosphi;
-    float sinphi2 = 1.f - cosphi2;
-    float alpha2 = cosphi2 * (alphaU * alphaU) + sinphi2 * (alphaV * alphaV);
-    float sqrD = alpha2 * tantheta * tantheta;
-    return 2.f / (1.f + sqrt_rn(1 + sqrD));
-}
-__device__ __forceinline__ float ggx_g(V3 wo, V3 wi, V3 normal, V3 wh, V3 dpdu, float aU, float aV)    // :103-105
-{
-    return smith_g(wo, normal, wh, dpdu, aU, aV) * smith_g(wi, normal, wh, dpdu, aU, aV);
-}
-__device__ __forceinline__ V3 sample_ggx(float alphaU, float alphaV, float u1, float u2)              // :107-138
-{
-    if (alphaU == alphaV) {
-        float costheta = sqrt_rn((1.f - u1) / (u1 * (alphaU * alphaV - 1.f) + 1.f));
-        float sintheta = sqrt_rn(1.f - costheta * costheta);
-        float phi = 2 * PI * u2;
-        float cosphi = gpt_cosf(phi);
-        float sinphi = gpt_sinf(phi);
-        return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-    } else {
-        float phi;
-        if (u2 <= 0.25f) phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2));
-        else if (u2 >= 0.75f) phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2)) + TWOPI;
-        else phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2)) + PI;
-        float sinphi = gpt_sinf(phi), cosphi = gpt_cosf(phi);
-        float sinphi2 = sinphi * sinphi;
-        float cosphi2 = 1.0f - sinphi2;
-        float inverseA = 1.0f / (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
-        float theta = gpt_atanf(sqrt_rn(inverseA * u1 / (1.0f - u1)));
-        float sintheta = gpt_sinf(theta), costheta = gpt_cosf(theta);
-        return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-    }
-}
-__device__ __forceinline__ V3 reflect(V3 in, V3 nor) { return 2.f * dot(in, nor) * nor - in; }       // :140-142
-__device__ __forceinline__ V3 refract(V3 in, V3 nor, float etai, float etat)                          // :144-158
-{
-    float cosi = dot(in, nor);
-    bool enter = cosi > 0;
-    if (!enter) {
-        float t = etai;
-        etai = etat;
-        etat = t;
-    }
-    float eta = etai / etat;
-    float sini2 = 1.f - cosi * cosi;
-    float sint2 = sini2 * eta * eta;
-    float cost = sqrt_rn(1.f - sint2);
-    return normalize((nor * cosi - in) * eta + (enter ? -cost : cost) * nor);
-}
-__device__ __forceinline__ V3 schlick_fresnel(V3 specular, float costheta)                            // :160-164
-{
-    V3 rs = specular;
-    float c = 1.f - costheta;
-    return rs + c * c * c * c * c * (v3(1.f, 1.f, 1.f) - rs);
-}
-__device__ __forceinline__ float power_heuristic(int nf, float fPdf, int ng, float gPdf)              // :166-169
-{
-    float f = nf * fPdf, g = ng * gPdf;
-    return (f * f) / (f * f + g * g);
-}
-__device__ __forceinline__ float luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)); }
-__device__ __forceinline__ bool same_hemisphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }
-// PT_ANALYSIS_LAMBERT (never shipped): compile only the lambertian / area-light path, to read its ISA
-#ifdef PT_ANALYSIS_LAMBERT
-#define PT_MATERIAL_TYPE(m) GPT_MT_LAMBERTIAN
-#else
-#define PT_MATERIAL_TYPE(m) (m).type
-#endif
-__device__ __forceinline__ bool is_delta(int type) { return type == GPT_MT_MIRROR || type == GPT_MT_DIELECTRIC; }
-__device__ __forceinline__ float max_(float a, float b) { return a > b ? a : b; }                     // common.h:98-101
-
-// ------------------------------------------------- SampleBSDF, :491-695 ------
-__device__ __forceinline__ void sample_bsdf(const DevParams &P, const gpt_material &material, V3 in, V3 nor, V2 uv,
-                                            V3 dpdu, V3 u, V3 &out, V3 &fr, float &pdf)
-{
-    const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
-    switch (PT_MATERIAL_TYPE(material)) {
-    case GPT_MT_LAMBERTIAN: {
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        out = cosine_hemisphere(u.x, u.y, pdf);
-        V3 uu = dpdu, ww;
-        ww = cross(uu, n);
-        out = to_world(out, uu, n, ww);
-        fr = get_texel(P, material, uv) * ONE_OVER_PI;
-        break;
-    }
-    case GPT_MT_MIRROR:
-        out = reflect(in, nor);
-        fr = m_spec / fabs_(dot(out, nor));
-        pdf = 1.f;
-        break;
-    case GPT_MT_DIELECTRIC: {
-        V3 wi = -in;
-        V3 normal = nor;
-        float ei = material.outsideIOR, et = material.insideIOR;
-        float cosi = dot(wi, normal);
-        bool enter = cosi < 0;
-        if (!enter) {
-            float t = ei;
-            ei = et;
-            et = t;
-        }
-        float eta = ei / et, cost;
-        float sint2 = eta * eta * (1.f - cosi * cosi);
-        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-        V3 rdir = reflect(-wi, normal);
-        V3 tdir = refract(in, nor, material.outsideIOR, material.insideIOR);
-        if (sint2 > 1.f) {   // total reflection
-            out = rdir;
-            fr = m_spec / fabs_(dot(out, normal));
-            pdf = 1.f;
-            return;
-        }
-        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
-        if (u.x > fresnel) {   // refract
-            out = tdir;
-            fr = m_spec / fabs_(dot(out, normal)) * (1.f - fresnel);
-            fr *= eta * eta;   // TransportMode::Radiance
-            pdf = 1.f - fresnel;
-        } else {               // reflect
-            out = rdir;
-            fr = m_spec / fabs_(dot(out, normal)) * fresnel;
-            pdf = fresnel;
-        }
-        break;
-    }
-    case GPT_MT_ROUGHCONDUCTOR: {
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        V3 wh = sample_ggx(material.alphaU, material.alphaV, u.x, u.y);
-        V3 uu = dpdu, ww;
-        ww = cross(uu, n);
-        wh = to_world(wh, uu, n, ww);
-        out = reflect(in, wh);
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0, 0, 0);
-            pdf = 0.f;
-            return;
-        }
-        float cosi = dot(out, wh);
-        V3 F = conduct_fresnel(fabs_(cosi), V3{material.eta.x, material.eta.y, material.eta.z},
-                               V3{material.k.x, material.k.y, material.k.z});
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-        fr = m_spec * F * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-        pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(in, wh)));
-        break;
-    }
-    case GPT_MT_SUBSTRATE: {
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        if (u.x < 0.5f) {
-            float ux = u.x * 2.f;
-            out = cosine_hemisphere(ux, u.y, pdf);
-            V3 uu = dpdu, ww;
-            ww = cross(uu, n);
-            out = to_world(out, uu, n, ww);
-        } else {
-            float ux = (u.x - 0.5f) * 2.f;
-            V3 wh = sample_ggx(material.alphaU, material.alphaV, ux, u.y);
-            V3 uu = dpdu, ww;
-            ww = cross(uu, n);
-            wh = to_world(wh, uu, n, ww);
-            out = reflect(in, wh);
-        }
-        if (!same_hemisphere(in, out, n)) {
-            fr = v3(0.f, 0.f, 0.f);
-            pdf = 0.f;
-            return;
-        }
-        float c0 = fabs_(dot(in, n));
-        float c1 = fabs_(dot(out, n));
-        V3 Rd = get_texel(P, material, uv);
-        V3 Rs = m_spec;
-        float cons0 = 1 - 0.5f * c0;
-        float cons1 = 1 - 0.5f * c1;
-        V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) *
-                     (1 - cons0 * cons0 * cons0 * cons0 * cons0) *
-                     (1 - cons1 * cons1 * cons1 * cons1 * cons1);
-        V3 wh = normalize(in + out);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        V3 specular = D / (4.f * fabs_(dot(out, wh)) * max_(c0, c1)) * schlick_fresnel(Rs, dot(out, wh));
-        fr = diffuse + specular;
-        pdf = 0.5f * (fabs_(dot(out, n)) * ONE_OVER_PI + D * fabs_(dot(wh, n)) / (4.f * dot(in, wh)));
-        break;
-    }
-    case GPT_MT_ROUGHDIELECTRIC: {
-        V3 wi = -in;
-        V3 n = nor;
-        V3 wh = sample_ggx(material.alphaU, material.alphaV, u.x, u.y);
-        V3 uu = dpdu, ww;
-        ww = cross(uu, n);
-        wh = to_world(wh, uu, n, ww);
-        float ei = material.outsideIOR, et = material.insideIOR;
-        float cosi = dot(wi, n);
-        bool enter = cosi < 0;
-        if (!enter) {
-            float t = ei;
-            ei = et;
-            et = t;
-        }
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        float eta = ei / et, cost;
-        cosi = dot(wi, wh);
-        float sint2 = eta * eta * (1.f - cosi * cosi);
-        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-        V3 rdir = reflect(-wi, wh);
-        V3 tdir = normalize((wi - wh * cosi) * eta + (enter ? -cost : cost) * wh);
-        if (sint2 > 1.f) {   // total reflection
-            out = rdir;
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            fr = m_spec * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-            pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in)));
-            return;
-        }
-        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
-        if (u.z > fresnel) {   // refract
-            out = tdir;
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            float c = et * dot(out, wh) + ei * dot(in, wh);
-            fr = m_spec * ei * ei * D * G * (1.f - fresnel) * fabs_(dot(in, wh)) * fabs_(dot(out, wh)) /
-                 (fabs_(dot(out, n)) * fabs_(dot(in, n)) * c * c);
-            fr *= (1.f / (eta * eta));
-            pdf = (1.f - fresnel) * D * fabs_(dot(wh, n)) * et * et * fabs_(dot(out, wh)) / (c * c);
-        } else {               // reflect
-            out = rdir;
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            fr = m_spec * fresnel * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-            pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in))) * fresnel;
-        }
-        break;
-    }
-    default:
-        out = v3(0, 0, 0);
-        fr = v3(0, 0, 0);
-        pdf = 0.f;
-        break;
-    }
-}
-
-// ----------------------------------------------------------- Fr, :698-826 ----
-__device__ __forceinline__ void eval_bsdf(const DevParams &P, const gpt_material &material, V3 in, V3 out, V3 nor,
-                                          V2 uv, V3 dpdu, V3 &fr, float &pdf)
-{
-    const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
-    switch (PT_MATERIAL_TYPE(material)) {
-    case GPT_MT_LAMBERTIAN:
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0.f, 0.f, 0.f);
-            pdf = 0.f;
-            return;
-        }
-        fr = get_texel(P, material, uv) * ONE_OVER_PI;
-        pdf = fabs_(dot(out, nor)) * ONE_OVER_PI;
-        break;
-    case GPT_MT_MIRROR:
-    case GPT_MT_DIELECTRIC:
-        fr = v3(0.f, 0.f, 0.f);
-        pdf = 0.f;
-        break;
-    case GPT_MT_ROUGHCONDUCTOR: {
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0, 0, 0);
-            pdf = 0;
-            return;
-        }
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        V3 wh = normalize(in + out);
-        float cosi = dot(out, wh);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-        V3 F = conduct_fresnel(fabs_(cosi), V3{material.eta.x, material.eta.y, material.eta.z},
-                               V3{material.k.x, material.k.y, material.k.z});
-        fr = m_spec * F * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-        pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(in, wh)));
-        break;
-    }
-    case GPT_MT_SUBSTRATE: {
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0, 0, 0);
-            pdf = 0;
-            return;
-        }
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        float c0 = fabs_(dot(in, n));
-        float c1 = fabs_(dot(out, n));
-        V3 Rd = get_texel(P, material, uv);
-        V3 Rs = m_spec;
-        float cons0 = 1 - 0.5f * c0;
-        float cons1 = 1 - 0.5f * c1;
-        V3 wh = normalize(in + out);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) *
-                     (1 - cons0 * cons0 * cons0 * cons0 * cons0) *
-                     (1 - cons1 * cons1 * cons1 * cons1 * cons1);
-        V3 specular = D / (4.f * fabs_(dot(out, wh)) * max_(c0, c1)) * schlick_fresnel(Rs, dot(out, wh));
-        fr = diffuse + specular;
-        pdf = 0.5f * (fabs_(dot(out, n)) * ONE_OVER_PI + D * fabs_(dot(wh, n)) / (4.f * dot(in, wh)));
-        break;
-    }
-    case GPT_MT_ROUGHDIELECTRIC: {
-        V3 wi = -in;
-        V3 n = nor;
-        bool refl = dot(in, n) * dot(out, n) > 0;
-        float ei = material.outsideIOR, et = material.insideIOR;
-        float cosi = dot(wi, n);
-        bool enter = cosi < 0;
-        if (!enter) {
-            float t = ei;
-            ei = et;
-            et = t;
-        }
-        V3 wh = normalize(-(ei * in + et * out));
-        float eta = ei / et, cost;
-        cosi = dot(wi, wh);
-        float sint2 = eta * eta * (1.f - cosi * cosi);
-        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        if (!refl) {   // refract
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            float c = et * dot(out, wh) + ei * dot(in, wh);
-            fr = m_spec * ei * ei * D * G * (1.f - fresnel) * fabs_(dot(in, wh)) * fabs_(dot(out, wh)) /
-                 (fabs_(dot(out, n)) * fabs_(dot(in, n)) * c * c);
-            fr *= (1.f / (eta * eta));
-            pdf = (1.f - fresnel) * D * fabs_(dot(wh, n)) * et * et * fabs_(dot(out, wh)) / (c * c);
-        } else {
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            fr = m_spec * fresnel * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-            pdf = fresnel * D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in)));
-        }
-        break;
-    }
-    default:
-        fr = v3(0, 0, 0);
-        pdf = 0.f;
-        break;
-    }
-}
-
-// --------------------------------------------------------------- lights ------
-// Area::SampleLight (area.h:14-19) -> Triangle::SampleShape (mesh.h:100-109)
-__device__ __forceinline__ void area_sample_light(const DevLight &L, V3 pos, V2 u, V3 &rad, Ray &ray, V3 &nor,
-                                                  float &pdf, float eps)
-{
-    float su1 = sqrt_rn(u.x);                         // UniformTriangle, wrap.h:110-115
-    V2 uv = v2(1.f - su1, u.y * su1);
-    V3 p = uv.x * ld3(L.v1) + uv.y * ld3(L.v2) + (1 - uv.x - uv.y) * ld3(L.v3);
-    V3 normal = normalize(uv.x * ld3(L.n1) + uv.y * ld3(L.n2) + (1 - uv.x - uv.y) * ld3(L.n3));
-    V3 dir = p - pos;
-    nor = normal;
-    pdf = 1.f / (L.area * fabs_(dot(normal, normalize(dir)))) * dot(dir, dir);
-    if (dot(normal, dir) >= 0.f)
-        pdf = 0.f;
-    rad = pdf != 0.f ? ld3(L.radiance) : v3(0.f, 0.f, 0.f);
-    ray.o = pos;
-    ray.d = normalize(dir);
-    ray.tmin = eps;
-    ray.tmax = sqrt_rn(dot(dir, dir) - eps);
-}
-__device__ __forceinline__ V3 area_le(const DevLight &L, V3 nor, V3 dir)   // area.h:38-41
-{
-    if (dot(nor, dir) > 0.f) return ld3(L.radiance);
-    return v3(0.f, 0.f, 0.f);
-}
-
-__device__ __forceinline__ V3 inf_texel(const DevInfinite &I, int x, int y)   // infinite.h:79-94
-{
-    int width = I.width, height = I.height;
-    float rx = x - (x / width) * width;
-    float ry = y - (y / height) * height;
-    x = (rx < 0) ? rx + width : rx;
-    y = (ry < 0) ? ry + height : ry;
-    if (x < 0) x = 0;
-    if (x > width - 1) x = width - 1;
-    if (y < 0) y = 0;
-    if (y > height - 1) y = height - 1;
-    const float *c = I.data + 3 * (size_t)(y * width + x);
-    return V3{c[0], c[1], c[2]};
-}
-__device__ __forceinline__ V3 inf_texel_bilinear(const DevInfinite &I, V2 uv)   // infinite.h:66-77
-{
-    float xx = I.width * uv.x;
-    float yy = I.height * uv.y;
-    int x = (int)__builtin_floorf(xx);
-    int y = (int)__builtin_floorf(yy);
-    float dx = fabs_(xx - x);
-    float dy = fabs_(yy - y);
-    V3 c00 = inf_texel(I, x, y);
-    V3 c10 = inf_texel(I, x + 1, y);
-    V3 c01 = inf_texel(I, x, y + 1);
-    V3 c11 = inf_texel(I, x + 1, y + 1);
-    return (1 - dy) * ((1 - dx) * c00 + dx * c10) + dy * ((1 - dx) * c01 + dx * c11);
-}
-// Infinite::Le (infinite.h:47-59); SampleLight's lookup (:22-36) is the same arithmetic
-__device__ __forceinline__ V3 inf_le(const DevInfinite &I, V3 dir)
-{
-    const V3 iu = ld3(I.u), iv = ld3(I.v), iw = ld3(I.w);
-    float costheta = dot(dir, iv);
-    float theta = gpt_acosf(costheta);
-    V3 d = normalize(dir - costheta * iv);
-    float cosphi = dot(d, iu);
-    float phi = gpt_acosf(cosphi);
-    float c = dot(d, iw);
-    phi = c > 0 ? TWOPI - phi : phi;
-    float uu = phi / TWOPI;
-    float vv = theta / PI;
-    return inf_texel_bilinear(I, v2(1.f - uu, vv));
-}
-__device__ __forceinline__ void inf_sample_light(const DevInfinite &I, V3 pos, V2 uniform, V3 &rad, Ray &ray, V3 &nor,
-                                                 float &pdf, float eps)   // infinite.h:17-36
-{
-    float pdfW;
-    V3 dir = uniform_sphere(uniform.x, uniform.y, pdfW);
-    nor = -dir;
-    ray.o = pos;
-    ray.d = dir;
-    ray.tmin = eps;
-    ray.tmax = 2.f * I.radius - eps;
-    pdf = pdfW;
-    rad = inf_le(I, dir);
-}
-
-// Would Triangle::Intersect (mesh.h:45-67) accept this ray on the emitter's triangle, with tmax = inf?
-// Same operations, same order as the traversal's triangle step.
-__device__ __forceinline__ bool emitter_accepts(const DevLight &L, V3 o, V3 d, float tmin)
-{
-    const V3 v1 = ld3(L.v1);
-    const V3 e1 = ld3(L.v2) - v1;
-    const V3 e2 = ld3(L.v3) - v1;
-    const V3 s1 = cross(d, e2);
-    const float divisor = dot(s1, e1);
-    const float invDivisor = 1.0f / divisor;
-    const V3 s = o - v1;
-    const float b1 = dot(s, s1) * invDivisor;
-    const V3 s2 = cross(s, e1);
-    const float b2 = dot(d, s2) * invDivisor;
-    const float tt = dot(e2, s2) * invDivisor;
-    return !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) && !(b2 < 0.0f || b1 + b2 > 1.0f) &&
-           !(tt < tmin || tt > __builtin_inff());
-}
-constexpr int kEmitterPretestMax = 8;
-
-// pathtracer.cu:172-181 (no match — only for NaN u — returns -1 here; the
-// reference falls off the end of a non-void function)
-__device__ __forceinline__ int lookup_light_distribution(const DevParams &P, float u, float &pdf)
-{
-    for (int i = 0; i + 1 < P.n_cdf; ++i) {
-        float s = P.light_cdf[i];
-        float e = P.light_cdf[i + 1];
-        if (u >= s && u <= e) {
-            pdf = e - s;
-            return i;
-        }
-    }
-    pdf = 0.f;
-    return -1;
-}
-__device__ __forceinline__ float pdf_from_light_distribution(const DevParams &P, int idx)
-{
-    return P.light_cdf[idx + 1] - P.light_cdf[idx];
-}
-
-// ----------------------------------------------------------------- film ------
-__device__ __forceinline__ V3 tonemap(V3 in, bool filmic)   // pathtracer.cu:187-204
-{
-    if (filmic) {
-        V3 c = in - v3(0.004f, 0.004f, 0.004f);
-        c = V3{fmax_(0.f, c.x), fmax_(0.f, c.y), fmax_(0.f, c.z)};
-        c = (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
-        return c;
-    }
-    float one_over_gamma = 1.f / 2.2f;
-    float exposure = 1.41421356f;
-    in = V3{fmax_(in.x, 1e-5f), fmax_(in.y, 1e-5f), fmax_(in.z, 1e-5f)};
-    in.x = gpt_powf(in.x * exposure, one_over_gamma);
-    in.y = gpt_powf(in.y * exposure, one_over_gamma);
-    in.z = gpt_powf(in.z * exposure, one_over_gamma);
-    return in;
-}
-
-// ------------------------------------------------ participating media -----
-// Homogeneous media and the Henyey-Greenstein phase function (src/medium.h:9-51,196-233), as oracle/pt_oracle.c
-// restates them (hom_tr, hom_sample, medium_phase, medium_sample_phase).
-__device__ __forceinline__ V3 exp3(V3 c) { return V3{gpt_expf(c.x), gpt_expf(c.y), gpt_expf(c.z)}; }       // common.h:81-86
-__device__ __forceinline__ V3 hom_tr(const DevMedium &m, float tmax)                                          // medium.h:14-17
-{
-    return exp3(V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]} * (-tmax));
-}
-__device__ __forceinline__ V3 hom_sample(const DevMedium &m, float ray_tmax, float u, float &t, bool &sampled)  // medium.h:19-50
-{
-    const V3 sigmaT = V3{m.sigmaT[0], m.sigmaT[1], m.sigmaT[2]}, sigmaS = V3{m.sigmaS[0], m.sigmaS[1], m.sigmaS[2]};
-    float sigma = dot(sigmaT, v3(0.212671f, 0.715160f, 0.072169f));
-    float dist = -gpt_logf(u) / sigma;                                  // wrap.h:158-160
-    V3 Tr = exp3(sigmaT * (-dist));
-    float pdf = sigma * gpt_expf(sigma * -dist);
-    bool sampledMedium = dist < ray_tmax;
-    sampled = sampledMedium;
-    t = dist;
-    return sampledMedium ? (Tr * sigmaS) / pdf : (sigmaT * Tr) / pdf;
-}
-__device__ __forceinline__ float medium_phase(const DevMedium &m, V3 in, V3 out)                               // medium.h:222-233
-{
-    float g = m.g;
-    if (g == 0) return ONE_OVER_FOUR_PI;
-    float costheta = dot(in, out);
-    float cubicTerm = (1.f + g * g - 2.f * g * costheta);
-    return ONE_OVER_FOUR_PI * (1.f - g * g) / sqrt_rn(cubicTerm * cubicTerm * cubicTerm);
-}
-__device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, float uy)                      // medium.h:196-220
-{
-    float g = m.g;
-    float unused;
-    if (g == 0) return uniform_sphere(ux, uy, unused);
-    float costheta;
-    if (fabs_(g) < 1e-3f)
-        costheta = 1.f - 2.f * ux;
-    else {
-        float sqrtTerm = (1.f - g * g) / (1.f - g + 2.f * g * ux);
-        costheta = (1.f + g * g - sqrtTerm * sqrtTerm) / (2.f * g);
-    }
-    float sintheta = sqrt_rn(1.f - costheta * costheta);
-    float phi = TWOPI * uy;
-    float sinphi = gpt_sinf(phi), cosphi = gpt_cosf(phi);
-    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-}
-
-// Heterogeneous media (src/medium.h:53-182), as oracle/pt_oracle.c restates them (het_d, het_density; het_tr and
-// het_sample are the shared tracking loop of the PT_IT_VPT_WALK kernel): a density grid in the box p0..p1, sampled by
-// delta tracking; transmittance by delta (0), ratio (1) or residual ratio (2) tracking.  Every loop draws from the
-// path's generator and ends after iterMax steps at the latest.
-__device__ __forceinline__ int f2i_sat(float f)        // float -> int: truncate, saturate, NaN -> 0 - which is v_cvt_i32_f32
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    int r;
-    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(f));      // (a C++ cast leaves the out-of-range cases undefined)
-    return r;
-#else
-    return (int)f;
-#endif
-}
-__device__ __forceinline__ float lerp_(float a, float b, float t) { return a + t * (b - a); }               // cutil_math.h:1008-1011
-// getDensity (medium.h:160-174) with d() (:176-181) folded in: the eight corners share six coordinate conversions and
-// six range tests (per axis, for psi and psi + 1) instead of doing 24 of each; a corner outside the grid reads as 0.
-__device__ __forceinline__ float het_density(const DevMedium &m, V3 p)
-{
-    const V3 ps = v3(p.x * m.nx, p.y * m.ny, p.z * m.nz);
-    const V3 psi = v3(__builtin_floorf(ps.x), __builtin_floorf(ps.y), __builtin_floorf(ps.z));
-    const V3 delta = ps - psi;
-    const int x0 = f2i_sat(psi.x), x1 = f2i_sat(psi.x + 1), y0 = f2i_sat(psi.y), y1 = f2i_sat(psi.y + 1),
-              z0 = f2i_sat(psi.z), z1 = f2i_sat(psi.z + 1);
-    // !(x < 0 || x > nx - 1) as one unsigned comparison (nx > 0)
-    const bool vx0 = (unsigned)x0 < (unsigned)m.nx, vx1 = (unsigned)x1 < (unsigned)m.nx, vy0 = (unsigned)y0 < (unsigned)m.ny,
-               vy1 = (unsigned)y1 < (unsigned)m.ny, vz0 = (unsigned)z0 < (unsigned)m.nz, vz1 = (unsigned)z1 < (unsigned)m.nz;
-    const int sy = m.nx, sz = m.ny * m.nx;               // int idx = z*ny*nx + y*nx + x
-    const int r00 = z0 * sz + y0 * sy, r10 = z0 * sz + y1 * sy, r01 = z1 * sz + y0 * sy, r11 = z1 * sz + y1 * sy;
-    const float *g = m.density;
-    // branch-free: a corner outside the grid reads cell 0 and is then replaced by 0
-    const bool v000 = vx0 && vy0 && vz0, v100 = vx1 && vy0 && vz0, v010 = vx0 && vy1 && vz0, v110 = vx1 && vy1 && vz0,
-               v001 = vx0 && vy0 && vz1, v101 = vx1 && vy0 && vz1, v011 = vx0 && vy1 && vz1, v111 = vx1 && vy1 && vz1;
-    const float g000 = g[v000 ? r00 + x0 : 0], g100 = g[v100 ? r00 + x1 : 0];
-    const float g010 = g[v010 ? r10 + x0 : 0], g110 = g[v110 ? r10 + x1 : 0];
-    const float g001 = g[v001 ? r01 + x0 : 0], g101 = g[v101 ? r01 + x1 : 0];
-    const float g011 = g[v011 ? r11 + x0 : 0], g111 = g[v111 ? r11 + x1 : 0];
-    const float d000 = v000 ? g000 : 0.f, d100 = v100 ? g100 : 0.f, d010 = v010 ? g010 : 0.f, d110 = v110 ? g110 : 0.f;
-    const float d001 = v001 ? g001 : 0.f, d101 = v101 ? g101 : 0.f, d011 = v011 ? g011 : 0.f, d111 = v111 ? g111 : 0.f;
-    const float d00 = lerp_(d000, d100, delta.x);
-    const float d10 = lerp_(d010, d110, delta.x);
-    const float d01 = lerp_(d001, d101, delta.x);
-    const float d11 = lerp_(d011, d111, delta.x);
-    const float d0 = lerp_(d00, d10, delta.y);
-    const float d1 = lerp_(d01, d11, delta.y);
-    return lerp_(d0, d1, delta.z);
-}
-__device__ __forceinline__ V3 het_local(const DevMedium &m, V3 o, V3 d, float dist)      // (r(dist) - p0) / (p1 - p0)
-{
-    const V3 p0 = V3{m.p0[0], m.p0[1], m.p0[2]}, ext = V3{m.p1[0], m.p1[1], m.p1[2]} - p0;
-    const V3 p = (o + d * dist) - p0;
-    return v3(p.x / ext.x, p.y / ext.y, p.z / ext.z);
-}
-
-// ----------------------------------------------------- the render kernel -----
-// normal + light index of a hit, for the MIS light ray (mesh.h:87-90): the
-// other Intersection fields are not read at pathtracer.cu:960-976
-__device__ __forceinline__ void make_light_hit(const DevParams &P, int prim, float b1, float b2, V3 &nor, int &lightIdx)
-{
-    const float4 *__restrict__ sp = reinterpret_cast<const float4 *>(P.shade) + 5 * prim;
-    const float4 s0 = sp[0], s1 = sp[1];
-    const float n3z = reinterpret_cast<const float *>(sp + 2)[0];
-    lightIdx = __float_as_int(reinterpret_cast<const float *>(sp + 4)[3]);
-    const V3 n1 = V3{s0.x, s0.y, s0.z}, n2 = V3{s0.w, s1.x, s1.y}, n3 = V3{s1.z, s1.w, n3z};
-    nor = normalize(n1 * (1.f - b1 - b2) + n2 * b1 + n3 * b2);
-}
 
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4
