@@ -810,6 +810,9 @@ bool read_jpeg(const char *path, int &width, int &height, int &components, std::
     // stb_image steps them (the filter looks up on even output rows, down on odd ones; the last source row repeats)
     struct Up { int hs, vs, ystep, w_lores, ypos, rows; const unsigned char *line0, *line1; std::vector<unsigned char> buf; } up[4];
     for (int i = 0; i < ncomp; ++i) {
+        // stb_image takes hmax / h as the integer factor and pads its planes; a file whose factors do not divide the largest
+        // one (e.g. H = 4, 3, 1) would be read past the plane here: refused
+        if (hmax % comp[i].h != 0 || vmax % comp[i].v != 0) return false;
         up[i].hs = hmax / comp[i].h;
         up[i].vs = vmax / comp[i].v;
         up[i].ystep = up[i].vs >> 1;
@@ -1403,52 +1406,48 @@ bool huf_uncompress(const unsigned char *src, size_t n, std::vector<uint16_t> &o
     std::vector<uint64_t> table;
     size_t used = 0;
     if (!huf_read_code_table(src + 20, n - 20, (int)im, (int)iM, table, used)) return false;
-    if ((size_t)(n_bits + 7) / 8 > n - 20 - used) return false;
+    if (((uint64_t)n_bits + 7) / 8 > (uint64_t)(n - 20 - used)) return false;      // (in 64 bits: n_bits + 7 wraps in 32)
     std::vector<HufDec> dec;
     if (!huf_build_decoder(table, (int)im, (int)iM, dec)) return false;
     return huf_decode(table, dec, src + 20 + used, n_bits, (int)iM, out, n_out);
 }
 
-// the inverse of the 2-D wavelet transform over an nx * ny grid of 16-bit values (strides ox, oy); mx: the largest value
+// The inverse of PIZ's 2-D Haar-style wavelet over an nx * ny grid of 16-bit values (strides ox, oy in elements); mx: the
+// largest value of the data.  Level by level from the coarsest: the grid points of level p are the multiples of p in both
+// directions (nx / p columns, ny / p rows), and a level undoes first the vertical lifting pairs {row 2j p, row (2j + 1) p}
+// in every column of the level, then the horizontal pairs {column 2j p, column (2j + 1) p} in every row of the level - an
+// odd last row / column of a level has no partner in that direction and is left as it is.  (The encoder's forward transform
+// pairs columns first and rows second within 2 x 2 blocks; block by block or pass by pass, every value sees the same two
+// operations in the same order.)  A pair (low, high) becomes the two samples it was made from: for data below 2^14 by
+// average / difference in signed 16-bit arithmetic, otherwise modulo 2^16 with the offset 0x8000.
 void wav_decode(uint16_t *v, int nx, int ox, int ny, int oy, uint16_t mx)
 {
-    const bool w14 = mx < (1 << 14);
-    auto undo = [w14](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
-        if (w14) {                                  // 14-bit data: plain average / difference in 16-bit signed arithmetic
-            const int ls = (int16_t)l, hs = (int16_t)h;
-            const int ai = ls + (hs & 1) + (hs >> 1);
-            a = (uint16_t)(int16_t)ai;
-            b = (uint16_t)(int16_t)(ai - hs);
-        } else {                                    // full 16-bit data: modulo arithmetic
-            const int m = l, d = h;
-            const int bb = (m - (d >> 1)) & 0xffff;
-            b = (uint16_t)bb;
-            a = (uint16_t)((d + bb - 0x8000) & 0xffff);
+    const bool small_range = mx < (1 << 14);
+    auto unlift = [small_range](uint16_t &low, uint16_t &high) {
+        if (small_range) {
+            const int l = (int16_t)low, h = (int16_t)high;
+            const int first = l + (h & 1) + (h >> 1);
+            low = (uint16_t)(int16_t)first;
+            high = (uint16_t)(int16_t)(first - h);
+        } else {
+            const int second = ((int)low - ((int)high >> 1)) & 0xffff;
+            const int first = ((int)high + second - 0x8000) & 0xffff;
+            low = (uint16_t)first;
+            high = (uint16_t)second;
         }
     };
-    const int n = nx > ny ? ny : nx;
-    int p = 1;
-    while (p <= n) p <<= 1;
-    p >>= 1;
-    int p2 = p;
-    p >>= 1;
-    for (; p >= 1; p2 = p, p >>= 1) {
-        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
-        uint16_t *py = v, *const ey = v + (ptrdiff_t)oy * (ny - p2);
-        for (; py <= ey; py += oy2) {
-            uint16_t *px = py, *const ex = py + (ptrdiff_t)ox * (nx - p2);
-            for (; px <= ex; px += ox2) {
-                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1, i00, i01, i10, i11;
-                undo(*px, *p10, i00, i10);
-                undo(*p01, *p11, i01, i11);
-                undo(i00, i01, *px, *p01);
-                undo(i10, i11, *p10, *p11);
-            }
-            if (nx & p) { uint16_t *p10 = px + oy1, i00; undo(*px, *p10, i00, *p10); *px = i00; }
+    const int shorter = nx < ny ? nx : ny;
+    int coarsest = 1;
+    while (2 * coarsest <= shorter) coarsest *= 2;                // the largest power of two that fits the shorter side
+    for (int p = coarsest / 2; p >= 1; p /= 2) {
+        const int cols = nx / p, rows = ny / p;
+        for (int j = 0; j < rows / 2; ++j) {
+            uint16_t *upper = v + (ptrdiff_t)oy * (2 * j) * p, *lower = upper + (ptrdiff_t)oy * p;
+            for (int k = 0; k < cols; ++k) unlift(upper[(ptrdiff_t)ox * k * p], lower[(ptrdiff_t)ox * k * p]);
         }
-        if (ny & p) {
-            uint16_t *px = py, *const ex = py + (ptrdiff_t)ox * (nx - p2);
-            for (; px <= ex; px += ox2) { uint16_t *p01 = px + ox1, i00; undo(*px, *p01, i00, *p01); *px = i00; }
+        for (int k = 0; k < rows; ++k) {
+            uint16_t *row = v + (ptrdiff_t)oy * k * p;
+            for (int j = 0; j < cols / 2; ++j) unlift(row[(ptrdiff_t)ox * (2 * j) * p], row[(ptrdiff_t)ox * (2 * j + 1) * p]);
         }
     }
 }

@@ -92,6 +92,12 @@ int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out)
         s->camera = new Camera(c.position, c.u, c.v, c.w, res, 0.1f, c.fov, c.apertureRadius, c.focalDistance, c.filmic != 0, c.medium);
         s->camera->environment = c.environment;
         s->scene.Init(s->camera, json_path);
+        // Scene::Init is void like the reference's; a builder that refused the primitives (a non-finite vertex after a singular
+        // transform ...) leaves them where they were and the tree empty: an error here, not a scene that renders the background
+        if (!s->scene.primitives.empty() && s->scene.bvh.prims.empty()) {
+            delete s;
+            return GPT_ERR_INVALID_ARG;
+        }
     } catch (const std::exception &e) {
         gpt_set_error("gpt_scene_load: %s while loading %s", e.what(), json_path);
         delete s;

@@ -49,6 +49,13 @@ struct Hit {
     V3 dpdu;
     int matIdx, lightIdx;
 };
+struct RayResults {    // the results of a path's own three rays
+    bool occluded;
+    int prim_m;
+    float t_m, b1_m, b2_m;
+    int prim_p;
+    float t_p, b1_p, b2_p;
+};
 struct Counters {
     uint32_t node_visits, prim_tests, bounce_iters, shadow_rays, closest_rays, samples;
     // utilisation probes (counting build): wave-level trips, incremented by one lane per wave per trip

@@ -2288,13 +2288,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4
 #endif
-struct RayResults {    // this lane's own rays, read back from the pool
-    bool occluded;
-    int prim_m;
-    float t_m, b1_m, b2_m;
-    int prim_p;
-    float t_p, b1_p, b2_p;
-};
 
 // Scenes that fit kSmallSceneFloat4 (nodes 2 float4 each, triangles 3, shading records 5, lights 6, materials
 // 72 B) are staged in LDS once per workgroup; traversal and shading then read LDS instead of going through

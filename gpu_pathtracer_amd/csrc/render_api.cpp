@@ -21,13 +21,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpt.h"
 #include "host_util.h"
 #include "pt_layout.h"
+#include "pt_wavefront.h"
 #include "../../include/gpt_traversal.h"
 #include "../../include/gpt_wide_bvh.h"
 
@@ -92,6 +95,16 @@ struct gpt_ctx {
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
     int wide_depth = 0, n_wide = 0;
     std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
+    // the decoupled scheduler (pt_wavefront.h): "scheduler" 0 = persistent per-wave kernel, 1 = shade / trace stages over queues
+    int scheduler = 0;
+    uint32_t wf_paths_opt = 1u << 20;     // "wf_paths": path slots in flight
+    pt::WfParams wf{};                    // device buffers of the stages (allocated by the first render that uses them)
+    unsigned long long *wf_flag = nullptr;   // pinned host word the trace stage publishes its progress in
+    uint32_t wf_seq = 0;
+    uint32_t wf_trace_blocks = 0;         // persistent grid of the trace stage the spill space was sized for
+    bool wf_trace_wide = false;
+    uint32_t last_rounds = 0;             // stage pairs the last batch took
+    bool last_wavefront = false;          // the last gpt_render went through the stages
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
@@ -237,6 +250,111 @@ void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
 {
     out.resize((size_t)n * 9);
     for (int v = 0; v < 9; ++v) thread_nodes_ordered(nodes, n, v - 1, v * n, out.data() + (size_t)v * n);
+}
+
+
+// ---- the decoupled scheduler's host side (pt_wavefront.h) ---------------------------------------------------------
+// Buffers of the shade / trace stages: n_paths slots of path state, rays and results, the ray-id queue, the control block,
+// the wide walk's stack spill space and one pinned host word for the trace stage's progress reports.
+int wf_ensure(gpt_ctx *ctx)
+{
+    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4;
+    uint32_t n_paths = (ctx->wf_paths_opt + 255u) & ~255u;
+    if (n_paths < 256u) n_paths = 256u;
+    const uint32_t trace_blocks = (uint32_t)(std::max(ctx->n_cus, 1) * wf_trace_blocks_per_cu(wide));
+    if (ctx->wf.s0 && ctx->wf.n_paths == n_paths && ctx->wf_trace_blocks >= trace_blocks && ctx->wf_trace_wide == wide) return GPT_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto drop = [&](void *q) {
+        if (!q) return;
+        (void)hipFree(q);
+        for (auto &a : ctx->allocs) if (a == q) a = nullptr;
+    };
+    drop(ctx->wf.s0); drop(ctx->wf.spill);
+    ctx->wf = WfParams{};
+    // one allocation: 6 state planes, 3 ray planes, 3 result planes (float4 each), the queue (3 ids per slot), the control block
+    const size_t plane = (size_t)n_paths * sizeof(float4);
+    const size_t bytes = 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + 256;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    ctx->allocs.push_back(p);
+    HIP_TRY(hipMemset(p, 0, bytes));                 // every slot starts dead (flags = 0)
+    char *c = static_cast<char *>(p);
+    WfParams &W = ctx->wf;
+    W.s0 = reinterpret_cast<float4 *>(c); W.s1 = reinterpret_cast<float4 *>(c + plane); W.s2 = reinterpret_cast<float4 *>(c + 2 * plane);
+    W.s3 = reinterpret_cast<float4 *>(c + 3 * plane); W.s4 = reinterpret_cast<float4 *>(c + 4 * plane); W.org = reinterpret_cast<float4 *>(c + 5 * plane);
+    W.ray = reinterpret_cast<float4 *>(c + 6 * plane);
+    W.hit = reinterpret_cast<float4 *>(c + 9 * plane);
+    W.rayq = reinterpret_cast<uint32_t *>(c + 12 * plane);
+    W.ctrl = reinterpret_cast<WfCtrl *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t));
+    W.n_paths = n_paths;
+    // stack levels a ray of the wide walk may need beyond the LDS ones (3 * depth + 1 in all)
+    int levels = wide ? 3 * ctx->wide_depth + 1 - wf_lds_stack_levels() : 0;
+    if (levels < 1) levels = 1;
+    void *sp = nullptr;
+    HIP_TRY(hipMalloc(&sp, (size_t)trace_blocks * 4 * 64 * (size_t)levels * sizeof(uint32_t)));
+    ctx->allocs.push_back(sp);
+    W.spill = static_cast<uint32_t *>(sp);
+    W.spill_levels = (uint32_t)levels;
+    ctx->wf_trace_blocks = trace_blocks;
+    ctx->wf_trace_wide = wide;
+    if (!ctx->wf_flag) {
+        void *h = nullptr;
+        HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        ctx->wf_flag = static_cast<unsigned long long *>(h);
+        *ctx->wf_flag = 0ull;
+    }
+    W.host_flag = ctx->wf_flag;
+    return GPT_OK;
+}
+
+// One batch through the stages: shade(r), trace(r), shade(r + 1) ... until a round has no rays and no sample is left.  How many
+// rounds that takes depends on the paths, so the host follows the device: the trace stage of every round publishes
+// {batch, round, done} in pinned host memory, and the host keeps at most kAhead rounds enqueued beyond the last one it has
+// seen running - the queue never runs dry, and after `done` at most kAhead empty rounds (a few microseconds each) remain.
+int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
+{
+    constexpr long kAhead = 8;
+    WfParams W = ctx->wf;
+    W.n_samples = (unsigned long long)P.plane * P.iter_count;
+    W.seq = ++ctx->wf_seq;
+    HIP_TRY(hipMemsetAsync(W.ctrl, 0, sizeof(WfCtrl), ctx->stream));
+    const int trace_blocks = (int)ctx->wf_trace_blocks;
+    volatile unsigned long long *flag = ctx->wf_flag;
+    long round = 0;
+    bool done = false;
+    auto last_progress = std::chrono::steady_clock::now();
+    long last_seen = -1;
+    while (!done) {
+        W.round = (uint32_t)round;
+        HIP_TRY(launch_wf_shade(P, W, ctx->stream));
+        HIP_TRY(launch_wf_trace(P, W, trace_blocks, ctx->stream));
+        ++round;
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned long long v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+            long seen = -1;
+            if ((uint32_t)(v >> 32) == W.seq) {
+                seen = (long)((v >> 1) & 0x3fffffffull);
+                if (v & 1ull) { done = true; break; }
+            }
+            if (round - 1 - seen <= kAhead) break;
+            if (seen != last_seen) { last_seen = seen; last_progress = std::chrono::steady_clock::now(); }
+            if ((spins & 255u) == 255u) {
+                // never spin for ever: the device finished everything enqueued, or nothing moved for a minute, and the
+                // progress word still lags - its stores do not reach the host
+                const bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
+                const unsigned long long v2 = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+                const bool moved = v2 != v;
+                if (!moved && (idle || std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(60))) {
+                    gpt_set_error("gpt_render: the stages' progress word stopped at round %ld of %ld enqueued (stream %s)", seen, round, idle ? "idle" : "busy");
+                    return GPT_ERR_HIP;
+                }
+                std::this_thread::yield();
+            }
+        }
+        if (round > (1l << 29)) { gpt_set_error("gpt_render: the stages did not finish"); return GPT_ERR_HIP; }
+    }
+    ctx->last_rounds = (uint32_t)round;
+    return GPT_OK;
 }
 
 }  // namespace
@@ -594,6 +712,8 @@ int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value)
     else if (n == "vpt_walk_kernel" && (value == 0 || value == 1)) ctx->force_walk = value != 0;
     else if (n == "max_batch" && value >= 1 && value <= 65536) { ctx->max_batch = (uint32_t)value; ctx->max_batch_set = true; }
     else if (n == "chunk_iters" && value >= 0 && value <= 65536) ctx->chunk_override = (uint32_t)value;
+    else if (n == "scheduler" && (value == 0 || value == 1)) ctx->scheduler = (int)value;
+    else if (n == "wf_paths" && value >= 256 && value <= (1 << 26)) ctx->wf_paths_opt = (uint32_t)value;
     else {
         gpt_set_error("gpt_set_option: unknown option or value out of range: %s = %lld", name, (long long)value);
         return GPT_ERR_INVALID_ARG;
@@ -609,6 +729,10 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "vpt_walk_kernel") *value = ctx->force_walk ? 1 : 0;
     else if (n == "max_batch") *value = ctx->max_batch;
     else if (n == "chunk_iters") *value = ctx->chunk_override;
+    else if (n == "scheduler") *value = ctx->scheduler;
+    else if (n == "wf_paths") *value = ctx->wf_paths_opt;
+    else if (n == "scheduler_active") *value = ctx->last_wavefront ? 1 : 0;
+    else if (n == "last_rounds") *value = ctx->last_rounds;
     // read-only: what the renderer actually does with the current scene and settings
     else if (n == "lds_scene_active") *value = (ctx->lds_scene && render_scene_fits_lds(ctx->P)) ? 1 : 0;
     else if (n == "walk_kernel_active") *value = render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0;
@@ -715,6 +839,18 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     }
     uint32_t by_memory = (uint32_t)(budget / plane_bytes);
     if (by_memory < 1) by_memory = 1;
+    // the decoupled scheduler: Path, Ao and the three-ray Volpath, in the reference's order or on the 4-wide tree (work counters
+    // come from the counting build of the per-wave kernel)
+    const bool use_wf = ctx->scheduler == 1 && !count && !render_uses_walk_kernel(ctx->P, ctx->force_walk) &&
+                        ctx->P.traversal != GPT_TRAVERSAL_NEAR_FIRST;
+    ctx->last_wavefront = use_wf;
+    if (use_wf) {
+        // a sample's plane slot and its number in the batch are 32-bit words of the path state
+        const uint64_t by_index = (uint64_t)0xffffffffu / ((uint64_t)n_owned * 64);
+        if (by_index < by_memory) by_memory = by_index < 1 ? 1u : (uint32_t)by_index;
+        int rc = wf_ensure(ctx);
+        if (rc != GPT_OK) return rc;
+    }
     // unless the caller fixed it, a rank that owns 1/N of the tiles takes N times the iterations per launch: the same plane
     // memory and the same work per launch as one GPU with the whole frame, so the fixed cost of a launch stays amortised
     const uint64_t wanted = ctx->max_batch_set ? (uint64_t)ctx->max_batch : (uint64_t)ctx->max_batch * n_ranks;
@@ -791,7 +927,12 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
             HIP_TRY(hipEventCreate(&ev.second));
         }
         HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-        HIP_TRY(launch_render(P, count, n_blocks, ctx->lds_scene, ctx->force_walk, ctx->stream));
+        if (use_wf) {
+            int rc = wf_render_batch(ctx, P);
+            if (rc != GPT_OK) return rc;
+        } else {
+            HIP_TRY(launch_render(P, count, n_blocks, ctx->lds_scene, ctx->force_walk, ctx->stream));
+        }
         HIP_TRY(hipEventRecord(ev.second, ctx->stream));
         ctx->events.push_back(ev);
         HIP_TRY(launch_output(P, ctx->stream));
@@ -1019,6 +1160,7 @@ int gpt_end(gpt_ctx *ctx)
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (void *p : ctx->allocs) if (p) (void)hipFree(p);
+    if (ctx->wf_flag) (void)hipHostFree(ctx->wf_flag);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GPT_OK;

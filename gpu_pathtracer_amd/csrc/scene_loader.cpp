@@ -72,14 +72,14 @@ struct JsonParser {
     bool fail(const char *m) { if (err.empty()) err = m; return false; }
     static double pow10(int n)                          // 1e0 .. 1e308, each the double nearest to the power
     {
-        static double table[309];
-        static bool ready = false;
-        if (!ready) {
+        struct Table { double v[309]; };
+        static const Table table = [] {                 // (initialised once, also when two threads load their first scene together)
+            Table t;
             char text[16];
-            for (int i = 0; i <= 308; ++i) { std::snprintf(text, sizeof(text), "1e%d", i); table[i] = std::strtod(text, nullptr); }
-            ready = true;
-        }
-        return table[n];
+            for (int i = 0; i <= 308; ++i) { std::snprintf(text, sizeof(text), "1e%d", i); t.v[i] = std::strtod(text, nullptr); }
+            return t;
+        }();
+        return table.v[n];
     }
     static double scale10(double d, int e) { return e < -308 ? 0.0 : (e >= 0 ? d * pow10(e) : d / pow10(-e)); }
     bool digit() const { return p < end && *p >= '0' && *p <= '9'; }
@@ -748,8 +748,10 @@ void BVH::BuildSplit(std::vector<Primitive> &primitives, float alpha)
     float box[6];
     int32_t nn = 0, np = 0;
     if (gpt_sbvh_build(primitives.data(), n, alpha, prims.data(), cap, &np, prim_origin.data(), linear_root, 2 * cap, &nn, box) != GPT_OK) {
-        prims.clear();
+        // no split tree (a non-finite vertex, or the duplicate budget ran out): the reference's builder takes the scene instead -
+        // and refuses what it must refuse with its own message - rather than an empty scene that renders the background
         prim_origin.clear();
+        Build(primitives);
         return;
     }
     prims.resize((size_t)np);

@@ -403,6 +403,44 @@ def test_damaged_files_are_refused_or_decoded_never_overrun(ref, tmp_path):
     assert decoded > 100 and refused > 100
 
 
+def test_piz_bit_count_and_jpeg_sampling_overreads_are_refused(ref, tmp_path):
+    """Two crafted files that made the readers read past a buffer (found by review, reproduced under AddressSanitizer): a PIZ
+    block whose Huffman bit count is within 7 of 2^32 (the byte count wrapped in 32 bits and passed the length check), and a
+    JPEG whose sampling factors do not divide the largest one (H = 4, 3, 1: stb_image pads its planes, this reader does not)."""
+    import struct
+    rng = np.random.default_rng(5)
+    path = tmp_path / "piz.exr"
+    ref_save_exr(ref, path, radiance(rng, 20, 24, "smooth"), 4, 1)
+    raw = bytearray(path.read_bytes())
+    assert api.load_exr(str(path)).shape == (20, 24, 3)
+    pos = 8                                              # magic, version; then the attributes up to an empty name
+    while raw[pos] != 0:
+        pos = raw.index(b"\0", pos) + 1                  # name
+        pos = raw.index(b"\0", pos) + 1                  # type
+        pos += 4 + struct.unpack_from("<i", raw, pos)[0]
+    block = struct.unpack_from("<Q", raw, pos + 1)[0]    # the offset table's first entry: {y, size} {min, max non-zero, bitmap, length, Huffman block}
+    assert struct.unpack_from("<i", raw, block + 4)[0] < 20 * 24 * 3 * 2      # (a block that did not shrink is stored as it is)
+    lo, hi = struct.unpack_from("<HH", raw, block + 8)
+    huf = block + 12 + (hi - lo + 1 if hi >= lo else 0) + 4
+    im, iM, _, n_bits = struct.unpack_from("<IIII", raw, huf)
+    assert im <= iM < 65537 and 0 < n_bits < 8 * len(raw)        # (this is the Huffman header)
+    for bad in (0xffffffff, 0xfffffffb, 0xfffffff9):
+        struct.pack_into("<I", raw, huf + 12, bad)
+        (tmp_path / "piz_bad.exr").write_bytes(raw)
+        with pytest.raises(RuntimeError):
+            api.load_exr(str(tmp_path / "piz_bad.exr"))
+
+    y, x = np.mgrid[0:8, 0:32]
+    img = np.stack([x * 8, y * 30, x + y], -1).astype(np.uint8)
+    data = bytearray(encode_baseline_jpeg(img, (1, 1)))
+    sof = data.index(b"\xff\xc0")
+    assert data[sof + 9] == 3                             # three components: {id, sampling, table} from sof + 10
+    data[sof + 11], data[sof + 14], data[sof + 17] = 0x41, 0x31, 0x11
+    (tmp_path / "h431.jpg").write_bytes(data)
+    with pytest.raises(RuntimeError):
+        api.decode_image8(str(tmp_path / "h431.jpg"))
+
+
 def test_decoder_entry_points_report_errors_and_sizes(tmp_path):
     """The C ABI of the decoders: size-only calls, buffers that are too small, files that are not pictures (no reference needed)."""
     import ctypes as C
