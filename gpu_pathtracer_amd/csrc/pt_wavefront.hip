@@ -23,14 +23,18 @@ __device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
 
 // ------------------------------------------------------------------------------------------------ shade stage ------
 // INTEG: GPT_IT_PT, GPT_IT_AO, GPT_IT_VPT (homogeneous media, no material-less surfaces: the three-ray form)
+#ifndef PT_WF_SHADE_WAVES
+#define PT_WF_SHADE_WAVES 4
+#endif
 template <int INTEG>
-__global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const WfParams W)
+__global__ void __launch_bounds__(256, PT_WF_SHADE_WAVES) wf_shade_kernel(const DevParams P, const WfParams W)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;           // path slot (n_paths is a multiple of 256)
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t np = W.n_paths;
     const unsigned par = W.round & 1u;
-    if (i == 0) W.ctrl->head = 0u;                                 // the trace stage of this round starts at ray 0
+    if (i < 8u) W.ctrl->head[i] = 0u;                              // the trace stage of this round starts at the first group of every XCD
+    if (i == 8u) W.ctrl->susp[(W.round + 1u) & 1u] = 0u;           // ... and has parked nothing yet for the next round
 
     const float4 a3 = W.s3[i];
     uint32_t flags = __float_as_uint(a3.w);
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const 
     res.prim_m = res.prim_p = -1;
     res.t_m = res.b1_m = res.b2_m = res.t_p = res.b1_p = res.b2_p = 0.f;
 
-    bool finish = false;
+    bool finish = false, waiting = false;
     if (alive) {
         const float4 a0 = W.s0[i], a1 = W.s1[i], a2 = W.s2[i], a4 = W.s4[i], ao = W.org[i];
         Li = xyz(a0);
@@ -77,13 +81,21 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const 
             const float4 r = W.ray[i], h = W.hit[i];
             dir_p = xyz(r);
             res.prim_p = __float_as_int(h.x); res.t_p = h.y; res.b1_p = h.z; res.b2_p = h.w;
+            waiting = waiting || res.prim_p == kWfPending;
         }
         if (has_m) {
             const float4 r = W.ray[np + i], h = W.hit[np + i];
             dir_m = xyz(r);
             res.prim_m = __float_as_int(h.x); res.t_m = h.y; res.b1_m = h.z; res.b2_m = h.w;
+            waiting = waiting || res.prim_m == kWfPending;
         }
-        if (has_s) res.occluded = __float_as_int(W.hit[2u * np + i].x) >= 0;
+        if (has_s) {
+            const int prim_s = __float_as_int(W.hit[2u * np + i].x);
+            res.occluded = prim_s >= 0;
+            waiting = waiting || prim_s == kWfPending;
+        }
+      // a path one of whose rays the trace stage has parked sits this round out: nothing of it changes, its results stay where they are
+      if (!waiting) {
 
         // ---- resolve the direct light of the previous bounce (pathtracer.cu:943-994) ------------------
         if (direct) {
@@ -393,8 +405,10 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const 
                 }
             }
         }
-    }
 
+
+      }
+    }
     if (finish) {
         // The sample goes to its iteration's plane as is; the finite-guard of pathtracer.cu:1019-1020 and the accumulation
         // run in iteration order in pt_output_kernel.
@@ -403,100 +417,128 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const 
         has_s = has_m = has_p = false;
     }
 
-    // ---- regenerate: pathtracer.cu:881-903.  Sample s of the batch = pixel s % 64 of iteration (s / 64) % iter_count of
-    // owned tile s / (64 iter_count) (tiles in strips, like the per-wave kernel's items): the 64 lanes of a wave that start
-    // together start one 8x8 tile, and the paths in flight cover a compact block of the frame.
+    // ---- regenerate: pathtracer.cu:881-903.  Samples are handed out as in the per-wave kernel: a WORK ITEM is the samples of one
+    // 8x8 tile for a chunk of iterations (sample k -> pixel k % 64, iteration chunk_first + k / 64); the 64 slots of a wave take
+    // consecutive samples of the wave's item, and a wave whose item is used up claims the next one with ONE atomic - so lanes
+    // that start together start on one tile, and atomics are per item, not per sample.  The wave's item survives between rounds
+    // in wave_item[wave].
     const bool was_alive = (flags & kWfAlive) != 0u;
-    bool start = false;
     {
-        const unsigned long long m_idle = ballot(!alive);
-        if (m_idle != 0ull) {
-            unsigned long long base = 0;
-            if (lane == 0) {       // (every lane is here: the branch is wave-uniform)
-                // (a stale read can only be too small: then the atomic tells)
-                const unsigned long long seen = __hip_atomic_load(&W.ctrl->next_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                base = seen >= W.n_samples ? seen : atomicAdd(&W.ctrl->next_sample, (unsigned long long)popc(m_idle));
-            }
-            base = uniform64(base);
-            const unsigned long long s64 = base + (unsigned)lane_rank(m_idle);
-            if (!alive && s64 < W.n_samples) {
-                const uint32_t s = (uint32_t)s64;
-                const uint32_t per = 64u * P.iter_count;
-                const uint32_t tile_seq = s / per, r = s - tile_seq * per;
-                const uint32_t iter_rel = r >> 6, pix = r & 63u;
-                const uint32_t n_owned = (uint32_t)(P.plane >> 6);
-                uint32_t tile_local = tile_seq;
-                {   // a bijection of [0, n_owned): the owned tiles seen as a grid of gw columns, strip by strip (pt_kernel.hip)
-                    constexpr uint32_t TILE_STRIP = 16u;
-                    const uint32_t gw = (P.tiles_x + P.n_ranks - 1u) / P.n_ranks, gh = n_owned / gw;
-                    if (tile_local < gw * gh) {
-                        const uint32_t strip_items = TILE_STRIP * gh;
-                        const uint32_t strip = tile_local / strip_items, rr = tile_local - strip * strip_items;
-                        const uint32_t left = gw - strip * TILE_STRIP;
-                        const uint32_t w = left < TILE_STRIP ? left : TILE_STRIP;
-                        const uint32_t ty = rr / w;
-                        tile_local = ty * gw + strip * TILE_STRIP + (rr - ty * w);
+        const uint32_t wave = i >> 6;
+        unsigned long long m_need = ballot(!alive);
+        if (m_need != 0ull) {
+            const uint2 wi = W.wave_item[wave];
+            uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)wi.x), taken = (uint32_t)__builtin_amdgcn_readfirstlane((int)wi.y);
+            const uint32_t item0 = item, taken0 = taken;
+            const uint32_t n_owned = (uint32_t)(P.plane >> 6);
+            bool need = !alive;
+            for (;;) {
+                uint32_t chunk = 0, tile_seq = 0, item_samples = 0;
+                if (item != 0xffffffffu) {
+                    chunk = item / n_owned;
+                    tile_seq = item - chunk * n_owned;
+                    const uint32_t its = (chunk + 1u == W.n_chunks) ? P.iter_count - chunk * W.item_iters : W.item_iters;
+                    item_samples = 64u * its;
+                }
+                if (item == 0xffffffffu || taken >= item_samples) {
+                    // the next item (a stale read of the counter can only be too small: then the atomic tells)
+                    uint32_t t = 0xffffffffu;
+                    if (lane == 0) {
+                        const uint32_t seen = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen < W.n_items) t = atomicAdd(&W.ctrl->next_item, 1u);
                     }
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                    if (t >= W.n_items) {
+                        item = 0xffffffffu;
+                        taken = 0xffffffffu;
+                        break;
+                    }
+                    item = t;
+                    taken = 0u;
+                    continue;
                 }
-                const uint32_t tile = P.rank + tile_local * P.n_ranks;
-                const uint32_t x = (tile % P.tiles_x) * 8u + (pix & 7u), y = (tile / P.tiles_x) * 8u + (pix >> 3);
-                if (x < P.stride && y < P.rows) {
-                    start = true;
-                    const uint32_t iter = P.iter_first + iter_rel;
-                    dst = iter_rel * (uint32_t)P.plane + tile_local * 64u + pix;
-                    const uint32_t pixel = x + y * P.stride;          // pathtracer.cu:881-883
-                    rng_seed(rng, wang_hash(pixel) + wang_hash(iter));
-                    float offsetx = rng_uniform(rng) - 0.5f;
-                    float offsety = rng_uniform(rng) - 0.5f;
-                    float du1 = rng_uniform(rng);
-                    float du2 = rng_uniform(rng);
-                    Ray r0 = primary_ray(P.cam, x + offsetx, y + offsety, du1, du2);
-                    org = r0.o;
-                    dir_p = r0.d;
-                    has_p = true;
-                    has_s = has_m = false;
-                    Li = v3(0.f, 0.f, 0.f);
-                    beta = v3(1.f, 1.f, 1.f);
-                    specular = false;
-                    bounces = 0;
-                    ending = false;
-                    direct = false;
-                    mis_any = false;
-                    poison_occluded = false;
-                    medium = INTEG == GPT_IT_VPT ? P.cam.medium : -1;      // pathtracer.cu:1043
-                    medium_ld = -1;
-                    alive = true;
+                const uint32_t k = taken + (uint32_t)lane_rank(m_need);
+                taken += (uint32_t)popc(m_need);
+                if (need && k < item_samples) {
+                    need = false;
+                    uint32_t tile_local = tile_seq;
+                    {   // a bijection of [0, n_owned): the owned tiles seen as a grid of gw columns, strip by strip (pt_kernel.hip)
+                        constexpr uint32_t TILE_STRIP = 16u;
+                        const uint32_t gw = (P.tiles_x + P.n_ranks - 1u) / P.n_ranks, gh = n_owned / gw;
+                        if (tile_local < gw * gh) {
+                            const uint32_t strip_items = TILE_STRIP * gh;
+                            const uint32_t strip = tile_local / strip_items, rr = tile_local - strip * strip_items;
+                            const uint32_t left = gw - strip * TILE_STRIP;
+                            const uint32_t w = left < TILE_STRIP ? left : TILE_STRIP;
+                            const uint32_t ty = rr / w;
+                            tile_local = ty * gw + strip * TILE_STRIP + (rr - ty * w);
+                        }
+                    }
+                    const uint32_t tile = P.rank + tile_local * P.n_ranks;
+                    const uint32_t pix = k & 63u, iter_rel = chunk * W.item_iters + (k >> 6);
+                    const uint32_t x = (tile % P.tiles_x) * 8u + (pix & 7u), y = (tile / P.tiles_x) * 8u + (pix >> 3);
+                    if (x < P.stride && y < P.rows) {
+                        const uint32_t iter = P.iter_first + iter_rel;
+                        dst = iter_rel * (uint32_t)P.plane + tile_local * 64u + pix;
+                        const uint32_t pixel = x + y * P.stride;          // pathtracer.cu:881-883
+                        rng_seed(rng, wang_hash(pixel) + wang_hash(iter));
+                        float offsetx = rng_uniform(rng) - 0.5f;
+                        float offsety = rng_uniform(rng) - 0.5f;
+                        float du1 = rng_uniform(rng);
+                        float du2 = rng_uniform(rng);
+                        Ray r0 = primary_ray(P.cam, x + offsetx, y + offsety, du1, du2);
+                        org = r0.o;
+                        dir_p = r0.d;
+                        has_p = true;
+                        has_s = has_m = false;
+                        Li = v3(0.f, 0.f, 0.f);
+                        beta = v3(1.f, 1.f, 1.f);
+                        specular = false;
+                        bounces = 0;
+                        ending = false;
+                        direct = false;
+                        mis_any = false;
+                        poison_occluded = false;
+                        medium = INTEG == GPT_IT_VPT ? P.cam.medium : -1;      // pathtracer.cu:1043
+                        medium_ld = -1;
+                        alive = true;
+                    }
+                    // (a pixel outside the frame: the sample is not rendered, the slot waits for the next round)
                 }
+                m_need = ballot(need);                               // lanes the item had no sample for: they take from the next item
+                if (m_need == 0ull) break;
             }
+            if (lane == 0 && (item != item0 || taken != taken0)) W.wave_item[wave] = make_uint2(item, taken);
         }
     }
-    (void)start;
 
-    // ---- this round's rays go to the queue: one atomic per wave; path rays first, then light rays, then shadow rays ----
+    // ---- this round's rays go to the wave's segment of the queue: path rays first, then light rays, then shadow rays ----
     {
-        const unsigned long long m_p = ballot(has_p), m_m = ballot(has_m), m_s = ballot(has_s);
+        const bool emit_p = has_p && !waiting, emit_m = has_m && !waiting, emit_s = has_s && !waiting;      // (a waiting path's rays are in flight already)
+        const unsigned long long m_p = ballot(emit_p), m_m = ballot(emit_m), m_s = ballot(emit_s);
         const int n_p = popc(m_p), n_m = popc(m_m), n_all = n_p + n_m + popc(m_s);
-        if (n_all > 0) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&W.ctrl->n_rays[par], (uint32_t)n_all);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (has_p) {
-                W.rayq[base + (uint32_t)lane_rank(m_p)] = i;
-                W.ray[i] = f4(dir_p, __builtin_inff());
-            }
-            if (has_m) {
-                W.rayq[base + (uint32_t)(n_p + lane_rank(m_m))] = i | (1u << kWfKindShift) | (mis_any ? kWfAnyHit : 0u);
-                W.ray[np + i] = f4(dir_m, __builtin_inff());
-            }
-            if (has_s) {
-                W.rayq[base + (uint32_t)(n_p + n_m + lane_rank(m_s))] = i | (2u << kWfKindShift) | kWfAnyHit;
-                W.ray[2u * np + i] = f4(dir_s, tmax_s);
-            }
+        const uint32_t wave = i >> 6;
+        uint32_t *seg = W.rayq + (size_t)wave * (uint32_t)kWfSegRays;
+        if (lane == 0) {
+            W.seg_count[wave] = (uint32_t)n_all;
+            if (n_all > 0) W.ctrl->any_rays[par] = 1u;
+        }
+        if (emit_p) {
+            seg[lane_rank(m_p)] = i;
+            W.ray[i] = f4(dir_p, __builtin_inff());
+        }
+        if (emit_m) {
+            seg[n_p + lane_rank(m_m)] = i | (1u << kWfKindShift) | (mis_any ? kWfAnyHit : 0u);
+            W.ray[np + i] = f4(dir_m, __builtin_inff());
+        }
+        if (emit_s) {
+            seg[n_p + n_m + lane_rank(m_s)] = i | (2u << kWfKindShift) | kWfAnyHit;
+            W.ray[2u * np + i] = f4(dir_s, tmax_s);
         }
     }
 
     // ---- the slot's state for the next round ----
-    if (alive) {
+    if (alive && !waiting) {
         flags = (uint32_t)bounces | (specular ? kWfSpecular : 0u) | (direct ? kWfDirect : 0u) | (ending ? kWfEnding : 0u) | kWfAlive |
                 (has_p ? kWfHasP : 0u) | (has_m ? kWfHasM : 0u) | (has_s ? kWfHasS : 0u) | (mis_any ? kWfMisAny : 0u) |
                 (poison_occluded ? kWfPoison : 0u);
@@ -506,7 +548,7 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const 
         W.s3[i] = f4u(beta_ld, flags);
         W.s4[i] = f4u(mis_fr, dst);
         W.org[i] = f4u(org, INTEG == GPT_IT_VPT ? (((uint32_t)medium & 0xffffu) | ((uint32_t)medium_ld << 16)) : 0u);
-    } else if (was_alive) {
+    } else if (was_alive && !alive) {
         W.s3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
@@ -518,19 +560,26 @@ __global__ void __launch_bounds__(256) wf_shade_kernel(const DevParams P, const 
 //   WIDE   the 4-wide tree, one lane per ray, per-lane stack in LDS (include/gpt_wide_bvh.h; trace_pool_wide<>)
 //   !WIDE  the reference's order on the threaded binary tree (trace_pool<>)
 // every box and triangle test in the same arithmetic (bbox.h:77-96, mesh.h:45-67).
-#ifndef PT_WF_CHUNK
-#define PT_WF_CHUNK 256
-#endif
 #ifndef PT_WF_STACK_LEVELS
 #define PT_WF_STACK_LEVELS 24
 #endif
 #ifndef PT_WF_FETCH_T
 #define PT_WF_FETCH_T 8              // idle lanes that trigger a refill
 #endif
+#ifndef PT_WF_PROBE
+#define PT_WF_PROBE 0
+#endif
+// A trace workgroup claims groups from the queue of its own XCD, then of the next PT_WF_QUEUES_TRIED - 1 XCDs.  Every queue a wave finds
+// empty costs it one returning atomic on a word that all the other waves are hammering at that moment (the end of a round): with all
+// eight tried, a round of the config-5 stand-in spent most of its time there.  The queues hold equal shares (groups are dealt
+// round-robin), so the own queue alone balances to within the last group.
+#ifndef PT_WF_QUEUES_TRIED
+#define PT_WF_QUEUES_TRIED 1
+#endif
 #ifndef PT_WF_TRACE_WAVES
 #define PT_WF_TRACE_WAVES 4
 #endif
-constexpr int kWfChunk = PT_WF_CHUNK, kWfStackLevels = PT_WF_STACK_LEVELS;
+constexpr int kWfChunk = kWfGroupWaves * kWfSegRays, kWfStackLevels = PT_WF_STACK_LEVELS;
 
 __device__ __forceinline__ void wf_cex(unsigned &ka, unsigned &ea, unsigned &kb, unsigned &eb)
 {
@@ -547,24 +596,30 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t *ids = lds_ids + wv * kWfChunk;
     const unsigned par = W.round & 1u;
-    const uint32_t n_rays = __hip_atomic_load(&W.ctrl->n_rays[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool any_rays = __hip_atomic_load(&W.ctrl->any_rays[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        W.ctrl->n_rays[par ^ 1u] = 0u;                            // the next round's shade stage counts from 0
-        // progress for the host's round loop: this round had no rays and no sample is left = the batch is complete
-        const unsigned long long next = __hip_atomic_load(&W.ctrl->next_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long done = (n_rays == 0u && next >= W.n_samples) ? 1ull : 0ull;
+        W.ctrl->any_rays[par ^ 1u] = 0u;                          // the next round's shade stage starts from "no rays"
+        // progress for the host's round loop: this round had no rays and no work item is left = the batch is complete
+        const uint32_t next = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long done = (!any_rays && next >= W.n_items) ? 1ull : 0ull;
         __hip_atomic_store(W.host_flag, ((unsigned long long)W.seq << 32) | ((unsigned long long)(W.round & 0x3fffffffu) << 1) | done,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (!any_rays) return;
     const uint32_t np = W.n_paths;
     const float tmin_ray = P.eps;
     const char *tris = reinterpret_cast<const char *>(P.tris);
 
-    // the wave's chunk of the queue: ids [cursor, chunk_end) of which ids[0 ..] holds [chunk_base, chunk_end)
-    uint32_t cursor = 0, chunk_base = 0, chunk_end = 0;
-    bool exhausted = n_rays == 0u;
+    // the wave's chunk of the queue: the ids of one segment group, compacted into ids[0 .. chunk_end); cursor = the next one to hand out.
+    // Groups are claimed from the share of this workgroup's XCD first (group g belongs to XCD g % 8), then from the others'.
+    const uint32_t n_groups = W.n_paths / (64u * (uint32_t)kWfGroupWaves);
+    uint32_t cursor = 0, chunk_end = 0, queues_done = 0;
+    bool exhausted = false;
 
     // lane state: one ray
+#if PT_WF_PROBE
+    uint32_t ray_trips = 0;       // probe builds (C++ walk): trips this lane's ray has taken part in -> histogram by log2 in P.counters[0..15]
+#endif
     uint32_t id = 0;
     bool has = false;
     V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
@@ -589,6 +644,9 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
         const unsigned long long m_has = ballot(has), m_fin = ballot(fin);
         if (m_fin != 0ull) {
             if (fin) {
+#if PT_WF_PROBE
+                atomicAdd(&P.counters[ray_trips < 2u ? 0 : (31 - __builtin_clz(ray_trips) > 15 ? 15 : 31 - __builtin_clz(ray_trips))], 1ull);
+#endif
                 const uint32_t path = id & kWfPathMask, kind = (id >> kWfKindShift) & 3u;
                 float4 r;
                 if (WIDE) r = make_float4(__int_as_float(bprim), bprim < 0 ? tmax : bt, bb1, bb2);   // a miss reports the end of the interval
@@ -600,33 +658,46 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
         const unsigned long long m_busy = m_has & ~m_fin;
         const int n_idle = 64 - popc(m_busy);
         if (!exhausted && n_idle >= PT_WF_FETCH_T) {
-            if (cursor >= chunk_end) {
-                // ---- claim the next chunk of the queue (one atomic per kWfChunk rays)
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(&W.ctrl->head, (uint32_t)kWfChunk);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= n_rays) {
-                    exhausted = true;
-                } else {
-                    chunk_base = cursor = b;
-                    chunk_end = b + (uint32_t)kWfChunk < n_rays ? b + (uint32_t)kWfChunk : n_rays;
-#pragma unroll
-                    for (int k = 0; k < kWfChunk / 64; ++k) {
-                        const uint32_t at = b + (uint32_t)(k * 64) + lane;
-                        if (at < chunk_end) ids[k * 64 + (int)lane] = W.rayq[at];
-                    }
-                    wave_lds_fence();
+            while (cursor >= chunk_end && !exhausted) {
+                // ---- claim the next segment group (one atomic per group)
+                uint32_t g = 0xffffffffu;
+                while (queues_done < (uint32_t)PT_WF_QUEUES_TRIED) {
+                    const uint32_t qi = (blockIdx.x + queues_done) & 7u;
+                    uint32_t k = 0;
+                    if (lane == 0) k = atomicAdd(&W.ctrl->head[qi], 1u);
+                    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                    // queue qi = the groups of the shade workgroups qi, qi + 8, ... (they ran on XCD qi), 4 / kWfGroupWaves groups each
+                    constexpr uint32_t per_block = 4u / (uint32_t)kWfGroupWaves;
+                    const uint32_t cand = (qi + 8u * (k / per_block)) * per_block + k % per_block;
+                    if (cand < n_groups) { g = cand; break; }
+                    queues_done++;
                 }
+                if (g == 0xffffffffu) { exhausted = true; break; }
+                const uint32_t w0 = g * (uint32_t)kWfGroupWaves;
+                uint32_t off = 0;
+#pragma unroll
+                for (int k = 0; k < kWfGroupWaves; ++k) {
+                    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.seg_count[w0 + (uint32_t)k]);
+                    const uint32_t *seg = W.rayq + (size_t)(w0 + (uint32_t)k) * (uint32_t)kWfSegRays;
+                    for (uint32_t j = lane; j < cnt; j += 64u) ids[off + j] = seg[j];
+                    off += cnt;
+                }
+                cursor = 0;
+                chunk_end = off;                                   // (an empty group: claim the next one)
+                wave_lds_fence();
             }
             if (!exhausted) {
                 // ---- refill: idle lanes take the next rays of the chunk, in lane order
                 const uint32_t nth = cursor + (uint32_t)lane_rank(~m_busy);
                 if (!has && nth < chunk_end) {
-                    id = ids[nth - chunk_base];
+                    id = ids[nth];
                     const uint32_t path = id & kWfPathMask, kind = (id >> kWfKindShift) & 3u;
                     const float4 r0 = W.ray[kind * np + path];
                     const float4 ro = W.org[path];
                     has = true;
+#if PT_WF_PROBE
+                    ray_trips = 0;
+#endif
                     o = xyz(ro);
                     d = xyz(r0);
                     inv = V3{1.f / d.x, 1.f / d.y, 1.f / d.z};     // bbox.h:79 computes 1/d at every node visit: the same quotient
@@ -649,6 +720,9 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
         }
         if (m_busy == 0ull) break;
         const bool any_hit = (id & kWfAnyHit) != 0u;
+#if PT_WF_PROBE
+        if (has) ray_trips++;
+#endif
 
         if (WIDE) {
             bool leaf = has && (cur >> 31) != 0u;
@@ -809,6 +883,1024 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
     }
 }
 
+
+// ---- the wide walk of the trace stage, hand-scheduled ----------------------------------------------------------------------
+// The node block, the triangle block, the sorting network, the pushes and pops are those of trace_pool_wide_asm (pt_kernel.hip:
+// the same instructions on the same registers, hence the same bits as the C++ walk above, which stays the specification and can
+// be selected with -DPT_WF_WIDE_ASM=0); what differs is where rays come from and where results go:
+//   * refill without a stall.  A free lane is handed the next ray index of the wave's current segment and issues the load of
+//     its ray id; one trip later (every trip waits for all outstanding loads anyway) it turns the id into the path's offsets and
+//     issues the gathers of direction and origin; another trip later it forms 1 / direction (the IEEE quotient: bbox.h:79
+//     divides) and starts at the root.  Two trips without work per ray, nobody else waits.
+//   * a finished ray stores {primitive, t, b1, b2} straight to hit[kind][path] (one global_store_dwordx4, never waited for).
+//   * segments: a claim (one returning atomic on the head of an XCD's queue + one scalar load of the group's four counts)
+//     yields up to four segments that are walked one after the other without further memory operations.
+//   * the stack: PT_WF_STACK_LEVELS levels per lane in LDS (nothing else is in LDS), deeper levels in the wave's spill slice.
+// Registers: v[0:2] origin (v3: its unused fourth word)  v[4:6] direction  v7 tmax as loaded  v[8:10] 1 / direction  v11 ray id
+//   v12 current entry (-1: finished)  v13 stack size  v14 end of the interval  v15 byte offset of the ray's result (-1: no ray)
+//   v16 spill column  v18 LDS stack column  v19 result offset of a ray being loaded  v[20:23] best hit  v[24:54] as in pt_kernel.hip
+//   s[64:65] lanes with a ray  s[86:87] lanes whose id is in flight  s[88:89] lanes whose ray record is in flight
+//   s70 cursor in the segment  s90 its ray count  s91 its byte offset in rayq  s92 segments of the group still to come
+//   s93 XCD queues found empty  s94 no group is left  s[96:99] the group's four counts
+#ifndef PT_WF_WIDE_ASM
+#define PT_WF_WIDE_ASM 1
+#endif
+#ifndef PT_WF_LEAF_MIN
+#define PT_WF_LEAF_MIN 8
+#endif
+#ifndef PT_WF_HIT_STORE             // (experiment hook: cache policy of the result store)
+#define PT_WF_HIT_STORE "global_store_dwordx4 v15, v[20:23], %[hit]\n"
+#endif
+#ifndef PT_WF_MIN_TRIPS
+#define PT_WF_MIN_TRIPS 32           // ... but not before the wave has made this many trips in the round
+#endif
+#ifndef PT_WF_STOP_T
+#define PT_WF_STOP_T 8               // no group left and at most this many lanes still walk: the wave parks their rays for the next round
+#endif
+__device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfParams &W, unsigned stack_lds, unsigned lane)
+{
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
+    const unsigned long long s_nodes = uniform64((unsigned long long)P.wide);
+    const unsigned s_trioff = __builtin_amdgcn_readfirstlane(P.wide_tris_off);
+    // level l of this lane's stack beyond the LDS levels: spill base + column + 256 l (the base is moved back by the LDS levels)
+    const unsigned long long s_spill = uniform64((unsigned long long)(W.spill - 64 * kWfStackLevels));
+    const unsigned long long s_rayq = uniform64((unsigned long long)W.rayq), s_ray = uniform64((unsigned long long)W.ray),
+                             s_org = uniform64((unsigned long long)W.org), s_hit = uniform64((unsigned long long)W.hit),
+                             s_segcnt = uniform64((unsigned long long)W.seg_count), s_heads = uniform64((unsigned long long)W.ctrl->head);
+    const unsigned s_np = __builtin_amdgcn_readfirstlane(W.n_paths);
+    const unsigned s_ngroups = __builtin_amdgcn_readfirstlane(W.n_paths / (64u * (unsigned)kWfGroupWaves));
+    const unsigned s_block = __builtin_amdgcn_readfirstlane(blockIdx.x);
+    // this wave's number among the waves of its XCD (workgroup b runs on XCD b % 8) and how many of them there are
+    const unsigned s_xwave = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
+    const unsigned s_xwaves = __builtin_amdgcn_readfirstlane(((gridDim.x + 7u) >> 3) * 4u);
+    const unsigned s_stack = __builtin_amdgcn_readfirstlane(stack_lds) - 768u;      // (the pushes address level size' - 3 .. size' - 1 from one base)
+    const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane) * 4u;
+    const unsigned long long s_save = uniform64((unsigned long long)W.save);
+    const unsigned v_save = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u + lane) * (unsigned)(kWfSaveDwords * 4);
+    const unsigned s_tag = __builtin_amdgcn_readfirstlane(W.round + 1u);                       // records parked FOR this round carry it
+    const unsigned s_suspoff = __builtin_amdgcn_readfirstlane(32u + 4u * ((W.round + 1u) & 1u)); // susp[(round + 1) & 1], from ctrl->head
+    static_assert(kWfStackLevels % 4 == 0 && kWfStackLevels >= 8 && kWfStackLevels <= 28 && 8 + kWfStackLevels <= kWfSaveDwords, "the save record holds the LDS levels");
+    asm volatile(
+        "s_mov_b32 s76, 0x322bcc77\n"
+        "s_mov_b32 s77, 0x71800000\n"
+        "s_mov_b64 s[64:65], 0\n"
+        "s_mov_b64 s[82:83], 0\n"
+        "s_mov_b64 s[86:87], 0\n"
+        "s_mov_b64 s[88:89], 0\n"
+        "s_mov_b32 s70, 0\n"
+        "s_mov_b32 s90, 0\n"
+        "s_mov_b32 s91, 0\n"
+        "s_mov_b32 s92, 0\n"
+        "s_mov_b32 s93, 0\n"
+        "s_mov_b32 s94, 0\n"
+        "s_mov_b32 s95, 0\n"
+        "s_mov_b32 s59, 0\n"
+        "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
+        "v_lshl_add_u32 v18, v33, 2, %[stack]\n"
+        "v_mov_b32_e32 v16, %[vspill]\n"
+        "v_mov_b32_e32 v15, -1\n"
+        "v_mov_b32_e32 v12, -1\n"
+        "v_mov_b32_e32 v13, 0\n"
+        /* ---------------------------------------------------------------- rays parked by the last round's trace stage come back to their lanes */
+        "v_mov_b32_e32 v17, %[vsave]\n"
+        "global_load_dwordx4 v[24:27], v17, %[save]\n"
+        "global_load_dwordx4 v[28:31], v17, %[save] offset:16\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_lshrrev_b32_e32 v33, 8, v26\n"
+        "v_cmp_eq_u32_e64 s[64:65], %[tag], v33\n"
+        "s_mov_b64 exec, s[64:65]\n"
+        "s_cbranch_execz TQ_NORESUME_%=\n"
+        "v_mov_b32_e32 v11, v24\n"
+        "v_mov_b32_e32 v12, v25\n"
+        "v_and_b32_e32 v13, 0xff, v26\n"
+        "v_mov_b32_e32 v14, v27\n"
+        "v_mov_b32_e32 v20, v28\n"
+        "v_mov_b32_e32 v21, v29\n"
+        "v_mov_b32_e32 v22, v30\n"
+        "v_mov_b32_e32 v23, v31\n"
+        "v_bfe_u32 v33, v11, 28, 2\n"
+        "v_and_b32_e32 v34, 0xfffffff, v11\n"
+        "v_mul_lo_u32 v33, v33, %[np]\n"
+        "v_add_lshl_u32 v15, v33, v34, 4\n"
+        "v_lshlrev_b32_e32 v19, 4, v34\n"
+        "global_load_dwordx4 v[24:27], v17, %[save] offset:32\n"
+        "global_load_dwordx4 v[28:31], v17, %[save] offset:48\n"
+#if PT_WF_STACK_LEVELS > 8
+        "global_load_dwordx4 v[32:35], v17, %[save] offset:64\n"
+#endif
+#if PT_WF_STACK_LEVELS > 12
+        "global_load_dwordx4 v[36:39], v17, %[save] offset:80\n"
+#endif
+#if PT_WF_STACK_LEVELS > 16
+        "global_load_dwordx4 v[40:43], v17, %[save] offset:96\n"
+#endif
+#if PT_WF_STACK_LEVELS > 20
+        "global_load_dwordx4 v[44:47], v17, %[save] offset:112\n"
+#endif
+#if PT_WF_STACK_LEVELS > 24
+        "global_load_dwordx4 v[48:51], v17, %[save] offset:128\n"
+#endif
+        "global_load_dwordx4 v[4:7], v15, %[ray]\n"
+        "global_load_dwordx4 v[0:3], v19, %[org]\n"
+        "s_waitcnt vmcnt(0)\n"
+        "ds_write_b32 v18, v24 offset:768\n"
+        "ds_write_b32 v18, v25 offset:1024\n"
+        "ds_write_b32 v18, v26 offset:1280\n"
+        "ds_write_b32 v18, v27 offset:1536\n"
+        "ds_write_b32 v18, v28 offset:1792\n"
+        "ds_write_b32 v18, v29 offset:2048\n"
+        "ds_write_b32 v18, v30 offset:2304\n"
+        "ds_write_b32 v18, v31 offset:2560\n"
+#if PT_WF_STACK_LEVELS > 8
+        "ds_write_b32 v18, v32 offset:2816\n"
+        "ds_write_b32 v18, v33 offset:3072\n"
+        "ds_write_b32 v18, v34 offset:3328\n"
+        "ds_write_b32 v18, v35 offset:3584\n"
+#endif
+#if PT_WF_STACK_LEVELS > 12
+        "ds_write_b32 v18, v36 offset:3840\n"
+        "ds_write_b32 v18, v37 offset:4096\n"
+        "ds_write_b32 v18, v38 offset:4352\n"
+        "ds_write_b32 v18, v39 offset:4608\n"
+#endif
+#if PT_WF_STACK_LEVELS > 16
+        "ds_write_b32 v18, v40 offset:4864\n"
+        "ds_write_b32 v18, v41 offset:5120\n"
+        "ds_write_b32 v18, v42 offset:5376\n"
+        "ds_write_b32 v18, v43 offset:5632\n"
+#endif
+#if PT_WF_STACK_LEVELS > 20
+        "ds_write_b32 v18, v44 offset:5888\n"
+        "ds_write_b32 v18, v45 offset:6144\n"
+        "ds_write_b32 v18, v46 offset:6400\n"
+        "ds_write_b32 v18, v47 offset:6656\n"
+#endif
+#if PT_WF_STACK_LEVELS > 24
+        "ds_write_b32 v18, v48 offset:6912\n"
+        "ds_write_b32 v18, v49 offset:7168\n"
+        "ds_write_b32 v18, v50 offset:7424\n"
+        "ds_write_b32 v18, v51 offset:7680\n"
+#endif
+        "v_div_scale_f32 v33, s[66:67], v4, v4, 1.0\n"
+        "v_div_scale_f32 v34, vcc, 1.0, v4, 1.0\n"
+        "v_rcp_f32_e32 v35, v33\n"
+        "s_nop 0\n"
+        "v_fma_f32 v36, -v33, v35, 1.0\n"
+        "v_fmac_f32_e32 v35, v36, v35\n"
+        "v_mul_f32_e32 v37, v34, v35\n"
+        "v_fma_f32 v36, -v33, v37, v34\n"
+        "v_fmac_f32_e32 v37, v36, v35\n"
+        "v_fma_f32 v33, -v33, v37, v34\n"
+        "v_div_fmas_f32 v33, v33, v35, v37\n"
+        "v_div_fixup_f32 v8, v33, v4, 1.0\n"
+        "v_div_scale_f32 v33, s[66:67], v5, v5, 1.0\n"
+        "v_div_scale_f32 v34, vcc, 1.0, v5, 1.0\n"
+        "v_rcp_f32_e32 v35, v33\n"
+        "s_nop 0\n"
+        "v_fma_f32 v36, -v33, v35, 1.0\n"
+        "v_fmac_f32_e32 v35, v36, v35\n"
+        "v_mul_f32_e32 v37, v34, v35\n"
+        "v_fma_f32 v36, -v33, v37, v34\n"
+        "v_fmac_f32_e32 v37, v36, v35\n"
+        "v_fma_f32 v33, -v33, v37, v34\n"
+        "v_div_fmas_f32 v33, v33, v35, v37\n"
+        "v_div_fixup_f32 v9, v33, v5, 1.0\n"
+        "v_div_scale_f32 v33, s[66:67], v6, v6, 1.0\n"
+        "v_div_scale_f32 v34, vcc, 1.0, v6, 1.0\n"
+        "v_rcp_f32_e32 v35, v33\n"
+        "s_nop 0\n"
+        "v_fma_f32 v36, -v33, v35, 1.0\n"
+        "v_fmac_f32_e32 v35, v36, v35\n"
+        "v_mul_f32_e32 v37, v34, v35\n"
+        "v_fma_f32 v36, -v33, v37, v34\n"
+        "v_fmac_f32_e32 v37, v36, v35\n"
+        "v_fma_f32 v33, -v33, v37, v34\n"
+        "v_div_fmas_f32 v33, v33, v35, v37\n"
+        "v_div_fixup_f32 v10, v33, v6, 1.0\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "TQ_NORESUME_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        /* ---------------------------------------------------------------- loop header */
+        "TQ_LOOP_%=:\n"
+        /* lanes whose ray record was fetched a trip ago: 1 / direction, start at the root */
+        "s_cmp_eq_u64 s[88:89], 0\n"
+        "s_cbranch_scc1 TQ_NOFINAL_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_mov_b64 exec, s[88:89]\n"
+        "v_div_scale_f32 v33, s[66:67], v4, v4, 1.0\n"
+        "v_div_scale_f32 v34, vcc, 1.0, v4, 1.0\n"
+        "v_rcp_f32_e32 v35, v33\n"
+        "s_nop 0\n"
+        "v_fma_f32 v36, -v33, v35, 1.0\n"
+        "v_fmac_f32_e32 v35, v36, v35\n"
+        "v_mul_f32_e32 v37, v34, v35\n"
+        "v_fma_f32 v36, -v33, v37, v34\n"
+        "v_fmac_f32_e32 v37, v36, v35\n"
+        "v_fma_f32 v33, -v33, v37, v34\n"
+        "v_div_fmas_f32 v33, v33, v35, v37\n"
+        "v_div_fixup_f32 v8, v33, v4, 1.0\n"
+        "v_div_scale_f32 v33, s[66:67], v5, v5, 1.0\n"
+        "v_div_scale_f32 v34, vcc, 1.0, v5, 1.0\n"
+        "v_rcp_f32_e32 v35, v33\n"
+        "s_nop 0\n"
+        "v_fma_f32 v36, -v33, v35, 1.0\n"
+        "v_fmac_f32_e32 v35, v36, v35\n"
+        "v_mul_f32_e32 v37, v34, v35\n"
+        "v_fma_f32 v36, -v33, v37, v34\n"
+        "v_fmac_f32_e32 v37, v36, v35\n"
+        "v_fma_f32 v33, -v33, v37, v34\n"
+        "v_div_fmas_f32 v33, v33, v35, v37\n"
+        "v_div_fixup_f32 v9, v33, v5, 1.0\n"
+        "v_div_scale_f32 v33, s[66:67], v6, v6, 1.0\n"
+        "v_div_scale_f32 v34, vcc, 1.0, v6, 1.0\n"
+        "v_rcp_f32_e32 v35, v33\n"
+        "s_nop 0\n"
+        "v_fma_f32 v36, -v33, v35, 1.0\n"
+        "v_fmac_f32_e32 v35, v36, v35\n"
+        "v_mul_f32_e32 v37, v34, v35\n"
+        "v_fma_f32 v36, -v33, v37, v34\n"
+        "v_fmac_f32_e32 v37, v36, v35\n"
+        "v_fma_f32 v33, -v33, v37, v34\n"
+        "v_div_fmas_f32 v33, v33, v35, v37\n"
+        "v_div_fixup_f32 v10, v33, v6, 1.0\n"
+        "v_mov_b32_e32 v14, v7\n"
+        "v_mov_b32_e32 v12, 0\n"
+        "v_mov_b32_e32 v13, 0\n"
+        "v_mov_b32_e32 v20, -1\n"
+        "v_mov_b32_e32 v21, 0\n"
+        "v_mov_b32_e32 v22, 0\n"
+        "v_mov_b32_e32 v23, 0\n"
+        "v_mov_b32_e32 v15, v19\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b64 s[88:89], 0\n"
+        "TQ_NOFINAL_%=:\n"
+        /* lanes whose ray id was fetched a trip ago: the gathers of direction (kind * paths + path) and origin (path) */
+        "s_cmp_eq_u64 s[86:87], 0\n"
+        "s_cbranch_scc1 TQ_NOGATHER_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_mov_b64 exec, s[86:87]\n"
+        "v_bfe_u32 v33, v11, 28, 2\n"
+        "v_and_b32_e32 v34, 0xfffffff, v11\n"
+        "v_mul_lo_u32 v33, v33, %[np]\n"
+        "v_add_lshl_u32 v19, v33, v34, 4\n"
+        "v_lshlrev_b32_e32 v34, 4, v34\n"
+        "global_load_dwordx4 v[4:7], v19, %[ray]\n"
+        "global_load_dwordx4 v[0:3], v34, %[org]\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b64 s[88:89], s[86:87]\n"
+        "s_mov_b64 s[86:87], 0\n"
+        "TQ_NOGATHER_%=:\n"
+        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"             /* lanes with a ray */
+        "v_cmp_eq_u32_e64 s[66:67], -1, v12\n"             /* ... that is finished */
+        "s_and_b64 s[68:69], s[64:65], s[66:67]\n"
+        "s_cbranch_scc0 TQ_FILL_%=\n"
+        /* ---------------------------------------------------------------- finished rays (s[68:69]): a miss reports the end of the interval */
+        "s_mov_b64 exec, s[68:69]\n"
+        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
+        "v_cndmask_b32_e32 v21, v21, v14, vcc\n"
+        PT_WF_HIT_STORE
+        "v_mov_b32_e32 v15, -1\n"
+        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"
+        "s_mov_b64 exec, -1\n"
+        /* ---------------------------------------------------------------- refill: free lanes take the next rays of the segment */
+        "TQ_FILL_%=:\n"
+        "s_cmp_lg_u32 s94, 0\n"
+        "s_cbranch_scc1 TQ_TRIPCHK_%=\n"
+        "s_or_b64 s[66:67], s[64:65], s[88:89]\n"          /* lanes that are taken */
+        "s_bcnt1_i32_b64 s71, s[66:67]\n"
+        "s_cmp_gt_u32 s71, %[maxbusy]\n"
+        "s_cbranch_scc1 TQ_TRIPCHK_%=\n"
+        "s_cmp_lt_u32 s70, s90\n"
+        "s_cbranch_scc1 TQ_ASSIGN_%=\n"
+        "TQ_NEXTSEG_%=:\n"
+        "s_cmp_eq_u32 s92, 0\n"
+        "s_cbranch_scc1 TQ_CLAIM_%=\n"
+        "s_sub_u32 s92, s92, 1\n"
+        "s_mov_b32 s90, s97\n"
+        "s_mov_b32 s97, s98\n"
+        "s_mov_b32 s98, s99\n"
+        "s_add_u32 s91, s91, 768\n"
+        "s_mov_b32 s70, 0\n"
+        "s_cmp_lg_u32 s90, 0\n"
+        "s_cbranch_scc1 TQ_ASSIGN_%=\n"
+        "s_branch TQ_NEXTSEG_%=\n"
+        /* the next group: of this workgroup's XCD first (group g was written on XCD g % 8), then of the others */
+        "TQ_CLAIM_%=:\n"
+        "s_cmp_ge_u32 s93, %[nqueues]\n"
+        "s_cbranch_scc1 TQ_EXHAUSTED_%=\n"
+        "s_add_u32 s71, %[block], s93\n"
+        "s_and_b32 s71, s71, 7\n"
+        /* the first group of a wave is dealt without an atomic: wave j of its XCD takes the queue's j-th group (the counters count
+           from behind those); an atomic on a word that hundreds of waves want at the same moment - the start of the round - costs
+           each of them its place in the line */
+        "s_cmp_lg_u32 s59, 0\n"
+        "s_cbranch_scc1 TQ_ATOMIC_%=\n"
+        "s_mov_b32 s59, 1\n"
+        "s_mov_b32 s73, %[xwave]\n"
+        "s_branch TQ_INDEX_%=\n"
+        "TQ_ATOMIC_%=:\n"
+        "s_lshl_b32 s72, s71, 2\n"
+        "s_mov_b64 exec, 1\n"
+        "v_mov_b32_e32 v33, s72\n"
+        "v_mov_b32_e32 v34, 1\n"
+        "global_atomic_add v35, v33, v34, %[heads] sc0\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_readfirstlane_b32 s73, v35\n"
+        "s_mov_b64 exec, -1\n"
+        "s_add_u32 s73, s73, %[xwaves]\n"
+        "TQ_INDEX_%=:\n"
+#if PT_WF_GROUP_WAVES == 4
+        "s_lshl_b32 s73, s73, 3\n"
+        "s_add_u32 s73, s73, s71\n"                       /* group qi + 8 k = the shade workgroup's four segments */
+#else
+        "s_lshr_b32 s74, s73, 2\n"                        /* a group is ONE segment: the k-th of queue qi is segment k % 4 of shade workgroup qi + 8 (k / 4) */
+        "s_lshl_b32 s74, s74, 3\n"
+        "s_add_u32 s74, s74, s71\n"
+        "s_and_b32 s73, s73, 3\n"
+        "s_lshl2_add_u32 s73, s74, s73\n"
+#endif
+        "s_cmp_lt_u32 s73, %[ngroups]\n"
+        "s_cbranch_scc1 TQ_GOT_%=\n"
+        "s_add_u32 s93, s93, 1\n"
+        "s_branch TQ_CLAIM_%=\n"
+        "TQ_GOT_%=:\n"
+#if PT_WF_GROUP_WAVES == 4
+        "s_lshl_b32 s72, s73, 4\n"
+        "s_load_dwordx4 s[96:99], %[segcnt], s72\n"
+        "s_mul_i32 s91, s73, 3072\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b32 s90, s96\n"
+        "s_mov_b32 s92, 3\n"
+#else
+        "s_lshl_b32 s72, s73, 2\n"
+        "s_load_dword s96, %[segcnt], s72\n"
+        "s_mul_i32 s91, s73, 768\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_mov_b32 s90, s96\n"
+        "s_mov_b32 s92, 0\n"
+#endif
+        "s_mov_b32 s70, 0\n"
+        "s_cmp_lg_u32 s90, 0\n"
+        "s_cbranch_scc1 TQ_ASSIGN_%=\n"
+        "s_branch TQ_NEXTSEG_%=\n"
+        "TQ_EXHAUSTED_%=:\n"
+        "s_mov_b32 s94, 1\n"
+        "s_branch TQ_TRIPCHK_%=\n"
+        "TQ_ASSIGN_%=:\n"
+        "s_not_b64 s[66:67], s[66:67]\n"                   /* free lanes */
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
+        "v_add_u32_e32 v33, s70, v33\n"                    /* index in the segment */
+        "v_cmp_gt_u32_e32 vcc, s90, v33\n"
+        "s_and_b64 s[86:87], vcc, s[66:67]\n"
+        "s_bcnt1_i32_b64 s71, s[66:67]\n"
+        "s_add_u32 s70, s70, s71\n"
+        "s_mov_b64 exec, s[86:87]\n"
+        "v_lshl_add_u32 v33, v33, 2, s91\n"
+        "global_load_dword v11, v33, %[rayq]\n"
+        "s_mov_b64 exec, -1\n"
+        "TQ_TRIPCHK_%=:\n"
+        "s_cmp_lg_u64 s[64:65], 0\n"
+        "s_cbranch_scc0 TQ_NOBUSY_%=\n"
+        /* no group is left, nothing is being loaded and only a few lanes still walk: the wave parks those rays for the next round */
+        "s_cmp_eq_u32 s94, 0\n"
+        "s_cbranch_scc1 TQ_TRIP_%=\n"
+        "s_or_b64 s[66:67], s[86:87], s[88:89]\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TQ_TRIP_%=\n"
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
+        "s_cmp_gt_u32 s71, %[tstop]\n"
+        "s_cbranch_scc1 TQ_TRIP_%=\n"
+        "s_cmp_lt_u32 s95, %[mintrips]\n"                /* ... but every round moves its rays on by some trips (a wave that resumes parked rays would park them again at once) */
+        "s_cbranch_scc1 TQ_TRIP_%=\n"
+        "s_mov_b64 exec, s[64:65]\n"
+        "v_mov_b32_e32 v33, -2\n"
+        "global_store_dword v15, v33, %[hit]\n"          /* the result slot says "not yet" */
+        "v_mov_b32_e32 v4, v11\n"                         /* (the ray's own registers are free now) */
+        "v_mov_b32_e32 v5, v12\n"
+        "v_mov_b32_e32 v6, %[tag]\n"
+        "v_add_u32_e32 v6, 1, v6\n"
+        "v_lshl_or_b32 v6, v6, 8, v13\n"
+        "v_mov_b32_e32 v7, v14\n"
+        "global_store_dwordx4 v17, v[4:7], %[save]\n"
+        "global_store_dwordx4 v17, v[20:23], %[save] offset:16\n"
+        "ds_read_b32 v24, v18 offset:768\n"
+        "ds_read_b32 v25, v18 offset:1024\n"
+        "ds_read_b32 v26, v18 offset:1280\n"
+        "ds_read_b32 v27, v18 offset:1536\n"
+        "ds_read_b32 v28, v18 offset:1792\n"
+        "ds_read_b32 v29, v18 offset:2048\n"
+        "ds_read_b32 v30, v18 offset:2304\n"
+        "ds_read_b32 v31, v18 offset:2560\n"
+#if PT_WF_STACK_LEVELS > 8
+        "ds_read_b32 v32, v18 offset:2816\n"
+        "ds_read_b32 v33, v18 offset:3072\n"
+        "ds_read_b32 v34, v18 offset:3328\n"
+        "ds_read_b32 v35, v18 offset:3584\n"
+#endif
+#if PT_WF_STACK_LEVELS > 12
+        "ds_read_b32 v36, v18 offset:3840\n"
+        "ds_read_b32 v37, v18 offset:4096\n"
+        "ds_read_b32 v38, v18 offset:4352\n"
+        "ds_read_b32 v39, v18 offset:4608\n"
+#endif
+#if PT_WF_STACK_LEVELS > 16
+        "ds_read_b32 v40, v18 offset:4864\n"
+        "ds_read_b32 v41, v18 offset:5120\n"
+        "ds_read_b32 v42, v18 offset:5376\n"
+        "ds_read_b32 v43, v18 offset:5632\n"
+#endif
+#if PT_WF_STACK_LEVELS > 20
+        "ds_read_b32 v44, v18 offset:5888\n"
+        "ds_read_b32 v45, v18 offset:6144\n"
+        "ds_read_b32 v46, v18 offset:6400\n"
+        "ds_read_b32 v47, v18 offset:6656\n"
+#endif
+#if PT_WF_STACK_LEVELS > 24
+        "ds_read_b32 v48, v18 offset:6912\n"
+        "ds_read_b32 v49, v18 offset:7168\n"
+        "ds_read_b32 v50, v18 offset:7424\n"
+        "ds_read_b32 v51, v18 offset:7680\n"
+#endif
+        "s_waitcnt lgkmcnt(0)\n"
+        "global_store_dwordx4 v17, v[24:27], %[save] offset:32\n"
+        "global_store_dwordx4 v17, v[28:31], %[save] offset:48\n"
+#if PT_WF_STACK_LEVELS > 8
+        "global_store_dwordx4 v17, v[32:35], %[save] offset:64\n"
+#endif
+#if PT_WF_STACK_LEVELS > 12
+        "global_store_dwordx4 v17, v[36:39], %[save] offset:80\n"
+#endif
+#if PT_WF_STACK_LEVELS > 16
+        "global_store_dwordx4 v17, v[40:43], %[save] offset:96\n"
+#endif
+#if PT_WF_STACK_LEVELS > 20
+        "global_store_dwordx4 v17, v[44:47], %[save] offset:112\n"
+#endif
+#if PT_WF_STACK_LEVELS > 24
+        "global_store_dwordx4 v17, v[48:51], %[save] offset:128\n"
+#endif
+        "s_mov_b64 exec, 1\n"
+        "v_mov_b32_e32 v33, %[suspoff]\n"
+        "v_mov_b32_e32 v34, 1\n"
+        "global_store_dword v33, v34, %[heads]\n"
+        "s_branch TQ_DONE_%=\n"
+        "TQ_NOBUSY_%=:\n"
+        /* no lane has a ray: the loop goes on while loads are in flight or groups are left */
+        "s_or_b64 s[66:67], s[86:87], s[88:89]\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TQ_LOOP_%=\n"
+        "s_cmp_eq_u32 s94, 0\n"
+        "s_cbranch_scc1 TQ_LOOP_%=\n"
+        "s_branch TQ_DONE_%=\n"
+        /* ---------------------------------------------------------------- one trip (pt_kernel.hip, trace_pool_wide_asm) */
+        "TQ_TRIP_%=:\n"
+        "s_add_u32 s95, s95, 1\n"
+        "v_cmp_gt_i32_e64 s[60:61], 0, v12\n"
+        "s_and_b64 s[60:61], s[60:61], s[64:65]\n"         /* at a leaf (bit 31 set, not -1: busy lanes only) */
+        "s_andn2_b64 s[62:63], s[64:65], s[60:61]\n"       /* at a wide node */
+        /* too few lanes at a leaf: they wait (unless nobody is at a wide node); else too few at a wide node: those wait */
+        "s_bcnt1_i32_b64 s71, s[60:61]\n"
+        "s_bcnt1_i32_b64 s72, s[62:63]\n"
+        "s_cmp_ge_u32 s71, %[leafmin]\n"
+        "s_cbranch_scc1 TQ_VOTE_NODE_%=\n"
+        "s_cmp_eq_u32 s72, 0\n"
+        "s_cbranch_scc1 TQ_VOTED_%=\n"
+        "s_mov_b64 s[60:61], 0\n"
+        "s_branch TQ_VOTED_%=\n"
+        "TQ_VOTE_NODE_%=:\n"
+        "s_cmp_ge_u32 s72, %[nodemin]\n"
+        "s_cbranch_scc1 TQ_VOTED_%=\n"
+        "s_mov_b64 s[62:63], 0\n"
+        "TQ_VOTED_%=:\n"
+        /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
+           wait for everything) */
+        /* one set of fetches serves both kinds: a lane's offset from the base of the wide nodes is its node's, or that of its
+           triangle in the copy behind the nodes; a node lane gets its 112-byte record, a leaf lane its triangle in v[24:32] and the
+           one after it in v[36:44] (the rest of what it reads is not used) */
+        "s_mov_b64 exec, s[60:61]\n"
+        "v_and_b32_e32 v53, 0x7ffffff, v12\n"              /* the leaf's first triangle */
+        "v_lshlrev_b32_e32 v54, 4, v53\n"
+        "v_lshl_add_u32 v54, v53, 5, v54\n"                /* * 48 */
+        "v_add_u32_e32 v54, %[trioff], v54\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_mov_b32_e32 v54, v12\n"
+        "s_or_b64 exec, s[60:61], s[62:63]\n"
+        "global_load_dwordx4 v[24:27], v54, %[nodes]\n"
+        "global_load_dwordx4 v[36:39], v54, %[nodes] offset:48\n"
+        "global_load_dwordx4 v[28:31], v54, %[nodes] offset:16\n"
+        "global_load_dwordx4 v[40:43], v54, %[nodes] offset:64\n"
+        "global_load_dwordx4 v[32:35], v54, %[nodes] offset:32\n"
+        "global_load_dwordx4 v[44:47], v54, %[nodes] offset:80\n"
+        "global_load_dwordx4 v[48:51], v54, %[nodes] offset:96\n"
+        "s_mov_b64 s[78:79], 0\n"
+        "s_mov_b64 s[82:83], 0\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "s_cbranch_execz TQ_LEAF_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
+        /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */
+        "v_sub_f32_e32 v24, v24, v0\n"
+        "v_sub_f32_e32 v36, v36, v0\n"
+        "v_sub_f32_e32 v28, v28, v1\n"
+        "v_sub_f32_e32 v32, v32, v2\n"
+        "v_sub_f32_e32 v40, v40, v1\n"
+        "v_sub_f32_e32 v44, v44, v2\n"
+        "v_mul_f32_e32 v24, v8, v24\n"
+        "v_mul_f32_e32 v36, v8, v36\n"
+        "v_mul_f32_e32 v28, v9, v28\n"
+        "v_mul_f32_e32 v40, v9, v40\n"
+        "v_mul_f32_e32 v32, v10, v32\n"
+        "v_mul_f32_e32 v44, v10, v44\n"
+        "v_min_f32_e32 v52, v24, v36\n"
+        "v_max_f32_e32 v24, v24, v36\n"
+        "v_min_f32_e32 v36, v28, v40\n"
+        "v_max_f32_e32 v28, v28, v40\n"
+        "v_min_f32_e32 v40, v32, v44\n"
+        "v_max_f32_e32 v32, v32, v44\n"
+        "v_min3_f32 v24, v24, v28, v32\n"
+        "v_max3_f32 v52, v52, v36, v40\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v24\n"
+        "v_min_f32_e32 v24, v24, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v24, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v48\n"
+        "v_and_or_b32 v52, v52, -4, 0\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v24, -1, v52, s[66:67]\n"
+        "v_sub_f32_e32 v25, v25, v0\n"
+        "v_sub_f32_e32 v37, v37, v0\n"
+        "v_sub_f32_e32 v29, v29, v1\n"
+        "v_sub_f32_e32 v33, v33, v2\n"
+        "v_sub_f32_e32 v41, v41, v1\n"
+        "v_sub_f32_e32 v45, v45, v2\n"
+        "v_mul_f32_e32 v25, v8, v25\n"
+        "v_mul_f32_e32 v37, v8, v37\n"
+        "v_mul_f32_e32 v29, v9, v29\n"
+        "v_mul_f32_e32 v41, v9, v41\n"
+        "v_mul_f32_e32 v33, v10, v33\n"
+        "v_mul_f32_e32 v45, v10, v45\n"
+        "v_min_f32_e32 v52, v25, v37\n"
+        "v_max_f32_e32 v25, v25, v37\n"
+        "v_min_f32_e32 v37, v29, v41\n"
+        "v_max_f32_e32 v29, v29, v41\n"
+        "v_min_f32_e32 v41, v33, v45\n"
+        "v_max_f32_e32 v33, v33, v45\n"
+        "v_min3_f32 v25, v25, v29, v33\n"
+        "v_max3_f32 v52, v52, v37, v41\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v25\n"
+        "v_min_f32_e32 v25, v25, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v25, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v49\n"
+        "v_and_or_b32 v52, v52, -4, 1\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v25, -1, v52, s[66:67]\n"
+        "v_sub_f32_e32 v26, v26, v0\n"
+        "v_sub_f32_e32 v38, v38, v0\n"
+        "v_sub_f32_e32 v30, v30, v1\n"
+        "v_sub_f32_e32 v34, v34, v2\n"
+        "v_sub_f32_e32 v42, v42, v1\n"
+        "v_sub_f32_e32 v46, v46, v2\n"
+        "v_mul_f32_e32 v26, v8, v26\n"
+        "v_mul_f32_e32 v38, v8, v38\n"
+        "v_mul_f32_e32 v30, v9, v30\n"
+        "v_mul_f32_e32 v42, v9, v42\n"
+        "v_mul_f32_e32 v34, v10, v34\n"
+        "v_mul_f32_e32 v46, v10, v46\n"
+        "v_min_f32_e32 v52, v26, v38\n"
+        "v_max_f32_e32 v26, v26, v38\n"
+        "v_min_f32_e32 v38, v30, v42\n"
+        "v_max_f32_e32 v30, v30, v42\n"
+        "v_min_f32_e32 v42, v34, v46\n"
+        "v_max_f32_e32 v34, v34, v46\n"
+        "v_min3_f32 v26, v26, v30, v34\n"
+        "v_max3_f32 v52, v52, v38, v42\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v26\n"
+        "v_min_f32_e32 v26, v26, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v26, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v50\n"
+        "v_and_or_b32 v52, v52, -4, 2\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v26, -1, v52, s[66:67]\n"
+        "v_sub_f32_e32 v27, v27, v0\n"
+        "v_sub_f32_e32 v39, v39, v0\n"
+        "v_sub_f32_e32 v31, v31, v1\n"
+        "v_sub_f32_e32 v35, v35, v2\n"
+        "v_sub_f32_e32 v43, v43, v1\n"
+        "v_sub_f32_e32 v47, v47, v2\n"
+        "v_mul_f32_e32 v27, v8, v27\n"
+        "v_mul_f32_e32 v39, v8, v39\n"
+        "v_mul_f32_e32 v31, v9, v31\n"
+        "v_mul_f32_e32 v43, v9, v43\n"
+        "v_mul_f32_e32 v35, v10, v35\n"
+        "v_mul_f32_e32 v47, v10, v47\n"
+        "v_min_f32_e32 v52, v27, v39\n"
+        "v_max_f32_e32 v27, v27, v39\n"
+        "v_min_f32_e32 v39, v31, v43\n"
+        "v_max_f32_e32 v31, v31, v43\n"
+        "v_min_f32_e32 v43, v35, v47\n"
+        "v_max_f32_e32 v35, v35, v47\n"
+        "v_min3_f32 v27, v27, v31, v35\n"
+        "v_max3_f32 v52, v52, v39, v43\n"
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v27\n"
+        "v_min_f32_e32 v27, v27, v14\n"
+        "v_cmp_nlt_f32_e64 s[66:67], v27, v52\n"
+        "v_max_f32_e32 v52, 0, v52\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v51\n"
+        "v_and_or_b32 v52, v52, -4, 3\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
+        /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the
+           register its lo.x plane value came in) */
+        "v_cmp_lt_u32_e32 vcc, v25, v24\n"
+        "v_min_u32_e32 v52, v24, v25\n"
+        "v_max_u32_e32 v25, v24, v25\n"
+        "v_cndmask_b32_e32 v53, v48, v49, vcc\n"
+        "v_cndmask_b32_e32 v49, v49, v48, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v27, v26\n"
+        "v_min_u32_e32 v24, v26, v27\n"
+        "v_max_u32_e32 v27, v26, v27\n"
+        "v_cndmask_b32_e32 v48, v50, v51, vcc\n"
+        "v_cndmask_b32_e32 v51, v51, v50, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v24, v52\n"
+        "v_min_u32_e32 v26, v52, v24\n"
+        "v_max_u32_e32 v24, v52, v24\n"
+        "v_cndmask_b32_e32 v50, v53, v48, vcc\n"
+        "v_cndmask_b32_e32 v48, v48, v53, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v27, v25\n"
+        "v_min_u32_e32 v52, v25, v27\n"
+        "v_max_u32_e32 v27, v25, v27\n"
+        "v_cndmask_b32_e32 v53, v49, v51, vcc\n"
+        "v_cndmask_b32_e32 v51, v51, v49, vcc\n"
+        "v_cmp_lt_u32_e32 vcc, v24, v52\n"
+        "v_min_u32_e32 v25, v52, v24\n"
+        "v_max_u32_e32 v24, v52, v24\n"
+        "v_cndmask_b32_e32 v49, v53, v48, vcc\n"
+        "v_cndmask_b32_e32 v48, v48, v53, vcc\n"
+        /* sorted: keys v26 <= v25 <= v24 <= v27, entries v50, v49, v48, v51 (a child that is not hit: key -1, sorts last) */
+        "v_cmp_ne_u32_e64 s[66:67], -1, v25\n"
+        "v_cmp_ne_u32_e64 s[68:69], -1, v24\n"
+        "v_cmp_ne_u32_e64 s[72:73], -1, v27\n"
+        "v_cmp_ne_u32_e64 s[80:81], -1, v26\n"             /* the node has a hit child */
+        "s_nop 0\n"
+        "v_addc_co_u32_e64 v28, s[74:75], v13, 0, s[66:67]\n"
+        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[68:69]\n"
+        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
+        /* the others are pushed farthest first: sorted child j ends at level size' - j */
+        "v_cmp_lt_u32_e64 s[74:75], %[depth], v28\n"
+        "v_lshl_add_u32 v29, v28, 8, v18\n"                /* address of level size' - 3 */
+        "s_cmp_lg_u64 s[74:75], 0\n"
+        "s_cbranch_scc1 TQ_PUSH_SLOW_%=\n"
+        "s_mov_b64 exec, s[72:73]\n"
+        "ds_write_b32 v29, v51\n"
+        "s_mov_b64 exec, s[68:69]\n"
+        "ds_write_b32 v29, v48 offset:256\n"
+        "s_mov_b64 exec, s[66:67]\n"
+        "ds_write_b32 v29, v49 offset:512\n"
+        "TQ_PUSHED_%=:\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_cndmask_b32_e64 v13, v13, v28, s[80:81]\n"
+        "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
+        "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
+        /* ---------------------------------------------------------------- leaf: one triangle (exec = s[60:61]) */
+        "s_branch TQ_LEAF_GO_%=\n"
+        "TQ_LEAF_%=:\n"                                     /* no lane at a wide node: the triangle fetches have not been waited for */
+        "s_waitcnt vmcnt(0)\n"
+        "TQ_LEAF_GO_%=:\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        "s_cbranch_execz TQ_POP_%=\n"
+        "v_mul_f32_e32 v33, v5, v32\n"
+        "v_mul_f32_e32 v50, v6, v31\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
+        "v_mul_f32_e32 v34, v6, v30\n"
+        "v_mul_f32_e32 v50, v4, v32\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
+        "v_mul_f32_e32 v35, v4, v31\n"
+        "v_mul_f32_e32 v50, v5, v30\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v45, v33, v27\n"
+        "v_mul_f32_e32 v50, v34, v28\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_mul_f32_e32 v50, v35, v29\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_rcp_f32_e32 v47, v45\n"
+        "v_sub_f32_e32 v24, v0, v24\n"
+        "v_sub_f32_e32 v25, v1, v25\n"
+        "v_sub_f32_e32 v26, v2, v26\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n"
+        "v_fma_f32 v49, -v45, v47, 1.0\n"
+        "v_fma_f32 v46, v49, v47, v47\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TQ_DIV_IEEE_%=\n"
+        "TQ_DIV_DONE_%=:\n"
+        "v_mul_f32_e32 v51, v24, v33\n"
+        "v_mul_f32_e32 v50, v25, v34\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v50, v26, v35\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v33, v25, v29\n"
+        "v_mul_f32_e32 v50, v26, v28\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
+        "v_mul_f32_e32 v34, v26, v27\n"
+        "v_mul_f32_e32 v50, v24, v29\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
+        "v_mul_f32_e32 v35, v24, v28\n"
+        "v_mul_f32_e32 v50, v25, v27\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */
+        "v_mul_f32_e32 v47, v4, v33\n"
+        "v_mul_f32_e32 v50, v5, v34\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v50, v6, v35\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v51\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v47\n"
+        "v_add_f32_e32 v50, v51, v47\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TQ_TRI_END_%=\n"
+        "v_mul_f32_e32 v48, v30, v33\n"
+        "v_mul_f32_e32 v50, v31, v34\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v50, v32, v35\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TQ_TRI_END_%=\n"
+        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
+           distance that is not NaN and nearer than the interval's end becomes the interval's end */
+        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v21\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_eq_f32_e32 vcc, v48, v21\n"
+        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v14\n"
+        "s_mov_b64 s[72:73], exec\n"
+        "v_cndmask_b32_e32 v14, v14, v48, vcc\n"
+        "v_and_b32_e32 v50, 0x80000000, v11\n"
+        "s_and_b64 exec, exec, s[68:69]\n"
+        "v_mov_b32_e32 v20, v53\n"
+        "v_mov_b32_e32 v21, v48\n"
+        "v_mov_b32_e32 v22, v51\n"
+        "v_mov_b32_e32 v23, v47\n"
+        "s_mov_b64 exec, s[72:73]\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */
+        "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
+        "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
+        "TQ_TRI_END_%=:\n"
+        "s_mov_b64 exec, s[60:61]\n"
+        /* a ray that goes on and whose leaf has another triangle tests it in the same trip (its record came with the first one's):
+           the order of the tests and the interval they see are those of two trips */
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
+        "v_bfe_u32 v50, v12, 27, 4\n"
+        "v_cmp_lt_u32_e64 s[66:67], 0, v50\n"
+        "s_nop 0\n"
+        "s_and_b64 s[84:85], s[66:67], vcc\n"             /* second test */
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"           /* the leaf is exhausted: pop */
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
+        "s_mov_b64 exec, s[84:85]\n"
+        "s_cbranch_execz TQ_POP_%=\n"
+        "v_add_u32_e32 v53, 1, v53\n"
+        "v_mul_f32_e32 v33, v5, v44\n"
+        "v_mul_f32_e32 v50, v6, v43\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
+        "v_mul_f32_e32 v34, v6, v42\n"
+        "v_mul_f32_e32 v50, v4, v44\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
+        "v_mul_f32_e32 v35, v4, v43\n"
+        "v_mul_f32_e32 v50, v5, v42\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v45, v33, v39\n"
+        "v_mul_f32_e32 v50, v34, v40\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_mul_f32_e32 v50, v35, v41\n"
+        "v_add_f32_e32 v45, v45, v50\n"
+        "v_rcp_f32_e32 v47, v45\n"
+        "v_sub_f32_e32 v36, v0, v36\n"
+        "v_sub_f32_e32 v37, v1, v37\n"
+        "v_sub_f32_e32 v38, v2, v38\n"
+        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n"
+        "v_fma_f32 v49, -v45, v47, 1.0\n"
+        "v_fma_f32 v46, v49, v47, v47\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TQ_DIV_IEEE2_%=\n"
+        "TQ_DIV_DONE2_%=:\n"
+        "v_mul_f32_e32 v51, v36, v33\n"
+        "v_mul_f32_e32 v50, v37, v34\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v50, v38, v35\n"
+        "v_add_f32_e32 v51, v51, v50\n"
+        "v_mul_f32_e32 v33, v37, v41\n"
+        "v_mul_f32_e32 v50, v38, v40\n"
+        "v_sub_f32_e32 v33, v33, v50\n"
+        "v_mul_f32_e32 v34, v38, v39\n"
+        "v_mul_f32_e32 v50, v36, v41\n"
+        "v_sub_f32_e32 v34, v34, v50\n"
+        "v_mul_f32_e32 v35, v36, v40\n"
+        "v_mul_f32_e32 v50, v37, v39\n"
+        "v_sub_f32_e32 v35, v35, v50\n"
+        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */
+        "v_mul_f32_e32 v47, v4, v33\n"
+        "v_mul_f32_e32 v50, v5, v34\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v50, v6, v35\n"
+        "v_add_f32_e32 v47, v47, v50\n"
+        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v51\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_ngt_f32_e32 vcc, 0, v47\n"
+        "v_add_f32_e32 v50, v51, v47\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TQ_TRI2_END_%=\n"
+        "v_mul_f32_e32 v48, v42, v33\n"
+        "v_mul_f32_e32 v50, v43, v34\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v50, v44, v35\n"
+        "v_add_f32_e32 v48, v48, v50\n"
+        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n"
+        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_and_b64 exec, exec, s[66:67]\n"
+        "s_cbranch_scc0 TQ_TRI2_END_%=\n"
+        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
+           distance that is not NaN and nearer than the interval's end becomes the interval's end */
+        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v21\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_eq_f32_e32 vcc, v48, v21\n"
+        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
+        "s_and_b64 vcc, vcc, s[72:73]\n"
+        "s_or_b64 s[68:69], s[68:69], vcc\n"
+        "v_cmp_lt_f32_e32 vcc, v48, v14\n"
+        "s_mov_b64 s[72:73], exec\n"
+        "v_cndmask_b32_e32 v14, v14, v48, vcc\n"
+        "v_and_b32_e32 v50, 0x80000000, v11\n"
+        "s_and_b64 exec, exec, s[68:69]\n"
+        "v_mov_b32_e32 v20, v53\n"
+        "v_mov_b32_e32 v21, v48\n"
+        "v_mov_b32_e32 v22, v51\n"
+        "v_mov_b32_e32 v23, v47\n"
+        "s_mov_b64 exec, s[72:73]\n"
+        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */
+        "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
+        "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
+        "TQ_TRI2_END_%=:\n"
+        "s_mov_b64 exec, s[84:85]\n"
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
+        "v_bfe_u32 v50, v12, 27, 4\n"
+        "v_add_u32_e32 v49, 0xf0000002, v12\n"             /* first + 2, two triangles fewer */
+        "v_cmp_lt_u32_e64 s[66:67], 1, v50\n"
+        "s_nop 0\n"
+        "s_and_b64 s[66:67], s[66:67], vcc\n"
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
+        "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n"
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
+        /* ---------------------------------------------------------------- pop (s[78:79]) */
+        "TQ_POP_%=:\n"
+        "s_mov_b64 exec, s[78:79]\n"
+        "s_cbranch_execz TQ_POP_NONE_%=\n"
+        "v_cmp_lt_i32_e32 vcc, 0, v13\n"
+        "v_mov_b32_e32 v12, -1\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "s_cbranch_execz TQ_POP_NONE_%=\n"
+        "v_add_u32_e32 v13, -1, v13\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
+        "s_mov_b64 s[72:73], exec\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "v_lshl_add_u32 v33, v13, 8, v18\n"
+        "ds_read_b32 v12, v33 offset:768\n"
+        "s_andn2_b64 exec, s[72:73], vcc\n"
+        "s_cbranch_execz TQ_POP_LDS_%=\n"
+        "v_lshl_add_u32 v33, v13, 8, v16\n"
+        "global_load_dword v12, v33, %[spill]\n"
+        "s_waitcnt vmcnt(0)\n"
+        "TQ_POP_LDS_%=:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "TQ_POP_NONE_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TQ_LOOP_%=\n"
+        /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
+        "TQ_PUSH_SLOW_%=:\n"
+        "v_add_u32_e32 v29, -3, v28\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
+        "s_and_b64 exec, s[72:73], vcc\n"
+        "v_lshl_add_u32 v30, v29, 8, v18\n"
+        "ds_write_b32 v30, v51 offset:768\n"
+        "s_andn2_b64 exec, s[72:73], vcc\n"
+        "v_lshl_add_u32 v30, v29, 8, v16\n"
+        "global_store_dword v30, v51, %[spill]\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_add_u32_e32 v29, -2, v28\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
+        "s_and_b64 exec, s[68:69], vcc\n"
+        "v_lshl_add_u32 v30, v29, 8, v18\n"
+        "ds_write_b32 v30, v48 offset:768\n"
+        "s_andn2_b64 exec, s[68:69], vcc\n"
+        "v_lshl_add_u32 v30, v29, 8, v16\n"
+        "global_store_dword v30, v48, %[spill]\n"
+        "s_mov_b64 exec, s[62:63]\n"
+        "v_add_u32_e32 v29, -1, v28\n"
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
+        "s_and_b64 exec, s[66:67], vcc\n"
+        "v_lshl_add_u32 v30, v29, 8, v18\n"
+        "ds_write_b32 v30, v49 offset:768\n"
+        "s_andn2_b64 exec, s[66:67], vcc\n"
+        "v_lshl_add_u32 v30, v29, 8, v16\n"
+        "global_store_dword v30, v49, %[spill]\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_branch TQ_PUSHED_%=\n"
+        /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
+        "TQ_DIV_IEEE_%=:\n"
+        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
+        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
+        "v_rcp_f32_e32 v47, v46\n"
+        "s_nop 0\n"
+        "v_fma_f32 v49, -v46, v47, 1.0\n"
+        "v_fmac_f32_e32 v47, v49, v47\n"
+        "v_mul_f32_e32 v52, v48, v47\n"
+        "v_fma_f32 v49, -v46, v52, v48\n"
+        "v_fmac_f32_e32 v52, v49, v47\n"
+        "v_fma_f32 v46, -v46, v52, v48\n"
+        "v_div_fmas_f32 v46, v46, v47, v52\n"
+        "v_div_fixup_f32 v46, v46, v45, 1.0\n"
+        "s_branch TQ_DIV_DONE_%=\n"
+        "TQ_DIV_IEEE2_%=:\n"
+        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
+        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
+        "v_rcp_f32_e32 v47, v46\n"
+        "s_nop 0\n"
+        "v_fma_f32 v49, -v46, v47, 1.0\n"
+        "v_fmac_f32_e32 v47, v49, v47\n"
+        "v_mul_f32_e32 v52, v48, v47\n"
+        "v_fma_f32 v49, -v46, v52, v48\n"
+        "v_fmac_f32_e32 v52, v49, v47\n"
+        "v_fma_f32 v46, -v46, v52, v48\n"
+        "v_div_fmas_f32 v46, v46, v47, v52\n"
+        "v_div_fixup_f32 v46, v46, v45, 1.0\n"
+        "s_branch TQ_DIV_DONE2_%=\n"
+        "TQ_DONE_%=:\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        :
+        : [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill), [stack] "s"(s_stack), [vspill] "v"(v_spill),
+          [rayq] "s"(s_rayq), [ray] "s"(s_ray), [org] "s"(s_org), [hit] "s"(s_hit), [segcnt] "s"(s_segcnt), [heads] "s"(s_heads),
+          [np] "s"(s_np), [ngroups] "s"(s_ngroups), [block] "s"(s_block), [save] "s"(s_save), [vsave] "v"(v_save), [tag] "s"(s_tag), [suspoff] "s"(s_suspoff),
+          [xwave] "s"(s_xwave), [xwaves] "s"(s_xwaves),
+          [tstop] "n"(PT_WF_STOP_T), [mintrips] "n"(PT_WF_MIN_TRIPS), [nqueues] "n"(PT_WF_QUEUES_TRIED),
+          [depth] "n"(kWfStackLevels), [maxbusy] "n"(64 - PT_WF_FETCH_T), [leafmin] "n"(PT_WF_LEAF_MIN), [nodemin] "n"(1)
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+          "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s59",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
+          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
+}
+
+// the trace stage on the 4-wide tree with the hand-scheduled walk: nothing in LDS but the per-lane stacks
+__global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_wide_kernel(const DevParams P, const WfParams W)
+{
+    __shared__ uint32_t lds_stack[256 + 4 * 64 * kWfStackLevels];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned par = W.round & 1u;
+    const bool any_rays = __hip_atomic_load(&W.ctrl->any_rays[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    const bool parked = __hip_atomic_load(&W.ctrl->susp[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        W.ctrl->any_rays[par ^ 1u] = 0u;
+        const uint32_t next = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long done = (!any_rays && !parked && next >= W.n_items) ? 1ull : 0ull;
+        __hip_atomic_store(W.host_flag, ((unsigned long long)W.seq << 32) | ((unsigned long long)(W.round & 0x3fffffffu) << 1) | done,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!any_rays && !parked) return;
+    wf_trace_wide_asm(P, W, lds_address(lds_stack + 256 + wv * 64 * kWfStackLevels), lane);
+}
+
 // ---------------------------------------------------------------------------------------------------- launchers ------
 hipError_t launch_wf_shade(const DevParams &P, const WfParams &W, hipStream_t stream)
 {
@@ -821,7 +1913,8 @@ hipError_t launch_wf_shade(const DevParams &P, const WfParams &W, hipStream_t st
 
 hipError_t launch_wf_trace(const DevParams &P, const WfParams &W, int n_blocks, hipStream_t stream)
 {
-    if (P.traversal == GPT_TRAVERSAL_WIDE4) hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(n_blocks), dim3(256), 0, stream, P, W);
+    if (P.traversal == GPT_TRAVERSAL_WIDE4 && PT_WF_WIDE_ASM) hipLaunchKernelGGL(wf_trace_wide_kernel, dim3(n_blocks), dim3(256), 0, stream, P, W);
+    else if (P.traversal == GPT_TRAVERSAL_WIDE4) hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(n_blocks), dim3(256), 0, stream, P, W);
     else hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(n_blocks), dim3(256), 0, stream, P, W);
     return hipGetLastError();
 }
@@ -829,7 +1922,8 @@ hipError_t launch_wf_trace(const DevParams &P, const WfParams &W, int n_blocks, 
 int wf_trace_blocks_per_cu(bool wide)
 {
     int n = 0;
-    const hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, 256, 0)
+    const hipError_t e = (wide && PT_WF_WIDE_ASM) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_wide_kernel, 256, 0)
+                       : wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, 256, 0)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, 256, 0);
     if (e != hipSuccess || n < 1) { (void)hipGetLastError(); n = 2; }
     return n > 8 ? 8 : n;

@@ -269,11 +269,14 @@ int wf_ensure(gpt_ctx *ctx)
         (void)hipFree(q);
         for (auto &a : ctx->allocs) if (a == q) a = nullptr;
     };
-    drop(ctx->wf.s0); drop(ctx->wf.spill);
+    drop(ctx->wf.s0);
+    if (ctx->wf.spill) drop(ctx->wf.spill - (size_t)64 * wf_lds_stack_levels());
+    drop(ctx->wf.save);
     ctx->wf = WfParams{};
     // one allocation: 6 state planes, 3 ray planes, 3 result planes (float4 each), the queue (3 ids per slot), the control block
     const size_t plane = (size_t)n_paths * sizeof(float4);
-    const size_t bytes = 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + 256;
+    const size_t n_waves = n_paths / 64;
+    const size_t bytes = 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_waves * (sizeof(uint32_t) + sizeof(uint2)) + 256;
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
     ctx->allocs.push_back(p);
@@ -285,15 +288,25 @@ int wf_ensure(gpt_ctx *ctx)
     W.ray = reinterpret_cast<float4 *>(c + 6 * plane);
     W.hit = reinterpret_cast<float4 *>(c + 9 * plane);
     W.rayq = reinterpret_cast<uint32_t *>(c + 12 * plane);
-    W.ctrl = reinterpret_cast<WfCtrl *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t));
+    W.wave_item = reinterpret_cast<uint2 *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t));
+    W.seg_count = reinterpret_cast<uint32_t *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_waves * sizeof(uint2));
+    W.ctrl = reinterpret_cast<WfCtrl *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_waves * (sizeof(uint32_t) + sizeof(uint2)));
     W.n_paths = n_paths;
     // stack levels a ray of the wide walk may need beyond the LDS ones (3 * depth + 1 in all)
     int levels = wide ? 3 * ctx->wide_depth + 1 - wf_lds_stack_levels() : 0;
     if (levels < 1) levels = 1;
+    // (the hand-scheduled walk addresses level l of a lane as base + column + 256 l with the base moved back by the LDS levels: that
+    // much room is kept in front of the first slice)
+    const size_t front = (size_t)64 * wf_lds_stack_levels();
     void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, (size_t)trace_blocks * 4 * 64 * (size_t)levels * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&sp, (front + (size_t)trace_blocks * 4 * 64 * (size_t)levels) * sizeof(uint32_t)));
     ctx->allocs.push_back(sp);
-    W.spill = static_cast<uint32_t *>(sp);
+    W.spill = static_cast<uint32_t *>(sp) + front;
+    // one record per lane of the trace grid for a ray that is parked between two rounds
+    void *sv = nullptr;
+    HIP_TRY(hipMalloc(&sv, (size_t)trace_blocks * 256 * kWfSaveDwords * sizeof(uint32_t)));
+    ctx->allocs.push_back(sv);
+    W.save = static_cast<uint32_t *>(sv);
     W.spill_levels = (uint32_t)levels;
     ctx->wf_trace_blocks = trace_blocks;
     ctx->wf_trace_wide = wide;
@@ -315,10 +328,22 @@ int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
 {
     constexpr long kAhead = 8;
     WfParams W = ctx->wf;
-    W.n_samples = (unsigned long long)P.plane * P.iter_count;
+    // work items = (tile, chunk of iterations): small enough that the waves which claimed the last ones do not keep the batch
+    // waiting (an item of 64 x 4 samples is ~20 rounds of one wave), large enough that claims are rare (one atomic per item)
+    const uint32_t n_owned = (uint32_t)(P.plane >> 6);
+    W.item_iters = P.iter_count < 4u ? P.iter_count : 4u;
+    W.n_chunks = (P.iter_count + W.item_iters - 1u) / W.item_iters;
+    if ((uint64_t)n_owned * W.n_chunks > 0xfffffff0ull) { gpt_set_error("gpt_render: too many work items in one batch"); return GPT_ERR_INVALID_ARG; }
+    W.n_items = n_owned * W.n_chunks;
     W.seq = ++ctx->wf_seq;
     HIP_TRY(hipMemsetAsync(W.ctrl, 0, sizeof(WfCtrl), ctx->stream));
+    HIP_TRY(hipMemsetAsync(W.wave_item, 0xff, (size_t)(W.n_paths / 64u) * sizeof(uint2), ctx->stream));      // no wave holds an item
+    HIP_TRY(hipMemsetAsync(W.save, 0, (size_t)ctx->wf_trace_blocks * 256 * kWfSaveDwords * sizeof(uint32_t), ctx->stream));   // no ray is parked
     const int trace_blocks = (int)ctx->wf_trace_blocks;
+    // far more rounds than any batch needs (a slot renders samples / slots samples of at most max_depth + 2 rounds each; parked rays
+    // make a path wait a few rounds more): a guard against a progress word that never says "done", not a budget
+    const int depth_bound = P.integrator == GPT_IT_AO ? 3 : P.max_depth + 2;
+    const long max_rounds = 256 + 16l * depth_bound * (long)((uint64_t)P.plane * P.iter_count / W.n_paths + 1);
     volatile unsigned long long *flag = ctx->wf_flag;
     long round = 0;
     bool done = false;
@@ -351,7 +376,7 @@ int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
                 std::this_thread::yield();
             }
         }
-        if (round > (1l << 29)) { gpt_set_error("gpt_render: the stages did not finish"); return GPT_ERR_HIP; }
+        if (round > max_rounds) { gpt_set_error("gpt_render: the stages did not finish within %ld rounds", max_rounds); return GPT_ERR_HIP; }
     }
     ctx->last_rounds = (uint32_t)round;
     return GPT_OK;

@@ -2,6 +2,7 @@
 per-wave kernel ("scheduler" 0) and of the shade / trace stages (1), whether the films are bit-equal, and the stage pairs a batch took.
 python tools/gpu_wavefront.py [c3,c4,c5] [reference,wide] [iterations] [wf_paths] [sbvh]"""
 import hashlib
+import os
 import sys
 import tempfile
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -22,7 +23,10 @@ def run(ls, mode, spp, scheduler, wf_paths=None, reps=2):
         r.set_option("scheduler", scheduler)
         if wf_paths:
             r.set_option("wf_paths", wf_paths)
-        r.render(ls.camera, 1, 2, reset=True); r.synchronize()
+        if not os.environ.get("GPT_WF_ONE_BATCH"):            # (counter runs: exactly one batch per scheduler)
+            r.render(ls.camera, 1, 2, reset=True); r.synchronize()
+        else:
+            reps = 1
         best = 1e9
         for rep in range(reps):
             r.kernel_time_reset(); r.render(ls.camera, 1, spp, reset=True); r.synchronize()
@@ -37,7 +41,7 @@ for which in which_list:
     spp = spp_arg or {"c3": 32, "c4": 32, "c5": 8}[which]
     ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which), sbvh=sbvh)
     for mode in modes:
-        base = run(ls, mode, spp, 0)
+        base = run(ls, mode, spp, 0) if not os.environ.get("GPT_WF_ONE_BATCH") else (1.0, 0.0, "-", 0, 0)
         print(f"WF {which} {mode:9s}{' sbvh' if sbvh else ''} per-wave kernel : {base[0]:8.1f} Msamples/s ({base[1]:7.2f} ms / {spp} iterations) film {base[2]}", flush=True)
         for n_paths in paths_list:
             wf = run(ls, mode, spp, 1, n_paths)
