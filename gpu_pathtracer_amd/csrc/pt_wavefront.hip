@@ -23,18 +23,13 @@ __device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
 
 // ------------------------------------------------------------------------------------------------ shade stage ------
 // INTEG: GPT_IT_PT, GPT_IT_AO, GPT_IT_VPT (homogeneous media, no material-less surfaces: the three-ray form)
-#ifndef PT_WF_SHADE_WAVES
-#define PT_WF_SHADE_WAVES 4
-#endif
+// One wave shades the 64 path slots of one chunk (slot = 64 chunk + lane).  Returns the number of rays the chunk put into its segment
+// of the queue (wave-uniform) and writes it to *seg_count_lds.
 template <int INTEG>
-__global__ void __launch_bounds__(256, PT_WF_SHADE_WAVES) wf_shade_kernel(const DevParams P, const WfParams W)
+__device__ __forceinline__ int wf_shade_chunk(const DevParams &P, const WfParams &W, uint32_t chunk, unsigned lane, uint32_t *seg_count_lds)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;           // path slot (n_paths is a multiple of 256)
-    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t i = chunk * 64u + lane;                         // path slot
     const uint32_t np = W.n_paths;
-    const unsigned par = W.round & 1u;
-    if (i < 8u) W.ctrl->head[i] = 0u;                              // the trace stage of this round starts at the first group of every XCD
-    if (i == 8u) W.ctrl->susp[(W.round + 1u) & 1u] = 0u;           // ... and has parked nothing yet for the next round
 
     const float4 a3 = W.s3[i];
     uint32_t flags = __float_as_uint(a3.w);
@@ -512,17 +507,16 @@ __global__ void __launch_bounds__(256, PT_WF_SHADE_WAVES) wf_shade_kernel(const 
         }
     }
 
-    // ---- this round's rays go to the wave's segment of the queue: path rays first, then light rays, then shadow rays ----
+    // ---- this round's rays go to the chunk's segment of the queue: path rays first, then light rays, then shadow rays ----
+    int n_emitted = 0;
     {
         const bool emit_p = has_p && !waiting, emit_m = has_m && !waiting, emit_s = has_s && !waiting;      // (a waiting path's rays are in flight already)
         const unsigned long long m_p = ballot(emit_p), m_m = ballot(emit_m), m_s = ballot(emit_s);
         const int n_p = popc(m_p), n_m = popc(m_m), n_all = n_p + n_m + popc(m_s);
         const uint32_t wave = i >> 6;
         uint32_t *seg = W.rayq + (size_t)wave * (uint32_t)kWfSegRays;
-        if (lane == 0) {
-            W.seg_count[wave] = (uint32_t)n_all;
-            if (n_all > 0) W.ctrl->any_rays[par] = 1u;
-        }
+        if (lane == 0) *seg_count_lds = (uint32_t)n_all;
+        n_emitted = n_all;
         if (emit_p) {
             seg[lane_rank(m_p)] = i;
             W.ray[i] = f4(dir_p, __builtin_inff());
@@ -551,12 +545,13 @@ __global__ void __launch_bounds__(256, PT_WF_SHADE_WAVES) wf_shade_kernel(const 
     } else if (was_alive && !alive) {
         W.s3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    return n_emitted;
 }
 
-// ------------------------------------------------------------------------------------------------ trace stage ------
-// Persistent waves over the round's ray queue.  A wave claims kWfChunk consecutive ray ids with one atomic and keeps them in
-// LDS; a lane that finishes a ray (its result goes straight to hit[kind][path]) takes the next id of the chunk, reads the
-// ray's direction and origin from the path's planes and starts at the root.  The walks are those of pt_kernel.hip:
+// ------------------------------------------------------------------------------------------------ trace phase ------
+// The waves of a workgroup take the segments the workgroup's shade phase filled, one segment at a time (an LDS atomic); a lane that
+// finishes a ray (its result goes straight to hit[kind][path]) takes the next id of the segment, reads the ray's direction and
+// origin from the path's planes and starts at the root.  The walks are those of pt_kernel.hip:
 //   WIDE   the 4-wide tree, one lane per ray, per-lane stack in LDS (include/gpt_wide_bvh.h; trace_pool_wide<>)
 //   !WIDE  the reference's order on the threaded binary tree (trace_pool<>)
 // every box and triangle test in the same arithmetic (bbox.h:77-96, mesh.h:45-67).
@@ -569,17 +564,10 @@ __global__ void __launch_bounds__(256, PT_WF_SHADE_WAVES) wf_shade_kernel(const 
 #ifndef PT_WF_PROBE
 #define PT_WF_PROBE 0
 #endif
-// A trace workgroup claims groups from the queue of its own XCD, then of the next PT_WF_QUEUES_TRIED - 1 XCDs.  Every queue a wave finds
-// empty costs it one returning atomic on a word that all the other waves are hammering at that moment (the end of a round): with all
-// eight tried, a round of the config-5 stand-in spent most of its time there.  The queues hold equal shares (groups are dealt
-// round-robin), so the own queue alone balances to within the last group.
-#ifndef PT_WF_QUEUES_TRIED
-#define PT_WF_QUEUES_TRIED 1
+#ifndef PT_WF_WAVES
+#define PT_WF_WAVES 4                // waves per SIMD the kernel is compiled for (launch bounds)
 #endif
-#ifndef PT_WF_TRACE_WAVES
-#define PT_WF_TRACE_WAVES 4
-#endif
-constexpr int kWfChunk = kWfGroupWaves * kWfSegRays, kWfStackLevels = PT_WF_STACK_LEVELS;
+constexpr int kWfStackLevels = PT_WF_STACK_LEVELS;
 
 __device__ __forceinline__ void wf_cex(unsigned &ka, unsigned &ea, unsigned &kb, unsigned &eb)
 {
@@ -588,32 +576,25 @@ __device__ __forceinline__ void wf_cex(unsigned &ka, unsigned &ea, unsigned &kb,
     ka = k0; kb = k1; ea = e0; eb = e1;
 }
 
+// Shared by the trace walks: what a workgroup keeps in LDS for its rounds
+struct WfShared {
+    uint32_t seg_count[kWfWgChunks];    // rays in each chunk's segment of the queue, written by the shade phase
+    uint32_t shade_next;                // shade phase: next chunk nobody has taken
+    uint32_t trace_next;                // trace phase: next segment nobody has taken
+    uint32_t emitted;                   // rays the shade phase put into the queue
+    uint32_t parked;                    // the trace phase parked rays for the next round
+    uint32_t items_left;                // the batch still has work items
+};
+
 template <bool WIDE>
-__global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const DevParams P, const WfParams W)
+__device__ __forceinline__ void wf_trace_cxx(const DevParams &P, const WfParams &W, WfShared &sh, uint32_t chunk0, uint32_t *ids, uint32_t *lds_stack_wave,
+                                             unsigned lane)
 {
-    __shared__ uint32_t lds_ids[4 * kWfChunk];
-    __shared__ uint32_t lds_stack[WIDE ? 4 * 64 * kWfStackLevels : 1];
-    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t *ids = lds_ids + wv * kWfChunk;
-    const unsigned par = W.round & 1u;
-    const bool any_rays = __hip_atomic_load(&W.ctrl->any_rays[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        W.ctrl->any_rays[par ^ 1u] = 0u;                          // the next round's shade stage starts from "no rays"
-        // progress for the host's round loop: this round had no rays and no work item is left = the batch is complete
-        const uint32_t next = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long done = (!any_rays && next >= W.n_items) ? 1ull : 0ull;
-        __hip_atomic_store(W.host_flag, ((unsigned long long)W.seq << 32) | ((unsigned long long)(W.round & 0x3fffffffu) << 1) | done,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (!any_rays) return;
     const uint32_t np = W.n_paths;
     const float tmin_ray = P.eps;
     const char *tris = reinterpret_cast<const char *>(P.tris);
-
-    // the wave's chunk of the queue: the ids of one segment group, compacted into ids[0 .. chunk_end); cursor = the next one to hand out.
-    // Groups are claimed from the share of this workgroup's XCD first (group g belongs to XCD g % 8), then from the others'.
-    const uint32_t n_groups = W.n_paths / (64u * (uint32_t)kWfGroupWaves);
-    uint32_t cursor = 0, chunk_end = 0, queues_done = 0;
+    // the wave's current segment: its ids in ids[0 .. chunk_end); cursor = the next one to hand out
+    uint32_t cursor = 0, chunk_end = 0;
     bool exhausted = false;
 
     // lane state: one ray
@@ -625,8 +606,8 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
     V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
     float tmax = 0.f;
     // wide walk
-    unsigned *stk = lds_stack + (WIDE ? wv * 64 * kWfStackLevels : 0) + lane;
-    uint32_t *spill = W.spill + (size_t)(blockIdx.x * 4u + wv) * 64u * W.spill_levels + lane;
+    unsigned *stk = lds_stack_wave + lane;
+    uint32_t *spill = W.spill + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane;
     const char *wnodes = reinterpret_cast<const char *>(P.wide);
     unsigned cur = GPT_WIDE_NONE;
     int sp = 0;
@@ -659,31 +640,16 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
         const int n_idle = 64 - popc(m_busy);
         if (!exhausted && n_idle >= PT_WF_FETCH_T) {
             while (cursor >= chunk_end && !exhausted) {
-                // ---- claim the next segment group (one atomic per group)
-                uint32_t g = 0xffffffffu;
-                while (queues_done < (uint32_t)PT_WF_QUEUES_TRIED) {
-                    const uint32_t qi = (blockIdx.x + queues_done) & 7u;
-                    uint32_t k = 0;
-                    if (lane == 0) k = atomicAdd(&W.ctrl->head[qi], 1u);
-                    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                    // queue qi = the groups of the shade workgroups qi, qi + 8, ... (they ran on XCD qi), 4 / kWfGroupWaves groups each
-                    constexpr uint32_t per_block = 4u / (uint32_t)kWfGroupWaves;
-                    const uint32_t cand = (qi + 8u * (k / per_block)) * per_block + k % per_block;
-                    if (cand < n_groups) { g = cand; break; }
-                    queues_done++;
-                }
-                if (g == 0xffffffffu) { exhausted = true; break; }
-                const uint32_t w0 = g * (uint32_t)kWfGroupWaves;
-                uint32_t off = 0;
-#pragma unroll
-                for (int k = 0; k < kWfGroupWaves; ++k) {
-                    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.seg_count[w0 + (uint32_t)k]);
-                    const uint32_t *seg = W.rayq + (size_t)(w0 + (uint32_t)k) * (uint32_t)kWfSegRays;
-                    for (uint32_t j = lane; j < cnt; j += 64u) ids[off + j] = seg[j];
-                    off += cnt;
-                }
+                // ---- claim the workgroup's next segment (an LDS atomic)
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&sh.trace_next, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= (uint32_t)kWfWgChunks) { exhausted = true; break; }
+                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.seg_count[c]);
+                const uint32_t *seg = W.rayq + (size_t)(chunk0 + c) * (uint32_t)kWfSegRays;
+                for (uint32_t j = lane; j < cnt; j += 64u) ids[j] = seg[j];
                 cursor = 0;
-                chunk_end = off;                                   // (an empty group: claim the next one)
+                chunk_end = cnt;                                   // (an empty segment: claim the next one)
                 wave_lds_fence();
             }
             if (!exhausted) {
@@ -900,8 +866,7 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
 //   v12 current entry (-1: finished)  v13 stack size  v14 end of the interval  v15 byte offset of the ray's result (-1: no ray)
 //   v16 spill column  v18 LDS stack column  v19 result offset of a ray being loaded  v[20:23] best hit  v[24:54] as in pt_kernel.hip
 //   s[64:65] lanes with a ray  s[86:87] lanes whose id is in flight  s[88:89] lanes whose ray record is in flight
-//   s70 cursor in the segment  s90 its ray count  s91 its byte offset in rayq  s92 segments of the group still to come
-//   s93 XCD queues found empty  s94 no group is left  s[96:99] the group's four counts
+//   s70 cursor in the segment  s90 its ray count  s91 its byte offset in rayq  s94 no segment is left  s95 trips made
 #ifndef PT_WF_WIDE_ASM
 #define PT_WF_WIDE_ASM 1
 #endif
@@ -917,7 +882,8 @@ __global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_kernel(const 
 #ifndef PT_WF_STOP_T
 #define PT_WF_STOP_T 8               // no group left and at most this many lanes still walk: the wave parks their rays for the next round
 #endif
-__device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfParams &W, unsigned stack_lds, unsigned lane)
+__device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfParams &W, unsigned stack_lds, unsigned lane, unsigned shared_lds, uint32_t chunk0,
+                                                  uint32_t round)
 {
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
     const unsigned long long s_nodes = uniform64((unsigned long long)P.wide);
@@ -925,20 +891,15 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
     // level l of this lane's stack beyond the LDS levels: spill base + column + 256 l (the base is moved back by the LDS levels)
     const unsigned long long s_spill = uniform64((unsigned long long)(W.spill - 64 * kWfStackLevels));
     const unsigned long long s_rayq = uniform64((unsigned long long)W.rayq), s_ray = uniform64((unsigned long long)W.ray),
-                             s_org = uniform64((unsigned long long)W.org), s_hit = uniform64((unsigned long long)W.hit),
-                             s_segcnt = uniform64((unsigned long long)W.seg_count), s_heads = uniform64((unsigned long long)W.ctrl->head);
+                             s_org = uniform64((unsigned long long)W.org), s_hit = uniform64((unsigned long long)W.hit);
     const unsigned s_np = __builtin_amdgcn_readfirstlane(W.n_paths);
-    const unsigned s_ngroups = __builtin_amdgcn_readfirstlane(W.n_paths / (64u * (unsigned)kWfGroupWaves));
-    const unsigned s_block = __builtin_amdgcn_readfirstlane(blockIdx.x);
-    // this wave's number among the waves of its XCD (workgroup b runs on XCD b % 8) and how many of them there are
-    const unsigned s_xwave = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
-    const unsigned s_xwaves = __builtin_amdgcn_readfirstlane(((gridDim.x + 7u) >> 3) * 4u);
+    const unsigned s_shared = __builtin_amdgcn_readfirstlane(shared_lds);                   // LDS address of the workgroup's WfShared
+    const unsigned s_segbase = __builtin_amdgcn_readfirstlane(chunk0 * (unsigned)(kWfSegRays * 4));     // byte offset of the workgroup's first segment in rayq
     const unsigned s_stack = __builtin_amdgcn_readfirstlane(stack_lds) - 768u;      // (the pushes address level size' - 3 .. size' - 1 from one base)
     const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane) * 4u;
     const unsigned long long s_save = uniform64((unsigned long long)W.save);
     const unsigned v_save = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u + lane) * (unsigned)(kWfSaveDwords * 4);
-    const unsigned s_tag = __builtin_amdgcn_readfirstlane(W.round + 1u);                       // records parked FOR this round carry it
-    const unsigned s_suspoff = __builtin_amdgcn_readfirstlane(32u + 4u * ((W.round + 1u) & 1u)); // susp[(round + 1) & 1], from ctrl->head
+    const unsigned s_tag = __builtin_amdgcn_readfirstlane(round + 1u);                       // records parked FOR this round carry it
     static_assert(kWfStackLevels % 4 == 0 && kWfStackLevels >= 8 && kWfStackLevels <= 28 && 8 + kWfStackLevels <= kWfSaveDwords, "the save record holds the LDS levels");
     asm volatile(
         "s_mov_b32 s76, 0x322bcc77\n"
@@ -950,11 +911,8 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "s_mov_b32 s70, 0\n"
         "s_mov_b32 s90, 0\n"
         "s_mov_b32 s91, 0\n"
-        "s_mov_b32 s92, 0\n"
-        "s_mov_b32 s93, 0\n"
         "s_mov_b32 s94, 0\n"
         "s_mov_b32 s95, 0\n"
-        "s_mov_b32 s59, 0\n"
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
         "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
         "v_lshl_add_u32 v18, v33, 2, %[stack]\n"
@@ -1173,78 +1131,29 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "s_cbranch_scc1 TQ_TRIPCHK_%=\n"
         "s_cmp_lt_u32 s70, s90\n"
         "s_cbranch_scc1 TQ_ASSIGN_%=\n"
+        /* the workgroup's next segment: one LDS atomic (nobody outside the workgroup touches the counter), then its ray count */
         "TQ_NEXTSEG_%=:\n"
-        "s_cmp_eq_u32 s92, 0\n"
-        "s_cbranch_scc1 TQ_CLAIM_%=\n"
-        "s_sub_u32 s92, s92, 1\n"
-        "s_mov_b32 s90, s97\n"
-        "s_mov_b32 s97, s98\n"
-        "s_mov_b32 s98, s99\n"
-        "s_add_u32 s91, s91, 768\n"
-        "s_mov_b32 s70, 0\n"
-        "s_cmp_lg_u32 s90, 0\n"
-        "s_cbranch_scc1 TQ_ASSIGN_%=\n"
-        "s_branch TQ_NEXTSEG_%=\n"
-        /* the next group: of this workgroup's XCD first (group g was written on XCD g % 8), then of the others */
-        "TQ_CLAIM_%=:\n"
-        "s_cmp_ge_u32 s93, %[nqueues]\n"
-        "s_cbranch_scc1 TQ_EXHAUSTED_%=\n"
-        "s_add_u32 s71, %[block], s93\n"
-        "s_and_b32 s71, s71, 7\n"
-        /* the first group of a wave is dealt without an atomic: wave j of its XCD takes the queue's j-th group (the counters count
-           from behind those); an atomic on a word that hundreds of waves want at the same moment - the start of the round - costs
-           each of them its place in the line */
-        "s_cmp_lg_u32 s59, 0\n"
-        "s_cbranch_scc1 TQ_ATOMIC_%=\n"
-        "s_mov_b32 s59, 1\n"
-        "s_mov_b32 s73, %[xwave]\n"
-        "s_branch TQ_INDEX_%=\n"
-        "TQ_ATOMIC_%=:\n"
-        "s_lshl_b32 s72, s71, 2\n"
         "s_mov_b64 exec, 1\n"
-        "v_mov_b32_e32 v33, s72\n"
+        "v_mov_b32_e32 v33, %[shared]\n"
         "v_mov_b32_e32 v34, 1\n"
-        "global_atomic_add v35, v33, v34, %[heads] sc0\n"
-        "s_waitcnt vmcnt(0)\n"
+        "ds_add_rtn_u32 v35, v33, v34 offset:%[o_next]\n"
+        "s_waitcnt lgkmcnt(0)\n"
         "v_readfirstlane_b32 s73, v35\n"
+        "s_cmp_lt_u32 s73, %[nchunks]\n"
+        "s_cbranch_scc0 TQ_EXHAUSTED_%=\n"
+        "v_lshl_add_u32 v33, s73, 2, v33\n"
+        "ds_read_b32 v35, v33\n"                          /* seg_count[c] leads the record */
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s90, v35\n"
         "s_mov_b64 exec, -1\n"
-        "s_add_u32 s73, s73, %[xwaves]\n"
-        "TQ_INDEX_%=:\n"
-#if PT_WF_GROUP_WAVES == 4
-        "s_lshl_b32 s73, s73, 3\n"
-        "s_add_u32 s73, s73, s71\n"                       /* group qi + 8 k = the shade workgroup's four segments */
-#else
-        "s_lshr_b32 s74, s73, 2\n"                        /* a group is ONE segment: the k-th of queue qi is segment k % 4 of shade workgroup qi + 8 (k / 4) */
-        "s_lshl_b32 s74, s74, 3\n"
-        "s_add_u32 s74, s74, s71\n"
-        "s_and_b32 s73, s73, 3\n"
-        "s_lshl2_add_u32 s73, s74, s73\n"
-#endif
-        "s_cmp_lt_u32 s73, %[ngroups]\n"
-        "s_cbranch_scc1 TQ_GOT_%=\n"
-        "s_add_u32 s93, s93, 1\n"
-        "s_branch TQ_CLAIM_%=\n"
-        "TQ_GOT_%=:\n"
-#if PT_WF_GROUP_WAVES == 4
-        "s_lshl_b32 s72, s73, 4\n"
-        "s_load_dwordx4 s[96:99], %[segcnt], s72\n"
-        "s_mul_i32 s91, s73, 3072\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b32 s90, s96\n"
-        "s_mov_b32 s92, 3\n"
-#else
-        "s_lshl_b32 s72, s73, 2\n"
-        "s_load_dword s96, %[segcnt], s72\n"
         "s_mul_i32 s91, s73, 768\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b32 s90, s96\n"
-        "s_mov_b32 s92, 0\n"
-#endif
+        "s_add_u32 s91, s91, %[segbase]\n"
         "s_mov_b32 s70, 0\n"
         "s_cmp_lg_u32 s90, 0\n"
         "s_cbranch_scc1 TQ_ASSIGN_%=\n"
         "s_branch TQ_NEXTSEG_%=\n"
         "TQ_EXHAUSTED_%=:\n"
+        "s_mov_b64 exec, -1\n"
         "s_mov_b32 s94, 1\n"
         "s_branch TQ_TRIPCHK_%=\n"
         "TQ_ASSIGN_%=:\n"
@@ -1342,9 +1251,9 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "global_store_dwordx4 v17, v[48:51], %[save] offset:128\n"
 #endif
         "s_mov_b64 exec, 1\n"
-        "v_mov_b32_e32 v33, %[suspoff]\n"
+        "v_mov_b32_e32 v33, %[shared]\n"
         "v_mov_b32_e32 v34, 1\n"
-        "global_store_dword v33, v34, %[heads]\n"
+        "ds_write_b32 v33, v34 offset:%[o_parked]\n"
         "s_branch TQ_DONE_%=\n"
         "TQ_NOBUSY_%=:\n"
         /* no lane has a ray: the loop goes on while loads are in flight or groups are left */
@@ -1869,66 +1778,105 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "s_mov_b64 exec, -1\n"
         :
         : [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill), [stack] "s"(s_stack), [vspill] "v"(v_spill),
-          [rayq] "s"(s_rayq), [ray] "s"(s_ray), [org] "s"(s_org), [hit] "s"(s_hit), [segcnt] "s"(s_segcnt), [heads] "s"(s_heads),
-          [np] "s"(s_np), [ngroups] "s"(s_ngroups), [block] "s"(s_block), [save] "s"(s_save), [vsave] "v"(v_save), [tag] "s"(s_tag), [suspoff] "s"(s_suspoff),
-          [xwave] "s"(s_xwave), [xwaves] "s"(s_xwaves),
-          [tstop] "n"(PT_WF_STOP_T), [mintrips] "n"(PT_WF_MIN_TRIPS), [nqueues] "n"(PT_WF_QUEUES_TRIED),
-          [depth] "n"(kWfStackLevels), [maxbusy] "n"(64 - PT_WF_FETCH_T), [leafmin] "n"(PT_WF_LEAF_MIN), [nodemin] "n"(1)
+          [rayq] "s"(s_rayq), [ray] "s"(s_ray), [org] "s"(s_org), [hit] "s"(s_hit), [np] "s"(s_np), [shared] "s"(s_shared), [segbase] "s"(s_segbase),
+          [save] "s"(s_save), [vsave] "v"(v_save), [tag] "s"(s_tag),
+          [depth] "n"(kWfStackLevels), [maxbusy] "n"(64 - PT_WF_FETCH_T), [leafmin] "n"(PT_WF_LEAF_MIN), [nodemin] "n"(1),
+          [tstop] "n"(PT_WF_STOP_T), [mintrips] "n"(PT_WF_MIN_TRIPS), [nchunks] "n"(kWfWgChunks),
+          [o_next] "n"(offsetof(WfShared, trace_next)), [o_parked] "n"(offsetof(WfShared, parked))
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-          "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s59",
+          "s94", "s95",
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 }
 
-// the trace stage on the 4-wide tree with the hand-scheduled walk: nothing in LDS but the per-lane stacks
-__global__ void __launch_bounds__(256, PT_WF_TRACE_WAVES) wf_trace_wide_kernel(const DevParams P, const WfParams W)
+// ------------------------------------------------------------------------------------------- the render kernel ------
+// Persistent workgroups of four waves; a workgroup owns kWfWgChunks chunks of 64 path slots (its pool) and alternates, for as long as
+// it has paths or the batch has work items:
+//   shade phase   the waves take the pool's chunks one at a time (LDS counter) and shade them: every slot whose rays are back
+//   trace phase   the waves take the segments the shade phase filled and trace them; when the segments are used up and only a few
+//                 rays of a wave are still walking, the wave parks them for the next round
+// Between the phases stands a workgroup barrier - nothing device-wide: no kernel boundary per bounce, no atomic on a word another
+// workgroup wants (the work-item counter aside: one claim per 256 samples), and a round waits for the slowest ray among the ~1 500
+// of its own pool, not among the frame's millions.  The four workgroups of a CU are in different phases at any time: the shade
+// phase's arithmetic runs while another workgroup's trace phase waits for memory.
+template <int INTEG, bool WIDE>
+__global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevParams P, const WfParams W)
 {
-    __shared__ uint32_t lds_stack[256 + 4 * 64 * kWfStackLevels];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
+    __shared__ uint32_t lds_stack[WIDE ? 256 + 4 * 64 * kWfStackLevels : 1];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
+    __shared__ uint32_t lds_ids[(WIDE && PT_WF_WIDE_ASM) ? 1 : 4 * kWfSegRays];   // the C++ walks stage a segment's ids
+    __shared__ WfShared sh;
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const unsigned par = W.round & 1u;
-    const bool any_rays = __hip_atomic_load(&W.ctrl->any_rays[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    const bool parked = __hip_atomic_load(&W.ctrl->susp[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        W.ctrl->any_rays[par ^ 1u] = 0u;
-        const uint32_t next = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long done = (!any_rays && !parked && next >= W.n_items) ? 1ull : 0ull;
-        __hip_atomic_store(W.host_flag, ((unsigned long long)W.seq << 32) | ((unsigned long long)(W.round & 0x3fffffffu) << 1) | done,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t chunk0 = blockIdx.x * (uint32_t)kWfWgChunks;
+    if (threadIdx.x == 0) {
+        sh.shade_next = sh.trace_next = sh.emitted = sh.parked = 0u;
+        sh.items_left = 1u;
     }
-    if (!any_rays && !parked) return;
-    wf_trace_wide_asm(P, W, lds_address(lds_stack + 256 + wv * 64 * kWfStackLevels), lane);
+    // no ray is parked for this lane (the record's third word carries the round a parked ray resumes in)
+    if (WIDE) W.save[(size_t)((blockIdx.x * 4u + wv) * 64u + lane) * (uint32_t)kWfSaveDwords + 2u] = 0u;
+    __syncthreads();
+    for (uint32_t round = 0;; ++round) {
+        // ---- shade phase
+        int emitted = 0;
+        for (;;) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&sh.shade_next, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c >= (uint32_t)kWfWgChunks) break;
+            emitted += wf_shade_chunk<INTEG>(P, W, chunk0 + c, lane, &sh.seg_count[c]);
+        }
+        if (lane == 0 && emitted > 0) atomicAdd(&sh.emitted, (uint32_t)emitted);
+        if (threadIdx.x == 0) sh.items_left = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < W.n_items ? 1u : 0u;
+        __syncthreads();
+        const bool work = sh.emitted != 0u || sh.parked != 0u;
+        const bool more = sh.items_left != 0u;
+        __syncthreads();
+        // no ray went out, none is parked and no work item is left: every path of the pool has ended (a wave that still held samples of
+        // its item would have started them: see wf_shade_chunk)
+        if (!work && !more) break;
+        const bool resume = sh.parked != 0u;
+        if (threadIdx.x == 0) sh.shade_next = sh.trace_next = sh.emitted = sh.parked = 0u;
+        __syncthreads();
+        // ---- trace phase
+        if (work) {
+            if (WIDE && PT_WF_WIDE_ASM) wf_trace_wide_asm(P, W, lds_address(lds_stack + 256 + wv * 64 * kWfStackLevels), lane, lds_address(&sh), chunk0, round);
+            else wf_trace_cxx<WIDE>(P, W, sh, chunk0, lds_ids + wv * kWfSegRays, lds_stack + (WIDE ? 256 + wv * 64 * kWfStackLevels : 0), lane);
+        }
+        (void)resume;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers ------
-hipError_t launch_wf_shade(const DevParams &P, const WfParams &W, hipStream_t stream)
+hipError_t launch_wf_render(const DevParams &P, const WfParams &W, int n_blocks, hipStream_t stream)
 {
-    const dim3 grid(W.n_paths / 256u), block(256);
-    if (P.integrator == GPT_IT_AO) hipLaunchKernelGGL((wf_shade_kernel<GPT_IT_AO>), grid, block, 0, stream, P, W);
-    else if (P.integrator == GPT_IT_VPT) hipLaunchKernelGGL((wf_shade_kernel<GPT_IT_VPT>), grid, block, 0, stream, P, W);
-    else hipLaunchKernelGGL((wf_shade_kernel<GPT_IT_PT>), grid, block, 0, stream, P, W);
+    const dim3 grid(n_blocks), block(256);
+    const bool wide = P.traversal == GPT_TRAVERSAL_WIDE4;
+#define PT_WF_LAUNCH(I) do { if (wide) hipLaunchKernelGGL((wf_render_kernel<I, true>), grid, block, 0, stream, P, W); \
+                             else hipLaunchKernelGGL((wf_render_kernel<I, false>), grid, block, 0, stream, P, W); } while (0)
+    if (P.integrator == GPT_IT_AO) PT_WF_LAUNCH(GPT_IT_AO);
+    else if (P.integrator == GPT_IT_VPT) PT_WF_LAUNCH(GPT_IT_VPT);
+    else PT_WF_LAUNCH(GPT_IT_PT);
+#undef PT_WF_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t launch_wf_trace(const DevParams &P, const WfParams &W, int n_blocks, hipStream_t stream)
-{
-    if (P.traversal == GPT_TRAVERSAL_WIDE4 && PT_WF_WIDE_ASM) hipLaunchKernelGGL(wf_trace_wide_kernel, dim3(n_blocks), dim3(256), 0, stream, P, W);
-    else if (P.traversal == GPT_TRAVERSAL_WIDE4) hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(n_blocks), dim3(256), 0, stream, P, W);
-    else hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(n_blocks), dim3(256), 0, stream, P, W);
-    return hipGetLastError();
-}
-
-int wf_trace_blocks_per_cu(bool wide)
+int wf_blocks_per_cu(int integrator, bool wide)
 {
     int n = 0;
-    const hipError_t e = (wide && PT_WF_WIDE_ASM) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_wide_kernel, 256, 0)
-                       : wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<true>, 256, 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace_kernel<false>, 256, 0);
+    hipError_t e;
+#define PT_WF_OCC(I) (wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, true>, 256, 0) \
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, false>, 256, 0))
+    if (integrator == GPT_IT_AO) e = PT_WF_OCC(GPT_IT_AO);
+    else if (integrator == GPT_IT_VPT) e = PT_WF_OCC(GPT_IT_VPT);
+    else e = PT_WF_OCC(GPT_IT_PT);
+#undef PT_WF_OCC
     if (e != hipSuccess || n < 1) { (void)hipGetLastError(); n = 2; }
     return n > 8 ? 8 : n;
 }
 
 int wf_lds_stack_levels() { return kWfStackLevels; }
+int wf_paths_per_block() { return 64 * kWfWgChunks; }
 
 }  // namespace pt

@@ -21,10 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <chrono>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/gpt.h"
@@ -95,16 +93,12 @@ struct gpt_ctx {
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
     int wide_depth = 0, n_wide = 0;
     std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
-    // the decoupled scheduler (pt_wavefront.h): "scheduler" 0 = persistent per-wave kernel, 1 = shade / trace stages over queues
+    // the decoupled scheduler (pt_wavefront.h): "scheduler" 0 = persistent per-wave kernel, 1 = shade / trace phases over workgroup pools
     int scheduler = 0;
-    uint32_t wf_paths_opt = 1u << 20;     // "wf_paths": path slots in flight
-    pt::WfParams wf{};                    // device buffers of the stages (allocated by the first render that uses them)
-    unsigned long long *wf_flag = nullptr;   // pinned host word the trace stage publishes its progress in
-    uint32_t wf_seq = 0;
-    uint32_t wf_trace_blocks = 0;         // persistent grid of the trace stage the spill space was sized for
-    bool wf_trace_wide = false;
-    uint32_t last_rounds = 0;             // stage pairs the last batch took
-    bool last_wavefront = false;          // the last gpt_render went through the stages
+    pt::WfParams wf{};                    // device buffers of the phases (allocated by the first render that uses them)
+    uint32_t wf_blocks = 0;               // persistent grid the buffers were sized for
+    bool wf_wide = false;
+    bool last_wavefront = false;          // the last gpt_render went through the phases
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
@@ -254,15 +248,14 @@ void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
 
 
 // ---- the decoupled scheduler's host side (pt_wavefront.h) ---------------------------------------------------------
-// Buffers of the shade / trace stages: n_paths slots of path state, rays and results, the ray-id queue, the control block,
-// the wide walk's stack spill space and one pinned host word for the trace stage's progress reports.
+// Buffers of the persistent shade / trace kernel: one pool of path slots per workgroup of its grid (state, rays and results as
+// float4 planes), the segmented ray-id queue, the wide walk's stack spill space and parked-ray records.
 int wf_ensure(gpt_ctx *ctx)
 {
     const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4;
-    uint32_t n_paths = (ctx->wf_paths_opt + 255u) & ~255u;
-    if (n_paths < 256u) n_paths = 256u;
-    const uint32_t trace_blocks = (uint32_t)(std::max(ctx->n_cus, 1) * wf_trace_blocks_per_cu(wide));
-    if (ctx->wf.s0 && ctx->wf.n_paths == n_paths && ctx->wf_trace_blocks >= trace_blocks && ctx->wf_trace_wide == wide) return GPT_OK;
+    const uint32_t n_blocks = (uint32_t)(std::max(ctx->n_cus, 1) * wf_blocks_per_cu(ctx->P.integrator, wide));
+    const uint32_t n_paths = n_blocks * (uint32_t)wf_paths_per_block();
+    if (ctx->wf.s0 && ctx->wf.n_paths == n_paths && ctx->wf_blocks == n_blocks && ctx->wf_wide == wide) return GPT_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     auto drop = [&](void *q) {
         if (!q) return;
@@ -273,10 +266,10 @@ int wf_ensure(gpt_ctx *ctx)
     if (ctx->wf.spill) drop(ctx->wf.spill - (size_t)64 * wf_lds_stack_levels());
     drop(ctx->wf.save);
     ctx->wf = WfParams{};
-    // one allocation: 6 state planes, 3 ray planes, 3 result planes (float4 each), the queue (3 ids per slot), the control block
+    // one allocation: 6 state planes, 3 ray planes, 3 result planes (float4 each), the queue (3 ids per slot), the chunks' work items, the control block
     const size_t plane = (size_t)n_paths * sizeof(float4);
-    const size_t n_waves = n_paths / 64;
-    const size_t bytes = 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_waves * (sizeof(uint32_t) + sizeof(uint2)) + 256;
+    const size_t n_chunks = n_paths / 64;
+    const size_t bytes = 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_chunks * sizeof(uint2) + 256;
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
     ctx->allocs.push_back(p);
@@ -289,44 +282,31 @@ int wf_ensure(gpt_ctx *ctx)
     W.hit = reinterpret_cast<float4 *>(c + 9 * plane);
     W.rayq = reinterpret_cast<uint32_t *>(c + 12 * plane);
     W.wave_item = reinterpret_cast<uint2 *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t));
-    W.seg_count = reinterpret_cast<uint32_t *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_waves * sizeof(uint2));
-    W.ctrl = reinterpret_cast<WfCtrl *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_waves * (sizeof(uint32_t) + sizeof(uint2)));
+    W.ctrl = reinterpret_cast<WfCtrl *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_chunks * sizeof(uint2));
     W.n_paths = n_paths;
-    // stack levels a ray of the wide walk may need beyond the LDS ones (3 * depth + 1 in all)
+    // stack levels a ray of the wide walk may need beyond the LDS ones (3 * depth + 1 in all).  (The hand-scheduled walk addresses
+    // level l of a lane as base + column + 256 l with the base moved back by the LDS levels: that much room is kept in front.)
     int levels = wide ? 3 * ctx->wide_depth + 1 - wf_lds_stack_levels() : 0;
     if (levels < 1) levels = 1;
-    // (the hand-scheduled walk addresses level l of a lane as base + column + 256 l with the base moved back by the LDS levels: that
-    // much room is kept in front of the first slice)
     const size_t front = (size_t)64 * wf_lds_stack_levels();
     void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, (front + (size_t)trace_blocks * 4 * 64 * (size_t)levels) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&sp, (front + (size_t)n_blocks * 4 * 64 * (size_t)levels) * sizeof(uint32_t)));
     ctx->allocs.push_back(sp);
     W.spill = static_cast<uint32_t *>(sp) + front;
-    // one record per lane of the trace grid for a ray that is parked between two rounds
+    W.spill_levels = (uint32_t)levels;
+    // one record per lane of the grid for a ray that is parked between two rounds
     void *sv = nullptr;
-    HIP_TRY(hipMalloc(&sv, (size_t)trace_blocks * 256 * kWfSaveDwords * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&sv, (size_t)n_blocks * 256 * kWfSaveDwords * sizeof(uint32_t)));
     ctx->allocs.push_back(sv);
     W.save = static_cast<uint32_t *>(sv);
-    W.spill_levels = (uint32_t)levels;
-    ctx->wf_trace_blocks = trace_blocks;
-    ctx->wf_trace_wide = wide;
-    if (!ctx->wf_flag) {
-        void *h = nullptr;
-        HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
-        ctx->wf_flag = static_cast<unsigned long long *>(h);
-        *ctx->wf_flag = 0ull;
-    }
-    W.host_flag = ctx->wf_flag;
+    ctx->wf_blocks = n_blocks;
+    ctx->wf_wide = wide;
     return GPT_OK;
 }
 
-// One batch through the stages: shade(r), trace(r), shade(r + 1) ... until a round has no rays and no sample is left.  How many
-// rounds that takes depends on the paths, so the host follows the device: the trace stage of every round publishes
-// {batch, round, done} in pinned host memory, and the host keeps at most kAhead rounds enqueued beyond the last one it has
-// seen running - the queue never runs dry, and after `done` at most kAhead empty rounds (a few microseconds each) remain.
+// One batch: ONE launch of the persistent kernel; every workgroup runs its own rounds until the work items are used up and its pool is empty.
 int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
 {
-    constexpr long kAhead = 8;
     WfParams W = ctx->wf;
     // work items = (tile, chunk of iterations): small enough that the waves which claimed the last ones do not keep the batch
     // waiting (an item of 64 x 4 samples is ~20 rounds of one wave), large enough that claims are rare (one atomic per item)
@@ -335,50 +315,9 @@ int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
     W.n_chunks = (P.iter_count + W.item_iters - 1u) / W.item_iters;
     if ((uint64_t)n_owned * W.n_chunks > 0xfffffff0ull) { gpt_set_error("gpt_render: too many work items in one batch"); return GPT_ERR_INVALID_ARG; }
     W.n_items = n_owned * W.n_chunks;
-    W.seq = ++ctx->wf_seq;
     HIP_TRY(hipMemsetAsync(W.ctrl, 0, sizeof(WfCtrl), ctx->stream));
-    HIP_TRY(hipMemsetAsync(W.wave_item, 0xff, (size_t)(W.n_paths / 64u) * sizeof(uint2), ctx->stream));      // no wave holds an item
-    HIP_TRY(hipMemsetAsync(W.save, 0, (size_t)ctx->wf_trace_blocks * 256 * kWfSaveDwords * sizeof(uint32_t), ctx->stream));   // no ray is parked
-    const int trace_blocks = (int)ctx->wf_trace_blocks;
-    // far more rounds than any batch needs (a slot renders samples / slots samples of at most max_depth + 2 rounds each; parked rays
-    // make a path wait a few rounds more): a guard against a progress word that never says "done", not a budget
-    const int depth_bound = P.integrator == GPT_IT_AO ? 3 : P.max_depth + 2;
-    const long max_rounds = 256 + 16l * depth_bound * (long)((uint64_t)P.plane * P.iter_count / W.n_paths + 1);
-    volatile unsigned long long *flag = ctx->wf_flag;
-    long round = 0;
-    bool done = false;
-    auto last_progress = std::chrono::steady_clock::now();
-    long last_seen = -1;
-    while (!done) {
-        W.round = (uint32_t)round;
-        HIP_TRY(launch_wf_shade(P, W, ctx->stream));
-        HIP_TRY(launch_wf_trace(P, W, trace_blocks, ctx->stream));
-        ++round;
-        for (unsigned spins = 0;; ++spins) {
-            const unsigned long long v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
-            long seen = -1;
-            if ((uint32_t)(v >> 32) == W.seq) {
-                seen = (long)((v >> 1) & 0x3fffffffull);
-                if (v & 1ull) { done = true; break; }
-            }
-            if (round - 1 - seen <= kAhead) break;
-            if (seen != last_seen) { last_seen = seen; last_progress = std::chrono::steady_clock::now(); }
-            if ((spins & 255u) == 255u) {
-                // never spin for ever: the device finished everything enqueued, or nothing moved for a minute, and the
-                // progress word still lags - its stores do not reach the host
-                const bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
-                const unsigned long long v2 = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
-                const bool moved = v2 != v;
-                if (!moved && (idle || std::chrono::steady_clock::now() - last_progress > std::chrono::seconds(60))) {
-                    gpt_set_error("gpt_render: the stages' progress word stopped at round %ld of %ld enqueued (stream %s)", seen, round, idle ? "idle" : "busy");
-                    return GPT_ERR_HIP;
-                }
-                std::this_thread::yield();
-            }
-        }
-        if (round > max_rounds) { gpt_set_error("gpt_render: the stages did not finish within %ld rounds", max_rounds); return GPT_ERR_HIP; }
-    }
-    ctx->last_rounds = (uint32_t)round;
+    HIP_TRY(hipMemsetAsync(W.wave_item, 0xff, (size_t)(W.n_paths / 64u) * sizeof(uint2), ctx->stream));      // no chunk holds an item
+    HIP_TRY(launch_wf_render(P, W, (int)ctx->wf_blocks, ctx->stream));
     return GPT_OK;
 }
 
@@ -738,7 +677,6 @@ int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value)
     else if (n == "max_batch" && value >= 1 && value <= 65536) { ctx->max_batch = (uint32_t)value; ctx->max_batch_set = true; }
     else if (n == "chunk_iters" && value >= 0 && value <= 65536) ctx->chunk_override = (uint32_t)value;
     else if (n == "scheduler" && (value == 0 || value == 1)) ctx->scheduler = (int)value;
-    else if (n == "wf_paths" && value >= 256 && value <= (1 << 26)) ctx->wf_paths_opt = (uint32_t)value;
     else {
         gpt_set_error("gpt_set_option: unknown option or value out of range: %s = %lld", name, (long long)value);
         return GPT_ERR_INVALID_ARG;
@@ -755,9 +693,8 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "max_batch") *value = ctx->max_batch;
     else if (n == "chunk_iters") *value = ctx->chunk_override;
     else if (n == "scheduler") *value = ctx->scheduler;
-    else if (n == "wf_paths") *value = ctx->wf_paths_opt;
+    else if (n == "wf_paths") *value = ctx->wf.n_paths;
     else if (n == "scheduler_active") *value = ctx->last_wavefront ? 1 : 0;
-    else if (n == "last_rounds") *value = ctx->last_rounds;
     // read-only: what the renderer actually does with the current scene and settings
     else if (n == "lds_scene_active") *value = (ctx->lds_scene && render_scene_fits_lds(ctx->P)) ? 1 : 0;
     else if (n == "walk_kernel_active") *value = render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0;
@@ -1185,7 +1122,6 @@ int gpt_end(gpt_ctx *ctx)
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (void *p : ctx->allocs) if (p) (void)hipFree(p);
-    if (ctx->wf_flag) (void)hipHostFree(ctx->wf_flag);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GPT_OK;

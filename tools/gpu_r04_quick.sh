@@ -19,10 +19,9 @@ for order in ("reference", "wide"):
     with api.Renderer(scene.desc, W, H, meta["epsilon"]) as r:
         r.set_traversal_order(order)
         r.set_option("scheduler", 1)
-        r.set_option("wf_paths", 4096)
         r.render(cam, 1, spp, reset=True)
         got = r.read_accum()
-        print("FIRST", order, "scheduler 1 active", r.get_option("scheduler_active"), "rounds", r.get_option("last_rounds"),
+        print("FIRST", order, "scheduler 1 active", r.get_option("scheduler_active"), "paths", r.get_option("wf_paths"),
               "floats differing from the oracle (reference order):", int(np.count_nonzero(got.view(np.uint32) != ref.view(np.uint32))), "of", got.size, flush=True)
 PY
 grep "FIRST\|Error\|error" $OUT/first.log | tail -4

@@ -1,6 +1,6 @@
 """The two schedulers side by side on the SURVEY stand-ins at full size: per (stand-in, traversal order) the path-kernel time of the
-per-wave kernel ("scheduler" 0) and of the shade / trace stages (1), whether the films are bit-equal, and the stage pairs a batch took.
-python tools/gpu_wavefront.py [c3,c4,c5] [reference,wide] [iterations] [wf_paths] [sbvh]"""
+per-wave kernel ("scheduler" 0) and of the shade / trace phases over workgroup pools (1), whether the films are bit-equal, and the path slots in flight.
+python tools/gpu_wavefront.py [c3,c4,c5] [reference,wide] [iterations] [-] [sbvh]"""
 import hashlib
 import os
 import sys
@@ -13,7 +13,7 @@ from gpu_pathtracer_amd import api
 which_list = (sys.argv[1] if len(sys.argv) > 1 else "c3,c4,c5").split(",")
 modes = (sys.argv[2] if len(sys.argv) > 2 else "reference,wide").split(",")
 spp_arg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-paths_list = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "1048576").split(",")]
+paths_list = [0]
 sbvh = len(sys.argv) > 5 and sys.argv[5] == "sbvh"
 
 
@@ -21,8 +21,6 @@ def run(ls, mode, spp, scheduler, wf_paths=None, reps=2):
     with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
         r.set_traversal_order(mode)
         r.set_option("scheduler", scheduler)
-        if wf_paths:
-            r.set_option("wf_paths", wf_paths)
         if not os.environ.get("GPT_WF_ONE_BATCH"):            # (counter runs: exactly one batch per scheduler)
             r.render(ls.camera, 1, 2, reset=True); r.synchronize()
         else:
@@ -32,7 +30,7 @@ def run(ls, mode, spp, scheduler, wf_paths=None, reps=2):
             r.kernel_time_reset(); r.render(ls.camera, 1, spp, reset=True); r.synchronize()
             best = min(best, r.kernel_time()[1])
         film = r.read_accum()
-        rounds = r.get_option("last_rounds") if scheduler else 0
+        rounds = r.get_option("wf_paths") if scheduler else 0
         active = r.get_option("scheduler_active")
     return ls.width * ls.height * spp / best / 1e3, best, hashlib.sha1(film.tobytes()).hexdigest()[:16], rounds, active
 
@@ -46,5 +44,5 @@ for which in which_list:
         for n_paths in paths_list:
             wf = run(ls, mode, spp, 1, n_paths)
             print(f"WF {which} {mode:9s}{' sbvh' if sbvh else ''} stages {n_paths:8d}: {wf[0]:8.1f} Msamples/s ({wf[1]:7.2f} ms / {spp} iterations) film {wf[2]} "
-                  f"{'EQUAL' if wf[2] == base[2] else 'DIFFERENT'} rounds {wf[3]} active {wf[4]} x{wf[0] / base[0]:.2f}", flush=True)
+                  f"{'EQUAL' if wf[2] == base[2] else 'DIFFERENT'} paths {wf[3]} active {wf[4]} x{wf[0] / base[0]:.2f}", flush=True)
     ls.close()
