@@ -898,6 +898,7 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
     const unsigned s_stack = __builtin_amdgcn_readfirstlane(stack_lds) - 768u;      // (the pushes address level size' - 3 .. size' - 1 from one base)
     const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane) * 4u;
     const unsigned long long s_save = uniform64((unsigned long long)W.save);
+    const unsigned long long s_counters = uniform64((unsigned long long)P.counters);         // (probe builds)
     const unsigned v_save = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u + lane) * (unsigned)(kWfSaveDwords * 4);
     const unsigned s_tag = __builtin_amdgcn_readfirstlane(round + 1u);                       // records parked FOR this round carry it
     static_assert(kWfStackLevels % 4 == 0 && kWfStackLevels >= 8 && kWfStackLevels <= 28 && 8 + kWfStackLevels <= kWfSaveDwords, "the save record holds the LDS levels");
@@ -913,6 +914,11 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "s_mov_b32 s91, 0\n"
         "s_mov_b32 s94, 0\n"
         "s_mov_b32 s95, 0\n"
+#if PT_WF_PROBE == 3
+        "s_mov_b32 s96, 0\n"
+        "s_mov_b32 s97, 0\n"
+        "s_mov_b32 s98, 0\n"
+#endif
         "v_mbcnt_lo_u32_b32 v33, -1, 0\n"
         "v_mbcnt_hi_u32_b32 v33, -1, v33\n"                /* lane */
         "v_lshl_add_u32 v18, v33, 2, %[stack]\n"
@@ -1266,6 +1272,10 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         /* ---------------------------------------------------------------- one trip (pt_kernel.hip, trace_pool_wide_asm) */
         "TQ_TRIP_%=:\n"
         "s_add_u32 s95, s95, 1\n"
+#if PT_WF_PROBE == 3
+        "s_bcnt1_i32_b64 s71, s[64:65]\n"
+        "s_add_u32 s96, s96, s71\n"
+#endif
         "v_cmp_gt_i32_e64 s[60:61], 0, v12\n"
         "s_and_b64 s[60:61], s[60:61], s[64:65]\n"         /* at a leaf (bit 31 set, not -1: busy lanes only) */
         "s_andn2_b64 s[62:63], s[64:65], s[60:61]\n"       /* at a wide node */
@@ -1283,6 +1293,12 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "s_cbranch_scc1 TQ_VOTED_%=\n"
         "s_mov_b64 s[62:63], 0\n"
         "TQ_VOTED_%=:\n"
+#if PT_WF_PROBE == 3
+        "s_bcnt1_i32_b64 s71, s[62:63]\n"
+        "s_add_u32 s97, s97, s71\n"
+        "s_bcnt1_i32_b64 s71, s[60:61]\n"
+        "s_add_u32 s98, s98, s71\n"
+#endif
         /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
            wait for everything) */
         /* one set of fetches serves both kinds: a lane's offset from the base of the wide nodes is its node's, or that of its
@@ -1774,18 +1790,30 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "v_div_fixup_f32 v46, v46, v45, 1.0\n"
         "s_branch TQ_DIV_DONE2_%=\n"
         "TQ_DONE_%=:\n"
+#if PT_WF_PROBE == 3
+        "s_mov_b64 exec, 1\n"
+        "v_mov_b32_e32 v33, 64\n"
+        "v_mov_b32_e32 v34, s95\n"
+        "global_atomic_add v33, v34, %[counters]\n"
+        "v_mov_b32_e32 v34, s96\n"
+        "global_atomic_add v33, v34, %[counters] offset:8\n"
+        "v_mov_b32_e32 v34, s97\n"
+        "global_atomic_add v33, v34, %[counters] offset:16\n"
+        "v_mov_b32_e32 v34, s98\n"
+        "global_atomic_add v33, v34, %[counters] offset:24\n"
+#endif
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
         :
         : [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill), [stack] "s"(s_stack), [vspill] "v"(v_spill),
           [rayq] "s"(s_rayq), [ray] "s"(s_ray), [org] "s"(s_org), [hit] "s"(s_hit), [np] "s"(s_np), [shared] "s"(s_shared), [segbase] "s"(s_segbase),
-          [save] "s"(s_save), [vsave] "v"(v_save), [tag] "s"(s_tag),
+          [save] "s"(s_save), [vsave] "v"(v_save), [tag] "s"(s_tag), [counters] "s"(s_counters),
           [depth] "n"(kWfStackLevels), [maxbusy] "n"(64 - PT_WF_FETCH_T), [leafmin] "n"(PT_WF_LEAF_MIN), [nodemin] "n"(1),
           [tstop] "n"(PT_WF_STOP_T), [mintrips] "n"(PT_WF_MIN_TRIPS), [nchunks] "n"(kWfWgChunks),
           [o_next] "n"(offsetof(WfShared, trace_next)), [o_parked] "n"(offsetof(WfShared, parked))
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-          "s94", "s95",
+          "s94", "s95", "s96", "s97", "s98",
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
@@ -1816,6 +1844,12 @@ __global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevPa
     // no ray is parked for this lane (the record's third word carries the round a parked ray resumes in)
     if (WIDE) W.save[(size_t)((blockIdx.x * 4u + wv) * 64u + lane) * (uint32_t)kWfSaveDwords + 2u] = 0u;
     __syncthreads();
+#if PT_WF_PROBE == 2      // probe builds: where a wave's time goes (shader-clock cycles, lane 0 of every wave) -> P.counters[0..5]
+    unsigned long long pr_shade = 0, pr_trace = 0, pr_wait = 0, pr_rounds = 0, pr_chunks = 0, pr_t0 = __builtin_readcyclecounter();
+#define PT_WF_TICK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - pr_t0; pr_t0 = now_; }
+#else
+#define PT_WF_TICK(acc)
+#endif
     for (uint32_t round = 0;; ++round) {
         // ---- shade phase
         int emitted = 0;
@@ -1825,7 +1859,11 @@ __global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevPa
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
             if (c >= (uint32_t)kWfWgChunks) break;
             emitted += wf_shade_chunk<INTEG>(P, W, chunk0 + c, lane, &sh.seg_count[c]);
+#if PT_WF_PROBE == 2
+            pr_chunks++;
+#endif
         }
+        PT_WF_TICK(pr_shade)
         if (lane == 0 && emitted > 0) atomicAdd(&sh.emitted, (uint32_t)emitted);
         if (threadIdx.x == 0) sh.items_left = __hip_atomic_load(&W.ctrl->next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < W.n_items ? 1u : 0u;
         __syncthreads();
@@ -1838,14 +1876,26 @@ __global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevPa
         const bool resume = sh.parked != 0u;
         if (threadIdx.x == 0) sh.shade_next = sh.trace_next = sh.emitted = sh.parked = 0u;
         __syncthreads();
+        PT_WF_TICK(pr_wait)
         // ---- trace phase
         if (work) {
             if (WIDE && PT_WF_WIDE_ASM) wf_trace_wide_asm(P, W, lds_address(lds_stack + 256 + wv * 64 * kWfStackLevels), lane, lds_address(&sh), chunk0, round);
             else wf_trace_cxx<WIDE>(P, W, sh, chunk0, lds_ids + wv * kWfSegRays, lds_stack + (WIDE ? 256 + wv * 64 * kWfStackLevels : 0), lane);
         }
         (void)resume;
+        PT_WF_TICK(pr_trace)
         __syncthreads();
+        PT_WF_TICK(pr_wait)
+#if PT_WF_PROBE == 2
+        pr_rounds++;
+#endif
     }
+#if PT_WF_PROBE == 2
+    if (lane == 0) {
+        atomicAdd(&P.counters[0], pr_shade); atomicAdd(&P.counters[1], pr_trace); atomicAdd(&P.counters[2], pr_wait);
+        atomicAdd(&P.counters[3], pr_rounds); atomicAdd(&P.counters[4], pr_chunks); atomicAdd(&P.counters[5], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers ------

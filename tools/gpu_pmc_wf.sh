@@ -14,13 +14,13 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(f"{out}/wf_{which}_{mode}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = "shade" if "wf_shade" in r["Kernel_Name"] else "trace" if "wf_trace" in r["Kernel_Name"] else None
+        k = "phases" if "wf_render" in r["Kernel_Name"] else None
         if k:
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
 print(open(glob.glob(f"{out}/wf_{which}_{mode}_FETCH_SIZE.log")[0]).read().strip())
-for k in ("shade", "trace"):
+for k in ("phases",):
     a = acc[k]
-    print(f"== {k} stage, all launches of the profiled run summed ({max(calls[k].values()) if calls[k] else 0} launches)")
+    print(f"== wf_render_kernel ({k}), all launches of the profiled run summed ({max(calls[k].values()) if calls[k] else 0} launches)")
     for c in sorted(a): print(f"   {c:26s} {a[c]:.5g}")
     if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
         print(f"   HBM-side traffic: fetch {a['FETCH_SIZE']*1024/1e9:.1f} GB raw ({2*a['FETCH_SIZE']*1024/1e9:.1f} GB with the gfx950 x2 correction), write {a['WRITE_SIZE']*1024/1e9:.1f} GB")
