@@ -81,32 +81,11 @@ constexpr int kWaveCarryFloat4 = kSuspOff + 128;
 #ifndef PT_FETCH_T
 #define PT_FETCH_T 12
 #endif
-#ifndef PT_TRI_LOOKAHEAD
-#define PT_TRI_LOOKAHEAD 1       // ... and two consecutive triangles per triangle trip (PT_TRI2_LOOKAHEAD); 0: one
-#endif
-#ifndef PT_NODE_LOOKAHEAD
-#define PT_NODE_LOOKAHEAD 1      // scenes in global memory fetch two consecutive nodes per node trip (PT_NODE2_LOOKAHEAD); 0: one
-#endif
-#ifndef PT_ORDER_BY_LANE
-#define PT_ORDER_BY_LANE 0      // 1 (experiment): fetch order by lane, then kind, instead of by kind (longest rays first), then lane
-#endif
 #ifndef PT_XCD_QUEUES
 #define PT_XCD_QUEUES 1          // 1 (scenes in global memory): one work queue per XCD (workgroup b runs on XCD b % 8), each a contiguous eighth of the items, so that
 #endif                           // an XCD's private L2 serves neighbouring tiles; a wave whose queue is empty takes from the next XCD's.  0: one queue
-#ifndef PT_XCD_BLOCK
-#define PT_XCD_BLOCK 0
-#endif
 #ifndef PT_TILE_STRIP
 #define PT_TILE_STRIP 16         // N > 0 (scenes in global memory): consecutive items walk down strips of N tiles instead of along whole tile rows (512 consecutive tiles = a compact block)
-#endif
-#ifndef PT_ASM_IN_COUNT
-#define PT_ASM_IN_COUNT 0         // 1: time-split probes (cyc_trace / cyc_shade) around the hand-scheduled loop
-#endif
-#ifndef PT_LANEPROBE
-#define PT_LANEPROBE 0            // 1 (with PT_ASM_IN_COUNT, without PT_SUBPROBES): lanes in the shading rounds (counters 6..9)
-#endif
-#ifndef PT_SUBPROBES
-#define PT_SUBPROBES 0            // 1 (with PT_ASM_IN_COUNT): finer time split of the hit-shading block
 #endif
 #ifndef PT_VOTE_NODE_SHIFT
 #define PT_VOTE_NODE_SHIFT 1      // a node trip costs half a triangle trip: 2 * node-waiters >= triangle-waiters
@@ -180,18 +159,9 @@ __device__ __forceinline__ int pool_deposit_fixed(float4 *pool, const RaySet &rs
         pool[2 * kPoolSlots + lane] = make_float4(rs.org.x, rs.org.y, rs.org.z, 0.f);
         pend[lane] = (dp ? 1u : 0u) | (dm ? 2u : 0u) | (ds ? 4u : 0u);
     }
-#if PT_ORDER_BY_LANE
-    // (experiment) a lane's rays next to each other in the fetch order: they finish around the same time, so fewer LANES wait when a drain stops
-    const int base = lane_rank(m_p) + lane_rank(m_m) + lane_rank(m_s);
-    if (dp) { pool_put(pool, (int)lane, rs.dir_p, P_TMAX ? rs.tmax_s : __builtin_inff(), lane, false); order[base] = (unsigned short)lane; }
-    if (dm) { pool_put(pool, 64 + (int)lane, rs.dir_m, __builtin_inff(), lane, rs.mis_any); order[base + (dp ? 1 : 0)] = (unsigned short)(64u + lane); }
-    if (ds) { pool_put(pool, 128 + (int)lane, rs.dir_s, rs.tmax_s, lane, true); order[base + (dp ? 1 : 0) + (dm ? 1 : 0)] = (unsigned short)(128u + lane); }
-    (void)n_p; (void)n_m;
-#else
     if (dp) { pool_put(pool, (int)lane, rs.dir_p, P_TMAX ? rs.tmax_s : __builtin_inff(), lane, false); order[lane_rank(m_p)] = (unsigned short)lane; }
     if (dm) { pool_put(pool, 64 + (int)lane, rs.dir_m, __builtin_inff(), lane, rs.mis_any); order[n_p + lane_rank(m_m)] = (unsigned short)(64u + lane); }
     if (ds) { pool_put(pool, 128 + (int)lane, rs.dir_s, rs.tmax_s, lane, true); order[n_p + n_m + lane_rank(m_s)] = (unsigned short)(128u + lane); }
-#endif
     return n_p + n_m + popc(m_s);
 }
 
@@ -620,10 +590,6 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
 // restored to all ones.
 // gfx950 hazards honoured by hand: >= 2 wait states between a VALU write of VCC/SGPR and a VALU read of it
 // (4 for v_div_fmas), >= 1 between v_rcp_f32 and the use of its result.
-// code placement of the hand-written loops (experiment hook): e.g. -DPT_LOOP_ALIGN='".p2align 6\n"'
-#ifndef PT_LOOP_ALIGN
-#define PT_LOOP_ALIGN ""
-#endif
 #define PT_COMMA ,
 #define PT_STR2(x) #x
 #define PT_STR(x) PT_STR2(x)
@@ -789,37 +755,6 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_branch TP_DIV_DONE2_%=\n" \
         "TP_T2X_%=:\n"
 
-// PT_LOOP_PROBE (probe builds): the binary loops count, per drain, their node / triangle trips, the lanes active in them, the
-// lanes that hold a ray at each trip, and the same for the trips after the pool ran dry (the drain's tail); the sums go to a
-// per-wave LDS record {node trips, node lanes, triangle trips, triangle lanes, busy lanes, dry trips, busy lanes in dry trips}.
-#ifndef PT_LOOP_PROBE
-#define PT_LOOP_PROBE 0
-#endif
-#if PT_LOOP_PROBE
-#define PT_PROBE_INIT "s_mov_b32 s78, 0\n" "s_mov_b32 s79, 0\n" "s_mov_b32 s80, 0\n" "s_mov_b32 s81, 0\n" "s_mov_b32 s82, 0\n" "s_mov_b32 s83, 0\n" "s_mov_b32 s84, 0\n"
-#define PT_PROBE_COMMON \
-        "s_bcnt1_i32_b64 s73, s[64:65]\n" "s_add_u32 s82, s82, s73\n" "s_cmp_ge_i32 s70, %[rays]\n" "s_cbranch_scc0 TP_PRB_%=\n" \
-        "s_add_u32 s83, s83, 1\n" "s_add_u32 s84, s84, s73\n"
-#define PT_PROBE_NODE PT_PROBE_COMMON "TP_PRB_%=:\n" "s_add_u32 s78, s78, 1\n" "s_bcnt1_i32_b64 s73, exec\n" "s_add_u32 s79, s79, s73\n"
-#define PT_PROBE_TRI "s_bcnt1_i32_b64 s73, s[64:65]\n" "s_add_u32 s82, s82, s73\n" "s_cmp_ge_i32 s70, %[rays]\n" "s_cbranch_scc0 TP_PRT_%=\n" \
-        "s_add_u32 s83, s83, 1\n" "s_add_u32 s84, s84, s73\n" "TP_PRT_%=:\n" "s_add_u32 s80, s80, 1\n" "s_bcnt1_i32_b64 s73, exec\n" "s_add_u32 s81, s81, s73\n"
-#define PT_PROBE_EXIT \
-        "s_mov_b64 exec, 1\n" "v_mov_b32_e32 v33, %[probe]\n" \
-        "v_mov_b32_e32 v34, s78\n" "ds_add_u32 v33, v34\n" "v_mov_b32_e32 v34, s79\n" "ds_add_u32 v33, v34 offset:4\n" \
-        "v_mov_b32_e32 v34, s80\n" "ds_add_u32 v33, v34 offset:8\n" "v_mov_b32_e32 v34, s81\n" "ds_add_u32 v33, v34 offset:12\n" \
-        "v_mov_b32_e32 v34, s82\n" "ds_add_u32 v33, v34 offset:16\n" "v_mov_b32_e32 v34, s83\n" "ds_add_u32 v33, v34 offset:20\n" \
-        "v_mov_b32_e32 v34, s84\n" "ds_add_u32 v33, v34 offset:24\n" "s_mov_b64 exec, -1\n"
-#define PT_PROBE_CLOBBERS "s73", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
-#define PT_PROBE_OPERAND , [probe] "s"(s_probe)
-#else
-#define PT_PROBE_INIT
-#define PT_PROBE_NODE
-#define PT_PROBE_TRI
-#define PT_PROBE_EXIT
-#define PT_PROBE_CLOBBERS
-#define PT_PROBE_OPERAND
-#endif
-
 // The loop as a macro over the memory space of the scene (the only difference: how node and triangle records are
 // loaded and which counter is waited on).  Comments live in the block above and in trace_pool<>.
 #define PT_TRACE_ASM(LD_NODE, NODE_W1, NODE_W0, NODE2, TRI2, LD_TRI, WAIT_1, WAIT_0, VOTE_WEIGHT, ENTRY_STATE, FETCH_SLOT, CURSOR_EARLY, CURSOR_LATE, RAY_END, FINISH_EXTRA, DRY_POOL, EXIT_EXTRA, MORE_CLOBBERS, ...) \
@@ -828,10 +763,8 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_mov_b32 s76, 0x322bcc77\n" \
         "s_mov_b32 s77, 0x71800000\n" \
         "s_mov_b64 s[64:65], 0\n" \
-        PT_PROBE_INIT \
         ENTRY_STATE \
         "s_branch TP_FILL_%=\n" \
-        PT_LOOP_ALIGN \
         "TP_LOOP_%=:\n" \
         "v_cmp_le_i32_e64 s[60:61], v13, v14\n" \
         "v_cmp_gt_i32_e64 s[62:63], " RAY_END ", v12\n" \
@@ -847,7 +780,6 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_cmp_ge_u32 s71, s72\n" \
         "s_cbranch_scc0 TP_TRI_%=\n" \
         "s_mov_b64 exec, s[62:63]\n" \
-        PT_PROBE_NODE \
         LD_NODE \
         NODE_W1 \
         "v_sub_f32_e32 v33, v24, v0\n" \
@@ -887,7 +819,6 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "s_branch TP_LOOP_%=\n" \
         "TP_TRI_%=:\n" \
         "s_mov_b64 exec, s[60:61]\n" \
-        PT_PROBE_TRI \
         LD_TRI \
         "v_add_u32_e32 v13, 48, v13\n" \
         WAIT_1 \
@@ -1037,18 +968,17 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         DRY_POOL \
         "TP_DONE_%=:\n" \
         EXIT_EXTRA \
-        PT_PROBE_EXIT \
         "s_waitcnt lgkmcnt(0)\n" \
         "s_mov_b64 exec, -1\n" \
         : \
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias), \
-          [eps] "s"(s_eps), __VA_ARGS__ PT_PROBE_OPERAND, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
+          [eps] "s"(s_eps), __VA_ARGS__, [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16) \
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", \
-          "s72", "s76", "s77", PT_PROBE_CLOBBERS MORE_CLOBBERS "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
+          "s72", "s76", "s77", MORE_CLOBBERS "v0", "v1", "v2", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", \
           "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
           "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
 
-__device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps, unsigned loop_probe_lds = 0)
+__device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
@@ -1056,8 +986,6 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
     const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
     const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    const unsigned s_probe = __builtin_amdgcn_readfirstlane(loop_probe_lds);
-    (void)s_probe;
     PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "", "",
                  "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
                  "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
@@ -1065,40 +993,9 @@ __device__ __forceinline__ void trace_pool_lds_asm(unsigned pool_lds, int n_rays
                  PT_ENTRY_IDLE, PT_FETCH_COMPACT, PT_CURSOR_FIRST, "", "%[end]", "", PT_DRY_DRAIN, "", , [unused] "n"(0))
 }
 
-// Experiment (PT_SMALL_CARRY=1; see kernel_variants.log): the LDS-resident scene with the carry machinery of the global-memory loop - fixed slots,
-// pending masks, a drain that may stop with rays in flight - so that the headline kernel's tail (60 % of its trips come after the
-// pool ran dry) can be traded against emptier shading rounds.  Cursors are LDS addresses: [first] + offset, v3 = one past the nodes.
-#ifndef PT_SMALL_CARRY
-#define PT_SMALL_CARRY 0
-#endif
-#ifndef PT_STOP_T_LDS
-#define PT_STOP_T_LDS 12
-#endif
-__device__ __forceinline__ void trace_pool_lds_carry_asm(unsigned pool_lds, int n_rays, const LdsScene mem, float eps, bool may_stop, unsigned loop_probe_lds = 0)
-{
-    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
-    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
-    const int s_end = __builtin_amdgcn_readfirstlane(mem.end - mem.first);      // bytes of the node array
-    const int s_first = __builtin_amdgcn_readfirstlane(mem.first);
-    const int s_bias = __builtin_amdgcn_readfirstlane(mem.tri_bias);
-    const int s_vstride = 0;
-    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
-    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
-    const int s_tstop = PT_STOP_T_LDS;
-    const unsigned s_probe = __builtin_amdgcn_readfirstlane(loop_probe_lds);
-    (void)s_probe;
-    PT_TRACE_ASM("ds_read_b128 v[24:27], v12\n" "ds_read_b128 v[28:31], v12 offset:16\n", "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n", "", "",
-                 "ds_read_b128 v[28:31], v13 offset:16\n" "ds_read_b32 v32, v13 offset:32\n" "ds_read_b128 v[24:27], v13\n",
-                 "s_waitcnt lgkmcnt(1)\n", "s_waitcnt lgkmcnt(0)\n",
-                 "s_lshl_b32 s71, s71, " PT_STR(PT_VOTE_NODE_SHIFT) "\n",
-                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,
-                 [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp), [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
-}
-
 // Scenes in global memory: cursors are byte offsets from the node / triangle arrays, loads use the SGPR-base +
 // 32-bit VGPR-offset form.  (vmcnt also counts this wave's earlier sample stores; they are long gone.)
-__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop, unsigned loop_probe_lds = 0)
+__device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
@@ -1110,319 +1007,18 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
     const int s_tstop = __builtin_amdgcn_readfirstlane(mem.end - mem.first >= 65536 * 32 ? PT_STOP_T : PT_STOP_T_SMALL);
-    const unsigned s_probe = __builtin_amdgcn_readfirstlane(loop_probe_lds);
-    (void)s_probe;
-#if PT_NODE_LOOKAHEAD
     PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
                  "global_load_dwordx4 v[44:47], v12, %[nodes] offset:32\n" "global_load_dwordx4 v[48:51], v12, %[nodes] offset:48\n",
                  "s_waitcnt vmcnt(3)\n", "s_waitcnt vmcnt(2)\n", PT_NODE2_LOOKAHEAD,
-#if PT_TRI_LOOKAHEAD
                  PT_TRI2_LOOKAHEAD("v3"),
                  "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n"
                  "global_load_dwordx4 v[48:51], v13, %[tris] offset:64\n" "global_load_dword v52, v13, %[tris] offset:80\n" "global_load_dwordx4 v[44:47], v13, %[tris] offset:48\n",
                  "s_waitcnt vmcnt(4)\n", "s_waitcnt vmcnt(3)\n", PT_GLOBAL_VOTE_WEIGHT,
-#else
-                 "",
-                 "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
-                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
-#endif
                  PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
                  "v3" PT_COMMA "v44" PT_COMMA "v45" PT_COMMA "v46" PT_COMMA "v47" PT_COMMA "v48" PT_COMMA "v49" PT_COMMA "v50" PT_COMMA "v51" PT_COMMA "v52" PT_COMMA,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
                  [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
-#else
-    PT_TRACE_ASM("global_load_dwordx4 v[24:27], v12, %[nodes]\n" "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n", "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", "", "",
-                 "global_load_dwordx4 v[28:31], v13, %[tris] offset:16\n" "global_load_dword v32, v13, %[tris] offset:32\n" "global_load_dwordx4 v[24:27], v13, %[tris]\n",
-                 "s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(0)\n", PT_GLOBAL_VOTE_WEIGHT,
-                 PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND, "v3" PT_COMMA,
-                 [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
-                 [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
-#endif
 }
-
-// Experiment (off): the global-memory loop with BOTH kinds of lanes served in every trip (PT_GLOBAL_BOTH=1): the registers, the arithmetic and every ray's own
-// sequence of visits are those of PT_TRACE_ASM (so the film is the same bit for bit), but a trip is no longer voted to be a node trip or
-// a triangle trip.  Nodes and triangles share one allocation (gpt_begin), a lane's 32-bit offset from the base of the nodes is its node
-// cursor or its triangle cursor + [trioff], and ONE set of fetches goes out under exec = node lanes | triangle lanes: a node lane
-// receives its node in v[24:31] and the next one in memory in v[32:35], v[44:47] (the lookahead), a triangle lane its triangle in
-// v[24:32] and the one after it in v[44:52] (two more fetches, triangle lanes only).  Then the node block runs under the node lanes and
-// the triangle block under the triangle lanes - lanes at a triangle wait until PT_BOTH_LEAF_MIN have gathered or nobody is at a node.
-// The node block's temporaries moved from v33-v41 to v36-v43, v48 (the second node's first half now lands in v32-v35).
-#ifndef PT_GLOBAL_BOTH
-#define PT_GLOBAL_BOTH 0          // measured: -5 % on the config 3 - 5 stand-ins in the reference order (kernel_variants.log): the voted loop stays
-#endif
-#ifndef PT_BOTH_LEAF_MIN
-#define PT_BOTH_LEAF_MIN 8
-#endif
-#define PT_NODE2_LOOKAHEAD_B \
-        "s_andn2_b64 s[66:67], s[66:67], vcc\n" "s_mov_b64 exec, s[66:67]\n" "s_cbranch_execz TP_N2B_%=\n" "s_waitcnt vmcnt(0)\n" \
-        "v_sub_f32_e32 v36, v32, v0\n" "v_sub_f32_e32 v37, v35, v0\n" "v_sub_f32_e32 v38, v33, v1\n" "v_sub_f32_e32 v40, v34, v2\n" \
-        "v_sub_f32_e32 v39, v44, v1\n" "v_sub_f32_e32 v41, v45, v2\n" \
-        "v_mul_f32_e32 v36, v8, v36\n" "v_mul_f32_e32 v37, v8, v37\n" "v_mul_f32_e32 v38, v9, v38\n" "v_mul_f32_e32 v39, v9, v39\n" \
-        "v_mul_f32_e32 v40, v10, v40\n" "v_mul_f32_e32 v41, v10, v41\n" \
-        "v_min_f32_e32 v42, v36, v37\n" "v_min_f32_e32 v43, v38, v39\n" "v_min_f32_e32 v48, v40, v41\n" \
-        "v_max_f32_e32 v36, v36, v37\n" "v_max_f32_e32 v38, v38, v39\n" "v_max_f32_e32 v40, v40, v41\n" \
-        "v_min3_f32 v36, v36, v38, v40\n" "v_max3_f32 v42, v42, v43, v48\n" \
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v36\n" "v_min_f32_e32 v36, v36, v21\n" "v_cmp_nlt_f32_e64 s[66:67], v36, v42\n" \
-        "s_and_b64 s[66:67], s[66:67], vcc\n" "v_cmp_lt_i32_e32 vcc, -1, v47\n" "v_add_u32_e32 v36, 32, v12\n" \
-        "s_or_b64 s[68:69], vcc, s[66:67]\n" "s_and_b64 vcc, vcc, s[66:67]\n" \
-        "v_cndmask_b32_e64 v12, v46, v36, s[68:69]\n" "v_cndmask_b32_e32 v14, v14, v47, vcc\n" "v_cndmask_b32_e32 v13, v13, v46, vcc\n" \
-        "TP_N2B_%=:\n"
-
-__device__ __forceinline__ void trace_pool_global_both_asm(unsigned pool_lds, int n_rays, const GlobalScene mem, float eps, bool may_stop)
-{
-    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
-    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
-    const int s_end = __builtin_amdgcn_readfirstlane(mem.end - mem.first);      // bytes of one node array
-    const int s_vstride = __builtin_amdgcn_readfirstlane(mem.near_stride);
-    const int s_first = s_vstride, s_bias = 0;                                   // variant 0, or variant 1 + octant
-    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
-    const unsigned long long s_nodes = uniform64((unsigned long long)mem.nodes);
-    const unsigned s_trioff = __builtin_amdgcn_readfirstlane((unsigned)(mem.tris - mem.nodes));     // one allocation, triangles behind the nodes
-    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
-    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
-    const int s_tstop = __builtin_amdgcn_readfirstlane(mem.end - mem.first >= 65536 * 32 ? PT_STOP_T : PT_STOP_T_SMALL);
-    asm volatile(
-        "s_mov_b32 s70, 0\n"
-        "s_mov_b32 s76, 0x322bcc77\n"
-        "s_mov_b32 s77, 0x71800000\n"
-        "s_mov_b64 s[64:65], 0\n"
-        PT_ENTRY_RESUME
-        "s_branch TP_FILL_%=\n"
-        PT_LOOP_ALIGN
-        "TP_LOOP_%=:\n"
-        "v_cmp_le_i32_e64 s[60:61], v13, v14\n"
-        "v_cmp_gt_i32_e64 s[62:63], v3, v12\n"
-        "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"
-        "s_or_b64 s[66:67], s[60:61], s[62:63]\n"
-        "s_andn2_b64 s[68:69], s[64:65], s[66:67]\n"
-        "s_cbranch_scc1 TP_FIN_%=\n"
-        "TP_VOTE_%=:\n"
-        "s_andn2_b64 s[62:63], s[62:63], s[60:61]\n"
-        "s_bcnt1_i32_b64 s71, s[62:63]\n"
-        "s_bcnt1_i32_b64 s72, s[60:61]\n"
-        /* too few lanes at a triangle: they wait (unless nobody is at a node) */
-        "s_cmp_ge_u32 s72, %[leafmin]\n"
-        "s_cbranch_scc1 TP_VOTED_%=\n"
-        "s_cmp_eq_u32 s71, 0\n"
-        "s_cbranch_scc1 TP_VOTED_%=\n"
-        "s_mov_b64 s[60:61], 0\n"
-        "TP_VOTED_%=:\n"
-        /* ---- one set of fetches (v33 is the offset: the fetch that overwrites it goes last) */
-        "s_mov_b64 exec, s[60:61]\n"
-        "v_add_u32_e32 v33, %[trioff], v13\n"
-        "s_mov_b64 exec, s[62:63]\n"
-        "v_mov_b32_e32 v33, v12\n"
-        "s_or_b64 exec, s[60:61], s[62:63]\n"
-        "global_load_dwordx4 v[24:27], v33, %[nodes]\n"
-        "global_load_dwordx4 v[28:31], v33, %[nodes] offset:16\n"
-        "global_load_dwordx4 v[44:47], v33, %[nodes] offset:48\n"
-        "s_mov_b64 exec, s[60:61]\n"
-        "global_load_dwordx4 v[48:51], v33, %[nodes] offset:64\n"
-        "global_load_dword v52, v33, %[nodes] offset:80\n"
-        "s_or_b64 exec, s[60:61], s[62:63]\n"
-        "global_load_dwordx4 v[32:35], v33, %[nodes] offset:32\n"
-        /* ---- node block (exec = s[62:63]) */
-        "s_mov_b64 exec, s[62:63]\n"
-        "s_cbranch_execz TP_TRI_%=\n"
-        "s_waitcnt vmcnt(0)\n"
-        "v_sub_f32_e32 v36, v24, v0\n"
-        "v_sub_f32_e32 v37, v27, v0\n"
-        "v_sub_f32_e32 v38, v25, v1\n"
-        "v_sub_f32_e32 v40, v26, v2\n"
-        "v_sub_f32_e32 v39, v28, v1\n"
-        "v_sub_f32_e32 v41, v29, v2\n"
-        "v_mul_f32_e32 v36, v8, v36\n"
-        "v_mul_f32_e32 v37, v8, v37\n"
-        "v_mul_f32_e32 v38, v9, v38\n"
-        "v_mul_f32_e32 v39, v9, v39\n"
-        "v_mul_f32_e32 v40, v10, v40\n"
-        "v_mul_f32_e32 v41, v10, v41\n"
-        "v_min_f32_e32 v42, v36, v37\n"
-        "v_min_f32_e32 v43, v38, v39\n"
-        "v_min_f32_e32 v48, v40, v41\n"
-        "v_max_f32_e32 v36, v36, v37\n"
-        "v_max_f32_e32 v38, v38, v39\n"
-        "v_max_f32_e32 v40, v40, v41\n"
-        "v_min3_f32 v36, v36, v38, v40\n"
-        "v_max3_f32 v42, v42, v43, v48\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v36\n"
-        "v_min_f32_e32 v36, v36, v21\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v36, v42\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_lt_i32_e32 vcc, -1, v31\n"
-        "v_add_u32_e32 v36, 32, v12\n"
-        "s_or_b64 s[68:69], vcc, s[66:67]\n"
-        "s_and_b64 vcc, vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v30, v36, s[68:69]\n"
-        "v_cndmask_b32_e32 v14, v14, v31, vcc\n"
-        "v_cndmask_b32_e32 v13, v13, v30, vcc\n"
-        PT_NODE2_LOOKAHEAD_B
-        /* ---- triangle block (exec = s[60:61]) */
-        "TP_TRI_%=:\n"
-        "s_mov_b64 exec, s[60:61]\n"
-        "s_cbranch_execz TP_BACK_%=\n"
-        "s_waitcnt vmcnt(0)\n"
-        "v_add_u32_e32 v13, 48, v13\n"
-        "v_mul_f32_e32 v33, v5, v32\n"
-        "v_mul_f32_e32 v42, v6, v31\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v6, v30\n"
-        "v_mul_f32_e32 v42, v4, v32\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v4, v31\n"
-        "v_mul_f32_e32 v42, v5, v30\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v36, v33, v27\n"
-        "v_mul_f32_e32 v42, v34, v28\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_mul_f32_e32 v42, v35, v29\n"
-        "v_add_f32_e32 v36, v36, v42\n"
-        "v_rcp_f32_e32 v38, v36\n"
-        "v_sub_f32_e32 v24, v0, v24\n"
-        "v_sub_f32_e32 v25, v1, v25\n"
-        "v_sub_f32_e32 v26, v2, v26\n"
-        "v_cmp_nle_f32_e64 s[66:67], abs(v36), s77\n"
-        "v_fma_f32 v41, -v36, v38, 1.0\n"
-        "v_fma_f32 v37, v41, v38, v38\n"
-        "s_cmp_lg_u64 s[66:67], 0\n"
-        "s_cbranch_scc1 TP_DIV_IEEE_%=\n"
-        "TP_DIV_DONE_%=:\n"
-        "v_mul_f32_e32 v43, v24, v33\n"
-        "v_mul_f32_e32 v42, v25, v34\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v42, v26, v35\n"
-        "v_add_f32_e32 v43, v43, v42\n"
-        "v_mul_f32_e32 v33, v25, v29\n"
-        "v_mul_f32_e32 v42, v26, v28\n"
-        "v_sub_f32_e32 v33, v33, v42\n"
-        "v_mul_f32_e32 v34, v26, v27\n"
-        "v_mul_f32_e32 v42, v24, v29\n"
-        "v_sub_f32_e32 v34, v34, v42\n"
-        "v_mul_f32_e32 v35, v24, v28\n"
-        "v_mul_f32_e32 v42, v25, v27\n"
-        "v_sub_f32_e32 v35, v35, v42\n"
-        "v_mul_f32_e32 v43, v43, v37\n"
-        "v_mul_f32_e32 v38, v4, v33\n"
-        "v_mul_f32_e32 v42, v5, v34\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v42, v6, v35\n"
-        "v_add_f32_e32 v38, v38, v42\n"
-        "v_mul_f32_e32 v38, v38, v37\n"
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v36), s76\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v43\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v43\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v38\n"
-        "v_add_f32_e32 v42, v43, v38\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v42\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TP_TRI_END_%=\n"
-        "v_mul_f32_e32 v39, v30, v33\n"
-        "v_mul_f32_e32 v42, v31, v34\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v42, v32, v35\n"
-        "v_add_f32_e32 v39, v39, v42\n"
-        "v_mul_f32_e32 v39, v39, v37\n"
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v39\n"
-        "v_cmp_ngt_f32_e64 s[66:67], v39, v21\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TP_TRI_END_%=\n"
-        "v_and_b32_e32 v42, 0x100, v11\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v42\n"
-        "v_mov_b32_e32 v24, v3\n"
-        "v_mov_b32_e32 v21, v39\n"
-        "v_subrev_u32_e32 v20, 48, v13\n"
-        "v_mov_b32_e32 v22, v43\n"
-        "v_mov_b32_e32 v23, v38\n"
-        "v_cndmask_b32_e32 v12, v12, v24, vcc\n"
-        "v_cndmask_b32_e64 v14, v14, -1, vcc\n"
-        "TP_TRI_END_%=:\n"
-        PT_TRI2_LOOKAHEAD("v3")
-        "TP_BACK_%=:\n"
-        "s_mov_b64 exec, -1\n"
-        "s_branch TP_LOOP_%=\n"
-        "TP_DIV_IEEE_%=:\n"
-        "v_div_scale_f32 v37, s[66:67], v36, v36, 1.0\n"
-        "v_div_scale_f32 v39, vcc, 1.0, v36, 1.0\n"
-        "v_rcp_f32_e32 v38, v37\n"
-        "s_nop 0\n"
-        "v_fma_f32 v41, -v37, v38, 1.0\n"
-        "v_fmac_f32_e32 v38, v41, v38\n"
-        "v_mul_f32_e32 v40, v39, v38\n"
-        "v_fma_f32 v41, -v37, v40, v39\n"
-        "v_fmac_f32_e32 v40, v41, v38\n"
-        "v_fma_f32 v37, -v37, v40, v39\n"
-        "v_div_fmas_f32 v37, v37, v38, v40\n"
-        "v_div_fixup_f32 v37, v37, v36, 1.0\n"
-        "s_branch TP_DIV_DONE_%=\n"
-        "TP_FIN_%=:\n"
-        "s_mov_b64 exec, s[68:69]\n"
-        "s_mov_b32 s72, 0xaaaaaaab\n"
-        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
-        "v_subrev_u32_e32 v33, %[bias], v20\n"
-        "v_mul_hi_u32 v33, v33, s72\n"
-        "v_lshrrev_b32_e32 v33, 5, v33\n"
-        "v_cndmask_b32_e64 v20, v33, -1, vcc\n"
-        "s_andn2_b64 s[64:65], s[64:65], s[68:69]\n"
-        "ds_write_b128 v15, v[20:23] offset:16\n"
-        PT_FINISH_PENDING
-        "v_mov_b32_e32 v15, -1\n"
-        "s_mov_b64 exec, -1\n"
-        "TP_FILL_%=:\n"
-        "s_cmp_ge_i32 s70, %[rays]\n"
-        "s_cbranch_scc1 TP_EMPTY_%=\n"
-        "s_bcnt1_i32_b64 s71, s[64:65]\n"
-        "s_cmp_gt_u32 s71, %[maxbusy]\n"
-        "s_cbranch_scc1 TP_VOTE_%=\n"
-        "s_not_b64 s[66:67], s[64:65]\n"
-        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
-        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
-        "v_add_u32_e32 v33, s70, v33\n"
-        "v_cmp_gt_i32_e32 vcc, %[rays], v33\n"
-        "s_and_b64 s[66:67], vcc, s[66:67]\n"
-        "s_sub_i32 s71, 64, s71\n"
-        "s_add_i32 s70, s70, s71\n"
-        "s_mov_b64 exec, s[66:67]\n"
-        PT_FETCH_ORDERED
-        "ds_read_b128 v[4:7], v15\n"
-        "ds_read_b128 v[8:11], v15 offset:16\n"
-        "v_mov_b32_e32 v13, 0\n"
-        "v_mov_b32_e32 v14, -1\n"
-        "v_mov_b32_e32 v20, -1\n"
-        "v_mov_b32_e32 v22, 0\n"
-        "v_mov_b32_e32 v23, 0\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        PT_CURSOR_VARIANT
-        "v_and_b32_e32 v33, 0xff, v11\n"
-        "v_lshl_add_u32 v33, v33, 4, %[pool]\n"
-        "ds_read_b96 v[0:2], v33 offset:%[org]\n"
-        "v_mov_b32_e32 v21, v7\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, -1\n"
-        "s_branch TP_LOOP_%=\n"
-        "TP_EMPTY_%=:\n"
-        PT_DRY_MAY_STOP
-        "TP_DONE_%=:\n"
-        PT_EXIT_SUSPEND
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_mov_b64 exec, -1\n"
-        :
-        : [pool] "s"(s_pool), [rays] "s"(s_rays), [end] "s"(s_end), [first] "s"(s_first), [bias] "s"(s_bias),
-          [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
-          [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop), [maxbusy] "n"(64 - kFetchThreshold), [org] "n"(2 * kPoolSlots * 16),
-          [leafmin] "n"(PT_BOTH_LEAF_MIN)
-        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71",
-          "s72", "s76", "s77", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14",
-          "v15", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32",
-          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52");
-}
-
-
 
 // ---- trace_pool_wide<>, hand-scheduled -------------------------------------------------------------------------------------
 // The instruction-for-instruction twin of trace_pool_wide<> above (which stays the specification and runs in the counting
@@ -1443,7 +1039,7 @@ __device__ __forceinline__ void trace_pool_global_both_asm(unsigned pool_lds, in
 //   v[20:23] best hit {triangle index or -1, t, b1, b2}
 //   lanes at a wide node: v[24:47] six planes of four boxes, worked on in place (child k: v24+k, v28+k, ... v44+k; its key ends in v24+k),
 //                         v[48:51] the children's entries, v52 v53 temporaries; after the sort v[28:30] (push addresses)
-//   lanes at a leaf:      v[24:32] the triangle record, v[44:52] the record after it (PT_WIDE_TRI2), v[33:43] temporaries (as in PT_TRACE_ASM),
+//   lanes at a leaf:      v[24:32] the triangle record, v[44:52] the record after it (1), v[33:43] temporaries (as in PT_TRACE_ASM),
 //                         v53 the triangle's index, v54 its byte offset
 //   s[60:61] lanes at a leaf  s[62:63] lanes at a wide node  s[64:65] lanes with a ray / busy lanes  s[66:69],s[72:75] scratch masks
 //   s70 next ray  s71 s72 counts  s76 1e-8f  s77 2^100  s[78:79] lanes that pop  s[80:81] node lanes with a hit child
@@ -1465,48 +1061,8 @@ __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, uns
     rec[4] = 0xffffffffu; rec[5] = 0u; rec[6] = 0u; rec[7] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
-#ifndef PT_WIDE_TRI2
-#define PT_WIDE_TRI2 1           // a leaf lane tests the leaf's next triangle in the same trip (its record is fetched with the first one's)
-#endif
-#ifndef PT_WIDE_EARLY
-#define PT_WIDE_EARLY 0          // (measured: -5 %, the extra vector-memory instructions cost more than the overlap gains) a lane that descends into a wide node fetches that record before the trip's triangle block
-#endif
-#if PT_WIDE_EARLY
-#error "PT_WIDE_EARLY went with the separate node / triangle fetches (see git history): the loop now fetches for both kinds with one set of instructions"
-#endif
-#ifndef PT_WIDE_EARLY_POP
-#define PT_WIDE_EARLY_POP 0      // (measured: +-0) 1: the entry a lane would pop is read from its LDS stack when the trip's fetches go out, not when it pops
-#endif
-#ifndef PT_WIDE_PK
-#define PT_WIDE_PK 0             // (measured: -2 %, packed fp32 issues no faster than two plain instructions here) 1: the node block forms (plane - origin) * inverse direction with v_pk_add_f32 / v_pk_mul_f32, two children at a time (24 VALU instructions fewer per node trip)
-#endif
-#ifndef PT_WIDE_EXTRA_NODE
-#define PT_WIDE_EXTRA_NODE         // experiment hook: extra VALU instructions in the node block (what would fewer of them be worth?)
-#endif
-#ifndef PT_WIDE_EXTRA_LOADS
-#define PT_WIDE_EXTRA_LOADS        // experiment hook: redundant fetches per trip (how much does a vector-memory instruction cost?)
-#endif
-#ifndef PT_WIDE_PROBE
-#define PT_WIDE_PROBE 0          // 1: the loop counts its trips, node / triangle blocks and the lanes in them (probe builds)
-#endif
-#if PT_WIDE_PROBE
-#define PT_WIDE_PROBE_TRIP \
-        "s_bcnt1_i32_b64 s71, s[62:63]\n" "s_bcnt1_i32_b64 s72, s[60:61]\n" \
-        "v_add_u32_e32 %[pr_trips], 1, %[pr_trips]\n" "v_add_u32_e32 %[pr_nlanes], s71, %[pr_nlanes]\n" "v_add_u32_e32 %[pr_tlanes], s72, %[pr_tlanes]\n" \
-        "s_min_u32 s71, s71, 1\n" "s_min_u32 s72, s72, 1\n" \
-        "v_add_u32_e32 %[pr_nblk], s71, %[pr_nblk]\n" "v_add_u32_e32 %[pr_tblk], s72, %[pr_tblk]\n" \
-        "s_bcnt1_i32_b64 s71, s[64:65]\n" "v_add_u32_e32 %[pr_busy], s71, %[pr_busy]\n"
-#else
-#define PT_WIDE_PROBE_TRIP
-#endif
-#if PT_WIDE_PROBE
-#define PT_WIDE_PROBE_SLOW "v_add_u32_e32 %[pr_slow], 1, %[pr_slow]\n"
-#else
-#define PT_WIDE_PROBE_SLOW
-#endif
-struct WideProbe { unsigned trips, nlanes, tlanes, nblk, tblk, busy, slow; };
 
-__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop, WideProbe &pr)
+__device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop)
 {
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
@@ -1551,7 +1107,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_mov_b64 exec, -1\n"
         "s_branch TW_FILL_%=\n"
         /* ---------------------------------------------------------------- loop header */
-        PT_LOOP_ALIGN
         "TW_LOOP_%=:\n"
         "v_cmp_lt_i32_e64 s[64:65], -1, v15\n"             /* lanes with a ray */
         "v_cmp_eq_u32_e64 s[66:67], -1, v12\n"             /* ... that is finished */
@@ -1575,7 +1130,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_cbranch_scc1 TW_VOTED_%=\n"
         "s_mov_b64 s[62:63], 0\n"
         "TW_VOTED_%=:\n"
-        PT_WIDE_PROBE_TRIP
         /* ---- fetches of both kinds (a vector-memory instruction whose exec is empty is not counted by vmcnt: both blocks
            wait for everything) */
         /* one set of fetches serves both kinds: a lane's offset from the base of the wide nodes is its node's, or that of its
@@ -1596,14 +1150,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "global_load_dwordx4 v[32:35], v54, %[nodes] offset:32\n"
         "global_load_dwordx4 v[44:47], v54, %[nodes] offset:80\n"
         "global_load_dwordx4 v[48:51], v54, %[nodes] offset:96\n"
-#if PT_WIDE_EARLY_POP
-        /* the top of the lane's stack, read now (v54 is free once the fetches are issued): a lane that pops at the end of this trip
-           has pushed nothing in it, so this is the entry it pops - and the LDS round trip hides behind the fetches */
-        "v_add_u32_e32 v54, -1, v13\n"
-        "v_lshl_add_u32 v54, v54, 8, v18\n"
-        "ds_read_b32 v54, v54 offset:768\n"
-#endif
-        PT_WIDE_EXTRA_LOADS
         "s_mov_b64 s[78:79], 0\n"
         "s_mov_b64 s[82:83], 0\n"
         "s_mov_b64 exec, s[62:63]\n"
@@ -1611,103 +1157,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_waitcnt vmcnt(0)\n"
         /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
         /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */
-        PT_WIDE_EXTRA_NODE
-#if PT_WIDE_PK
-        /* children 0 and 1: (plane - origin) * inverse direction, two at a time (the same roundings as v_sub_f32 / v_mul_f32) */
-        "v_pk_add_f32 v[24:25], v[24:25], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[36:37], v[36:37], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[28:29], v[28:29], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[32:33], v[32:33], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[40:41], v[40:41], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[44:45], v[44:45], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_mul_f32 v[24:25], v[8:9], v[24:25] op_sel_hi:[0,1]\n"
-        "v_pk_mul_f32 v[36:37], v[8:9], v[36:37] op_sel_hi:[0,1]\n"
-        "v_pk_mul_f32 v[28:29], v[8:9], v[28:29] op_sel:[1,0] op_sel_hi:[1,1]\n"
-        "v_pk_mul_f32 v[40:41], v[8:9], v[40:41] op_sel:[1,0] op_sel_hi:[1,1]\n"
-        "v_pk_mul_f32 v[32:33], v[10:11], v[32:33] op_sel_hi:[0,1]\n"
-        "v_pk_mul_f32 v[44:45], v[10:11], v[44:45] op_sel_hi:[0,1]\n"
-        "v_min_f32_e32 v52, v24, v36\n"
-        "v_max_f32_e32 v24, v24, v36\n"
-        "v_min_f32_e32 v36, v28, v40\n"
-        "v_max_f32_e32 v28, v28, v40\n"
-        "v_min_f32_e32 v40, v32, v44\n"
-        "v_max_f32_e32 v32, v32, v44\n"
-        "v_min3_f32 v24, v24, v28, v32\n"
-        "v_max3_f32 v52, v52, v36, v40\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v24\n"
-        "v_min_f32_e32 v24, v24, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v24, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v48\n"
-        "v_and_or_b32 v52, v52, -4, 0\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v24, -1, v52, s[66:67]\n"
-        "v_min_f32_e32 v52, v25, v37\n"
-        "v_max_f32_e32 v25, v25, v37\n"
-        "v_min_f32_e32 v37, v29, v41\n"
-        "v_max_f32_e32 v29, v29, v41\n"
-        "v_min_f32_e32 v41, v33, v45\n"
-        "v_max_f32_e32 v33, v33, v45\n"
-        "v_min3_f32 v25, v25, v29, v33\n"
-        "v_max3_f32 v52, v52, v37, v41\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v25\n"
-        "v_min_f32_e32 v25, v25, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v25, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v49\n"
-        "v_and_or_b32 v52, v52, -4, 1\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v25, -1, v52, s[66:67]\n"
-        /* children 2 and 3: (plane - origin) * inverse direction, two at a time (the same roundings as v_sub_f32 / v_mul_f32) */
-        "v_pk_add_f32 v[26:27], v[26:27], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[38:39], v[38:39], v[0:1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[30:31], v[30:31], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[34:35], v[34:35], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[42:43], v[42:43], v[0:1] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_add_f32 v[46:47], v[46:47], v[2:3] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-        "v_pk_mul_f32 v[26:27], v[8:9], v[26:27] op_sel_hi:[0,1]\n"
-        "v_pk_mul_f32 v[38:39], v[8:9], v[38:39] op_sel_hi:[0,1]\n"
-        "v_pk_mul_f32 v[30:31], v[8:9], v[30:31] op_sel:[1,0] op_sel_hi:[1,1]\n"
-        "v_pk_mul_f32 v[42:43], v[8:9], v[42:43] op_sel:[1,0] op_sel_hi:[1,1]\n"
-        "v_pk_mul_f32 v[34:35], v[10:11], v[34:35] op_sel_hi:[0,1]\n"
-        "v_pk_mul_f32 v[46:47], v[10:11], v[46:47] op_sel_hi:[0,1]\n"
-        "v_min_f32_e32 v52, v26, v38\n"
-        "v_max_f32_e32 v26, v26, v38\n"
-        "v_min_f32_e32 v38, v30, v42\n"
-        "v_max_f32_e32 v30, v30, v42\n"
-        "v_min_f32_e32 v42, v34, v46\n"
-        "v_max_f32_e32 v34, v34, v46\n"
-        "v_min3_f32 v26, v26, v30, v34\n"
-        "v_max3_f32 v52, v52, v38, v42\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v26\n"
-        "v_min_f32_e32 v26, v26, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v26, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v50\n"
-        "v_and_or_b32 v52, v52, -4, 2\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v26, -1, v52, s[66:67]\n"
-        "v_min_f32_e32 v52, v27, v39\n"
-        "v_max_f32_e32 v27, v27, v39\n"
-        "v_min_f32_e32 v39, v31, v43\n"
-        "v_max_f32_e32 v31, v31, v43\n"
-        "v_min_f32_e32 v43, v35, v47\n"
-        "v_max_f32_e32 v35, v35, v47\n"
-        "v_min3_f32 v27, v27, v31, v35\n"
-        "v_max3_f32 v52, v52, v39, v43\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v27\n"
-        "v_min_f32_e32 v27, v27, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v27, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v51\n"
-        "v_and_or_b32 v52, v52, -4, 3\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
-#else
         "v_sub_f32_e32 v24, v24, v0\n"
         "v_sub_f32_e32 v36, v36, v0\n"
         "v_sub_f32_e32 v28, v28, v1\n"
@@ -1824,7 +1273,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_and_or_b32 v52, v52, -4, 3\n"
         "s_and_b64 s[66:67], s[66:67], vcc\n"
         "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
-#endif
         /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the
            register its lo.x plane value came in) */
         "v_cmp_lt_u32_e32 vcc, v25, v24\n"
@@ -1877,20 +1325,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e64 v13, v13, v28, s[80:81]\n"
         "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
         "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
-#if PT_WIDE_EARLY
-        /* a lane that descends into a wide node fetches that record NOW: the fetch overlaps the triangle block, the pops and
-           the loop overhead (nothing below touches v[24:64] of these lanes) */
-        "v_cmp_lt_i32_e32 vcc, -1, v50\n"
-        "s_and_b64 s[82:83], vcc, s[80:81]\n"
-        "s_mov_b64 exec, s[82:83]\n"
-        "global_load_dwordx4 v[24:27], v12, %[nodes]\n"
-        "global_load_dwordx4 v[36:39], v12, %[nodes] offset:48\n"
-        "global_load_dwordx4 v[28:31], v12, %[nodes] offset:16\n"
-        "global_load_dwordx4 v[40:43], v12, %[nodes] offset:64\n"
-        "global_load_dwordx4 v[32:35], v12, %[nodes] offset:32\n"
-        "global_load_dwordx4 v[44:47], v12, %[nodes] offset:80\n"
-        "global_load_dwordx4 v[48:51], v12, %[nodes] offset:96\n"
-#endif
         /* ---------------------------------------------------------------- leaf: one triangle (exec = s[60:61]) */
         "s_branch TW_LEAF_GO_%=\n"
         "TW_LEAF_%=:\n"                                     /* no lane at a wide node: the triangle fetches have not been waited for */
@@ -1990,7 +1424,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
         "TW_TRI_END_%=:\n"
         "s_mov_b64 exec, s[60:61]\n"
-#if PT_WIDE_TRI2
         /* a ray that goes on and whose leaf has another triangle tests it in the same trip (its record came with the first one's):
            the order of the tests and the interval they see are those of two trips */
         "v_cmp_ne_u32_e32 vcc, -1, v12\n"
@@ -2104,18 +1537,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
         "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n"
         "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
-#else
-        /* a ray that goes on: the leaf's next triangle if it has one, else pop */
-        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
-        "v_bfe_u32 v50, v12, 27, 4\n"
-        "v_add_u32_e32 v49, 0xf8000001, v12\n"             /* first + 1, one triangle fewer */
-        "v_cmp_lt_u32_e64 s[66:67], 0, v50\n"
-        "s_nop 0\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n"
-        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
-#endif
         /* ---------------------------------------------------------------- pop (s[78:79]) */
         "TW_POP_%=:\n"
         "s_mov_b64 exec, s[78:79]\n"
@@ -2128,13 +1549,8 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
         "s_mov_b64 s[72:73], exec\n"
         "s_and_b64 exec, exec, vcc\n"
-#if PT_WIDE_EARLY_POP
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_mov_b32_e32 v12, v54\n"
-#else
         "v_lshl_add_u32 v33, v13, 8, v18\n"
         "ds_read_b32 v12, v33 offset:768\n"
-#endif
         "s_andn2_b64 exec, s[72:73], vcc\n"
         "s_cbranch_execz TW_POP_LDS_%=\n"
         "v_lshl_add_u32 v33, v13, 8, v16\n"
@@ -2147,7 +1563,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_branch TW_LOOP_%=\n"
         /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
         "TW_PUSH_SLOW_%=:\n"
-        PT_WIDE_PROBE_SLOW
         "v_add_u32_e32 v29, -3, v28\n"
         "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
         "s_and_b64 exec, s[72:73], vcc\n"
@@ -2191,7 +1606,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_div_fmas_f32 v46, v46, v47, v52\n"
         "v_div_fixup_f32 v46, v46, v45, 1.0\n"
         "s_branch TW_DIV_DONE_%=\n"
-#if PT_WIDE_TRI2
         "TW_DIV_IEEE2_%=:\n"
         "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
         "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
@@ -2206,7 +1620,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "v_div_fmas_f32 v46, v46, v47, v52\n"
         "v_div_fixup_f32 v46, v46, v45, 1.0\n"
         "s_branch TW_DIV_DONE2_%=\n"
-#endif
 
         /* ---------------------------------------------------------------- finished rays (s[68:69]) */
         "TW_FIN_%=:\n"
@@ -2268,11 +1681,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "global_store_dwordx4 v17, v[20:23], %[spill] offset:16" PT_WIDE_SC "\n"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
-#if PT_WIDE_PROBE
-        : [pr_trips] "+v"(pr.trips), [pr_nlanes] "+v"(pr.nlanes), [pr_tlanes] "+v"(pr.tlanes), [pr_nblk] "+v"(pr.nblk), [pr_tblk] "+v"(pr.tblk), [pr_busy] "+v"(pr.busy), [pr_slow] "+v"(pr.slow)
-#else
         :
-#endif
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill),
           [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [allow] "s"(s_allow), [vspill] "v"(v_spill), [vsusp] "v"(v_susp),
           [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
@@ -2294,9 +1703,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
 // the vector-memory pipe.
 #ifndef PT_SMALL_FLOAT4
 #define PT_SMALL_FLOAT4 768
-#endif
-#ifndef PT_LDS_SHADE
-#define PT_LDS_SHADE 1          // 0 (experiment): shading records, lights and materials stay in global memory, only nodes and triangles are staged
 #endif
 #ifndef PT_SMALL_WAVES
 #define PT_SMALL_WAVES PT_MIN_WAVES
@@ -2335,14 +1741,7 @@ template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
 __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : (SMALL ? PT_SMALL_WAVES : PT_MIN_WAVES))) pt_render_kernel(const DevParams P_in)
 {
     static_assert(!(WIDE && SMALL), "the wide tree is walked from global memory");
-    __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 - (PT_LOOP_PROBE ? 8 : 0) : 1];
-#if PT_LOOP_PROBE
-    __shared__ unsigned lds_loop_probe[4 * 8];
-    if ((threadIdx.x & 63u) < 8u) lds_loop_probe[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63u)] = 0u;
-    const unsigned loop_probe = lds_address(lds_loop_probe + (threadIdx.x >> 6) * 8);
-#else
-    const unsigned loop_probe = 0u;
-#endif
+    __shared__ float4 lds_scene[SMALL ? kSmallSceneFloat4 - (0 ? 8 : 0) : 1];
     DevParams P = P_in;
     if (SMALL) {
         // layout: nodes | triangles | shading records | lights | materials (all 16-byte multiples except the
@@ -2368,7 +1767,6 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
             lds_scene[i] = v;
         }
         for (int i = threadIdx.x; i < 3 * P.n_prims; i += 256) lds_scene[o_tri + i] = gt[i];
-#if PT_LDS_SHADE
         for (int i = threadIdx.x; i < 5 * P.n_prims; i += 256) lds_scene[o_shade + i] = gs[i];
         for (int i = threadIdx.x; i < 6 * P.n_lights; i += 256) lds_scene[o_light + i] = gl[i];
         uint32_t *lm = reinterpret_cast<uint32_t *>(lds_scene + o_mat);
@@ -2377,12 +1775,8 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         P.shade = reinterpret_cast<const DevShade *>(lds_scene + o_shade);
         P.lights = reinterpret_cast<const DevLight *>(lds_scene + o_light);
         P.materials = reinterpret_cast<const gpt_material *>(lds_scene + o_mat);
-#else
-        (void)gs; (void)gl; (void)gm; (void)o_mat;
-        __syncthreads();
-#endif
     }
-    constexpr bool CARRY = !SMALL || PT_SMALL_CARRY;    // scenes in global memory: fixed slots, drains may stop early
+    constexpr bool CARRY = !SMALL;    // scenes in global memory: fixed slots, drains may stop early
     constexpr int kWaveFloat4 = WIDE ? kWaveWideFloat4 : (CARRY ? kWaveCarryFloat4 : kWaveLdsFloat4);
     __shared__ float4 lds_pool[4 * kWaveFloat4];        // one private ray pool per wavefront
     float4 *pool = lds_pool + (threadIdx.x >> 6) * kWaveFloat4;
@@ -2400,8 +1794,6 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     bool poison_occluded = false;
     const uint32_t n_owned = (P.n_tiles > P.rank) ? (P.n_tiles - P.rank + P.n_ranks - 1) / P.n_ranks : 0u;
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    WideProbe wprobe = {0, 0, 0, 0, 0, 0, 0};
-    (void)wprobe;
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
     unsigned long long cyc_direct = 0, cyc_hit = 0, cyc_regen = 0, cyc_sub = 0;                                // ... split of cyc_shade
 #define PT_SUBPHASE(acc)                                                                     \
@@ -2410,19 +1802,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         if (lane == 0) acc += now_ - cyc_sub;                                                \
         cyc_sub = now_;                                                                      \
     }
-    // PT_SUBPROBES (probe builds only): marks inside divergent code, booked by whichever lane is first active
+    // 0 (probe builds only): marks inside divergent code, booked by whichever lane is first active
     // through a per-wave LDS record {mark, h[0..6]}
-#if PT_SUBPROBES
-    __shared__ unsigned long long lds_probe[4 * 8];
-    unsigned long long *probe = lds_probe + (threadIdx.x >> 6) * 8;
-    if (lane < 8) probe[lane] = 0;
-#define PT_MARK(i)                                                                           \
-    if (first_active_lane()) {                                                               \
-        const unsigned long long now_ = __builtin_readcyclecounter();                        \
-        probe[1 + (i)] += now_ - probe[0];                                                   \
-        probe[0] = now_;                                                                     \
-    }
-#elif defined(PT_ISA_MARKS)        // analysis builds: comments in the .s that delimit the shading sub-phases
+#if defined(PT_ISA_MARKS)        // analysis builds: comments in the .s that delimit the shading sub-phases
 #define PT_MARK(i) asm volatile("; ISA_MARK " #i);
 #else
 #define PT_MARK(i)
@@ -3030,9 +2412,6 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                         const gpt_material material = P.materials[isect.matIdx];
                         q.has_s = q.has_m = q.has_p = false;
                         PT_MARK(1)
-#if PT_LANEPROBE
-                        if (COUNT) { const int h_ = popc(ballot(true)); if (first_active_lane()) { cnt.w_shade++; cnt.l_shade += (uint32_t)h_; } }
-#endif
 
                         // Volpath (pathtracer.cu:1062-1070): the medium decides whether the ray gets as far as the surface
                         bool scattered = false;
@@ -3306,19 +2685,11 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                         uint32_t k = 0;
                         if (lane == 0) k = atomicAdd(P.tile_counter + qi, 1u);
                         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-#if PT_XCD_BLOCK      // (experiment) queue qi = blocks qi, qi + 8, ... of PT_XCD_BLOCK consecutive items: the XCDs advance through the frame together
-                        const uint32_t cand = ((k / (uint32_t)PT_XCD_BLOCK) * 8u + qi) * (uint32_t)PT_XCD_BLOCK + k % (uint32_t)PT_XCD_BLOCK;
-                        if (k < n_items && cand < n_items) {
-                            t = cand;
-                            break;
-                        }
-#else                 // queue qi = the qi-th eighth of the items
                         const uint32_t lo = (uint32_t)(((uint64_t)n_items * qi) >> 3), hi = (uint32_t)(((uint64_t)n_items * (qi + 1u)) >> 3);
                         if (k < hi - lo) {
                             t = lo + k;
                             break;
                         }
-#endif
                         queues_done++;
                     }
                 } else {
@@ -3418,27 +2789,20 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 c0 = __builtin_readcyclecounter();
                 if (lane == 0) cyc_shade += c0 - cyc_mark;
             }
-#if PT_LANEPROBE
-            if (COUNT) { const int a_ = popc(ballot(alive && !waiting)); if (lane == 0) { cnt.w_nee++; cnt.l_nee += (uint32_t)a_; } }
-#endif
             if (SMALL) {
                 LdsScene mem;
                 mem.first = (int)lds_address(lds_scene);
                 mem.end = mem.first + 32 * P.n_nodes;
                 mem.tri_bias = mem.end;
-#if PT_SMALL_CARRY
-                trace_pool_lds_carry_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0, loop_probe);
-#else
-                if (COUNT && !PT_ASM_IN_COUNT)      // the counting build runs the C++ twin (it has the counters)
+                if (COUNT)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool<COUNT, false>(P, pool, L.n_rays, cnt, mem);
                 else
-                    trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps, loop_probe);
-#endif
+                    trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
             } else if (WIDE) {
-                if ((COUNT && !PT_ASM_IN_COUNT) || !PT_WIDE_ASM)      // the counting build runs the C++ twin (it has the counters)
+                if (COUNT || !PT_WIDE_ASM)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
                 else
-                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0, wprobe);
+                    trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0);
             } else {
                 GlobalScene mem;
                 mem.nodes = reinterpret_cast<const char *>(P.nodes);
@@ -3447,14 +2811,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 mem.end = 32 * P.n_nodes;
                 mem.tri_bias = 0;
                 mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
-                if (COUNT && !PT_ASM_IN_COUNT)      // (the twin always drains to the end: nothing is ever suspended)
+                if (COUNT)      // (the twin always drains to the end: nothing is ever suspended)
                     trace_pool<COUNT, true>(P, pool, n_new, cnt, mem);
                 else
-#if PT_GLOBAL_BOTH && !PT_LOOP_PROBE
-                    trace_pool_global_both_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0);
-#else
-                    trace_pool_global_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0, loop_probe);
-#endif
+                    trace_pool_global_asm(lds_address(pool), n_new, mem, P.eps, n_new > 0);
             }
             if (COUNT) {
                 cyc_mark = __builtin_readcyclecounter();
@@ -3487,30 +2847,6 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         }
     }
 
-#if PT_LOOP_PROBE
-    if (!WIDE && !COUNT && lane == 0) {       // probe builds: what the hand-scheduled binary loop counted (per wave)
-        wave_lds_fence();
-        const unsigned *pr = lds_loop_probe + (threadIdx.x >> 6) * 8;
-        atomicAdd(&P.counters[6], (unsigned long long)pr[0]);      // node trips
-        atomicAdd(&P.counters[0], (unsigned long long)pr[1]);      // lanes in them
-        atomicAdd(&P.counters[7], (unsigned long long)pr[2]);      // triangle trips
-        atomicAdd(&P.counters[1], (unsigned long long)pr[3]);      // lanes in them
-        atomicAdd(&P.counters[9], (unsigned long long)pr[4]);      // lanes holding a ray, summed over the trips
-        atomicAdd(&P.counters[8], (unsigned long long)pr[5]);      // trips after the pool ran dry
-        atomicAdd(&P.counters[13], (unsigned long long)pr[6]);     // lanes holding a ray in those
-    }
-#endif
-#if PT_WIDE_PROBE
-    if (WIDE && !COUNT && lane == 0) {      // probe builds: what the hand-scheduled wide loop counted (per wave)
-        atomicAdd(&P.counters[0], (unsigned long long)wprobe.nlanes);
-        atomicAdd(&P.counters[1], (unsigned long long)wprobe.tlanes);
-        atomicAdd(&P.counters[6], (unsigned long long)wprobe.nblk);
-        atomicAdd(&P.counters[7], (unsigned long long)wprobe.tblk);
-        atomicAdd(&P.counters[8], (unsigned long long)wprobe.trips);
-        atomicAdd(&P.counters[9], (unsigned long long)wprobe.busy);
-        atomicAdd(&P.counters[13], (unsigned long long)wprobe.slow);
-    }
-#endif
     if (COUNT) {
         atomicAdd(&P.counters[0], (unsigned long long)cnt.node_visits);
         atomicAdd(&P.counters[1], (unsigned long long)cnt.prim_tests);
@@ -3522,21 +2858,6 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         atomicAdd(&P.counters[7], (unsigned long long)cnt.w_prim);
         atomicAdd(&P.counters[8], (unsigned long long)cnt.w_trip);
         atomicAdd(&P.counters[9], (unsigned long long)cnt.l_trip);
-#if PT_LANEPROBE
-        atomicAdd(&P.counters[6], (unsigned long long)cnt.w_shade);     // rounds in which some lane shades a hit
-        atomicAdd(&P.counters[7], (unsigned long long)cnt.l_shade);     // ... lanes that do
-        atomicAdd(&P.counters[8], (unsigned long long)cnt.w_nee);       // drains (one per round)
-        atomicAdd(&P.counters[9], (unsigned long long)cnt.l_nee);       // lanes with a path that is not waiting for a suspended ray, when a drain starts
-#endif
-#if PT_SUBPROBES
-        if (lane == 0) {
-            atomicAdd(&P.counters[6], probe[2]);    // make_hit + material      (reuses w_node..l_trip, unused with the asm loop)
-            atomicAdd(&P.counters[7], probe[3]);    // light sample + BSDF eval
-            atomicAdd(&P.counters[8], probe[4]);    // MIS sample + emitter pre-test
-            atomicAdd(&P.counters[9], probe[5]);    // continuation sample + roulette
-            atomicAdd(&P.counters[13], probe[1]);   // everything between the last mark of a round and the first of the next
-        }
-#endif
         if (lane == 0) {     // split of cyc_shade: direct-light resolution | hit shading | finish + regeneration | (rest: pool)
             atomicAdd(&P.counters[10], cyc_direct);
             atomicAdd(&P.counters[11], cyc_hit);
@@ -3644,8 +2965,6 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
     if (WIDE) wide_init_suspend_record(P, lane);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)cnt;
-    WideProbe wprobe = {0, 0, 0, 0, 0, 0, 0};
-    (void)wprobe;
     const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = (int)gridDim.x * 4;
     for (int base = wave * 64; base < n; base += n_waves * 64) {      // wave-uniform
         const int i = base + (int)lane;
@@ -3683,7 +3002,7 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
             for (int round = 0;; ++round) {
                 const int fresh = round == 0 ? n_new : 0;
                 if (WIDE) {
-                    if (PT_WIDE_ASM) trace_pool_wide_asm(lds_address(pool), fresh, P, lane, fresh > 0, wprobe);
+                    if (PT_WIDE_ASM) trace_pool_wide_asm(lds_address(pool), fresh, P, lane, fresh > 0);
                     else trace_pool_wide<false>(P, pool, fresh, cnt);
                 } else {
                     GlobalScene mem;
@@ -3693,11 +3012,7 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
                     mem.end = 32 * P.n_nodes;
                     mem.tri_bias = 0;
                     mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
-#if PT_GLOBAL_BOTH && !PT_LOOP_PROBE
-                    trace_pool_global_both_asm(lds_address(pool), fresh, mem, P.eps, fresh > 0);
-#else
                     trace_pool_global_asm(lds_address(pool), fresh, mem, P.eps, fresh > 0);
-#endif
                 }
                 wave_lds_fence();
                 const bool pending = valid && reinterpret_cast<const volatile unsigned *>(pool + kPendOff)[lane] != 0u;
@@ -3779,7 +3094,7 @@ int render_kernel_blocks_per_cu(bool count, bool walk, bool wide)
 
 bool render_scene_fits_lds(const DevParams &P)
 {
-    return P.traversal == 0 && 2 * P.n_nodes + (PT_LDS_SHADE ? 8 : 3) * P.n_prims + (PT_LDS_SHADE ? 6 * P.n_lights + (18 * P.n_materials + 3) / 4 : 0) <= kSmallSceneFloat4;
+    return P.traversal == 0 && 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4;
 }
 
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream)

@@ -24,9 +24,13 @@ struct WfCtrl {
 
 // A workgroup's pool: kWfWgChunks chunks of 64 path slots.  Chunk c of the pool owns ray ids rayq[192 c ..]: its segment of the
 // ray queue, filled by whichever wave shaded the chunk, with the count in LDS - no atomic, no compaction across chunks.
-#ifndef PT_WF_WG_CHUNKS
-#define PT_WF_WG_CHUNKS 16
+#ifndef PT_WF_WG_WAVES
+#define PT_WF_WG_WAVES 4             // waves per workgroup (1: a wave is its own workgroup - no barrier between the phases at all)
 #endif
+#ifndef PT_WF_WG_CHUNKS
+#define PT_WF_WG_CHUNKS (4 * PT_WF_WG_WAVES)
+#endif
+constexpr int kWfWgWaves = PT_WF_WG_WAVES;
 constexpr int kWfWgChunks = PT_WF_WG_CHUNKS;
 constexpr int kWfSegRays = 192;
 // A ray the trace phase parks when its wave runs out of segments (the round must not wait for its longest ray): {id, entry, stack size |
@@ -73,5 +77,6 @@ hipError_t launch_wf_render(const struct DevParams &P, const WfParams &W, int n_
 int wf_blocks_per_cu(int integrator, bool wide);
 int wf_lds_stack_levels();
 int wf_paths_per_block();
+int wf_waves_per_block();
 
 }  // namespace pt

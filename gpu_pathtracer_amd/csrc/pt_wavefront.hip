@@ -31,7 +31,12 @@ __device__ __forceinline__ int wf_shade_chunk(const DevParams &P, const WfParams
     const uint32_t i = chunk * 64u + lane;                         // path slot
     const uint32_t np = W.n_paths;
 
+    // everything the slot may need is requested at once, whatever its flags turn out to be: one memory round trip instead of two in a
+    // phase that is bound by them (the BSDF-sampled light ray's planes aside: few paths have one)
     const float4 a3 = W.s3[i];
+    const float4 a0 = W.s0[i], a1 = W.s1[i], a2 = W.s2[i], a4 = W.s4[i], ao = W.org[i];
+    const float4 ld_rp = W.ray[i], ld_hp = W.hit[i];
+    const float ld_hs = W.hit[2u * np + i].x;
     uint32_t flags = __float_as_uint(a3.w);
     bool alive = (flags & kWfAlive) != 0u;
 
@@ -56,7 +61,6 @@ __device__ __forceinline__ int wf_shade_chunk(const DevParams &P, const WfParams
 
     bool finish = false, waiting = false;
     if (alive) {
-        const float4 a0 = W.s0[i], a1 = W.s1[i], a2 = W.s2[i], a4 = W.s4[i], ao = W.org[i];
         Li = xyz(a0);
         beta = V3{a0.w, a1.x, a1.y};
         mis_cos = a1.z;
@@ -73,7 +77,7 @@ __device__ __forceinline__ int wf_shade_chunk(const DevParams &P, const WfParams
             medium_ld = (int)(int16_t)(mm >> 16);
         }
         if (has_p) {
-            const float4 r = W.ray[i], h = W.hit[i];
+            const float4 r = ld_rp, h = ld_hp;
             dir_p = xyz(r);
             res.prim_p = __float_as_int(h.x); res.t_p = h.y; res.b1_p = h.z; res.b2_p = h.w;
             waiting = waiting || res.prim_p == kWfPending;
@@ -85,7 +89,7 @@ __device__ __forceinline__ int wf_shade_chunk(const DevParams &P, const WfParams
             waiting = waiting || res.prim_m == kWfPending;
         }
         if (has_s) {
-            const int prim_s = __float_as_int(W.hit[2u * np + i].x);
+            const int prim_s = __float_as_int(ld_hs);
             res.occluded = prim_s >= 0;
             waiting = waiting || prim_s == kWfPending;
         }
@@ -607,7 +611,7 @@ __device__ __forceinline__ void wf_trace_cxx(const DevParams &P, const WfParams 
     float tmax = 0.f;
     // wide walk
     unsigned *stk = lds_stack_wave + lane;
-    uint32_t *spill = W.spill + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane;
+    uint32_t *spill = W.spill + (size_t)(blockIdx.x * (unsigned)kWfWgWaves + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane;
     const char *wnodes = reinterpret_cast<const char *>(P.wide);
     unsigned cur = GPT_WIDE_NONE;
     int sp = 0;
@@ -896,10 +900,10 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
     const unsigned s_shared = __builtin_amdgcn_readfirstlane(shared_lds);                   // LDS address of the workgroup's WfShared
     const unsigned s_segbase = __builtin_amdgcn_readfirstlane(chunk0 * (unsigned)(kWfSegRays * 4));     // byte offset of the workgroup's first segment in rayq
     const unsigned s_stack = __builtin_amdgcn_readfirstlane(stack_lds) - 768u;      // (the pushes address level size' - 3 .. size' - 1 from one base)
-    const unsigned v_spill = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane) * 4u;
+    const unsigned v_spill = ((blockIdx.x * (unsigned)kWfWgWaves + (threadIdx.x >> 6)) * 64u * W.spill_levels + lane) * 4u;
     const unsigned long long s_save = uniform64((unsigned long long)W.save);
     const unsigned long long s_counters = uniform64((unsigned long long)P.counters);         // (probe builds)
-    const unsigned v_save = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u + lane) * (unsigned)(kWfSaveDwords * 4);
+    const unsigned v_save = ((blockIdx.x * (unsigned)kWfWgWaves + (threadIdx.x >> 6)) * 64u + lane) * (unsigned)(kWfSaveDwords * 4);
     const unsigned s_tag = __builtin_amdgcn_readfirstlane(round + 1u);                       // records parked FOR this round carry it
     static_assert(kWfStackLevels % 4 == 0 && kWfStackLevels >= 8 && kWfStackLevels <= 28 && 8 + kWfStackLevels <= kWfSaveDwords, "the save record holds the LDS levels");
     asm volatile(
@@ -1830,10 +1834,10 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
 // of its own pool, not among the frame's millions.  The four workgroups of a CU are in different phases at any time: the shade
 // phase's arithmetic runs while another workgroup's trace phase waits for memory.
 template <int INTEG, bool WIDE>
-__global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevParams P, const WfParams W)
+__global__ void __launch_bounds__(64 * kWfWgWaves, PT_WF_WAVES) wf_render_kernel(const DevParams P, const WfParams W)
 {
-    __shared__ uint32_t lds_stack[WIDE ? 256 + 4 * 64 * kWfStackLevels : 1];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
-    __shared__ uint32_t lds_ids[(WIDE && PT_WF_WIDE_ASM) ? 1 : 4 * kWfSegRays];   // the C++ walks stage a segment's ids
+    __shared__ uint32_t lds_stack[WIDE ? 256 + kWfWgWaves * 64 * kWfStackLevels : 1];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
+    __shared__ uint32_t lds_ids[(WIDE && PT_WF_WIDE_ASM) ? 1 : kWfWgWaves * kWfSegRays];   // the C++ walks stage a segment's ids
     __shared__ WfShared sh;
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t chunk0 = blockIdx.x * (uint32_t)kWfWgChunks;
@@ -1842,7 +1846,7 @@ __global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevPa
         sh.items_left = 1u;
     }
     // no ray is parked for this lane (the record's third word carries the round a parked ray resumes in)
-    if (WIDE) W.save[(size_t)((blockIdx.x * 4u + wv) * 64u + lane) * (uint32_t)kWfSaveDwords + 2u] = 0u;
+    if (WIDE) W.save[(size_t)((blockIdx.x * (unsigned)kWfWgWaves + wv) * 64u + lane) * (uint32_t)kWfSaveDwords + 2u] = 0u;
     __syncthreads();
 #if PT_WF_PROBE == 2      // probe builds: where a wave's time goes (shader-clock cycles, lane 0 of every wave) -> P.counters[0..5]
     unsigned long long pr_shade = 0, pr_trace = 0, pr_wait = 0, pr_rounds = 0, pr_chunks = 0, pr_t0 = __builtin_readcyclecounter();
@@ -1901,7 +1905,7 @@ __global__ void __launch_bounds__(256, PT_WF_WAVES) wf_render_kernel(const DevPa
 // ---------------------------------------------------------------------------------------------------- launchers ------
 hipError_t launch_wf_render(const DevParams &P, const WfParams &W, int n_blocks, hipStream_t stream)
 {
-    const dim3 grid(n_blocks), block(256);
+    const dim3 grid(n_blocks), block(64 * kWfWgWaves);
     const bool wide = P.traversal == GPT_TRAVERSAL_WIDE4;
 #define PT_WF_LAUNCH(I) do { if (wide) hipLaunchKernelGGL((wf_render_kernel<I, true>), grid, block, 0, stream, P, W); \
                              else hipLaunchKernelGGL((wf_render_kernel<I, false>), grid, block, 0, stream, P, W); } while (0)
@@ -1916,17 +1920,18 @@ int wf_blocks_per_cu(int integrator, bool wide)
 {
     int n = 0;
     hipError_t e;
-#define PT_WF_OCC(I) (wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, true>, 256, 0) \
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, false>, 256, 0))
+#define PT_WF_OCC(I) (wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, true>, 64 * kWfWgWaves, 0) \
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, false>, 64 * kWfWgWaves, 0))
     if (integrator == GPT_IT_AO) e = PT_WF_OCC(GPT_IT_AO);
     else if (integrator == GPT_IT_VPT) e = PT_WF_OCC(GPT_IT_VPT);
     else e = PT_WF_OCC(GPT_IT_PT);
 #undef PT_WF_OCC
     if (e != hipSuccess || n < 1) { (void)hipGetLastError(); n = 2; }
-    return n > 8 ? 8 : n;
+    return n > 32 / kWfWgWaves ? 32 / kWfWgWaves : n;
 }
 
 int wf_lds_stack_levels() { return kWfStackLevels; }
 int wf_paths_per_block() { return 64 * kWfWgChunks; }
+int wf_waves_per_block() { return kWfWgWaves; }
 
 }  // namespace pt

@@ -290,13 +290,13 @@ int wf_ensure(gpt_ctx *ctx)
     if (levels < 1) levels = 1;
     const size_t front = (size_t)64 * wf_lds_stack_levels();
     void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, (front + (size_t)n_blocks * 4 * 64 * (size_t)levels) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&sp, (front + (size_t)n_blocks * wf_waves_per_block() * 64 * (size_t)levels) * sizeof(uint32_t)));
     ctx->allocs.push_back(sp);
     W.spill = static_cast<uint32_t *>(sp) + front;
     W.spill_levels = (uint32_t)levels;
     // one record per lane of the grid for a ray that is parked between two rounds
     void *sv = nullptr;
-    HIP_TRY(hipMalloc(&sv, (size_t)n_blocks * 256 * kWfSaveDwords * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&sv, (size_t)n_blocks * wf_waves_per_block() * 64 * kWfSaveDwords * sizeof(uint32_t)));
     ctx->allocs.push_back(sv);
     W.save = static_cast<uint32_t *>(sv);
     ctx->wf_blocks = n_blocks;
