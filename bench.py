@@ -132,7 +132,7 @@ STANDINS = {"c3": ("config 3 stand-in: 3 x sphere.obj + cube-subdiv.obj, shaderb
             "c5": ("config 5 stand-in: Cornell walls + dragon + bunny2 + teapot + 9 spheres (248 574 triangles); 3840x2160, depth 16", 8)}
 
 
-def load_standin(which):
+def load_standin(which, sbvh=False):
     """The stand-in's scene directory is written, loaded through the product loader and removed.  The loader reports its progress
     on stdout like the reference's (parsescene.cpp): that goes to stderr here - stdout carries the one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -143,7 +143,7 @@ def load_standin(which):
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        return api.LoadedScene(standins.write_standin_scene(d, which))      # (the loader copies everything it reads)
+        return api.LoadedScene(standins.write_standin_scene(d, which), sbvh=sbvh)      # (the loader copies everything it reads)
     finally:
         os.dup2(saved, 1)
         os.close(saved)
@@ -161,10 +161,11 @@ def counter_child(which="c2", mode="reference"):
             r.render(cam, SPP_PER_STEP + 1, SPP_PER_STEP, reset=False)
             r.synchronize()
         return
-    ls = load_standin(which)
+    ls = load_standin(which, sbvh=mode.startswith("sbvh"))
     spp = STANDINS[which][1]
     with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-        r.set_traversal_order(mode)
+        if mode == "reference":
+            r.set_traversal_order("reference")          # ("default" and "sbvh+default": what gpt_begin chose)
         r.render(ls.camera, 1, spp, reset=True)
         r.render(ls.camera, spp + 1, spp, reset=False)
         r.synchronize()
@@ -188,7 +189,7 @@ def rocprof_pass(counters, workdir, tag, child=("c2", "reference")):
     vals = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "pt_render_kernel" in row.get("Kernel_Name", ""):
+            if "render_kernel" in row.get("Kernel_Name", ""):
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     if not vals:
         raise RuntimeError(f"rocprofv3 pass {tag} produced no counters (rc {p.returncode}): {p.stderr[-300:]}")
@@ -220,16 +221,23 @@ def live_counters():
 
 
 def standin_leg(api, which, counters=True):
-    """One BASELINE stand-in at full size: a launch per traversal order timed with the library's HIP events; counters of the faster
-    order from one extra rocprofv3 pass set (SQ, FETCH_SIZE, WRITE_SIZE: each in its own pass)."""
+    """One BASELINE stand-in at full size, three legs, each one launch timed with the library's HIP events:
+      "default"       what a caller gets who loads the scene and calls gpt_begin / gpt_render and nothing else: the reference builder's
+                      tree, walked in the order gpt_begin picks (the 4-wide walk for every scene that does not fit LDS)
+      "reference"     the same tree in the reference's own traversal order (opt-in: gpt_set_traversal_order)
+      "sbvh+default"  the split BVH (loader flag GPT_LOAD_SBVH) in gpt_begin's order
+    and for "default" and "sbvh+default" VALU-issue fraction, lanes and HBM-side traffic from rocprofv3 passes inside this run (SQ,
+    FETCH_SIZE, WRITE_SIZE: each in its own pass)."""
+    import numpy as np
     label, spp = STANDINS[which]
-    ls = load_standin(which)
-    out = {"workload": label, "triangles": int(ls.desc.n_prims), "bvh_nodes": int(ls.desc.n_nodes), "iterations_per_launch": spp, "orders": {}}
-    n_samples = ls.width * ls.height * spp
-    sha, film = {}, {}
-    with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-        for mode in ("reference", "near", "wide"):
-            r.set_traversal_order(mode)
+    out = {"workload": label, "iterations_per_launch": spp, "legs": {}}
+    film = {}
+    for leg in ("default", "reference", "sbvh+default"):
+        ls = load_standin(which, sbvh=leg.startswith("sbvh"))
+        n_samples = ls.width * ls.height * spp
+        with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
+            if leg == "reference":
+                r.set_traversal_order("reference")
             r.render(ls.camera, 1, spp, reset=True)             # same call as the timed one: the sample planes exist afterwards
             r.synchronize()
             best = None
@@ -239,44 +247,43 @@ def standin_leg(api, which, counters=True):
                 r.synchronize()
                 n, ms = r.kernel_time()
                 best = ms / max(1, n) if best is None else min(best, ms / max(1, n))
-            film[mode] = r.read_accum()
-            sha[mode] = hashlib.sha1(film[mode].tobytes()).hexdigest()[:16]
-            out["orders"][mode] = {"value": n_samples / best / 1e3, "unit": "Msamples/s", "launch_ms": best}
-    # the other orders against the reference order: equal films except where two hits tie within rounding (include/gpt_traversal.h,
-    # include/gpt_wide_bvh.h)
-    import numpy as np
+            film[leg] = r.read_accum()
+            out["legs"][leg] = {"value": n_samples / best / 1e3, "unit": "Msamples/s", "launch_ms": best,
+                                "traversal_order": {0: "reference", 2: "wide4"}[r.get_option("traversal_order")],
+                                "scheduler": "stages" if r.get_option("scheduler_active") else "per-wave",
+                                "triangles": int(ls.desc.n_prims), "bvh_nodes": int(ls.desc.n_nodes),
+                                "accumulator_sha1": hashlib.sha1(film[leg].tobytes()).hexdigest()[:16]}
+        ls.close()
+    # against the reference order on the reference's tree: equal films except where two hits tie within rounding (include/gpt_wide_bvh.h)
     b = film["reference"].reshape(-1, 3).astype(np.float64)
-    for mode in ("near", "wide"):
-        a = film[mode].reshape(-1, 3).astype(np.float64)
-        out[mode + "_vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film[mode] != film["reference"])), "floats": int(film[mode].size),
-                                             "rel_rms": [float(x) for x in np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))], "tolerance": 1e-4}
-    out["accumulator_sha1"] = sha
-    fast = max(out["orders"], key=lambda m: out["orders"][m]["value"])
-    out["faster_order"] = fast
-    if counters:
+    for leg in ("default", "sbvh+default"):
+        a = film[leg].reshape(-1, 3).astype(np.float64)
+        out["legs"][leg]["vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film[leg] != film["reference"])), "floats": int(film[leg].size),
+                                                  "rel_rms": [float(x) for x in np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))], "tolerance": 1e-4}
+    for leg in (("default", "sbvh+default") if counters else ()):
         work = tempfile.mkdtemp(prefix="gpt_pmc_")
         try:
             sq, _ = rocprof_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
-                                 work, "sq", (which, fast))
-            fetch, _ = rocprof_pass(["FETCH_SIZE"], work, "fetch", (which, fast))
-            write, _ = rocprof_pass(["WRITE_SIZE"], work, "write", (which, fast))
-            ms = out["orders"][fast]["launch_ms"]
+                                 work, "sq", (which, leg))
+            fetch, _ = rocprof_pass(["FETCH_SIZE"], work, "fetch", (which, leg))
+            write, _ = rocprof_pass(["WRITE_SIZE"], work, "write", (which, leg))
+            ms = out["legs"][leg]["launch_ms"]
             peak_issue = N_SIMD * CLOCK_HZ / VALU_CYCLES
             traffic = (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0
-            out["roofline"] = {"order": fast, "bound": "valu_issue + memory latency (DESIGN.md section 4)",
-                               "valu_issue_frac": sq["SQ_INSTS_VALU"] / (ms * 1e-3) / peak_issue,
+            lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+            frac = sq["SQ_INSTS_VALU"] / (ms * 1e-3) / peak_issue
+            out["legs"][leg]["roofline"] = {"bound": "valu_issue + memory latency (DESIGN.md section 4)",
+                               "valu_issue_frac": frac, "active_lanes_of_64": lanes, "useful_frac": frac * lanes / 64.0,
                                "valu_insts_per_sample_lane": sq["SQ_INSTS_VALU"] / n_samples * 64,
-                               "active_lanes_of_64": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
                                "wait_any_over_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
                                "hbm_GBps": traffic / (ms * 1e-3) / 1e9, "hbm_frac_of_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "fetch_KiB_raw_per_launch": fetch["FETCH_SIZE"], "write_KiB_per_launch": write["WRITE_SIZE"],
                                "compulsory_bytes_per_launch": 16.0 * n_samples,
                                "counters": "rocprofv3 --pmc on launches of the same size of this libgpt.so, inside this run"}
         except Exception as e:
-            out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["legs"][leg]["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
             shutil.rmtree(work, ignore_errors=True)
-    ls.close()
     return out
 
 
@@ -487,7 +494,7 @@ def main():
             others = {}
             for which in ("c3", "c4", "c5"):
                 try:
-                    others[which] = standin_leg(api, which, counters=not args.no_counters and which != "c4")
+                    others[which] = standin_leg(api, which, counters=not args.no_counters)
                 except Exception as e:
                     others[which] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 note(f"other_configs {which} done")

@@ -274,9 +274,10 @@ class Renderer:
         check(self.lib.gpt_set_tile_owner(self.ctx, rank, n_ranks))
 
     def set_traversal_order(self, order):
-        """"reference" / False / 0: the reference's order (default); "near" / True / 1: the same tree, nearer child first
-        (include/gpt_traversal.h); "wide" / 2: the 4-wide tree walked by four lanes per ray (include/gpt_wide_bvh.h)"""
-        code = {"reference": 0, "near": 1, "wide": 2}.get(order, order)
+        """"reference" / 0: the reference's order on its binary tree; "wide" / 2: the 4-wide tree walked one lane per ray
+        (include/gpt_wide_bvh.h); "auto" / -1: gpt_begin's choice again - "wide" for scenes that do not fit LDS, "reference"
+        otherwise.  get_option("traversal_order") reads the order in force."""
+        code = {"reference": 0, "wide": 2, "auto": -1}.get(order, order)
         check(self.lib.gpt_set_traversal_order(self.ctx, int(code)))
 
     def set_integrator(self, kind, value):

@@ -40,6 +40,7 @@
 #include "pt_device.h"
 #include "pt_shade.h"
 #include "../../include/gpt_wide_bvh.h"
+#include "../../include/gpt_traversal.h"
 
 namespace pt {
 
@@ -182,14 +183,9 @@ __device__ __forceinline__ RayResult pool_result(const float4 *pool, int slot)
 //   LdsScene     the scene was staged into LDS with every link rebased to an absolute LDS address
 struct GlobalScene {
     const char *nodes, *tris;
-    int first, end;                        // cursor of node 0, cursor one past the last node (of variant 0)
+    int first, end;                        // cursor of node 0, cursor one past the last node
     int tri_bias;                          // cursor of triangle 0
-    int near_stride;                       // near-first traversal: bytes per node-array variant (0 = reference order)
-    __device__ __forceinline__ int first_of(V3 d) const   // the ray's variant: 0, or 1 + octant of its direction
-    {
-        const int oct = (int)((__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2));
-        return near_stride ? (1 + oct) * near_stride : 0;
-    }
+    __device__ __forceinline__ int first_of(V3) const { return 0; }
     static constexpr int vote_node_shift = 0, vote_tri_shift = PT_GLOBAL_VOTE_TRI_SHIFT;
     __device__ __forceinline__ float4 node4(int c) const { return *reinterpret_cast<const float4 *>(nodes + (unsigned)c); }
     __device__ __forceinline__ float4 tri4(int c) const { return *reinterpret_cast<const float4 *>(tris + (unsigned)c); }
@@ -218,7 +214,7 @@ struct LdsScene {
 template <bool COUNT, bool FIXED, class Mem>
 __device__ __forceinline__ void trace_pool(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, const Mem mem)
 {
-    const int n_bytes = mem.end - mem.first;      // one node array (every ray walks exactly one variant)
+    const int n_bytes = mem.end - mem.first;      // the node array
     const int tri_bias = mem.tri_bias;
     const float tmin_ray = P.eps;          // every ray of the integrator starts at epsilon
 
@@ -599,13 +595,9 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "v_mov_b32_e32 v12, %[end]\n" "v_mov_b32_e32 v13, 0\n" "v_mov_b32_e32 v14, -1\n" "v_mov_b32_e32 v15, -1\n"
 #define PT_FETCH_COMPACT "v_lshl_add_u32 v15, v33, 5, %[pool]\n"
 #define PT_CURSOR_FIRST "v_mov_b32_e32 v12, %[first]\n"
-//  per-ray node array (global scenes): variant = 0, or 1 + octant of the direction in near-first mode
-//  ([vstride] = bytes per variant or 0, [first] = cursor of the variant octant 0 maps to); v3 = one past its last node
+//  scenes in global memory: cursors are byte offsets from the node array; v3 = one past its last node
 #define PT_CURSOR_VARIANT \
-        "v_mov_b32_e32 v34, 0\n" "s_cmp_eq_u32 %[vstride], 0\n" "s_cbranch_scc1 TP_CV1_%=\n" \
-        "v_lshrrev_b32_e32 v34, 31, v4\n" "v_lshrrev_b32_e32 v35, 31, v5\n" "v_lshrrev_b32_e32 v36, 31, v6\n" \
-        "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
-        "TP_CV1_%=:\n" "v_add_u32_e32 v12, %[first], v34\n" "v_add_u32_e32 v3, %[end], v12\n"
+        "v_mov_b32_e32 v12, %[first]\n" "v_add_u32_e32 v3, %[end], v12\n"
 #define PT_DRY_DRAIN "s_cmp_lg_u64 s[64:65], 0\n" "s_cbranch_scc1 TP_VOTE_%=\n"
 //  carry (scenes in global memory): a lane resumes the ray it was tracing when the last drain stopped (its cursors and
 //  partial result come back from its suspend record, direction and origin from the ray's slot); the i-th new ray is
@@ -616,10 +608,7 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         "ds_read_b128 v[12:15], v34\n" "ds_read_b128 v[20:23], v34 offset:16\n" "s_waitcnt lgkmcnt(0)\n" \
         "v_mov_b32_e32 v3, 0\n" "v_cmp_lt_i32_e64 s[64:65], -1, v15\n" "s_mov_b64 exec, s[64:65]\n" \
         "ds_read_b128 v[4:7], v15\n" "ds_read_b128 v[8:11], v15 offset:16\n" "s_waitcnt lgkmcnt(0)\n" \
-        "v_mov_b32_e32 v34, 0\n" "s_cmp_eq_u32 %[vstride], 0\n" "s_cbranch_scc1 TP_CV2_%=\n" \
-        "v_lshrrev_b32_e32 v34, 31, v4\n" "v_lshrrev_b32_e32 v35, 31, v5\n" "v_lshrrev_b32_e32 v36, 31, v6\n" \
-        "v_lshl_or_b32 v34, v35, 1, v34\n" "v_lshl_or_b32 v34, v36, 2, v34\n" "v_mul_lo_u32 v34, v34, %[vstride]\n" \
-        "TP_CV2_%=:\n" "v_add_u32_e32 v34, %[first], v34\n" "v_add_u32_e32 v3, %[end], v34\n" \
+        "v_mov_b32_e32 v34, %[first]\n" "v_add_u32_e32 v3, %[end], v34\n" \
         "v_and_b32_e32 v33, 0xff, v11\n" "v_lshl_add_u32 v33, v33, 4, %[pool]\n" "ds_read_b96 v[0:2], v33 offset:%[org]\n" \
         "s_waitcnt lgkmcnt(0)\n" "s_mov_b64 exec, -1\n" \
         "v_cmp_le_i32_e64 s[60:61], v13, v14\n" "v_cmp_gt_i32_e64 s[62:63], v3, v12\n"   /* the vote masks of the loop header: a drain that starts with resumed rays and nothing to fetch goes from the dry-pool test straight to the vote */
@@ -1000,8 +989,7 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
     const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
     const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
     const int s_end = __builtin_amdgcn_readfirstlane(mem.end - mem.first);      // bytes of one node array
-    const int s_vstride = __builtin_amdgcn_readfirstlane(mem.near_stride);
-    const int s_first = s_vstride, s_bias = 0;                                   // variant 0, or variant 1 + octant
+    const int s_first = 0, s_bias = 0;
     const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(eps));
     const unsigned long long s_nodes = uniform64((unsigned long long)mem.nodes), s_tris = uniform64((unsigned long long)mem.tris);
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16, s_susp = s_pool + kSuspOff * 16;
@@ -1017,7 +1005,7 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
                  PT_ENTRY_RESUME, PT_FETCH_ORDERED, "", PT_CURSOR_VARIANT, "v3", PT_FINISH_PENDING, PT_DRY_MAY_STOP, PT_EXIT_SUSPEND,
                  "v3" PT_COMMA "v44" PT_COMMA "v45" PT_COMMA "v46" PT_COMMA "v47" PT_COMMA "v48" PT_COMMA "v49" PT_COMMA "v50" PT_COMMA "v51" PT_COMMA "v52" PT_COMMA,
                  [nodes] "s"(s_nodes), [tris] "s"(s_tris), [order] "s"(s_order), [pend] "s"(s_pend), [susp] "s"(s_susp),
-                 [allow] "s"(s_allow), [vstride] "s"(s_vstride), [tstop] "s"(s_tstop))
+                 [allow] "s"(s_allow), [tstop] "s"(s_tstop))
 }
 
 // ---- trace_pool_wide<>, hand-scheduled -------------------------------------------------------------------------------------
@@ -1702,7 +1690,7 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
 // 72 B) are staged in LDS once per workgroup; traversal and shading then read LDS instead of going through
 // the vector-memory pipe.
 #ifndef PT_SMALL_FLOAT4
-#define PT_SMALL_FLOAT4 768
+#define PT_SMALL_FLOAT4 GPT_LDS_SCENE_FLOAT4
 #endif
 #ifndef PT_SMALL_WAVES
 #define PT_SMALL_WAVES PT_MIN_WAVES
@@ -2810,7 +2798,6 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 mem.first = 0;
                 mem.end = 32 * P.n_nodes;
                 mem.tri_bias = 0;
-                mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
                 if (COUNT)      // (the twin always drains to the end: nothing is ever suspended)
                     trace_pool<COUNT, true>(P, pool, n_new, cnt, mem);
                 else
@@ -3011,7 +2998,6 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
                     mem.first = 0;
                     mem.end = 32 * P.n_nodes;
                     mem.tri_bias = 0;
-                    mem.near_stride = P.traversal ? 32 * P.n_nodes : 0;
                     trace_pool_global_asm(lds_address(pool), fresh, mem, P.eps, fresh > 0);
                 }
                 wave_lds_fence();
@@ -3094,7 +3080,8 @@ int render_kernel_blocks_per_cu(bool count, bool walk, bool wide)
 
 bool render_scene_fits_lds(const DevParams &P)
 {
-    return P.traversal == 0 && 2 * P.n_nodes + 8 * P.n_prims + 6 * P.n_lights + (18 * P.n_materials + 3) / 4 <= kSmallSceneFloat4;
+    static_assert(kSmallSceneFloat4 == GPT_LDS_SCENE_FLOAT4, "gpt_scene_fits_lds (include/gpt_traversal.h) describes this kernel's LDS scene");
+    return P.traversal == 0 && gpt_scene_fits_lds(P.n_nodes, P.n_prims, P.n_lights, P.n_materials);
 }
 
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream)

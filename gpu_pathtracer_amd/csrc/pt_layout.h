@@ -149,7 +149,7 @@ struct DevParams {
     uint32_t n_chunks;           // ceil(iter_count / chunk_iters)
     uint32_t *tile_counter;      // work queue heads, one per XCD (8 words, zeroed before every launch)
     unsigned long long *counters;  // work counters (counting build only)
-    int32_t traversal;           // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_NEAR_FIRST (nodes holds 9 threaded variants)
+    int32_t traversal;           // GPT_TRAVERSAL_REFERENCE / GPT_TRAVERSAL_WIDE4
     // Volpath only (new fields go at the END: the kernarg layout steers the register allocation of the headline kernel)
     const struct DevMedium *mediums;
     const int32_t *prim_media;         // per primitive (BVH order): mediumInside, mediumOutside

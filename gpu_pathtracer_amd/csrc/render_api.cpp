@@ -184,66 +184,32 @@ void pack_triangle(const gpt_triangle &t, DevTri &dt, DevShade &ds)
     ds.lightIdx = t.lightIdx;
 }
 
-// Threaded traversal: the nodes are laid out in the order they are visited; an inner node continues at the next node
-// when its box is hit and at its "escape" (the first node after its subtree in that order) when it is missed.
-// Variant 0 is the reference's order (left child first, pathtracer.cu:221-252); variants 1..8 are the near-first orders
-// of the eight ray-direction octants (include/gpt_traversal.h): the same tree, children swapped where the octant says so.
-// Every variant is a complete array of n nodes; a ray uses exactly one of them.
-void thread_nodes_ordered(const gpt_bvh_node *nodes, int n, int octant /* -1 = reference order */, int variant_base, DevNode *out)
+// Threaded traversal: the nodes stay in the reference's preorder (left child first, pathtracer.cu:221-252); an inner node continues at
+// the next node when its box is hit and at its "escape" - the first node after its subtree - when it is missed.  That reproduces the
+// reference's push-right / push-left stack order with no stack at all.
+void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
 {
+    out.resize((size_t)n);
     if (n <= 0) return;
-    std::vector<int> order;                 // visiting order: order[k] = original node index
-    order.reserve((size_t)n);
-    std::vector<int> subtree_end((size_t)n, 0);      // position (in the new order) one past the node's subtree
-    std::vector<int> pos((size_t)n, 0);
-    // iterative preorder with the octant's child order; post-visit fixes subtree_end
-    struct Frame { int node; int stage; };
-    std::vector<Frame> stack;
-    stack.push_back({0, 0});
-    while (!stack.empty()) {
-        Frame &f = stack.back();
-        const gpt_bvh_node &nd = nodes[f.node];
-        if (f.stage == 0) {
-            pos[(size_t)f.node] = (int)order.size();
-            order.push_back(f.node);
-            f.stage = 1;
-            if (!nd.is_leaf && nd.second_child_offset > 0) {
-                const bool right_first = octant >= 0 && gpt_right_child_first(gpt_node_order_code(nodes, f.node), octant);
-                const int first = right_first ? nd.second_child_offset : f.node + 1;
-                const int second = right_first ? f.node + 1 : nd.second_child_offset;
-                const int me = f.node;
-                (void)me;
-                stack.push_back({second, 0});     // popped after the first child's whole subtree
-                stack.push_back({first, 0});
-            }
-        } else {
-            subtree_end[(size_t)f.node] = (int)order.size();
-            stack.pop_back();
-        }
-    }
-    // NB: the loop above pushes both children at once, so a node's post-visit runs after BOTH subtrees: exactly what
-    // subtree_end needs.
-    for (int k = 0; k < n; ++k) {
-        const int i = order[(size_t)k];
+    std::vector<int> subtree_end((size_t)n, 0);      // index one past the node's subtree
+    // in preorder a subtree is a contiguous range: leaf [i, i + 1); inner node [i, end of its right child's subtree)
+    for (int i = n - 1; i >= 0; --i) {
         const gpt_bvh_node &nd = nodes[i];
-        DevNode &d = out[(size_t)k];
+        subtree_end[(size_t)i] = (nd.is_leaf || nd.second_child_offset <= 0) ? i + 1 : subtree_end[(size_t)nd.second_child_offset];
+    }
+    for (int i = 0; i < n; ++i) {
+        const gpt_bvh_node &nd = nodes[i];
+        DevNode &d = out[(size_t)i];
         d.bmin[0] = nd.fmin.x; d.bmin[1] = nd.fmin.y; d.bmin[2] = nd.fmin.z;
         d.bmax[0] = nd.fmax.x; d.bmax[1] = nd.fmax.y; d.bmax[2] = nd.fmax.z;
         if (nd.is_leaf) {
             d.link = nd.start * (int32_t)sizeof(DevTri);
             d.last = nd.end * (int32_t)sizeof(DevTri);
         } else {
-            d.link = (variant_base + subtree_end[(size_t)i]) * (int32_t)sizeof(DevNode);
+            d.link = subtree_end[(size_t)i] * (int32_t)sizeof(DevNode);
             d.last = -1;
         }
     }
-}
-
-// all nine variants, variant v at [v * n, (v + 1) * n)
-void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
-{
-    out.resize((size_t)n * 9);
-    for (int v = 0; v < 9; ++v) thread_nodes_ordered(nodes, n, v - 1, v * n, out.data() + (size_t)v * n);
 }
 
 
@@ -343,7 +309,7 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
         return GPT_ERR_INVALID_ARG;
     }
     // traversal cursors are 32-bit byte offsets into the packed node / triangle arrays (pt_layout.h)
-    if ((int64_t)scene->n_nodes * 9 * (int64_t)sizeof(DevNode) > INT32_MAX || (int64_t)scene->n_prims * (int64_t)sizeof(DevTri) > INT32_MAX) {
+    if ((int64_t)scene->n_nodes * (int64_t)sizeof(DevNode) > INT32_MAX || (int64_t)scene->n_prims * (int64_t)sizeof(DevTri) > INT32_MAX) {
         gpt_set_error("gpt_begin: scene too large (%d nodes, %d primitives; limits 7456540 / 44739242)", scene->n_nodes, scene->n_prims);
         return GPT_ERR_UNSUPPORTED;
     }
@@ -632,6 +598,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.plane = 0;                                   // set per gpt_render call: 64 slots per owned tile
     P.counters = ctx->counters;
     if (hipDeviceSynchronize() != hipSuccess) { gpt_set_error("gpt_begin: device sync failed"); return fail(GPT_ERR_HIP); }
+    // the default traversal order (include/gpt_traversal.h): the 4-wide tree for every scene that does not fit LDS
+    if ((rc = gpt_set_traversal_order(ctx, GPT_TRAVERSAL_AUTO)) != GPT_OK) return fail(rc);
     *out = ctx;
     return GPT_OK;
 }
@@ -694,6 +662,7 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "chunk_iters") *value = ctx->chunk_override;
     else if (n == "scheduler") *value = ctx->scheduler;
     else if (n == "wf_paths") *value = ctx->wf.n_paths;
+    else if (n == "traversal_order") *value = ctx->P.traversal;
     else if (n == "scheduler_active") *value = ctx->last_wavefront ? 1 : 0;
     // read-only: what the renderer actually does with the current scene and settings
     else if (n == "lds_scene_active") *value = (ctx->lds_scene && render_scene_fits_lds(ctx->P)) ? 1 : 0;
@@ -710,10 +679,13 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
 
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
 {
-    if (!ctx || (order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_NEAR_FIRST && order != GPT_TRAVERSAL_WIDE4)) {
+    if (!ctx || (order != GPT_TRAVERSAL_AUTO && order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_WIDE4)) {
         gpt_set_error("gpt_set_traversal_order: invalid argument");
         return GPT_ERR_INVALID_ARG;
     }
+    if (order == GPT_TRAVERSAL_AUTO)
+        order = (ctx->wide_ok && !gpt_scene_fits_lds(ctx->P.n_nodes, ctx->P.n_prims, ctx->P.n_lights, ctx->P.n_materials)) ? GPT_TRAVERSAL_WIDE4
+                                                                                                                         : GPT_TRAVERSAL_REFERENCE;
     if (order == GPT_TRAVERSAL_WIDE4) {
         if (!ctx->wide_ok) {
             gpt_set_error("gpt_set_traversal_order: the scene has no wide tree (empty scene, or deeper than %d wide levels)", (GPT_WIDE_STACK_MAX - 1) / 3);
@@ -803,8 +775,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     if (by_memory < 1) by_memory = 1;
     // the decoupled scheduler: Path, Ao and the three-ray Volpath, in the reference's order or on the 4-wide tree (work counters
     // come from the counting build of the per-wave kernel)
-    const bool use_wf = ctx->scheduler == 1 && !count && !render_uses_walk_kernel(ctx->P, ctx->force_walk) &&
-                        ctx->P.traversal != GPT_TRAVERSAL_NEAR_FIRST;
+    const bool use_wf = ctx->scheduler == 1 && !count && !render_uses_walk_kernel(ctx->P, ctx->force_walk);
     ctx->last_wavefront = use_wf;
     if (use_wf) {
         // a sample's plane slot and its number in the batch are 32-bit words of the path state

@@ -73,17 +73,19 @@ int gpt_set_tile_owner(gpt_ctx *ctx, int rank, int n_ranks);
 int gpt_set_integrator(gpt_ctx *ctx, int32_t integrator_type, int32_t max_depth, float max_dist);
 
 /* Traversal order of the BVH:
- *   GPT_TRAVERSAL_REFERENCE (0, default)  the reference's order; results are the reference's bit for bit.
- *   GPT_TRAVERSAL_NEAR_FIRST (1)          the same tree, nearer child first (include/gpt_traversal.h): fewer node visits on
- *                                         large scenes.
+ *   GPT_TRAVERSAL_REFERENCE (0)           the reference's order on its binary tree; results are the reference's bit for bit.
  *   GPT_TRAVERSAL_WIDE4 (2)               a 4-wide tree collapsed from the reference's, walked one lane per ray
- *                                         (include/gpt_wide_bvh.h): a quarter of the node visits, faster where leaves are
- *                                         large; GPT_ERR_UNSUPPORTED for an empty scene or a tree deeper than 85 wide levels (the reference's own 64-entry stack ends at binary depth 64).
- * Modes 1 and 2 change only the ORDER of the reference's box and triangle tests: each is bit-identical to the oracle in the
- * same mode and within 1e-4 relative RMS of the reference order (measured: identical films, or single pixels where two hits
- * tie within rounding - relative RMS <= 2e-7).  Both always traverse from global memory.  The first selection of mode 2 uploads
- * the wide tree with a copy of the triangle records behind it (128 B per wide node + 48 B per triangle, one allocation below
- * 4 GB - GPT_ERR_UNSUPPORTED beyond) and the per-wave stack spill space. */
+ *                                         (include/gpt_wide_bvh.h): a quarter of the node visits; GPT_ERR_UNSUPPORTED for an empty
+ *                                         scene or a tree deeper than 85 wide levels (the reference's own 64-entry stack ends at
+ *                                         binary depth 64).
+ *   GPT_TRAVERSAL_AUTO (-1)               back to gpt_begin's choice (include/gpt_traversal.h): the wide tree for every scene that
+ *                                         does not fit LDS and has one, the reference order otherwise.
+ * The wide order changes only the ORDER of the reference's box and triangle tests: it is bit-identical to the oracle in the same
+ * mode and within 1e-4 relative RMS of the reference order (measured: identical films, or single pixels where two hits tie within
+ * rounding - relative RMS <= 2e-7).  It always traverses from global memory.  gpt_begin selects it for every scene that does not fit
+ * LDS (where it is 9 - 74 % faster) and the reference order for scenes that do; this call overrides the choice either way.  The first
+ * selection of the wide order uploads the wide tree with a copy of the triangle records behind it (128 B per wide node + 48 B per
+ * triangle, one allocation below 4 GB - GPT_ERR_UNSUPPORTED beyond) and the per-wave stack spill space. */
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
 
 /* Renderer options, by name; none of them changes a result.  Nothing in the library is steered by environment

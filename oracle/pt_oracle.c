@@ -283,7 +283,6 @@ typedef struct {
     const gpt_scene_desc *d;
     gpt_infinite inf;     /* copy; isvalid = 0 when desc->infinite is NULL */
     float eps;
-    const unsigned char *order;   /* near-first traversal: one gpt_node_order_code per node; NULL = reference order */
     const gpt_wide_node *wide;    /* GPT_TRAVERSAL_WIDE4: the 4-wide tree (include/gpt_wide_bvh.h); NULL otherwise */
     int n_wide;
 } scene_t;
@@ -369,18 +368,12 @@ static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isec
 }
 
 /* ---- traversal: pathtracer.cu:214-296 ------------------------------------------ */
-/* Traversal order (include/gpt_traversal.h): the reference pushes the right child, then the left one.  In
- * near-first mode the child that lies first along the ray is popped first; `order` holds one code per node. */
-static int g_traversal = GPT_TRAVERSAL_REFERENCE;
-static inline void push_children(const scene_t *sc, const gpt_bvh_node *node, int node_idx, int oct, int *stack, int *top)
+/* Traversal order (include/gpt_traversal.h): the reference pushes the right child, then the left one (the left one is visited first). */
+static int g_traversal = GPT_TRAVERSAL_AUTO;       /* include/gpt_traversal.h: the product's default rule */
+static inline void push_children(const gpt_bvh_node *node, int node_idx, int *stack, int *top)
 {
-    if (sc->order && gpt_right_child_first(sc->order[node_idx], oct)) {
-        stack[(*top)++] = node_idx + 1;
-        stack[(*top)++] = node->second_child_offset;
-    } else {
-        stack[(*top)++] = node->second_child_offset;
-        stack[(*top)++] = node_idx + 1;
-    }
+    stack[(*top)++] = node->second_child_offset;
+    stack[(*top)++] = node_idx + 1;
 }
 
 /* ---- GPT_TRAVERSAL_WIDE4: the walk of include/gpt_wide_bvh.h ------------------------------------------------------
@@ -495,7 +488,6 @@ static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
     int top = 0;
     int ret = 0;
     int node_idx = 0;
-    const int oct = gpt_direction_octant(ray->d.x, ray->d.y, ray->d.z);
     t_cnt.closest_rays++;
     if (sc->d->n_nodes <= 0) return 0;
     for (;;) {
@@ -503,7 +495,7 @@ static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
         t_cnt.node_visits++;
         if (bbox_intersect(node, ray)) {
             if (!node->is_leaf) {
-                push_children(sc, node, node_idx, oct, stack, &top);
+                push_children(node, node_idx, stack, &top);
             } else {
                 for (int i = node->start; i <= node->end; ++i) {
                     const gpt_primitive *prim = &sc->d->prims[i];
@@ -530,7 +522,6 @@ static int intersect_any(const scene_t *sc, ray_t *ray)
     int stack[64];
     int top = 0;
     int node_idx = 0;
-    const int oct = gpt_direction_octant(ray->d.x, ray->d.y, ray->d.z);
     t_cnt.shadow_rays++;
     if (sc->d->n_nodes <= 0) return 0;
     for (;;) {
@@ -538,7 +529,7 @@ static int intersect_any(const scene_t *sc, ray_t *ray)
         t_cnt.node_visits++;
         if (bbox_intersect(node, ray)) {
             if (!node->is_leaf) {
-                push_children(sc, node, node_idx, oct, stack, &top);
+                push_children(node, node_idx, stack, &top);
             } else {
                 for (int i = node->start; i <= node->end; ++i) {
                     const gpt_primitive *prim = &sc->d->prims[i];
@@ -1666,6 +1657,28 @@ static inline f3 tonemap(f3 color, int filmic)
  * rendered (multi-GPU tile ownership, same rule as gpt_set_tile_owner;
  * rank=0,n_ranks=1 renders everything).
  */
+/* the 4-wide tree of a render / trace call, or none: GPT_TRAVERSAL_WIDE4 asks for it (-1 when the scene has none), GPT_TRAVERSAL_AUTO
+ * takes it for every scene that does not fit LDS and has one - gpt_begin's rule (include/gpt_traversal.h) */
+static int scene_wide_tree(const gpt_scene_desc *desc, gpt_wide_node **out, int *n_out)
+{
+    *out = NULL;
+    *n_out = 0;
+    const int auto_wide = g_traversal == GPT_TRAVERSAL_AUTO && desc->n_prims < (1 << 27) &&
+                          !gpt_scene_fits_lds(desc->n_nodes, desc->n_prims, desc->n_lights, desc->n_materials);
+    if (!(g_traversal == GPT_TRAVERSAL_WIDE4 || auto_wide) || desc->n_nodes <= 0) return 0;
+    const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
+    int depth = 0;
+    gpt_wide_node *wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
+    const int n = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, wide, cap, &depth);
+    if (n <= 0 || 3 * depth + 1 > GPT_WIDE_STACK_MAX) {
+        free(wide);
+        return auto_wide ? 0 : -1;
+    }
+    *out = wide;
+    *n_out = n;
+    return 0;
+}
+
 API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_t width, uint32_t height,
                       float eps, uint32_t iter_first, uint32_t iter_count, int reset,
                       float *acc, float *color, float *out, int rank, int n_ranks, int n_threads)
@@ -1687,25 +1700,12 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     int filmic = cam->filmic;
     if (n_threads < 1) n_threads = 1;
     memset(&g_cnt, 0, sizeof(g_cnt));
-    unsigned char *order = NULL;
-    if (g_traversal == GPT_TRAVERSAL_NEAR_FIRST && desc->n_nodes > 0) {
-        order = (unsigned char *)calloc((size_t)desc->n_nodes, 1);
-        for (int i = 0; i < desc->n_nodes; ++i)
-            if (!desc->nodes[i].is_leaf) order[i] = (unsigned char)gpt_node_order_code(desc->nodes, i);
-    }
-    sc.order = order;
     gpt_wide_node *wide = NULL;
     sc.wide = NULL;
     sc.n_wide = 0;
     g_wide_stack_max = 0;
-    if (g_traversal == GPT_TRAVERSAL_WIDE4 && desc->n_nodes > 0) {
-        const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
-        int depth = 0;
-        wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
-        sc.n_wide = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, wide, cap, &depth);
-        if (sc.n_wide < 0 || 3 * depth + 1 > GPT_WIDE_STACK_MAX) { free(wide); free(order); return -3; }
-        sc.wide = wide;
-    }
+    if (scene_wide_tree(desc, &wide, &sc.n_wide) < 0) return -3;
+    sc.wide = wide;
 
 #pragma omp parallel num_threads(n_threads)
     {
@@ -1746,7 +1746,6 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
             g_cnt.samples += t_cnt.samples;
         }
     }
-    free(order);
     free(wide);
     return 0;
 }
@@ -1760,24 +1759,11 @@ API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *ra
     sc.d = desc;
     sc.eps = eps;
     memset(&sc.inf, 0, sizeof(sc.inf));
-    unsigned char *order = NULL;
-    if (g_traversal == GPT_TRAVERSAL_NEAR_FIRST && desc->n_nodes > 0) {
-        order = (unsigned char *)calloc((size_t)desc->n_nodes, 1);
-        for (int i = 0; i < desc->n_nodes; ++i)
-            if (!desc->nodes[i].is_leaf) order[i] = (unsigned char)gpt_node_order_code(desc->nodes, i);
-    }
-    sc.order = order;
     gpt_wide_node *wide = NULL;
     sc.wide = NULL;
     sc.n_wide = 0;
-    if (g_traversal == GPT_TRAVERSAL_WIDE4 && desc->n_nodes > 0) {
-        const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
-        int depth = 0;
-        wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
-        sc.n_wide = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, wide, cap, &depth);
-        if (sc.n_wide < 0 || 3 * depth + 1 > GPT_WIDE_STACK_MAX) { free(wide); free(order); return -3; }
-        sc.wide = wide;
-    }
+    if (scene_wide_tree(desc, &wide, &sc.n_wide) < 0) return -3;
+    sc.wide = wide;
     if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for num_threads(n_threads) schedule(dynamic, 256)
     for (int i = 0; i < n; ++i) {
@@ -1791,7 +1777,6 @@ API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *ra
         tb_out[3 * (size_t)i + 1] = hit ? t_hit_b1 : 0.f;
         tb_out[3 * (size_t)i + 2] = hit ? t_hit_b2 : 0.f;
     }
-    free(order);
     free(wide);
     return 0;
 }
@@ -1799,10 +1784,10 @@ API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *ra
 /* deepest traversal stack of the last GPT_TRAVERSAL_WIDE4 render (the GPU keeps 24 entries per ray in LDS and spills the rest) */
 API int oracle_wide_stack_max(void) { return g_wide_stack_max; }
 
-/* GPT_TRAVERSAL_REFERENCE (default), GPT_TRAVERSAL_NEAR_FIRST or GPT_TRAVERSAL_WIDE4 for the following oracle_render calls */
+/* GPT_TRAVERSAL_AUTO (default: the product's rule), GPT_TRAVERSAL_REFERENCE or GPT_TRAVERSAL_WIDE4 for the following calls */
 API int oracle_set_traversal(int mode)
 {
-    if (mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_NEAR_FIRST && mode != GPT_TRAVERSAL_WIDE4) return -1;
+    if (mode != GPT_TRAVERSAL_AUTO && mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_WIDE4) return -1;
     g_traversal = mode;
     return 0;
 }

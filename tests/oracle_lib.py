@@ -148,8 +148,16 @@ def make_camera(position, lookat, up=(0, 1, 0), res=(512, 512), fov=60.0, apertu
 
 
 def render(scene, cam, width, height, eps, iter_first, iter_count, reset=True, acc=None, color=None, kind="soft",
-           rank=0, n_ranks=1, threads=None, want_out=False):
+           rank=0, n_ranks=1, threads=None, want_out=False, order=None):
+    """oracle_render.  order: None = whatever oracle_set_traversal left (initially -1: the product's default rule, wide tree for scenes
+    that do not fit LDS - include/gpt_traversal.h); 0 / 2 / -1 = that order for this call only"""
     lib = load(kind)
+    if order is not None:
+        assert lib.oracle_set_traversal(int(order)) == 0
+        try:
+            return render(scene, cam, width, height, eps, iter_first, iter_count, reset, acc, color, kind, rank, n_ranks, threads, want_out)
+        finally:
+            lib.oracle_set_traversal(-1)
     n = width * height * 3
     acc = np.zeros(n, dtype=np.float32) if acc is None else acc
     color = np.zeros(n, dtype=np.float32) if color is None else color
@@ -162,7 +170,7 @@ def render(scene, cam, width, height, eps, iter_first, iter_count, reset=True, a
 
 
 def trace_rays(scene, eps, rays8, order=0, kind="soft", threads=None):
-    """The traversal operators alone (Intersect / IntersectP) in traversal order `order` (0 reference, 1 near-first, 2 wide):
+    """The traversal operators alone (Intersect / IntersectP) in traversal order `order` (0 reference, 2 wide, -1 the product's default):
     rays8 (n, 8) = origin, direction, tmax, any_hit -> (prim (n,) int32, tb (n, 3) = t, b1, b2)"""
     lib = load(kind)
     rays8 = np.ascontiguousarray(rays8, dtype=np.float32).reshape(-1, 8)
@@ -173,7 +181,7 @@ def trace_rays(scene, eps, rays8, order=0, kind="soft", threads=None):
     try:
         rc = lib.oracle_trace_rays(C.byref(scene.desc), eps, st.ptr(rays8), n, st.ptr(prim), st.ptr(tb), threads or min(64, os.cpu_count() or 1))
     finally:
-        lib.oracle_set_traversal(0)
+        lib.oracle_set_traversal(-1)
     assert rc == 0
     return prim, tb
 

@@ -203,32 +203,9 @@ def test_ambient_occlusion_oracle_properties():
     assert 0.25 < (c_soft.reshape(H, W, 3) / np.float32(4))[hit].mean() < 1.0
 
 
-def test_near_first_traversal_agrees_with_the_reference_order():
-    """include/gpt_traversal.h: visiting the nearer child first changes the work, not the picture (bar: 1e-4 relative
-    RMS; only exact ties and rounding coincidences between box and triangle tests could differ)."""
-    import scenes
-    lib = ol.load("soft")
-    for scene, meta, W, H, spp in ((ol.load_cornell(8) + (96, 96, 8)), (scenes.stress_scene(0.25, max_depth=12) + (96, 72, 4))):
-        cam = ol.cornell_camera(meta, W, H)
-        ref, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
-        c_ref = ol.counters("soft")
-        try:
-            assert lib.oracle_set_traversal(1) == 0
-            near, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
-            c_near = ol.counters("soft")
-        finally:
-            lib.oracle_set_traversal(0)
-        a, b = near.reshape(-1, 3).astype(np.float64), ref.reshape(-1, 3).astype(np.float64)
-        rms = np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))
-        assert (rms <= 1e-4).all()
-        assert c_near["samples"] == c_ref["samples"] and c_near["closest_rays"] == c_ref["closest_rays"]
-        assert c_near["node_visits"] <= c_ref["node_visits"] and c_near["prim_tests"] <= c_ref["prim_tests"]
-    assert lib.oracle_set_traversal(7) == -1
-
-
 def test_traversal_operators_do_not_depend_on_the_order():
     """Intersect / IntersectP as operators (oracle_trace_rays) on 60 000 rays with edge cases (axis-aligned directions, origins on
-    the walls, short / zero intervals): whether an any-hit ray is blocked is the same in all three orders, and the wide walk finds
+    the walls, short / zero intervals): whether an any-hit ray is blocked is the same in both orders, and the wide walk finds
     the reference order's closest hit - primitive, t, b1, b2 - on every ray with a proper direction, exactly equal hits included."""
     import scenes
     import test_gpu_parity as tg
@@ -236,10 +213,9 @@ def test_traversal_operators_do_not_depend_on_the_order():
     proper = ~np.isnan(rays).any(axis=1) & (np.abs(rays[:, 3:6]).sum(axis=1) > 0)
     closest, anyhit = proper & (rays[:, 7] == 0), proper & (rays[:, 7] != 0)
     for scene in (ol.load_cornell(4)[0], scenes.zoo_scene(max_depth=4, extra=scenes.random_soup(2000, 5, size=0.3))[0]):
-        res = {order: ol.trace_rays(scene, 0.001, rays, order, threads=8) for order in (0, 1, 2)}
+        res = {order: ol.trace_rays(scene, 0.001, rays, order, threads=8) for order in (0, 2)}
         assert 0.3 < (res[0][0] >= 0).mean() < 0.999
-        for order in (1, 2):
-            assert np.array_equal(res[order][0][anyhit] >= 0, res[0][0][anyhit] >= 0)
+        assert np.array_equal(res[2][0][anyhit] >= 0, res[0][0][anyhit] >= 0)
         assert np.array_equal(res[2][0][closest], res[0][0][closest])
         assert res[2][1][closest].tobytes() == res[0][1][closest].tobytes()
         hit = res[0][0] >= 0
@@ -257,15 +233,18 @@ def test_wide_traversal_agrees_with_the_reference_order():
     for scene, meta, W, H, spp in ((ol.load_cornell(8) + (96, 96, 8)), (scenes.zoo_scene(max_depth=8, with_env=True) + (96, 72, 6)),
                                    (scenes.stress_scene(0.25, max_depth=12) + (96, 72, 4))):
         cam = ol.cornell_camera(meta, W, H)
-        ref, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
+        ref, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", order=0)
         c_ref = ol.counters("soft")
+        auto, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")          # the product's rule: wide unless the scene fits LDS
+        small = len(scene.prims) <= 40
+        assert (ol.counters("soft")["node_visits"] == c_ref["node_visits"]) == small and auto.tobytes() == ref.tobytes()
         try:
             assert lib.oracle_set_traversal(2) == 0
             wide, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
             c_wide = ol.counters("soft")
             again, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", threads=1)
         finally:
-            lib.oracle_set_traversal(0)
+            lib.oracle_set_traversal(-1)
         assert wide.tobytes() == again.tobytes()
         a, b = wide.reshape(-1, 3).astype(np.float64), ref.reshape(-1, 3).astype(np.float64)
         rms = np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))
@@ -273,7 +252,7 @@ def test_wide_traversal_agrees_with_the_reference_order():
         assert np.count_nonzero(wide != ref) == 0          # stronger than the bar, and what has been observed on every scene so far
         assert c_wide["closest_rays"] == c_ref["closest_rays"] and c_wide["shadow_rays"] == c_ref["shadow_rays"]
         assert c_wide["node_visits"] * 3 < c_ref["node_visits"]
-
+    assert lib.oracle_set_traversal(7) == -1 and lib.oracle_set_traversal(1) == -1
 
 
 def test_volpath_oracle_properties():

@@ -167,7 +167,7 @@ def test_loader_flag_builds_the_split_tree(gpt_host):
     res = {}
     for name, sc in (("ref", ref), ("new", new)):
         cam = ol.make_camera((-0.3, 0.5, -0.5), (0.0, 0.075, 0.0), (0, 1, 0), (W, H), 37.0)          # the stand-in's camera at this size
-        acc, _ = ol.render(sc, cam, W, H, ref.epsilon, 1, 2, kind="soft")
+        acc, _ = ol.render(sc, cam, W, H, ref.epsilon, 1, 2, kind="soft", order=0)      # (the reference order on both trees)
         c = ol.counters("soft")
         res[name] = (acc.copy(), c["prim_tests"] / c["samples"])
     assert res["new"][1] < 0.1 * res["ref"][1]
@@ -192,7 +192,7 @@ def test_kernel_on_the_split_tree(gpt):
             try:
                 want, _ = ol.render(split, cam, W, H, 0.001, 1, spp, kind="soft")
             finally:
-                lib.oracle_set_traversal(0)
+                lib.oracle_set_traversal(-1)
             r.set_traversal_order(name)
             r.render(cam, 1, spp, reset=True)
             got = r.read_accum()

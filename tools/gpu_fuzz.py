@@ -67,7 +67,7 @@ while time.time() < t_end:
     else:
         cam = ol.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.2, 2.5)), float(rng.uniform(3, 8))), (0, 1, 0), (0, 1, 0), (W, H), float(rng.uniform(15, 70)))
     ao = bool(rng.random() < 0.2) and not vpt
-    order = int(rng.choice([0, 0, 1, 2, 2]))            # reference / nearer child first / 4-wide tree, one lane per ray
+    order = int(rng.choice([0, 0, -1, 2, 2]))           # reference / the product's default rule / 4-wide tree, one lane per ray
     near = order
     force_global = bool(rng.random() < 0.4)
     eps = float(rng.choice([0.001, 0.0005, 0.01]))
@@ -92,7 +92,7 @@ while time.time() < t_end:
     try:
         ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
     finally:
-        lib.oracle_set_traversal(0)
+        lib.oracle_set_traversal(-1)
     api.DEFAULT_OPTIONS["lds_scene"] = 0 if force_global else 1
     api.DEFAULT_OPTIONS["vpt_walk_kernel"] = 1 if force_walk else 0
     with api.Renderer(scene.desc, W, H, eps) as r:

@@ -18,7 +18,7 @@ def run(stage):
         cam = ol.cornell_camera(meta, W, H)
         assert ol.load("soft").oracle_set_traversal(2) == 0
         want, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
-        ol.load("soft").oracle_set_traversal(0)
+        ol.load("soft").oracle_set_traversal(-1)
         with api.Renderer(scene.desc, W, H, 0.001) as r:
             r.set_option("lds_scene", 0)
             r.set_traversal_order("wide")
