@@ -1,4 +1,4 @@
-"""Traversal alone: Mrays/s of the three loops (reference order / nearer child first / 4-wide) through gpt_debug_trace, one ray per lane per
+"""Traversal alone: Mrays/s of the two loops (reference order / 4-wide) through gpt_debug_trace, one ray per lane per
 round, on the Cornell box (LDS and global memory) and the config-5 stand-in, for incoherent rays (random origins and directions) and for
 coherent ones (a pinhole camera's primary rays).  usage (GPU box): python tools/gpu_trace_rate.py [million rays]"""
 import sys, tempfile
@@ -25,7 +25,7 @@ ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), "c5"))
 for name, scene, lds in (("cornell, LDS", scene_c, 1), ("cornell, global memory", scene_c, 0), ("config-5 stand-in", ls, 0)):
     with api.Renderer(scene.desc, 64, 64, 0.001) as r:
         r.set_option("lds_scene", lds)
-        for order, oname in ((0, "reference"), (1, "near-first"), (2, "wide")):
+        for order, oname in ((0, "reference"), (2, "wide")):
             if lds and order:
                 continue
             r.set_traversal_order(order)
