@@ -402,6 +402,12 @@ def main():
     dt_max = float(t.item())
 
     samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
+    mine = {"rank": rank, "owned_tiles": r.get_option("owned_tiles"), "sample_plane_bytes": r.get_option("sample_plane_bytes"),
+            "launches": launches, "kernel_ms": kernel_ms, "wall_s": dt}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         acc_host = comm.read_reduced() if comm is not None else r.read_accum()
         img = acc_host.reshape(-1, 3) / np.float32(args.steps * SPP_PER_STEP)
@@ -517,7 +523,7 @@ def main():
                        "accumulator_sha1": frame_sha1, "libgpt_sha1": lib_sha1,
                        "renderer_options": options, "options_set": dict(r.options_set),
                        "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND", "GPT_BENCH_TRY_NATIVE") if os.environ.get(k)}),
-                       "reduce": (comm.kind if comm is not None else None),
+                       "reduce": (comm.kind if comm is not None else None), "per_rank": per_rank,
                        "square_frame": square, "other_configs": others,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": roof,

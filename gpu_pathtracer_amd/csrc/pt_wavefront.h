@@ -5,7 +5,9 @@
 //   shade phase   one lane per PATH SLOT: consume the three rays' results (direct light of the previous bounce, :943-994;
 //                 the surface hit, :906-941, 953-956, 997-1016), write a finished sample, start the next sample in the
 //                 same slot (:881-903), emit up to three rays
-//   trace phase   one lane per RAY: a lane that finishes a ray takes the next ray of the pool, whatever path it belongs to
+//   trace phase   one lane per RAY: a lane that finishes a ray takes the next ray of the pool, whatever path it belongs to ("scheduler" 1),
+//                 or a RAY STREAM: the rays live in LDS and every trip steps a batch of rays that are all at a wide node or all at a
+//                 leaf ("scheduler" 2, the 4-wide walk only)
 // A persistent workgroup alternates the two phases over its own POOL of path slots (kWfWgChunks x 64); everything a path
 // carries between the phases lives in HBM as a structure of arrays of float4 planes (kWfStateBytes per slot) - what decouples
 // ray supply and shading from one wave's 64 paths is that any wave of the workgroup may take any chunk of the pool.
@@ -73,9 +75,12 @@ struct WfParams {
 
 constexpr int kWfStateBytes = 6 * 16 + 3 * 16 + 3 * 16 + 3 * 4;
 
-hipError_t launch_wf_render(const struct DevParams &P, const WfParams &W, int n_blocks, hipStream_t stream);
-int wf_blocks_per_cu(int integrator, bool wide);
-int wf_lds_stack_levels();
+// stream_trace: the wide walk of the trace phase as a ray stream (a wave's rays live in LDS, a batch of them is stepped per trip) instead of
+// one lane per ray; the binary tree is walked one lane per ray either way
+hipError_t launch_wf_render(const struct DevParams &P, const WfParams &W, int n_blocks, bool stream_trace, hipStream_t stream);
+int wf_blocks_per_cu(int integrator, bool wide, bool stream_trace);
+int wf_lds_stack_levels(bool stream_trace);
+int wf_spill_columns(bool stream_trace);
 int wf_paths_per_block();
 int wf_waves_per_block();
 

@@ -854,6 +854,903 @@ __device__ __forceinline__ void wf_trace_cxx(const DevParams &P, const WfParams 
 }
 
 
+// ---- the wide walk of the trace stage as a RAY STREAM ---------------------------------------------------------------------
+// One lane per ray wastes the trace stage's lanes on the walk itself: a trip runs its node block for the lanes that are at a wide
+// node and its triangle block for the lanes that are at a leaf, and a lane is at one or at the other (measured on the config-5
+// stand-in: 45 lanes hold a ray, 22 of 64 are active per VALU instruction).  Here a ray does not belong to a lane.  A wave keeps up to
+// kWfR rays in flight with ALL their walk state in its LDS block (origin, direction, 1 / direction, interval end, current entry,
+// stack size, best hit, id; the stack's first kWfS levels as columns of the same block), and two lists name the slots whose next
+// step is a wide node and those whose next step is a leaf.  A trip takes up to 64 slots off ONE list - every lane runs the same
+// block - loads what that step needs, makes the step, writes back what changed and puts the slot on the list of its next step; a
+// finished ray's result goes to hit[kind][path], its slot is free again and the next ray of the wave's current segment moves in.
+// The walk of a ray is include/gpt_wide_bvh.h's, step for step (wf_trace_cxx above with the state in LDS): same bits.
+// Rays still in flight when the segments are used up and few are left simply stay where they are for the next round (their result
+// slot says kWfPending meanwhile): parking costs nothing here.
+#ifndef PT_WF_STREAM_CXX
+#define PT_WF_STREAM_CXX 0              // 1: the stream runs as the C++ specification below instead of its hand-scheduled twin
+#endif
+#ifndef PT_WF_STREAM_RAYS
+#define PT_WF_STREAM_RAYS 96
+#endif
+#ifndef PT_WF_STREAM_LEVELS
+#define PT_WF_STREAM_LEVELS 6
+#endif
+#ifndef PT_WF_STREAM_REFILL_T
+#define PT_WF_STREAM_REFILL_T 16        // free slots that trigger a refill
+#endif
+#ifndef PT_WF_STREAM_PARK_T
+#define PT_WF_STREAM_PARK_T 32          // segments used up and fewer rays than this in flight: they wait for the next round ...
+#endif
+#ifndef PT_WF_STREAM_DEPTH
+#define PT_WF_STREAM_DEPTH 2            // batches a wave has on their way (1: the step follows its loads at once)
+#endif
+#ifndef PT_WF_STREAM_MIN_TRIPS
+#define PT_WF_STREAM_MIN_TRIPS 16       // ... but every round moves its rays on by some trips
+#endif
+constexpr int kWfR = PT_WF_STREAM_RAYS, kWfS = PT_WF_STREAM_LEVELS;
+enum { SF_OX, SF_OY, SF_OZ, SF_DX, SF_DY, SF_DZ, SF_IX, SF_IY, SF_IZ, SF_TMAX, SF_CUR, SF_SP, SF_BPRIM, SF_BT, SF_B1, SF_B2, SF_ID, SF_N };
+struct WfStreamWave {
+    uint32_t f[SF_N][kWfR];             // field-major: a trip's 64 slots are different words of one row (two-way bank conflicts at most)
+    uint32_t stack[kWfS][kWfR];
+    uint32_t qn[kWfR], ql[kWfR];        // slots whose next step is a wide node / a leaf (used as stacks)
+    uint32_t freel[kWfR];
+    uint32_t n_qn, n_ql, n_free, pad;   // (between two rounds)
+};
+
+__device__ __forceinline__ uint32_t wf_bperm(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+
+// what a wave has asked memory for and not looked at yet: one batch of up to 64 rays, all at a wide node or all at a leaf (seven
+// dwordx4 from the node / from the leaf's next two triangles - the copy behind the wide nodes, DevParams::wide_tris_off), and the
+// rays that move into free slots (direction and origin)
+struct WfFetch {
+    uint32_t slot;
+    int n;                    // wave-uniform: rays in the batch (lane i < n has one)
+    bool node;                // wave-uniform
+    float4 d0, d1, d2, d3, d4, d5, d6;
+    int take;                 // wave-uniform: rays that move in (lane i < take has one)
+    uint32_t new_id, new_slot;
+    float4 nr, no;
+};
+
+__device__ __forceinline__ void wf_trace_stream(const DevParams &P, const WfParams &W, WfShared &sh, uint32_t chunk0, WfStreamWave &L, unsigned lane)
+{
+    const uint32_t np = W.n_paths;
+    const float tmin_ray = P.eps;
+    const char *wnodes = reinterpret_cast<const char *>(P.wide);
+    const uint32_t tri_off = P.wide_tris_off;
+    uint32_t *spill = W.spill + (size_t)(blockIdx.x * (unsigned)kWfWgWaves + (threadIdx.x >> 6)) * (uint32_t)kWfR * W.spill_levels;
+    int qn = __builtin_amdgcn_readfirstlane((int)L.n_qn), ql = __builtin_amdgcn_readfirstlane((int)L.n_ql);
+    int nfree = __builtin_amdgcn_readfirstlane((int)L.n_free);
+    uint32_t seg0 = 0, seg1 = 0, seg2 = 0;          // the wave's current segment: id j in lane j % 64, register j / 64
+    uint32_t cursor = 0, chunk_end = 0;
+    bool exhausted = false, parking = false;
+    int trips = 0;
+#if PT_WF_PROBE == 2
+    unsigned long long pr_nt = 0, pr_nl = 0, pr_lt = 0, pr_ll = 0, pr_in = 0;       // node trips, lanes in them, leaf trips, lanes in them, rays in flight
+    unsigned long long pr_t = __builtin_readcyclecounter(), pr_pre = 0, pr_wait = 0, pr_proc = 0;      // cycles: up to the loads, until they are back, the step
+#define PT_WFS_TICK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - pr_t; pr_t = now_; }
+#else
+#define PT_WFS_TICK(acc)
+#endif
+
+    // ---- ask for the next batch (`others` rays are in the batch that is still on its way) and for the rays that move in
+    auto issue = [&](WfFetch &F, int others) {
+        F.n = 0;
+        F.take = 0;
+        F.node = true;
+        F.slot = 0;
+        F.new_id = F.new_slot = 0;
+        if (parking) return;
+        if (!exhausted && nfree >= PT_WF_STREAM_REFILL_T) {
+            while (cursor >= chunk_end && !exhausted) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&sh.trace_next, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= (uint32_t)kWfWgChunks) { exhausted = true; break; }
+                const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.seg_count[c]);
+                const uint32_t *seg = W.rayq + (size_t)(chunk0 + c) * (uint32_t)kWfSegRays;
+                seg0 = lane < cnt ? seg[lane] : 0u;
+                seg1 = lane + 64u < cnt ? seg[lane + 64u] : 0u;
+                seg2 = lane + 128u < cnt ? seg[lane + 128u] : 0u;
+                cursor = 0;
+                chunk_end = cnt;
+            }
+            if (!exhausted) {
+                const int left = (int)(chunk_end - cursor);
+                int take = nfree < left ? nfree : left;
+                if (take > 64) take = 64;
+                const uint32_t q = cursor + lane;
+                const uint32_t a = wf_bperm(seg0, (int)(q & 63u)), b = wf_bperm(seg1, (int)(q & 63u)), c2 = wf_bperm(seg2, (int)(q & 63u));
+                F.new_id = (q >> 6) == 0u ? a : ((q >> 6) == 1u ? b : c2);
+                if ((int)lane < take) {
+                    F.new_slot = L.freel[nfree - 1 - (int)lane];
+                    const uint32_t path = F.new_id & kWfPathMask, kind = (F.new_id >> kWfKindShift) & 3u;
+                    F.nr = W.ray[kind * np + path];
+                    F.no = W.org[path];
+                }
+                cursor += (uint32_t)take;
+                nfree -= take;
+                F.take = take;
+            }
+        }
+        const int n_in = qn + ql;
+        if (exhausted && F.take == 0 && n_in + others < PT_WF_STREAM_PARK_T && trips >= PT_WF_STREAM_MIN_TRIPS && n_in + others > 0) {
+            parking = true;             // the rest waits for the next round where it is (see below)
+            return;
+        }
+        if (n_in == 0) return;
+        ++trips;
+        // a full batch of either kind if there is one, else the longer list (a node step costs about twice a leaf step: it goes first)
+        F.node = qn >= 64 || (ql < 64 && qn >= ql);
+        const int have = F.node ? qn : ql;
+        const int n = have < 64 ? have : 64;
+#if PT_WF_PROBE == 2
+        pr_in += (unsigned)(n_in + others);
+        if (F.node) { pr_nt++; pr_nl += (unsigned)n; } else { pr_lt++; pr_ll += (unsigned)n; }
+#endif
+        F.n = n;
+        if ((int)lane < n) {
+            F.slot = F.node ? L.qn[qn - n + (int)lane] : L.ql[ql - n + (int)lane];
+            const unsigned cur = L.f[SF_CUR][F.slot];
+            const uint32_t off = F.node ? cur : tri_off + (cur & 0x07ffffffu) * 48u;
+            const float4 *g = reinterpret_cast<const float4 *>(wnodes + (size_t)off);
+            F.d0 = g[0]; F.d1 = g[1]; F.d2 = g[2]; F.d3 = g[3]; F.d4 = g[4]; F.d5 = g[5]; F.d6 = g[6];
+        }
+        if (F.node) qn -= n; else ql -= n;
+        PT_WFS_TICK(pr_pre)
+    };
+
+    // ---- make the batch's step with what has arrived, put its rays on the list of their next step, let the new rays in
+    auto process = [&](const WfFetch &F) {
+#if PT_WF_PROBE == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PT_WFS_TICK(pr_wait)
+#endif
+        if (F.n > 0) {
+            const bool act = (int)lane < F.n;
+            const uint32_t slot = F.slot;
+            bool to_node = false, to_leaf = false, fin = false;
+            if (F.node) {
+                if (act) {
+                    const V3 o = V3{__uint_as_float(L.f[SF_OX][slot]), __uint_as_float(L.f[SF_OY][slot]), __uint_as_float(L.f[SF_OZ][slot])};
+                    const V3 inv = V3{__uint_as_float(L.f[SF_IX][slot]), __uint_as_float(L.f[SF_IY][slot]), __uint_as_float(L.f[SF_IZ][slot])};
+                    const float tmax = __uint_as_float(L.f[SF_TMAX][slot]);
+                    unsigned cur;
+                    int sp = (int)L.f[SF_SP][slot];
+                    // ---- a wide node: four boxes, bbox.h:77-96 each
+                    const float4 lx = F.d0, ly = F.d1, lz = F.d2, hx = F.d3, hy = F.d4, hz = F.d5;
+                    const uint4 en = make_uint4(__float_as_uint(F.d6.x), __float_as_uint(F.d6.y), __float_as_uint(F.d6.z), __float_as_uint(F.d6.w));
+                    const float blx[4] = {lx.x, lx.y, lx.z, lx.w}, bly[4] = {ly.x, ly.y, ly.z, ly.w}, blz[4] = {lz.x, lz.y, lz.z, lz.w};
+                    const float bhx[4] = {hx.x, hx.y, hx.z, hx.w}, bhy[4] = {hy.x, hy.y, hy.z, hy.w}, bhz[4] = {hz.x, hz.y, hz.z, hz.w};
+                    unsigned e[4] = {en.x, en.y, en.z, en.w}, key[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t1 = (blx[k] - o.x) * inv.x;
+                        const float t2 = (bhx[k] - o.x) * inv.x;
+                        const float t3 = (bly[k] - o.y) * inv.y;
+                        const float t4 = (bhy[k] - o.y) * inv.y;
+                        const float t5 = (blz[k] - o.z) * inv.z;
+                        const float t6 = (bhz[k] - o.z) * inv.z;
+                        const float tn = fmax_(fmax_(fmin_(t1, t2), fmin_(t3, t4)), fmin_(t5, t6));
+                        const float tf = fmin_(fmin_(fmax_(t1, t2), fmax_(t3, t4)), fmax_(t5, t6));
+                        const bool hit = e[k] != GPT_WIDE_NONE && !(tf <= 0.00001f) && !(tn > tf) && !(tn > tmax);
+                        key[k] = hit ? ((__float_as_uint(tn > 0.0f ? tn : 0.0f) & ~3u) | (unsigned)k) : 0xffffffffu;
+                    }
+                    wf_cex(key[0], e[0], key[1], e[1]);
+                    wf_cex(key[2], e[2], key[3], e[3]);
+                    wf_cex(key[0], e[0], key[2], e[2]);
+                    wf_cex(key[1], e[1], key[3], e[3]);
+                    wf_cex(key[1], e[1], key[2], e[2]);
+                    if (key[0] == 0xffffffffu) {
+                        if (sp > 0) {
+                            --sp;
+                            cur = sp < kWfS ? L.stack[sp][slot] : spill[(size_t)(sp - kWfS) * (uint32_t)kWfR + slot];
+                        } else {
+                            cur = GPT_WIDE_NONE;
+                        }
+                    } else {
+                        const int top = sp + 3 - (key[1] == 0xffffffffu ? 1 : 0) - (key[2] == 0xffffffffu ? 1 : 0) - (key[3] == 0xffffffffu ? 1 : 0);
+#pragma unroll
+                        for (int jj = 3; jj >= 1; --jj)
+                            if (key[jj] != 0xffffffffu) {
+                                const int at = top - jj;
+                                if (at < kWfS) L.stack[at][slot] = e[jj];
+                                else spill[(size_t)(at - kWfS) * (uint32_t)kWfR + slot] = e[jj];
+                            }
+                        sp = top;
+                        cur = e[0];
+                    }
+                    L.f[SF_CUR][slot] = cur;
+                    L.f[SF_SP][slot] = (uint32_t)sp;
+                    fin = cur == GPT_WIDE_NONE;
+                    to_leaf = !fin && (cur >> 31) != 0u;
+                    to_node = !fin && (cur >> 31) == 0u;
+                }
+            } else {
+                if (act) {
+                    const V3 o = V3{__uint_as_float(L.f[SF_OX][slot]), __uint_as_float(L.f[SF_OY][slot]), __uint_as_float(L.f[SF_OZ][slot])};
+                    const V3 d = V3{__uint_as_float(L.f[SF_DX][slot]), __uint_as_float(L.f[SF_DY][slot]), __uint_as_float(L.f[SF_DZ][slot])};
+                    float tmax = __uint_as_float(L.f[SF_TMAX][slot]);
+                    unsigned cur = L.f[SF_CUR][slot];
+                    int sp = (int)L.f[SF_SP][slot];
+                    const bool any_hit = (L.f[SF_ID][slot] & kWfAnyHit) != 0u;
+                    int bprim = (int)L.f[SF_BPRIM][slot];
+                    float bt = __uint_as_float(L.f[SF_BT][slot]), bb1 = 0.f, bb2 = 0.f;
+                    bool better = false, ended = false;
+                    int prim = (int)(cur & 0x07ffffffu), left = (int)((cur >> 27) & 15u);        // left = triangles of the leaf after this one
+                    // ---- a leaf: its next triangle and, if the ray goes on, the one after it (mesh.h:45-67 each, each against the
+                    // interval it would see in a trip of its own)
+#pragma unroll
+                    for (int rep = 0; rep < 2; ++rep) {
+                        if (rep == 1 && (ended || left <= 0)) break;
+                        if (rep == 1) { ++prim; --left; }
+                        const float4 q0 = rep ? F.d3 : F.d0, q1 = rep ? F.d4 : F.d1;
+                        const float e2z = rep ? F.d5.x : F.d2.x;
+                        const V3 v1 = V3{q0.x, q0.y, q0.z};
+                        const V3 e1 = V3{q0.w, q1.x, q1.y};
+                        const V3 e2 = V3{q1.z, q1.w, e2z};
+                        const V3 s1 = cross(d, e2);
+                        const float divisor = dot(s1, e1);
+                        const float invDivisor = 1.0f / divisor;           // == (float)(1.0 / divisor): 53 >= 2 * 24 + 2 bits
+                        const V3 s = o - v1;
+                        const float b1 = dot(s, s1) * invDivisor;
+                        const V3 s2 = cross(s, e1);
+                        const float b2 = dot(d, s2) * invDivisor;
+                        const float tt = dot(e2, s2) * invDivisor;
+                        const bool accept = !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) &&
+                                            !(b2 < 0.0f || b1 + b2 > 1.0f) && !(tt < tmin_ray || tt > tmax);
+                        if (accept) {
+                            if (bprim < 0 || tt < bt || (tt == bt && prim > bprim)) {
+                                bprim = prim;
+                                bt = tt;
+                                bb1 = b1;
+                                bb2 = b2;
+                                better = true;
+                            }
+                            if (tt < tmax) tmax = tt;                      // (a NaN distance never becomes the interval's end)
+                            ended = any_hit;                               // IntersectP: the first accepted triangle ends the ray
+                        }
+                    }
+                    if (better) {
+                        L.f[SF_BPRIM][slot] = (uint32_t)bprim;
+                        L.f[SF_BT][slot] = __float_as_uint(bt);
+                        L.f[SF_B1][slot] = __float_as_uint(bb1);
+                        L.f[SF_B2][slot] = __float_as_uint(bb2);
+                    }
+                    L.f[SF_TMAX][slot] = __float_as_uint(tmax);
+                    if (ended) {
+                        cur = GPT_WIDE_NONE;
+                        sp = 0;
+                    } else if (left > 0) {
+                        cur = 0x80000000u | ((unsigned)(left - 1) << 27) | (unsigned)(prim + 1);
+                    } else if (sp > 0) {
+                        --sp;
+                        cur = sp < kWfS ? L.stack[sp][slot] : spill[(size_t)(sp - kWfS) * (uint32_t)kWfR + slot];
+                    } else {
+                        cur = GPT_WIDE_NONE;
+                    }
+                    L.f[SF_CUR][slot] = cur;
+                    L.f[SF_SP][slot] = (uint32_t)sp;
+                    fin = cur == GPT_WIDE_NONE;
+                    to_leaf = !fin && (cur >> 31) != 0u;
+                    to_node = !fin && (cur >> 31) == 0u;
+                }
+            }
+            // ---- where the batch's rays go next
+            const unsigned long long m_n = ballot(to_node), m_l = ballot(to_leaf), m_f = ballot(fin);
+            if (to_node) L.qn[qn + lane_rank(m_n)] = slot;
+            if (to_leaf) L.ql[ql + lane_rank(m_l)] = slot;
+            qn += popc(m_n);
+            ql += popc(m_l);
+            if (m_f != 0ull) {
+                if (fin) {
+                    const uint32_t id = L.f[SF_ID][slot];
+                    const int bprim = (int)L.f[SF_BPRIM][slot];
+                    // a miss reports the end of the interval
+                    W.hit[((id >> kWfKindShift) & 3u) * np + (id & kWfPathMask)] =
+                        make_float4(__int_as_float(bprim), __uint_as_float(bprim < 0 ? L.f[SF_TMAX][slot] : L.f[SF_BT][slot]),
+                                    __uint_as_float(L.f[SF_B1][slot]), __uint_as_float(L.f[SF_B2][slot]));
+                    L.freel[nfree + lane_rank(m_f)] = slot;
+                }
+                nfree += popc(m_f);
+            }
+        }
+        // ---- the new rays start at the root
+        if (F.take > 0) {
+            if ((int)lane < F.take) {
+                const uint32_t ns = F.new_slot;
+                const V3 d = xyz(F.nr);
+                L.f[SF_OX][ns] = __float_as_uint(F.no.x); L.f[SF_OY][ns] = __float_as_uint(F.no.y); L.f[SF_OZ][ns] = __float_as_uint(F.no.z);
+                L.f[SF_DX][ns] = __float_as_uint(d.x); L.f[SF_DY][ns] = __float_as_uint(d.y); L.f[SF_DZ][ns] = __float_as_uint(d.z);
+                L.f[SF_IX][ns] = __float_as_uint(1.f / d.x);      // bbox.h:79 computes 1/d at every node visit: the same quotient
+                L.f[SF_IY][ns] = __float_as_uint(1.f / d.y);
+                L.f[SF_IZ][ns] = __float_as_uint(1.f / d.z);
+                L.f[SF_TMAX][ns] = __float_as_uint(F.nr.w);
+                L.f[SF_CUR][ns] = 0u;
+                L.f[SF_SP][ns] = 0u;
+                L.f[SF_BPRIM][ns] = 0xffffffffu;
+                L.f[SF_BT][ns] = 0u; L.f[SF_B1][ns] = 0u; L.f[SF_B2][ns] = 0u;
+                L.f[SF_ID][ns] = F.new_id;
+                L.qn[qn + (int)lane] = ns;
+            }
+            qn += F.take;
+        }
+        wave_lds_fence();
+        PT_WFS_TICK(pr_proc)
+    };
+
+    // two batches are on their way at any time: while one's step is computed the other's loads are in flight
+    WfFetch A, B;
+    issue(A, 0);
+    for (;;) {
+#if PT_WF_STREAM_DEPTH == 1
+        process(A);
+        if (A.n == 0 && A.take == 0 && qn + ql == 0 && (exhausted || parking)) break;
+        if (parking) break;
+        issue(A, 0);
+#else
+        issue(B, A.n);
+        process(A);
+        if (B.n == 0 && B.take == 0 && ((qn + ql == 0 && exhausted) || parking)) break;
+        issue(A, B.n);
+        process(B);
+        if (A.n == 0 && A.take == 0 && ((qn + ql == 0 && exhausted) || parking)) break;
+#endif
+    }
+    if (parking) {
+        // ---- rays left for the next round: the shade phase lets their paths sit the round out
+        const int n_in = qn + ql;
+        for (int j = (int)lane; j < n_in; j += 64) {
+            const uint32_t slot = j < qn ? L.qn[j] : L.ql[j - qn];
+            const uint32_t id = L.f[SF_ID][slot];
+            reinterpret_cast<int *>(W.hit + ((id >> kWfKindShift) & 3u) * np + (id & kWfPathMask))[0] = kWfPending;
+        }
+        if (lane == 0 && n_in > 0) sh.parked = 1u;
+    }
+    if (lane == 0) { L.n_qn = (uint32_t)qn; L.n_ql = (uint32_t)ql; L.n_free = (uint32_t)nfree; }
+#if PT_WF_PROBE == 2
+    if (lane == 0) {
+        atomicAdd(&P.counters[6], pr_nt); atomicAdd(&P.counters[7], pr_nl); atomicAdd(&P.counters[8], pr_lt); atomicAdd(&P.counters[9], pr_ll);
+        atomicAdd(&P.counters[10], pr_in);
+        atomicAdd(&P.counters[11], pr_pre); atomicAdd(&P.counters[12], pr_wait); atomicAdd(&P.counters[13], pr_proc);
+    }
+#endif
+    wave_lds_fence();
+}
+
+
+// 1 / direction as the IEEE quotient (bbox.h:79 divides): v[8:10] = 1.0 / v[4:6]; temporaries v[33:37], s[66:67], vcc
+#define PT_WF_ASM_INV_DIR \
+        "v_div_scale_f32 v33, s[66:67], v4, v4, 1.0\n" \
+        "v_div_scale_f32 v34, vcc, 1.0, v4, 1.0\n" \
+        "v_rcp_f32_e32 v35, v33\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v36, -v33, v35, 1.0\n" \
+        "v_fmac_f32_e32 v35, v36, v35\n" \
+        "v_mul_f32_e32 v37, v34, v35\n" \
+        "v_fma_f32 v36, -v33, v37, v34\n" \
+        "v_fmac_f32_e32 v37, v36, v35\n" \
+        "v_fma_f32 v33, -v33, v37, v34\n" \
+        "v_div_fmas_f32 v33, v33, v35, v37\n" \
+        "v_div_fixup_f32 v8, v33, v4, 1.0\n" \
+        "v_div_scale_f32 v33, s[66:67], v5, v5, 1.0\n" \
+        "v_div_scale_f32 v34, vcc, 1.0, v5, 1.0\n" \
+        "v_rcp_f32_e32 v35, v33\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v36, -v33, v35, 1.0\n" \
+        "v_fmac_f32_e32 v35, v36, v35\n" \
+        "v_mul_f32_e32 v37, v34, v35\n" \
+        "v_fma_f32 v36, -v33, v37, v34\n" \
+        "v_fmac_f32_e32 v37, v36, v35\n" \
+        "v_fma_f32 v33, -v33, v37, v34\n" \
+        "v_div_fmas_f32 v33, v33, v35, v37\n" \
+        "v_div_fixup_f32 v9, v33, v5, 1.0\n" \
+        "v_div_scale_f32 v33, s[66:67], v6, v6, 1.0\n" \
+        "v_div_scale_f32 v34, vcc, 1.0, v6, 1.0\n" \
+        "v_rcp_f32_e32 v35, v33\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v36, -v33, v35, 1.0\n" \
+        "v_fmac_f32_e32 v35, v36, v35\n" \
+        "v_mul_f32_e32 v37, v34, v35\n" \
+        "v_fma_f32 v36, -v33, v37, v34\n" \
+        "v_fmac_f32_e32 v37, v36, v35\n" \
+        "v_fma_f32 v33, -v33, v37, v34\n" \
+        "v_div_fmas_f32 v33, v33, v35, v37\n" \
+        "v_div_fixup_f32 v10, v33, v6, 1.0\n"
+
+// The trip of the hand-scheduled walks as two pieces of text, used by wf_trace_wide_asm (one lane per ray: the lanes at a wide node are
+// s[62:63], those at a leaf s[60:61]) and by wf_trace_stream_asm (a batch of rays that are all at a wide node or all at a leaf: one of the two
+// masks is empty).  In: v[0:2] origin, v[4:6] direction, v[8:10] 1 / direction, v11 id (bit 31: any hit), v12 current entry, v13 stack size,
+// v14 end of the interval, v16 the ray's spill column, v18 its LDS stack column (moved back by three levels), v[20:23] best hit; out: v12,
+// v13, v14, v[20:23] and the stack.  PT_WF_LVL(dst, level, column) forms the address of a level of a column, PT_WF_O1..3 are the byte
+// offsets of one, two and three levels: the two walks differ in how far apart the levels of a column are.
+#define PT_WF_ASM_TRIP \
+        "s_mov_b64 exec, s[60:61]\n" \
+        "v_and_b32_e32 v53, 0x7ffffff, v12\n"              /* the leaf's first triangle */ \
+        "v_lshlrev_b32_e32 v54, 4, v53\n" \
+        "v_lshl_add_u32 v54, v53, 5, v54\n"                /* * 48 */ \
+        "v_add_u32_e32 v54, %[trioff], v54\n" \
+        "s_mov_b64 exec, s[62:63]\n" \
+        "v_mov_b32_e32 v54, v12\n" \
+        "s_or_b64 exec, s[60:61], s[62:63]\n" \
+        "global_load_dwordx4 v[24:27], v54, %[nodes]\n" \
+        "global_load_dwordx4 v[36:39], v54, %[nodes] offset:48\n" \
+        "global_load_dwordx4 v[28:31], v54, %[nodes] offset:16\n" \
+        "global_load_dwordx4 v[40:43], v54, %[nodes] offset:64\n" \
+        "global_load_dwordx4 v[32:35], v54, %[nodes] offset:32\n" \
+        "global_load_dwordx4 v[44:47], v54, %[nodes] offset:80\n" \
+        "global_load_dwordx4 v[48:51], v54, %[nodes] offset:96\n" \
+        "s_mov_b64 s[78:79], 0\n" \
+        "s_mov_b64 s[82:83], 0\n" \
+        "s_mov_b64 exec, s[62:63]\n" \
+        "s_cbranch_execz TQ_LEAF_%=\n" \
+        "s_waitcnt vmcnt(0)\n" \
+        /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */ \
+        /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */ \
+        "v_sub_f32_e32 v24, v24, v0\n" \
+        "v_sub_f32_e32 v36, v36, v0\n" \
+        "v_sub_f32_e32 v28, v28, v1\n" \
+        "v_sub_f32_e32 v32, v32, v2\n" \
+        "v_sub_f32_e32 v40, v40, v1\n" \
+        "v_sub_f32_e32 v44, v44, v2\n" \
+        "v_mul_f32_e32 v24, v8, v24\n" \
+        "v_mul_f32_e32 v36, v8, v36\n" \
+        "v_mul_f32_e32 v28, v9, v28\n" \
+        "v_mul_f32_e32 v40, v9, v40\n" \
+        "v_mul_f32_e32 v32, v10, v32\n" \
+        "v_mul_f32_e32 v44, v10, v44\n" \
+        "v_min_f32_e32 v52, v24, v36\n" \
+        "v_max_f32_e32 v24, v24, v36\n" \
+        "v_min_f32_e32 v36, v28, v40\n" \
+        "v_max_f32_e32 v28, v28, v40\n" \
+        "v_min_f32_e32 v40, v32, v44\n" \
+        "v_max_f32_e32 v32, v32, v44\n" \
+        "v_min3_f32 v24, v24, v28, v32\n" \
+        "v_max3_f32 v52, v52, v36, v40\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v24\n" \
+        "v_min_f32_e32 v24, v24, v14\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], v24, v52\n" \
+        "v_max_f32_e32 v52, 0, v52\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ne_u32_e32 vcc, -1, v48\n" \
+        "v_and_or_b32 v52, v52, -4, 0\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cndmask_b32_e64 v24, -1, v52, s[66:67]\n" \
+        "v_sub_f32_e32 v25, v25, v0\n" \
+        "v_sub_f32_e32 v37, v37, v0\n" \
+        "v_sub_f32_e32 v29, v29, v1\n" \
+        "v_sub_f32_e32 v33, v33, v2\n" \
+        "v_sub_f32_e32 v41, v41, v1\n" \
+        "v_sub_f32_e32 v45, v45, v2\n" \
+        "v_mul_f32_e32 v25, v8, v25\n" \
+        "v_mul_f32_e32 v37, v8, v37\n" \
+        "v_mul_f32_e32 v29, v9, v29\n" \
+        "v_mul_f32_e32 v41, v9, v41\n" \
+        "v_mul_f32_e32 v33, v10, v33\n" \
+        "v_mul_f32_e32 v45, v10, v45\n" \
+        "v_min_f32_e32 v52, v25, v37\n" \
+        "v_max_f32_e32 v25, v25, v37\n" \
+        "v_min_f32_e32 v37, v29, v41\n" \
+        "v_max_f32_e32 v29, v29, v41\n" \
+        "v_min_f32_e32 v41, v33, v45\n" \
+        "v_max_f32_e32 v33, v33, v45\n" \
+        "v_min3_f32 v25, v25, v29, v33\n" \
+        "v_max3_f32 v52, v52, v37, v41\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v25\n" \
+        "v_min_f32_e32 v25, v25, v14\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], v25, v52\n" \
+        "v_max_f32_e32 v52, 0, v52\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ne_u32_e32 vcc, -1, v49\n" \
+        "v_and_or_b32 v52, v52, -4, 1\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cndmask_b32_e64 v25, -1, v52, s[66:67]\n" \
+        "v_sub_f32_e32 v26, v26, v0\n" \
+        "v_sub_f32_e32 v38, v38, v0\n" \
+        "v_sub_f32_e32 v30, v30, v1\n" \
+        "v_sub_f32_e32 v34, v34, v2\n" \
+        "v_sub_f32_e32 v42, v42, v1\n" \
+        "v_sub_f32_e32 v46, v46, v2\n" \
+        "v_mul_f32_e32 v26, v8, v26\n" \
+        "v_mul_f32_e32 v38, v8, v38\n" \
+        "v_mul_f32_e32 v30, v9, v30\n" \
+        "v_mul_f32_e32 v42, v9, v42\n" \
+        "v_mul_f32_e32 v34, v10, v34\n" \
+        "v_mul_f32_e32 v46, v10, v46\n" \
+        "v_min_f32_e32 v52, v26, v38\n" \
+        "v_max_f32_e32 v26, v26, v38\n" \
+        "v_min_f32_e32 v38, v30, v42\n" \
+        "v_max_f32_e32 v30, v30, v42\n" \
+        "v_min_f32_e32 v42, v34, v46\n" \
+        "v_max_f32_e32 v34, v34, v46\n" \
+        "v_min3_f32 v26, v26, v30, v34\n" \
+        "v_max3_f32 v52, v52, v38, v42\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v26\n" \
+        "v_min_f32_e32 v26, v26, v14\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], v26, v52\n" \
+        "v_max_f32_e32 v52, 0, v52\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ne_u32_e32 vcc, -1, v50\n" \
+        "v_and_or_b32 v52, v52, -4, 2\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cndmask_b32_e64 v26, -1, v52, s[66:67]\n" \
+        "v_sub_f32_e32 v27, v27, v0\n" \
+        "v_sub_f32_e32 v39, v39, v0\n" \
+        "v_sub_f32_e32 v31, v31, v1\n" \
+        "v_sub_f32_e32 v35, v35, v2\n" \
+        "v_sub_f32_e32 v43, v43, v1\n" \
+        "v_sub_f32_e32 v47, v47, v2\n" \
+        "v_mul_f32_e32 v27, v8, v27\n" \
+        "v_mul_f32_e32 v39, v8, v39\n" \
+        "v_mul_f32_e32 v31, v9, v31\n" \
+        "v_mul_f32_e32 v43, v9, v43\n" \
+        "v_mul_f32_e32 v35, v10, v35\n" \
+        "v_mul_f32_e32 v47, v10, v47\n" \
+        "v_min_f32_e32 v52, v27, v39\n" \
+        "v_max_f32_e32 v27, v27, v39\n" \
+        "v_min_f32_e32 v39, v31, v43\n" \
+        "v_max_f32_e32 v31, v31, v43\n" \
+        "v_min_f32_e32 v43, v35, v47\n" \
+        "v_max_f32_e32 v35, v35, v47\n" \
+        "v_min3_f32 v27, v27, v31, v35\n" \
+        "v_max3_f32 v52, v52, v39, v43\n" \
+        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v27\n" \
+        "v_min_f32_e32 v27, v27, v14\n" \
+        "v_cmp_nlt_f32_e64 s[66:67], v27, v52\n" \
+        "v_max_f32_e32 v52, 0, v52\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ne_u32_e32 vcc, -1, v51\n" \
+        "v_and_or_b32 v52, v52, -4, 3\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n" \
+        /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the \
+           register its lo.x plane value came in) */ \
+        "v_cmp_lt_u32_e32 vcc, v25, v24\n" \
+        "v_min_u32_e32 v52, v24, v25\n" \
+        "v_max_u32_e32 v25, v24, v25\n" \
+        "v_cndmask_b32_e32 v53, v48, v49, vcc\n" \
+        "v_cndmask_b32_e32 v49, v49, v48, vcc\n" \
+        "v_cmp_lt_u32_e32 vcc, v27, v26\n" \
+        "v_min_u32_e32 v24, v26, v27\n" \
+        "v_max_u32_e32 v27, v26, v27\n" \
+        "v_cndmask_b32_e32 v48, v50, v51, vcc\n" \
+        "v_cndmask_b32_e32 v51, v51, v50, vcc\n" \
+        "v_cmp_lt_u32_e32 vcc, v24, v52\n" \
+        "v_min_u32_e32 v26, v52, v24\n" \
+        "v_max_u32_e32 v24, v52, v24\n" \
+        "v_cndmask_b32_e32 v50, v53, v48, vcc\n" \
+        "v_cndmask_b32_e32 v48, v48, v53, vcc\n" \
+        "v_cmp_lt_u32_e32 vcc, v27, v25\n" \
+        "v_min_u32_e32 v52, v25, v27\n" \
+        "v_max_u32_e32 v27, v25, v27\n" \
+        "v_cndmask_b32_e32 v53, v49, v51, vcc\n" \
+        "v_cndmask_b32_e32 v51, v51, v49, vcc\n" \
+        "v_cmp_lt_u32_e32 vcc, v24, v52\n" \
+        "v_min_u32_e32 v25, v52, v24\n" \
+        "v_max_u32_e32 v24, v52, v24\n" \
+        "v_cndmask_b32_e32 v49, v53, v48, vcc\n" \
+        "v_cndmask_b32_e32 v48, v48, v53, vcc\n" \
+        /* sorted: keys v26 <= v25 <= v24 <= v27, entries v50, v49, v48, v51 (a child that is not hit: key -1, sorts last) */ \
+        "v_cmp_ne_u32_e64 s[66:67], -1, v25\n" \
+        "v_cmp_ne_u32_e64 s[68:69], -1, v24\n" \
+        "v_cmp_ne_u32_e64 s[72:73], -1, v27\n" \
+        "v_cmp_ne_u32_e64 s[80:81], -1, v26\n"             /* the node has a hit child */ \
+        "s_nop 0\n" \
+        "v_addc_co_u32_e64 v28, s[74:75], v13, 0, s[66:67]\n" \
+        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[68:69]\n" \
+        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */ \
+        /* the others are pushed farthest first: sorted child j ends at level size' - j */ \
+        "v_cmp_lt_u32_e64 s[74:75], %[depth], v28\n" \
+        PT_WF_LVL("v29", "v28", "v18")                /* address of level size' - 3 */ \
+        "s_cmp_lg_u64 s[74:75], 0\n" \
+        "s_cbranch_scc1 TQ_PUSH_SLOW_%=\n" \
+        "s_mov_b64 exec, s[72:73]\n" \
+        "ds_write_b32 v29, v51\n" \
+        "s_mov_b64 exec, s[68:69]\n" \
+        "ds_write_b32 v29, v48 offset:" PT_WF_O1 "\n" \
+        "s_mov_b64 exec, s[66:67]\n" \
+        "ds_write_b32 v29, v49 offset:" PT_WF_O2 "\n" \
+        "TQ_PUSHED_%=:\n" \
+        "s_mov_b64 exec, s[62:63]\n" \
+        "v_cndmask_b32_e64 v13, v13, v28, s[80:81]\n" \
+        "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */ \
+        "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */ \
+        /* ---------------------------------------------------------------- leaf: one triangle (exec = s[60:61]) */ \
+        "s_branch TQ_LEAF_GO_%=\n" \
+        "TQ_LEAF_%=:\n"                                     /* no lane at a wide node: the triangle fetches have not been waited for */ \
+        "s_waitcnt vmcnt(0)\n" \
+        "TQ_LEAF_GO_%=:\n" \
+        "s_mov_b64 exec, s[60:61]\n" \
+        "s_cbranch_execz TQ_POP_%=\n" \
+        "v_mul_f32_e32 v33, v5, v32\n" \
+        "v_mul_f32_e32 v50, v6, v31\n" \
+        "v_sub_f32_e32 v33, v33, v50\n" \
+        "v_mul_f32_e32 v34, v6, v30\n" \
+        "v_mul_f32_e32 v50, v4, v32\n" \
+        "v_sub_f32_e32 v34, v34, v50\n" \
+        "v_mul_f32_e32 v35, v4, v31\n" \
+        "v_mul_f32_e32 v50, v5, v30\n" \
+        "v_sub_f32_e32 v35, v35, v50\n" \
+        "v_mul_f32_e32 v45, v33, v27\n" \
+        "v_mul_f32_e32 v50, v34, v28\n" \
+        "v_add_f32_e32 v45, v45, v50\n" \
+        "v_mul_f32_e32 v50, v35, v29\n" \
+        "v_add_f32_e32 v45, v45, v50\n" \
+        "v_rcp_f32_e32 v47, v45\n" \
+        "v_sub_f32_e32 v24, v0, v24\n" \
+        "v_sub_f32_e32 v25, v1, v25\n" \
+        "v_sub_f32_e32 v26, v2, v26\n" \
+        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n" \
+        "v_fma_f32 v49, -v45, v47, 1.0\n" \
+        "v_fma_f32 v46, v49, v47, v47\n" \
+        "s_cmp_lg_u64 s[66:67], 0\n" \
+        "s_cbranch_scc1 TQ_DIV_IEEE_%=\n" \
+        "TQ_DIV_DONE_%=:\n" \
+        "v_mul_f32_e32 v51, v24, v33\n" \
+        "v_mul_f32_e32 v50, v25, v34\n" \
+        "v_add_f32_e32 v51, v51, v50\n" \
+        "v_mul_f32_e32 v50, v26, v35\n" \
+        "v_add_f32_e32 v51, v51, v50\n" \
+        "v_mul_f32_e32 v33, v25, v29\n" \
+        "v_mul_f32_e32 v50, v26, v28\n" \
+        "v_sub_f32_e32 v33, v33, v50\n" \
+        "v_mul_f32_e32 v34, v26, v27\n" \
+        "v_mul_f32_e32 v50, v24, v29\n" \
+        "v_sub_f32_e32 v34, v34, v50\n" \
+        "v_mul_f32_e32 v35, v24, v28\n" \
+        "v_mul_f32_e32 v50, v25, v27\n" \
+        "v_sub_f32_e32 v35, v35, v50\n" \
+        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */ \
+        "v_mul_f32_e32 v47, v4, v33\n" \
+        "v_mul_f32_e32 v50, v5, v34\n" \
+        "v_add_f32_e32 v47, v47, v50\n" \
+        "v_mul_f32_e32 v50, v6, v35\n" \
+        "v_add_f32_e32 v47, v47, v50\n" \
+        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */ \
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v51\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v47\n" \
+        "v_add_f32_e32 v50, v51, v47\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TQ_TRI_END_%=\n" \
+        "v_mul_f32_e32 v48, v30, v33\n" \
+        "v_mul_f32_e32 v50, v31, v34\n" \
+        "v_add_f32_e32 v48, v48, v50\n" \
+        "v_mul_f32_e32 v50, v32, v35\n" \
+        "v_add_f32_e32 v48, v48, v50\n" \
+        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */ \
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n" \
+        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TQ_TRI_END_%=\n" \
+        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a \
+           distance that is not NaN and nearer than the interval's end becomes the interval's end */ \
+        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n" \
+        "v_cmp_lt_f32_e32 vcc, v48, v21\n" \
+        "s_or_b64 s[68:69], s[68:69], vcc\n" \
+        "v_cmp_eq_f32_e32 vcc, v48, v21\n" \
+        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n" \
+        "s_and_b64 vcc, vcc, s[72:73]\n" \
+        "s_or_b64 s[68:69], s[68:69], vcc\n" \
+        "v_cmp_lt_f32_e32 vcc, v48, v14\n" \
+        "s_mov_b64 s[72:73], exec\n" \
+        "v_cndmask_b32_e32 v14, v14, v48, vcc\n" \
+        "v_and_b32_e32 v50, 0x80000000, v11\n" \
+        "s_and_b64 exec, exec, s[68:69]\n" \
+        "v_mov_b32_e32 v20, v53\n" \
+        "v_mov_b32_e32 v21, v48\n" \
+        "v_mov_b32_e32 v22, v51\n" \
+        "v_mov_b32_e32 v23, v47\n" \
+        "s_mov_b64 exec, s[72:73]\n" \
+        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */ \
+        "v_cndmask_b32_e64 v12, v12, -1, vcc\n" \
+        "v_cndmask_b32_e64 v13, v13, 0, vcc\n" \
+        "TQ_TRI_END_%=:\n" \
+        "s_mov_b64 exec, s[60:61]\n" \
+        /* a ray that goes on and whose leaf has another triangle tests it in the same trip (its record came with the first one's): \
+           the order of the tests and the interval they see are those of two trips */ \
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n" \
+        "v_bfe_u32 v50, v12, 27, 4\n" \
+        "v_cmp_lt_u32_e64 s[66:67], 0, v50\n" \
+        "s_nop 0\n" \
+        "s_and_b64 s[84:85], s[66:67], vcc\n"             /* second test */ \
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"           /* the leaf is exhausted: pop */ \
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n" \
+        "s_mov_b64 exec, s[84:85]\n" \
+        "s_cbranch_execz TQ_POP_%=\n" \
+        "v_add_u32_e32 v53, 1, v53\n" \
+        "v_mul_f32_e32 v33, v5, v44\n" \
+        "v_mul_f32_e32 v50, v6, v43\n" \
+        "v_sub_f32_e32 v33, v33, v50\n" \
+        "v_mul_f32_e32 v34, v6, v42\n" \
+        "v_mul_f32_e32 v50, v4, v44\n" \
+        "v_sub_f32_e32 v34, v34, v50\n" \
+        "v_mul_f32_e32 v35, v4, v43\n" \
+        "v_mul_f32_e32 v50, v5, v42\n" \
+        "v_sub_f32_e32 v35, v35, v50\n" \
+        "v_mul_f32_e32 v45, v33, v39\n" \
+        "v_mul_f32_e32 v50, v34, v40\n" \
+        "v_add_f32_e32 v45, v45, v50\n" \
+        "v_mul_f32_e32 v50, v35, v41\n" \
+        "v_add_f32_e32 v45, v45, v50\n" \
+        "v_rcp_f32_e32 v47, v45\n" \
+        "v_sub_f32_e32 v36, v0, v36\n" \
+        "v_sub_f32_e32 v37, v1, v37\n" \
+        "v_sub_f32_e32 v38, v2, v38\n" \
+        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n" \
+        "v_fma_f32 v49, -v45, v47, 1.0\n" \
+        "v_fma_f32 v46, v49, v47, v47\n" \
+        "s_cmp_lg_u64 s[66:67], 0\n" \
+        "s_cbranch_scc1 TQ_DIV_IEEE2_%=\n" \
+        "TQ_DIV_DONE2_%=:\n" \
+        "v_mul_f32_e32 v51, v36, v33\n" \
+        "v_mul_f32_e32 v50, v37, v34\n" \
+        "v_add_f32_e32 v51, v51, v50\n" \
+        "v_mul_f32_e32 v50, v38, v35\n" \
+        "v_add_f32_e32 v51, v51, v50\n" \
+        "v_mul_f32_e32 v33, v37, v41\n" \
+        "v_mul_f32_e32 v50, v38, v40\n" \
+        "v_sub_f32_e32 v33, v33, v50\n" \
+        "v_mul_f32_e32 v34, v38, v39\n" \
+        "v_mul_f32_e32 v50, v36, v41\n" \
+        "v_sub_f32_e32 v34, v34, v50\n" \
+        "v_mul_f32_e32 v35, v36, v40\n" \
+        "v_mul_f32_e32 v50, v37, v39\n" \
+        "v_sub_f32_e32 v35, v35, v50\n" \
+        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */ \
+        "v_mul_f32_e32 v47, v4, v33\n" \
+        "v_mul_f32_e32 v50, v5, v34\n" \
+        "v_add_f32_e32 v47, v47, v50\n" \
+        "v_mul_f32_e32 v50, v6, v35\n" \
+        "v_add_f32_e32 v47, v47, v50\n" \
+        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */ \
+        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v51\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_ngt_f32_e32 vcc, 0, v47\n" \
+        "v_add_f32_e32 v50, v51, v47\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TQ_TRI2_END_%=\n" \
+        "v_mul_f32_e32 v48, v42, v33\n" \
+        "v_mul_f32_e32 v50, v43, v34\n" \
+        "v_add_f32_e32 v48, v48, v50\n" \
+        "v_mul_f32_e32 v50, v44, v35\n" \
+        "v_add_f32_e32 v48, v48, v50\n" \
+        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */ \
+        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n" \
+        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_and_b64 exec, exec, s[66:67]\n" \
+        "s_cbranch_scc0 TQ_TRI2_END_%=\n" \
+        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a \
+           distance that is not NaN and nearer than the interval's end becomes the interval's end */ \
+        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n" \
+        "v_cmp_lt_f32_e32 vcc, v48, v21\n" \
+        "s_or_b64 s[68:69], s[68:69], vcc\n" \
+        "v_cmp_eq_f32_e32 vcc, v48, v21\n" \
+        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n" \
+        "s_and_b64 vcc, vcc, s[72:73]\n" \
+        "s_or_b64 s[68:69], s[68:69], vcc\n" \
+        "v_cmp_lt_f32_e32 vcc, v48, v14\n" \
+        "s_mov_b64 s[72:73], exec\n" \
+        "v_cndmask_b32_e32 v14, v14, v48, vcc\n" \
+        "v_and_b32_e32 v50, 0x80000000, v11\n" \
+        "s_and_b64 exec, exec, s[68:69]\n" \
+        "v_mov_b32_e32 v20, v53\n" \
+        "v_mov_b32_e32 v21, v48\n" \
+        "v_mov_b32_e32 v22, v51\n" \
+        "v_mov_b32_e32 v23, v47\n" \
+        "s_mov_b64 exec, s[72:73]\n" \
+        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */ \
+        "v_cndmask_b32_e64 v12, v12, -1, vcc\n" \
+        "v_cndmask_b32_e64 v13, v13, 0, vcc\n" \
+        "TQ_TRI2_END_%=:\n" \
+        "s_mov_b64 exec, s[84:85]\n" \
+        "v_cmp_ne_u32_e32 vcc, -1, v12\n" \
+        "v_bfe_u32 v50, v12, 27, 4\n" \
+        "v_add_u32_e32 v49, 0xf0000002, v12\n"             /* first + 2, two triangles fewer */ \
+        "v_cmp_lt_u32_e64 s[66:67], 1, v50\n" \
+        "s_nop 0\n" \
+        "s_and_b64 s[66:67], s[66:67], vcc\n" \
+        "s_andn2_b64 s[68:69], vcc, s[66:67]\n" \
+        "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n" \
+        "s_or_b64 s[78:79], s[78:79], s[68:69]\n" \
+        /* ---------------------------------------------------------------- pop (s[78:79]) */ \
+        "TQ_POP_%=:\n" \
+        "s_mov_b64 exec, s[78:79]\n" \
+        "s_cbranch_execz TQ_POP_NONE_%=\n" \
+        "v_cmp_lt_i32_e32 vcc, 0, v13\n" \
+        "v_mov_b32_e32 v12, -1\n" \
+        "s_and_b64 exec, exec, vcc\n" \
+        "s_cbranch_execz TQ_POP_NONE_%=\n" \
+        "v_add_u32_e32 v13, -1, v13\n" \
+        "v_cmp_gt_i32_e32 vcc, %[depth], v13\n" \
+        "s_mov_b64 s[72:73], exec\n" \
+        "s_and_b64 exec, exec, vcc\n" \
+        PT_WF_LVL("v33", "v13", "v18") \
+        "ds_read_b32 v12, v33 offset:" PT_WF_O3 "\n" \
+        "s_andn2_b64 exec, s[72:73], vcc\n" \
+        "s_cbranch_execz TQ_POP_LDS_%=\n" \
+        PT_WF_LVL("v33", "v13", "v16") \
+        "global_load_dword v12, v33, %[spill]\n" \
+        "s_waitcnt vmcnt(0)\n" \
+        "TQ_POP_LDS_%=:\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "TQ_POP_NONE_%=:\n" \
+        "s_mov_b64 exec, -1\n"
+
+#define PT_WF_ASM_SLOW \
+        "TQ_PUSH_SLOW_%=:\n" \
+        "v_add_u32_e32 v29, -3, v28\n" \
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n" \
+        "s_and_b64 exec, s[72:73], vcc\n" \
+        PT_WF_LVL("v30", "v29", "v18") \
+        "ds_write_b32 v30, v51 offset:" PT_WF_O3 "\n" \
+        "s_andn2_b64 exec, s[72:73], vcc\n" \
+        PT_WF_LVL("v30", "v29", "v16") \
+        "global_store_dword v30, v51, %[spill]\n" \
+        "s_mov_b64 exec, s[62:63]\n" \
+        "v_add_u32_e32 v29, -2, v28\n" \
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n" \
+        "s_and_b64 exec, s[68:69], vcc\n" \
+        PT_WF_LVL("v30", "v29", "v18") \
+        "ds_write_b32 v30, v48 offset:" PT_WF_O3 "\n" \
+        "s_andn2_b64 exec, s[68:69], vcc\n" \
+        PT_WF_LVL("v30", "v29", "v16") \
+        "global_store_dword v30, v48, %[spill]\n" \
+        "s_mov_b64 exec, s[62:63]\n" \
+        "v_add_u32_e32 v29, -1, v28\n" \
+        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n" \
+        "s_and_b64 exec, s[66:67], vcc\n" \
+        PT_WF_LVL("v30", "v29", "v18") \
+        "ds_write_b32 v30, v49 offset:" PT_WF_O3 "\n" \
+        "s_andn2_b64 exec, s[66:67], vcc\n" \
+        PT_WF_LVL("v30", "v29", "v16") \
+        "global_store_dword v30, v49, %[spill]\n" \
+        "s_waitcnt vmcnt(0)\n" \
+        "s_branch TQ_PUSHED_%=\n" \
+        /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */ \
+        "TQ_DIV_IEEE_%=:\n" \
+        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n" \
+        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n" \
+        "v_rcp_f32_e32 v47, v46\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v49, -v46, v47, 1.0\n" \
+        "v_fmac_f32_e32 v47, v49, v47\n" \
+        "v_mul_f32_e32 v52, v48, v47\n" \
+        "v_fma_f32 v49, -v46, v52, v48\n" \
+        "v_fmac_f32_e32 v52, v49, v47\n" \
+        "v_fma_f32 v46, -v46, v52, v48\n" \
+        "v_div_fmas_f32 v46, v46, v47, v52\n" \
+        "v_div_fixup_f32 v46, v46, v45, 1.0\n" \
+        "s_branch TQ_DIV_DONE_%=\n" \
+        "TQ_DIV_IEEE2_%=:\n" \
+        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n" \
+        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n" \
+        "v_rcp_f32_e32 v47, v46\n" \
+        "s_nop 0\n" \
+        "v_fma_f32 v49, -v46, v47, 1.0\n" \
+        "v_fmac_f32_e32 v47, v49, v47\n" \
+        "v_mul_f32_e32 v52, v48, v47\n" \
+        "v_fma_f32 v49, -v46, v52, v48\n" \
+        "v_fmac_f32_e32 v52, v49, v47\n" \
+        "v_fma_f32 v46, -v46, v52, v48\n" \
+        "v_div_fmas_f32 v46, v46, v47, v52\n" \
+        "v_div_fixup_f32 v46, v46, v45, 1.0\n" \
+        "s_branch TQ_DIV_DONE2_%=\n"
+
 // ---- the wide walk of the trace stage, hand-scheduled ----------------------------------------------------------------------
 // The node block, the triangle block, the sorting network, the pushes and pops are those of trace_pool_wide_asm (pt_kernel.hip:
 // the same instructions on the same registers, hence the same bits as the C++ walk above, which stays the specification and can
@@ -886,6 +1783,10 @@ __device__ __forceinline__ void wf_trace_cxx(const DevParams &P, const WfParams 
 #ifndef PT_WF_STOP_T
 #define PT_WF_STOP_T 8               // no group left and at most this many lanes still walk: the wave parks their rays for the next round
 #endif
+#define PT_WF_LVL(dst, lvl, col) "v_lshl_add_u32 " dst ", " lvl ", 8, " col "\n"      /* one lane per ray: a level is 64 words */
+#define PT_WF_O1 "256"
+#define PT_WF_O2 "512"
+#define PT_WF_O3 "768"
 __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfParams &W, unsigned stack_lds, unsigned lane, unsigned shared_lds, uint32_t chunk0,
                                                   uint32_t round)
 {
@@ -1010,42 +1911,7 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "ds_write_b32 v18, v50 offset:7424\n"
         "ds_write_b32 v18, v51 offset:7680\n"
 #endif
-        "v_div_scale_f32 v33, s[66:67], v4, v4, 1.0\n"
-        "v_div_scale_f32 v34, vcc, 1.0, v4, 1.0\n"
-        "v_rcp_f32_e32 v35, v33\n"
-        "s_nop 0\n"
-        "v_fma_f32 v36, -v33, v35, 1.0\n"
-        "v_fmac_f32_e32 v35, v36, v35\n"
-        "v_mul_f32_e32 v37, v34, v35\n"
-        "v_fma_f32 v36, -v33, v37, v34\n"
-        "v_fmac_f32_e32 v37, v36, v35\n"
-        "v_fma_f32 v33, -v33, v37, v34\n"
-        "v_div_fmas_f32 v33, v33, v35, v37\n"
-        "v_div_fixup_f32 v8, v33, v4, 1.0\n"
-        "v_div_scale_f32 v33, s[66:67], v5, v5, 1.0\n"
-        "v_div_scale_f32 v34, vcc, 1.0, v5, 1.0\n"
-        "v_rcp_f32_e32 v35, v33\n"
-        "s_nop 0\n"
-        "v_fma_f32 v36, -v33, v35, 1.0\n"
-        "v_fmac_f32_e32 v35, v36, v35\n"
-        "v_mul_f32_e32 v37, v34, v35\n"
-        "v_fma_f32 v36, -v33, v37, v34\n"
-        "v_fmac_f32_e32 v37, v36, v35\n"
-        "v_fma_f32 v33, -v33, v37, v34\n"
-        "v_div_fmas_f32 v33, v33, v35, v37\n"
-        "v_div_fixup_f32 v9, v33, v5, 1.0\n"
-        "v_div_scale_f32 v33, s[66:67], v6, v6, 1.0\n"
-        "v_div_scale_f32 v34, vcc, 1.0, v6, 1.0\n"
-        "v_rcp_f32_e32 v35, v33\n"
-        "s_nop 0\n"
-        "v_fma_f32 v36, -v33, v35, 1.0\n"
-        "v_fmac_f32_e32 v35, v36, v35\n"
-        "v_mul_f32_e32 v37, v34, v35\n"
-        "v_fma_f32 v36, -v33, v37, v34\n"
-        "v_fmac_f32_e32 v37, v36, v35\n"
-        "v_fma_f32 v33, -v33, v37, v34\n"
-        "v_div_fmas_f32 v33, v33, v35, v37\n"
-        "v_div_fixup_f32 v10, v33, v6, 1.0\n"
+        PT_WF_ASM_INV_DIR
         "s_waitcnt lgkmcnt(0)\n"
         "TQ_NORESUME_%=:\n"
         "s_mov_b64 exec, -1\n"
@@ -1056,42 +1922,7 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         "s_cbranch_scc1 TQ_NOFINAL_%=\n"
         "s_waitcnt vmcnt(0)\n"
         "s_mov_b64 exec, s[88:89]\n"
-        "v_div_scale_f32 v33, s[66:67], v4, v4, 1.0\n"
-        "v_div_scale_f32 v34, vcc, 1.0, v4, 1.0\n"
-        "v_rcp_f32_e32 v35, v33\n"
-        "s_nop 0\n"
-        "v_fma_f32 v36, -v33, v35, 1.0\n"
-        "v_fmac_f32_e32 v35, v36, v35\n"
-        "v_mul_f32_e32 v37, v34, v35\n"
-        "v_fma_f32 v36, -v33, v37, v34\n"
-        "v_fmac_f32_e32 v37, v36, v35\n"
-        "v_fma_f32 v33, -v33, v37, v34\n"
-        "v_div_fmas_f32 v33, v33, v35, v37\n"
-        "v_div_fixup_f32 v8, v33, v4, 1.0\n"
-        "v_div_scale_f32 v33, s[66:67], v5, v5, 1.0\n"
-        "v_div_scale_f32 v34, vcc, 1.0, v5, 1.0\n"
-        "v_rcp_f32_e32 v35, v33\n"
-        "s_nop 0\n"
-        "v_fma_f32 v36, -v33, v35, 1.0\n"
-        "v_fmac_f32_e32 v35, v36, v35\n"
-        "v_mul_f32_e32 v37, v34, v35\n"
-        "v_fma_f32 v36, -v33, v37, v34\n"
-        "v_fmac_f32_e32 v37, v36, v35\n"
-        "v_fma_f32 v33, -v33, v37, v34\n"
-        "v_div_fmas_f32 v33, v33, v35, v37\n"
-        "v_div_fixup_f32 v9, v33, v5, 1.0\n"
-        "v_div_scale_f32 v33, s[66:67], v6, v6, 1.0\n"
-        "v_div_scale_f32 v34, vcc, 1.0, v6, 1.0\n"
-        "v_rcp_f32_e32 v35, v33\n"
-        "s_nop 0\n"
-        "v_fma_f32 v36, -v33, v35, 1.0\n"
-        "v_fmac_f32_e32 v35, v36, v35\n"
-        "v_mul_f32_e32 v37, v34, v35\n"
-        "v_fma_f32 v36, -v33, v37, v34\n"
-        "v_fmac_f32_e32 v37, v36, v35\n"
-        "v_fma_f32 v33, -v33, v37, v34\n"
-        "v_div_fmas_f32 v33, v33, v35, v37\n"
-        "v_div_fixup_f32 v10, v33, v6, 1.0\n"
+        PT_WF_ASM_INV_DIR
         "v_mov_b32_e32 v14, v7\n"
         "v_mov_b32_e32 v12, 0\n"
         "v_mov_b32_e32 v13, 0\n"
@@ -1308,491 +2139,10 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
         /* one set of fetches serves both kinds: a lane's offset from the base of the wide nodes is its node's, or that of its
            triangle in the copy behind the nodes; a node lane gets its 112-byte record, a leaf lane its triangle in v[24:32] and the
            one after it in v[36:44] (the rest of what it reads is not used) */
-        "s_mov_b64 exec, s[60:61]\n"
-        "v_and_b32_e32 v53, 0x7ffffff, v12\n"              /* the leaf's first triangle */
-        "v_lshlrev_b32_e32 v54, 4, v53\n"
-        "v_lshl_add_u32 v54, v53, 5, v54\n"                /* * 48 */
-        "v_add_u32_e32 v54, %[trioff], v54\n"
-        "s_mov_b64 exec, s[62:63]\n"
-        "v_mov_b32_e32 v54, v12\n"
-        "s_or_b64 exec, s[60:61], s[62:63]\n"
-        "global_load_dwordx4 v[24:27], v54, %[nodes]\n"
-        "global_load_dwordx4 v[36:39], v54, %[nodes] offset:48\n"
-        "global_load_dwordx4 v[28:31], v54, %[nodes] offset:16\n"
-        "global_load_dwordx4 v[40:43], v54, %[nodes] offset:64\n"
-        "global_load_dwordx4 v[32:35], v54, %[nodes] offset:32\n"
-        "global_load_dwordx4 v[44:47], v54, %[nodes] offset:80\n"
-        "global_load_dwordx4 v[48:51], v54, %[nodes] offset:96\n"
-        "s_mov_b64 s[78:79], 0\n"
-        "s_mov_b64 s[82:83], 0\n"
-        "s_mov_b64 exec, s[62:63]\n"
-        "s_cbranch_execz TQ_LEAF_%=\n"
-        "s_waitcnt vmcnt(0)\n"
-        /* ---------------------------------------------------------------- wide node: four boxes (exec = s[62:63]) */
-        /* child k's six plane values are worked on in place (v24+k, v28+k, ... v44+k); v52 is the one temporary */
-        "v_sub_f32_e32 v24, v24, v0\n"
-        "v_sub_f32_e32 v36, v36, v0\n"
-        "v_sub_f32_e32 v28, v28, v1\n"
-        "v_sub_f32_e32 v32, v32, v2\n"
-        "v_sub_f32_e32 v40, v40, v1\n"
-        "v_sub_f32_e32 v44, v44, v2\n"
-        "v_mul_f32_e32 v24, v8, v24\n"
-        "v_mul_f32_e32 v36, v8, v36\n"
-        "v_mul_f32_e32 v28, v9, v28\n"
-        "v_mul_f32_e32 v40, v9, v40\n"
-        "v_mul_f32_e32 v32, v10, v32\n"
-        "v_mul_f32_e32 v44, v10, v44\n"
-        "v_min_f32_e32 v52, v24, v36\n"
-        "v_max_f32_e32 v24, v24, v36\n"
-        "v_min_f32_e32 v36, v28, v40\n"
-        "v_max_f32_e32 v28, v28, v40\n"
-        "v_min_f32_e32 v40, v32, v44\n"
-        "v_max_f32_e32 v32, v32, v44\n"
-        "v_min3_f32 v24, v24, v28, v32\n"
-        "v_max3_f32 v52, v52, v36, v40\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v24\n"
-        "v_min_f32_e32 v24, v24, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v24, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v48\n"
-        "v_and_or_b32 v52, v52, -4, 0\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v24, -1, v52, s[66:67]\n"
-        "v_sub_f32_e32 v25, v25, v0\n"
-        "v_sub_f32_e32 v37, v37, v0\n"
-        "v_sub_f32_e32 v29, v29, v1\n"
-        "v_sub_f32_e32 v33, v33, v2\n"
-        "v_sub_f32_e32 v41, v41, v1\n"
-        "v_sub_f32_e32 v45, v45, v2\n"
-        "v_mul_f32_e32 v25, v8, v25\n"
-        "v_mul_f32_e32 v37, v8, v37\n"
-        "v_mul_f32_e32 v29, v9, v29\n"
-        "v_mul_f32_e32 v41, v9, v41\n"
-        "v_mul_f32_e32 v33, v10, v33\n"
-        "v_mul_f32_e32 v45, v10, v45\n"
-        "v_min_f32_e32 v52, v25, v37\n"
-        "v_max_f32_e32 v25, v25, v37\n"
-        "v_min_f32_e32 v37, v29, v41\n"
-        "v_max_f32_e32 v29, v29, v41\n"
-        "v_min_f32_e32 v41, v33, v45\n"
-        "v_max_f32_e32 v33, v33, v45\n"
-        "v_min3_f32 v25, v25, v29, v33\n"
-        "v_max3_f32 v52, v52, v37, v41\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v25\n"
-        "v_min_f32_e32 v25, v25, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v25, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v49\n"
-        "v_and_or_b32 v52, v52, -4, 1\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v25, -1, v52, s[66:67]\n"
-        "v_sub_f32_e32 v26, v26, v0\n"
-        "v_sub_f32_e32 v38, v38, v0\n"
-        "v_sub_f32_e32 v30, v30, v1\n"
-        "v_sub_f32_e32 v34, v34, v2\n"
-        "v_sub_f32_e32 v42, v42, v1\n"
-        "v_sub_f32_e32 v46, v46, v2\n"
-        "v_mul_f32_e32 v26, v8, v26\n"
-        "v_mul_f32_e32 v38, v8, v38\n"
-        "v_mul_f32_e32 v30, v9, v30\n"
-        "v_mul_f32_e32 v42, v9, v42\n"
-        "v_mul_f32_e32 v34, v10, v34\n"
-        "v_mul_f32_e32 v46, v10, v46\n"
-        "v_min_f32_e32 v52, v26, v38\n"
-        "v_max_f32_e32 v26, v26, v38\n"
-        "v_min_f32_e32 v38, v30, v42\n"
-        "v_max_f32_e32 v30, v30, v42\n"
-        "v_min_f32_e32 v42, v34, v46\n"
-        "v_max_f32_e32 v34, v34, v46\n"
-        "v_min3_f32 v26, v26, v30, v34\n"
-        "v_max3_f32 v52, v52, v38, v42\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v26\n"
-        "v_min_f32_e32 v26, v26, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v26, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v50\n"
-        "v_and_or_b32 v52, v52, -4, 2\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v26, -1, v52, s[66:67]\n"
-        "v_sub_f32_e32 v27, v27, v0\n"
-        "v_sub_f32_e32 v39, v39, v0\n"
-        "v_sub_f32_e32 v31, v31, v1\n"
-        "v_sub_f32_e32 v35, v35, v2\n"
-        "v_sub_f32_e32 v43, v43, v1\n"
-        "v_sub_f32_e32 v47, v47, v2\n"
-        "v_mul_f32_e32 v27, v8, v27\n"
-        "v_mul_f32_e32 v39, v8, v39\n"
-        "v_mul_f32_e32 v31, v9, v31\n"
-        "v_mul_f32_e32 v43, v9, v43\n"
-        "v_mul_f32_e32 v35, v10, v35\n"
-        "v_mul_f32_e32 v47, v10, v47\n"
-        "v_min_f32_e32 v52, v27, v39\n"
-        "v_max_f32_e32 v27, v27, v39\n"
-        "v_min_f32_e32 v39, v31, v43\n"
-        "v_max_f32_e32 v31, v31, v43\n"
-        "v_min_f32_e32 v43, v35, v47\n"
-        "v_max_f32_e32 v35, v35, v47\n"
-        "v_min3_f32 v27, v27, v31, v35\n"
-        "v_max3_f32 v52, v52, v39, v43\n"
-        "v_cmp_nge_f32_e32 vcc, 0x3727c5ac, v27\n"
-        "v_min_f32_e32 v27, v27, v14\n"
-        "v_cmp_nlt_f32_e64 s[66:67], v27, v52\n"
-        "v_max_f32_e32 v52, 0, v52\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v51\n"
-        "v_and_or_b32 v52, v52, -4, 3\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cndmask_b32_e64 v27, -1, v52, s[66:67]\n"
-        /* five-exchange sorting network on (key, entry); registers are renamed from exchange to exchange (a child's key sits in the
-           register its lo.x plane value came in) */
-        "v_cmp_lt_u32_e32 vcc, v25, v24\n"
-        "v_min_u32_e32 v52, v24, v25\n"
-        "v_max_u32_e32 v25, v24, v25\n"
-        "v_cndmask_b32_e32 v53, v48, v49, vcc\n"
-        "v_cndmask_b32_e32 v49, v49, v48, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v27, v26\n"
-        "v_min_u32_e32 v24, v26, v27\n"
-        "v_max_u32_e32 v27, v26, v27\n"
-        "v_cndmask_b32_e32 v48, v50, v51, vcc\n"
-        "v_cndmask_b32_e32 v51, v51, v50, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v24, v52\n"
-        "v_min_u32_e32 v26, v52, v24\n"
-        "v_max_u32_e32 v24, v52, v24\n"
-        "v_cndmask_b32_e32 v50, v53, v48, vcc\n"
-        "v_cndmask_b32_e32 v48, v48, v53, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v27, v25\n"
-        "v_min_u32_e32 v52, v25, v27\n"
-        "v_max_u32_e32 v27, v25, v27\n"
-        "v_cndmask_b32_e32 v53, v49, v51, vcc\n"
-        "v_cndmask_b32_e32 v51, v51, v49, vcc\n"
-        "v_cmp_lt_u32_e32 vcc, v24, v52\n"
-        "v_min_u32_e32 v25, v52, v24\n"
-        "v_max_u32_e32 v24, v52, v24\n"
-        "v_cndmask_b32_e32 v49, v53, v48, vcc\n"
-        "v_cndmask_b32_e32 v48, v48, v53, vcc\n"
-        /* sorted: keys v26 <= v25 <= v24 <= v27, entries v50, v49, v48, v51 (a child that is not hit: key -1, sorts last) */
-        "v_cmp_ne_u32_e64 s[66:67], -1, v25\n"
-        "v_cmp_ne_u32_e64 s[68:69], -1, v24\n"
-        "v_cmp_ne_u32_e64 s[72:73], -1, v27\n"
-        "v_cmp_ne_u32_e64 s[80:81], -1, v26\n"             /* the node has a hit child */
-        "s_nop 0\n"
-        "v_addc_co_u32_e64 v28, s[74:75], v13, 0, s[66:67]\n"
-        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[68:69]\n"
-        "v_addc_co_u32_e64 v28, s[74:75], v28, 0, s[72:73]\n"      /* the new stack size: the nearest child is not pushed */
-        /* the others are pushed farthest first: sorted child j ends at level size' - j */
-        "v_cmp_lt_u32_e64 s[74:75], %[depth], v28\n"
-        "v_lshl_add_u32 v29, v28, 8, v18\n"                /* address of level size' - 3 */
-        "s_cmp_lg_u64 s[74:75], 0\n"
-        "s_cbranch_scc1 TQ_PUSH_SLOW_%=\n"
-        "s_mov_b64 exec, s[72:73]\n"
-        "ds_write_b32 v29, v51\n"
-        "s_mov_b64 exec, s[68:69]\n"
-        "ds_write_b32 v29, v48 offset:256\n"
-        "s_mov_b64 exec, s[66:67]\n"
-        "ds_write_b32 v29, v49 offset:512\n"
-        "TQ_PUSHED_%=:\n"
-        "s_mov_b64 exec, s[62:63]\n"
-        "v_cndmask_b32_e64 v13, v13, v28, s[80:81]\n"
-        "v_cndmask_b32_e64 v12, v12, v50, s[80:81]\n"      /* the nearest hit child is the current entry */
-        "s_andn2_b64 s[78:79], s[62:63], s[80:81]\n"       /* the lanes without a hit child pop */
-        /* ---------------------------------------------------------------- leaf: one triangle (exec = s[60:61]) */
-        "s_branch TQ_LEAF_GO_%=\n"
-        "TQ_LEAF_%=:\n"                                     /* no lane at a wide node: the triangle fetches have not been waited for */
-        "s_waitcnt vmcnt(0)\n"
-        "TQ_LEAF_GO_%=:\n"
-        "s_mov_b64 exec, s[60:61]\n"
-        "s_cbranch_execz TQ_POP_%=\n"
-        "v_mul_f32_e32 v33, v5, v32\n"
-        "v_mul_f32_e32 v50, v6, v31\n"
-        "v_sub_f32_e32 v33, v33, v50\n"
-        "v_mul_f32_e32 v34, v6, v30\n"
-        "v_mul_f32_e32 v50, v4, v32\n"
-        "v_sub_f32_e32 v34, v34, v50\n"
-        "v_mul_f32_e32 v35, v4, v31\n"
-        "v_mul_f32_e32 v50, v5, v30\n"
-        "v_sub_f32_e32 v35, v35, v50\n"
-        "v_mul_f32_e32 v45, v33, v27\n"
-        "v_mul_f32_e32 v50, v34, v28\n"
-        "v_add_f32_e32 v45, v45, v50\n"
-        "v_mul_f32_e32 v50, v35, v29\n"
-        "v_add_f32_e32 v45, v45, v50\n"
-        "v_rcp_f32_e32 v47, v45\n"
-        "v_sub_f32_e32 v24, v0, v24\n"
-        "v_sub_f32_e32 v25, v1, v25\n"
-        "v_sub_f32_e32 v26, v2, v26\n"
-        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n"
-        "v_fma_f32 v49, -v45, v47, 1.0\n"
-        "v_fma_f32 v46, v49, v47, v47\n"
-        "s_cmp_lg_u64 s[66:67], 0\n"
-        "s_cbranch_scc1 TQ_DIV_IEEE_%=\n"
-        "TQ_DIV_DONE_%=:\n"
-        "v_mul_f32_e32 v51, v24, v33\n"
-        "v_mul_f32_e32 v50, v25, v34\n"
-        "v_add_f32_e32 v51, v51, v50\n"
-        "v_mul_f32_e32 v50, v26, v35\n"
-        "v_add_f32_e32 v51, v51, v50\n"
-        "v_mul_f32_e32 v33, v25, v29\n"
-        "v_mul_f32_e32 v50, v26, v28\n"
-        "v_sub_f32_e32 v33, v33, v50\n"
-        "v_mul_f32_e32 v34, v26, v27\n"
-        "v_mul_f32_e32 v50, v24, v29\n"
-        "v_sub_f32_e32 v34, v34, v50\n"
-        "v_mul_f32_e32 v35, v24, v28\n"
-        "v_mul_f32_e32 v50, v25, v27\n"
-        "v_sub_f32_e32 v35, v35, v50\n"
-        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */
-        "v_mul_f32_e32 v47, v4, v33\n"
-        "v_mul_f32_e32 v50, v5, v34\n"
-        "v_add_f32_e32 v47, v47, v50\n"
-        "v_mul_f32_e32 v50, v6, v35\n"
-        "v_add_f32_e32 v47, v47, v50\n"
-        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v51\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v47\n"
-        "v_add_f32_e32 v50, v51, v47\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TQ_TRI_END_%=\n"
-        "v_mul_f32_e32 v48, v30, v33\n"
-        "v_mul_f32_e32 v50, v31, v34\n"
-        "v_add_f32_e32 v48, v48, v50\n"
-        "v_mul_f32_e32 v50, v32, v35\n"
-        "v_add_f32_e32 v48, v48, v50\n"
-        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n"
-        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TQ_TRI_END_%=\n"
-        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
-           distance that is not NaN and nearer than the interval's end becomes the interval's end */
-        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
-        "v_cmp_lt_f32_e32 vcc, v48, v21\n"
-        "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_eq_f32_e32 vcc, v48, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
-        "s_and_b64 vcc, vcc, s[72:73]\n"
-        "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_lt_f32_e32 vcc, v48, v14\n"
-        "s_mov_b64 s[72:73], exec\n"
-        "v_cndmask_b32_e32 v14, v14, v48, vcc\n"
-        "v_and_b32_e32 v50, 0x80000000, v11\n"
-        "s_and_b64 exec, exec, s[68:69]\n"
-        "v_mov_b32_e32 v20, v53\n"
-        "v_mov_b32_e32 v21, v48\n"
-        "v_mov_b32_e32 v22, v51\n"
-        "v_mov_b32_e32 v23, v47\n"
-        "s_mov_b64 exec, s[72:73]\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */
-        "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
-        "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
-        "TQ_TRI_END_%=:\n"
-        "s_mov_b64 exec, s[60:61]\n"
-        /* a ray that goes on and whose leaf has another triangle tests it in the same trip (its record came with the first one's):
-           the order of the tests and the interval they see are those of two trips */
-        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
-        "v_bfe_u32 v50, v12, 27, 4\n"
-        "v_cmp_lt_u32_e64 s[66:67], 0, v50\n"
-        "s_nop 0\n"
-        "s_and_b64 s[84:85], s[66:67], vcc\n"             /* second test */
-        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"           /* the leaf is exhausted: pop */
-        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
-        "s_mov_b64 exec, s[84:85]\n"
-        "s_cbranch_execz TQ_POP_%=\n"
-        "v_add_u32_e32 v53, 1, v53\n"
-        "v_mul_f32_e32 v33, v5, v44\n"
-        "v_mul_f32_e32 v50, v6, v43\n"
-        "v_sub_f32_e32 v33, v33, v50\n"
-        "v_mul_f32_e32 v34, v6, v42\n"
-        "v_mul_f32_e32 v50, v4, v44\n"
-        "v_sub_f32_e32 v34, v34, v50\n"
-        "v_mul_f32_e32 v35, v4, v43\n"
-        "v_mul_f32_e32 v50, v5, v42\n"
-        "v_sub_f32_e32 v35, v35, v50\n"
-        "v_mul_f32_e32 v45, v33, v39\n"
-        "v_mul_f32_e32 v50, v34, v40\n"
-        "v_add_f32_e32 v45, v45, v50\n"
-        "v_mul_f32_e32 v50, v35, v41\n"
-        "v_add_f32_e32 v45, v45, v50\n"
-        "v_rcp_f32_e32 v47, v45\n"
-        "v_sub_f32_e32 v36, v0, v36\n"
-        "v_sub_f32_e32 v37, v1, v37\n"
-        "v_sub_f32_e32 v38, v2, v38\n"
-        "v_cmp_nle_f32_e64 s[66:67], abs(v45), s77\n"
-        "v_fma_f32 v49, -v45, v47, 1.0\n"
-        "v_fma_f32 v46, v49, v47, v47\n"
-        "s_cmp_lg_u64 s[66:67], 0\n"
-        "s_cbranch_scc1 TQ_DIV_IEEE2_%=\n"
-        "TQ_DIV_DONE2_%=:\n"
-        "v_mul_f32_e32 v51, v36, v33\n"
-        "v_mul_f32_e32 v50, v37, v34\n"
-        "v_add_f32_e32 v51, v51, v50\n"
-        "v_mul_f32_e32 v50, v38, v35\n"
-        "v_add_f32_e32 v51, v51, v50\n"
-        "v_mul_f32_e32 v33, v37, v41\n"
-        "v_mul_f32_e32 v50, v38, v40\n"
-        "v_sub_f32_e32 v33, v33, v50\n"
-        "v_mul_f32_e32 v34, v38, v39\n"
-        "v_mul_f32_e32 v50, v36, v41\n"
-        "v_sub_f32_e32 v34, v34, v50\n"
-        "v_mul_f32_e32 v35, v36, v40\n"
-        "v_mul_f32_e32 v50, v37, v39\n"
-        "v_sub_f32_e32 v35, v35, v50\n"
-        "v_mul_f32_e32 v51, v51, v46\n"                    /* b1 */
-        "v_mul_f32_e32 v47, v4, v33\n"
-        "v_mul_f32_e32 v50, v5, v34\n"
-        "v_add_f32_e32 v47, v47, v50\n"
-        "v_mul_f32_e32 v50, v6, v35\n"
-        "v_add_f32_e32 v47, v47, v50\n"
-        "v_mul_f32_e32 v47, v47, v46\n"                    /* b2 */
-        "v_cmp_nlt_f32_e64 s[66:67], abs(v45), s76\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v51\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v51\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_ngt_f32_e32 vcc, 0, v47\n"
-        "v_add_f32_e32 v50, v51, v47\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "v_cmp_nlt_f32_e32 vcc, 1.0, v50\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TQ_TRI2_END_%=\n"
-        "v_mul_f32_e32 v48, v42, v33\n"
-        "v_mul_f32_e32 v50, v43, v34\n"
-        "v_add_f32_e32 v48, v48, v50\n"
-        "v_mul_f32_e32 v50, v44, v35\n"
-        "v_add_f32_e32 v48, v48, v50\n"
-        "v_mul_f32_e32 v48, v48, v46\n"                    /* tt */
-        "v_cmp_ngt_f32_e32 vcc, %[eps], v48\n"
-        "v_cmp_ngt_f32_e64 s[66:67], v48, v14\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_and_b64 exec, exec, s[66:67]\n"
-        "s_cbranch_scc0 TQ_TRI2_END_%=\n"
-        /* accepted (exec).  It replaces the best hit when it is nearer, or exactly as near with a larger triangle index; a
-           distance that is not NaN and nearer than the interval's end becomes the interval's end */
-        "v_cmp_gt_i32_e64 s[68:69], 0, v20\n"
-        "v_cmp_lt_f32_e32 vcc, v48, v21\n"
-        "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_eq_f32_e32 vcc, v48, v21\n"
-        "v_cmp_gt_i32_e64 s[72:73], v53, v20\n"
-        "s_and_b64 vcc, vcc, s[72:73]\n"
-        "s_or_b64 s[68:69], s[68:69], vcc\n"
-        "v_cmp_lt_f32_e32 vcc, v48, v14\n"
-        "s_mov_b64 s[72:73], exec\n"
-        "v_cndmask_b32_e32 v14, v14, v48, vcc\n"
-        "v_and_b32_e32 v50, 0x80000000, v11\n"
-        "s_and_b64 exec, exec, s[68:69]\n"
-        "v_mov_b32_e32 v20, v53\n"
-        "v_mov_b32_e32 v21, v48\n"
-        "v_mov_b32_e32 v22, v51\n"
-        "v_mov_b32_e32 v23, v47\n"
-        "s_mov_b64 exec, s[72:73]\n"
-        "v_cmp_ne_u32_e32 vcc, 0, v50\n"                   /* IntersectP: the first accepted triangle ends the ray */
-        "v_cndmask_b32_e64 v12, v12, -1, vcc\n"
-        "v_cndmask_b32_e64 v13, v13, 0, vcc\n"
-        "TQ_TRI2_END_%=:\n"
-        "s_mov_b64 exec, s[84:85]\n"
-        "v_cmp_ne_u32_e32 vcc, -1, v12\n"
-        "v_bfe_u32 v50, v12, 27, 4\n"
-        "v_add_u32_e32 v49, 0xf0000002, v12\n"             /* first + 2, two triangles fewer */
-        "v_cmp_lt_u32_e64 s[66:67], 1, v50\n"
-        "s_nop 0\n"
-        "s_and_b64 s[66:67], s[66:67], vcc\n"
-        "s_andn2_b64 s[68:69], vcc, s[66:67]\n"
-        "v_cndmask_b32_e64 v12, v12, v49, s[66:67]\n"
-        "s_or_b64 s[78:79], s[78:79], s[68:69]\n"
-        /* ---------------------------------------------------------------- pop (s[78:79]) */
-        "TQ_POP_%=:\n"
-        "s_mov_b64 exec, s[78:79]\n"
-        "s_cbranch_execz TQ_POP_NONE_%=\n"
-        "v_cmp_lt_i32_e32 vcc, 0, v13\n"
-        "v_mov_b32_e32 v12, -1\n"
-        "s_and_b64 exec, exec, vcc\n"
-        "s_cbranch_execz TQ_POP_NONE_%=\n"
-        "v_add_u32_e32 v13, -1, v13\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v13\n"
-        "s_mov_b64 s[72:73], exec\n"
-        "s_and_b64 exec, exec, vcc\n"
-        "v_lshl_add_u32 v33, v13, 8, v18\n"
-        "ds_read_b32 v12, v33 offset:768\n"
-        "s_andn2_b64 exec, s[72:73], vcc\n"
-        "s_cbranch_execz TQ_POP_LDS_%=\n"
-        "v_lshl_add_u32 v33, v13, 8, v16\n"
-        "global_load_dword v12, v33, %[spill]\n"
-        "s_waitcnt vmcnt(0)\n"
-        "TQ_POP_LDS_%=:\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "TQ_POP_NONE_%=:\n"
-        "s_mov_b64 exec, -1\n"
+        PT_WF_ASM_TRIP
         "s_branch TQ_LOOP_%=\n"
         /* ---------------------------------------------------------------- a push beyond the LDS levels (rare): level by level */
-        "TQ_PUSH_SLOW_%=:\n"
-        "v_add_u32_e32 v29, -3, v28\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
-        "s_and_b64 exec, s[72:73], vcc\n"
-        "v_lshl_add_u32 v30, v29, 8, v18\n"
-        "ds_write_b32 v30, v51 offset:768\n"
-        "s_andn2_b64 exec, s[72:73], vcc\n"
-        "v_lshl_add_u32 v30, v29, 8, v16\n"
-        "global_store_dword v30, v51, %[spill]\n"
-        "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v29, -2, v28\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
-        "s_and_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v30, v29, 8, v18\n"
-        "ds_write_b32 v30, v48 offset:768\n"
-        "s_andn2_b64 exec, s[68:69], vcc\n"
-        "v_lshl_add_u32 v30, v29, 8, v16\n"
-        "global_store_dword v30, v48, %[spill]\n"
-        "s_mov_b64 exec, s[62:63]\n"
-        "v_add_u32_e32 v29, -1, v28\n"
-        "v_cmp_gt_i32_e32 vcc, %[depth], v29\n"
-        "s_and_b64 exec, s[66:67], vcc\n"
-        "v_lshl_add_u32 v30, v29, 8, v18\n"
-        "ds_write_b32 v30, v49 offset:768\n"
-        "s_andn2_b64 exec, s[66:67], vcc\n"
-        "v_lshl_add_u32 v30, v29, 8, v16\n"
-        "global_store_dword v30, v49, %[spill]\n"
-        "s_waitcnt vmcnt(0)\n"
-        "s_branch TQ_PUSHED_%=\n"
-        /* ---------------------------------------------------------------- IEEE reciprocal for divisors outside the Newton range */
-        "TQ_DIV_IEEE_%=:\n"
-        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
-        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
-        "v_rcp_f32_e32 v47, v46\n"
-        "s_nop 0\n"
-        "v_fma_f32 v49, -v46, v47, 1.0\n"
-        "v_fmac_f32_e32 v47, v49, v47\n"
-        "v_mul_f32_e32 v52, v48, v47\n"
-        "v_fma_f32 v49, -v46, v52, v48\n"
-        "v_fmac_f32_e32 v52, v49, v47\n"
-        "v_fma_f32 v46, -v46, v52, v48\n"
-        "v_div_fmas_f32 v46, v46, v47, v52\n"
-        "v_div_fixup_f32 v46, v46, v45, 1.0\n"
-        "s_branch TQ_DIV_DONE_%=\n"
-        "TQ_DIV_IEEE2_%=:\n"
-        "v_div_scale_f32 v46, s[66:67], v45, v45, 1.0\n"
-        "v_div_scale_f32 v48, vcc, 1.0, v45, 1.0\n"
-        "v_rcp_f32_e32 v47, v46\n"
-        "s_nop 0\n"
-        "v_fma_f32 v49, -v46, v47, 1.0\n"
-        "v_fmac_f32_e32 v47, v49, v47\n"
-        "v_mul_f32_e32 v52, v48, v47\n"
-        "v_fma_f32 v49, -v46, v52, v48\n"
-        "v_fmac_f32_e32 v52, v49, v47\n"
-        "v_fma_f32 v46, -v46, v52, v48\n"
-        "v_div_fmas_f32 v46, v46, v47, v52\n"
-        "v_div_fixup_f32 v46, v46, v45, 1.0\n"
-        "s_branch TQ_DIV_DONE2_%=\n"
+        PT_WF_ASM_SLOW
         "TQ_DONE_%=:\n"
 #if PT_WF_PROBE == 3
         "s_mov_b64 exec, 1\n"
@@ -1823,6 +2173,403 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 }
 
+#undef PT_WF_LVL
+#undef PT_WF_O1
+#undef PT_WF_O2
+#undef PT_WF_O3
+
+// ---- the ray stream, hand-scheduled ------------------------------------------------------------------------------------------
+// wf_trace_stream above is the specification of the scheduling (and, with -DPT_WF_STREAM_CXX=1, runs); this is the same loop around the SAME
+// node block, triangle block, sorting network, pushes and pops as wf_trace_wide_asm (PT_WF_ASM_TRIP: the batch's lanes are s[62:63]
+// for a batch at wide nodes, s[60:61] for a batch at leaves).  A wave's block in LDS, R = kWfR slots, one row of R words per field:
+//   rows 0-16  ox oy oz b1 | dx dy dz b2 | 1/dx 1/dy 1/dz id | cur sp tmax bprim | bt        rows 17 .. 17 + kWfS - 1  the stack's first levels
+//   then three byte lists of R entries - slots whose next step is a wide node / a leaf / free slots - and their three counts.
+// Registers beyond those of the trip: v55 lane, v56 address of the slot's column (block + 4 slot), v57 slot; a group of rays moving in:
+// v58 id, v59 slot, v[60:63] direction and interval end, v[64:67] origin, s[86:87] ids on their way, s[88:89] records on their way (one
+// group at a time, one stage per trip: id -> record -> 1 / direction and the slot's rows).  s96 / s97 / s98 entries of the three lists,
+// s70 s90 s91 s94 s95 as in wf_trace_wide_asm, s99 s100 s71 temporaries.
+constexpr int kWfsRowBytes = 4 * kWfR;
+constexpr int kWfsRows = 17 + kWfS;
+constexpr int kWfsLists = kWfsRows * kWfsRowBytes;              // byte offset of the three lists
+constexpr int kWfsCounts = kWfsLists + 3 * kWfR;                // ... of the three counts
+constexpr int kWfsBlockBytes = (kWfsCounts + 12 + 15) & ~15;
+static_assert(kWfR % 4 == 0 && kWfR <= 255 && kWfsBlockBytes < 65536, "slots are bytes, offsets are 16-bit immediates");
+
+#define PT_WF_LVL(dst, lvl, col) "v_mad_u32_u24 " dst ", " lvl ", %[lstride], " col "\n"      /* a level is R words */
+#define PT_WF_O1 "%[o1]"
+#define PT_WF_O2 "%[o2]"
+#define PT_WF_O3 "%[o3]"
+__device__ __forceinline__ void wf_trace_stream_asm(const DevParams &P, const WfParams &W, unsigned block_lds, unsigned shared_lds, uint32_t chunk0)
+{
+    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
+    const unsigned long long s_nodes = uniform64((unsigned long long)P.wide);
+    const unsigned s_trioff = __builtin_amdgcn_readfirstlane(P.wide_tris_off);
+    // level l >= kWfS of slot s: spill + 4 (R l + s), with the base of the wave's slice moved back by the LDS levels
+    const unsigned long long s_spill = uniform64((unsigned long long)(W.spill + (size_t)(blockIdx.x * (unsigned)kWfWgWaves + (threadIdx.x >> 6)) * (uint32_t)kWfR * W.spill_levels)
+                                                 - (unsigned long long)(4 * kWfR * kWfS));
+    const unsigned long long s_rayq = uniform64((unsigned long long)W.rayq), s_ray = uniform64((unsigned long long)W.ray),
+                             s_org = uniform64((unsigned long long)W.org), s_hit = uniform64((unsigned long long)W.hit);
+    const unsigned s_np = __builtin_amdgcn_readfirstlane(W.n_paths);
+    const unsigned s_shared = __builtin_amdgcn_readfirstlane(shared_lds);
+    const unsigned s_segbase = __builtin_amdgcn_readfirstlane(chunk0 * (unsigned)(kWfSegRays * 4));
+    const unsigned s_blk = __builtin_amdgcn_readfirstlane(block_lds);
+    const unsigned s_lstride = __builtin_amdgcn_readfirstlane((unsigned)kWfsRowBytes);
+    asm volatile(
+        "s_mov_b32 s76, 0x322bcc77\n"
+        "s_mov_b32 s77, 0x71800000\n"
+        "s_mov_b64 s[86:87], 0\n"
+        "s_mov_b64 s[88:89], 0\n"
+        "s_mov_b32 s70, 0\n"
+        "s_mov_b32 s90, 0\n"
+        "s_mov_b32 s91, 0\n"
+        "s_mov_b32 s94, 0\n"
+        "s_mov_b32 s95, 0\n"
+        "v_mbcnt_lo_u32_b32 v55, -1, 0\n"
+        "v_mbcnt_hi_u32_b32 v55, -1, v55\n"                /* lane */
+        "v_mov_b32_e32 v33, %[blk]\n"
+        "ds_read_b32 v34, v33 offset:%[o_cnt0]\n"
+        "ds_read_b32 v35, v33 offset:%[o_cnt1]\n"
+        "ds_read_b32 v36, v33 offset:%[o_cnt2]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s96, v34\n"                   /* slots on the node list */
+        "v_readfirstlane_b32 s97, v35\n"                   /* ... on the leaf list */
+        "v_readfirstlane_b32 s98, v36\n"                   /* free slots */
+        /* ---------------------------------------------------------------- loop header */
+        "TS_LOOP_%=:\n"
+        /* rays whose record was fetched a trip ago: 1 / direction, the slot's rows, onto the node list (they start at the root) */
+        "s_cmp_eq_u64 s[88:89], 0\n"
+        "s_cbranch_scc1 TS_NOFINAL_%=\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        "s_mov_b64 exec, s[88:89]\n"
+        "v_mov_b32_e32 v4, v60\n"
+        "v_mov_b32_e32 v5, v61\n"
+        "v_mov_b32_e32 v6, v62\n"
+        PT_WF_ASM_INV_DIR
+        "v_lshl_add_u32 v56, v59, 2, %[blk]\n"
+        "v_mov_b32_e32 v33, 0\n"
+        "v_mov_b32_e32 v34, -1\n"
+        "ds_write_b32 v56, v64 offset:%[f0]\n"
+        "ds_write_b32 v56, v65 offset:%[f1]\n"
+        "ds_write_b32 v56, v66 offset:%[f2]\n"
+        "ds_write_b32 v56, v33 offset:%[f3]\n"
+        "ds_write_b32 v56, v4 offset:%[f4]\n"
+        "ds_write_b32 v56, v5 offset:%[f5]\n"
+        "ds_write_b32 v56, v6 offset:%[f6]\n"
+        "ds_write_b32 v56, v33 offset:%[f7]\n"
+        "ds_write_b32 v56, v8 offset:%[f8]\n"
+        "ds_write_b32 v56, v9 offset:%[f9]\n"
+        "ds_write_b32 v56, v10 offset:%[f10]\n"
+        "ds_write_b32 v56, v58 offset:%[f11]\n"
+        "ds_write_b32 v56, v33 offset:%[f12]\n"            /* wide node 0 */
+        "ds_write_b32 v56, v33 offset:%[f13]\n"
+        "ds_write_b32 v56, v63 offset:%[f14]\n"
+        "ds_write_b32 v56, v34 offset:%[f15]\n"
+        "ds_write_b32 v56, v33 offset:%[f16]\n"
+        "v_add_u32_e32 v35, s96, v55\n"                    /* (the group's lanes are 0 .. take - 1) */
+        "v_add_u32_e32 v35, %[blk], v35\n"
+        "ds_write_b8 v35, v59 offset:%[o_qn]\n"
+        "s_bcnt1_i32_b64 s71, s[88:89]\n"
+        "s_add_u32 s96, s96, s71\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b64 s[88:89], 0\n"
+        "TS_NOFINAL_%=:\n"
+        /* rays whose id was fetched a trip ago: the gathers of direction (kind * paths + path) and origin (path) */
+        "s_cmp_eq_u64 s[86:87], 0\n"
+        "s_cbranch_scc1 TS_NOGATHER_%=\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_mov_b64 exec, s[86:87]\n"
+        "v_bfe_u32 v33, v58, 28, 2\n"
+        "v_and_b32_e32 v34, 0xfffffff, v58\n"
+        "v_mul_lo_u32 v33, v33, %[np]\n"
+        "v_add_lshl_u32 v33, v33, v34, 4\n"
+        "v_lshlrev_b32_e32 v34, 4, v34\n"
+        "global_load_dwordx4 v[60:63], v33, %[ray]\n"
+        "global_load_dwordx4 v[64:67], v34, %[org]\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b64 s[88:89], s[86:87]\n"
+        "s_mov_b64 s[86:87], 0\n"
+        "s_branch TS_TRIPCHK_%=\n"                          /* (one group at a time) */
+        "TS_NOGATHER_%=:\n"
+        /* ---------------------------------------------------------------- a new group: free slots take the next rays of the segment */
+        "s_cmp_lg_u32 s94, 0\n"
+        "s_cbranch_scc1 TS_TRIPCHK_%=\n"
+        "s_cmp_lt_u32 s98, %[refill_t]\n"
+        "s_cbranch_scc1 TS_TRIPCHK_%=\n"
+        "s_cmp_lt_u32 s70, s90\n"
+        "s_cbranch_scc1 TS_ASSIGN_%=\n"
+        /* the workgroup's next segment: one LDS atomic (nobody outside the workgroup touches the counter), then its ray count */
+        "TS_NEXTSEG_%=:\n"
+        "s_mov_b64 exec, 1\n"
+        "v_mov_b32_e32 v33, %[shared]\n"
+        "v_mov_b32_e32 v34, 1\n"
+        "ds_add_rtn_u32 v35, v33, v34 offset:%[o_next]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s73, v35\n"
+        "s_cmp_lt_u32 s73, %[nchunks]\n"
+        "s_cbranch_scc0 TS_EXHAUSTED_%=\n"
+        "v_lshl_add_u32 v33, s73, 2, v33\n"
+        "ds_read_b32 v35, v33\n"                          /* seg_count[c] leads the record */
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_readfirstlane_b32 s90, v35\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mul_i32 s91, s73, 768\n"
+        "s_add_u32 s91, s91, %[segbase]\n"
+        "s_mov_b32 s70, 0\n"
+        "s_cmp_lg_u32 s90, 0\n"
+        "s_cbranch_scc1 TS_ASSIGN_%=\n"
+        "s_branch TS_NEXTSEG_%=\n"
+        "TS_EXHAUSTED_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_mov_b32 s94, 1\n"
+        "s_branch TS_TRIPCHK_%=\n"
+        "TS_ASSIGN_%=:\n"
+        "s_sub_u32 s71, s90, s70\n"                        /* rays left in the segment */
+        "s_min_u32 s71, s71, s98\n"
+        "s_min_u32 s71, s71, 64\n"                         /* the group */
+        "v_cmp_gt_u32_e64 s[86:87], s71, v55\n"
+        "s_sub_u32 s98, s98, s71\n"
+        "s_mov_b64 exec, s[86:87]\n"
+        "v_add_u32_e32 v33, s98, v55\n"                    /* the topmost entries of the free list */
+        "v_add_u32_e32 v33, %[blk], v33\n"
+        "ds_read_u8 v59, v33 offset:%[o_free]\n"
+        "v_add_u32_e32 v33, s70, v55\n"
+        "v_lshl_add_u32 v33, v33, 2, s91\n"
+        "global_load_dword v58, v33, %[rayq]\n"
+        "s_add_u32 s70, s70, s71\n"
+        "s_mov_b64 exec, -1\n"
+        "TS_TRIPCHK_%=:\n"
+        "s_add_u32 s99, s96, s97\n"                        /* rays on the two lists */
+        "s_cmp_lg_u32 s99, 0\n"
+        "s_cbranch_scc1 TS_HAVE_%=\n"
+        /* none: the loop goes on while a group is moving in or segments are left */
+        "s_or_b64 s[66:67], s[86:87], s[88:89]\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TS_LOOP_%=\n"
+        "s_cmp_eq_u32 s94, 0\n"
+        "s_cbranch_scc1 TS_LOOP_%=\n"
+        "s_branch TS_DONE_%=\n"
+        "TS_HAVE_%=:\n"
+        /* no segment is left, no group is moving in and only a few rays are left: they wait for the next round where they are ... */
+        "s_cmp_eq_u32 s94, 0\n"
+        "s_cbranch_scc1 TS_TRIP_%=\n"
+        "s_or_b64 s[66:67], s[86:87], s[88:89]\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc1 TS_TRIP_%=\n"
+        "s_cmp_ge_u32 s99, %[park_t]\n"
+        "s_cbranch_scc1 TS_TRIP_%=\n"
+        "s_cmp_lt_u32 s95, %[mintrips]\n"                  /* ... but every round moves its rays on by some trips */
+        "s_cbranch_scc1 TS_TRIP_%=\n"
+        "s_branch TS_PARK_%=\n"
+        /* ---------------------------------------------------------------- one trip: a batch off one list */
+        "TS_TRIP_%=:\n"
+        "s_add_u32 s95, s95, 1\n"
+        /* a full batch of either kind if there is one, else the longer list (a node step costs about twice a leaf step: it goes first) */
+        "s_cmp_ge_u32 s96, 64\n"
+        "s_cbranch_scc1 TS_KNODE_%=\n"
+        "s_cmp_ge_u32 s97, 64\n"
+        "s_cbranch_scc1 TS_KLEAF_%=\n"
+        "s_cmp_ge_u32 s96, s97\n"
+        "s_cbranch_scc1 TS_KNODE_%=\n"
+        "TS_KLEAF_%=:\n"
+        "s_min_u32 s99, s97, 64\n"
+        "s_sub_u32 s97, s97, s99\n"
+        "v_cmp_gt_u32_e64 s[64:65], s99, v55\n"
+        "s_add_u32 s100, s97, %[o_ql]\n"
+        "s_mov_b64 s[62:63], 0\n"
+        "s_mov_b64 s[60:61], s[64:65]\n"
+        "s_branch TS_POPQ_%=\n"
+        "TS_KNODE_%=:\n"
+        "s_min_u32 s99, s96, 64\n"
+        "s_sub_u32 s96, s96, s99\n"
+        "v_cmp_gt_u32_e64 s[64:65], s99, v55\n"
+        "s_add_u32 s100, s96, %[o_qn]\n"
+        "s_mov_b64 s[60:61], 0\n"
+        "s_mov_b64 s[62:63], s[64:65]\n"
+        "TS_POPQ_%=:\n"
+        "s_add_u32 s100, s100, %[blk]\n"
+        "s_mov_b64 exec, s[64:65]\n"
+        "v_add_u32_e32 v33, s100, v55\n"
+        "ds_read_u8 v57, v33\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_lshl_add_u32 v56, v57, 2, %[blk]\n"
+        "v_lshlrev_b32_e32 v16, 2, v57\n"
+        "v_add_u32_e32 v18, %[o_stk], v56\n"
+        "ds_read_b32 v12, v56 offset:%[f12]\n"
+        "ds_read_b32 v13, v56 offset:%[f13]\n"
+        "ds_read_b32 v14, v56 offset:%[f14]\n"
+        "ds_read_b32 v0, v56 offset:%[f0]\n"
+        "ds_read_b32 v1, v56 offset:%[f1]\n"
+        "ds_read_b32 v2, v56 offset:%[f2]\n"
+        "s_cmp_lg_u64 s[62:63], 0\n"
+        "s_cbranch_scc0 TS_LDLEAF_%=\n"
+        "ds_read_b32 v8, v56 offset:%[f8]\n"
+        "ds_read_b32 v9, v56 offset:%[f9]\n"
+        "ds_read_b32 v10, v56 offset:%[f10]\n"
+        "s_branch TS_LDDONE_%=\n"
+        "TS_LDLEAF_%=:\n"
+        "ds_read_b32 v4, v56 offset:%[f4]\n"
+        "ds_read_b32 v5, v56 offset:%[f5]\n"
+        "ds_read_b32 v6, v56 offset:%[f6]\n"
+        "ds_read_b32 v11, v56 offset:%[f11]\n"
+        "ds_read_b32 v20, v56 offset:%[f15]\n"
+        "ds_read_b32 v21, v56 offset:%[f16]\n"
+        "ds_read_b32 v22, v56 offset:%[f3]\n"
+        "ds_read_b32 v23, v56 offset:%[f7]\n"
+        "TS_LDDONE_%=:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        PT_WF_ASM_TRIP
+        /* ---------------------------------------------------------------- what changed goes back to the slot's rows */
+        "s_mov_b64 exec, s[64:65]\n"
+        "ds_write_b32 v56, v12 offset:%[f12]\n"
+        "ds_write_b32 v56, v13 offset:%[f13]\n"
+        "s_cmp_lg_u64 s[60:61], 0\n"
+        "s_cbranch_scc0 TS_WBDONE_%=\n"
+        "ds_write_b32 v56, v14 offset:%[f14]\n"
+        "ds_write_b32 v56, v20 offset:%[f15]\n"
+        "ds_write_b32 v56, v21 offset:%[f16]\n"
+        "ds_write_b32 v56, v22 offset:%[f3]\n"
+        "ds_write_b32 v56, v23 offset:%[f7]\n"
+        "TS_WBDONE_%=:\n"
+        /* ---------------------------------------------------------------- the batch's rays go onto the list of their next step */
+        "v_cmp_eq_u32_e64 s[66:67], -1, v12\n"             /* finished */
+        "v_cmp_gt_i32_e64 s[68:69], 0, v12\n"
+        "s_andn2_b64 s[68:69], s[68:69], s[66:67]\n"       /* at a leaf */
+        "s_andn2_b64 s[72:73], s[64:65], s[66:67]\n"
+        "s_andn2_b64 s[72:73], s[72:73], s[68:69]\n"       /* at a wide node */
+        "s_mov_b64 exec, s[72:73]\n"
+        "v_mbcnt_lo_u32_b32 v33, s72, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s73, v33\n"
+        "v_add_u32_e32 v33, s96, v33\n"
+        "v_add_u32_e32 v33, %[blk], v33\n"
+        "ds_write_b8 v33, v57 offset:%[o_qn]\n"
+        "s_bcnt1_i32_b64 s71, s[72:73]\n"
+        "s_add_u32 s96, s96, s71\n"
+        "s_mov_b64 exec, s[68:69]\n"
+        "v_mbcnt_lo_u32_b32 v33, s68, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s69, v33\n"
+        "v_add_u32_e32 v33, s97, v33\n"
+        "v_add_u32_e32 v33, %[blk], v33\n"
+        "ds_write_b8 v33, v57 offset:%[o_ql]\n"
+        "s_bcnt1_i32_b64 s71, s[68:69]\n"
+        "s_add_u32 s97, s97, s71\n"
+        "s_cmp_lg_u64 s[66:67], 0\n"
+        "s_cbranch_scc0 TS_NOFIN_%=\n"
+        /* ---------------------------------------------------------------- finished rays: the result (a miss reports the end of the interval), the slot is free */
+        "s_mov_b64 exec, s[66:67]\n"
+        "s_cmp_lg_u64 s[62:63], 0\n"
+        "s_cbranch_scc0 TS_FINHAVE_%=\n"
+        "ds_read_b32 v11, v56 offset:%[f11]\n"            /* (a batch at wide nodes has not loaded them) */
+        "ds_read_b32 v20, v56 offset:%[f15]\n"
+        "ds_read_b32 v21, v56 offset:%[f16]\n"
+        "ds_read_b32 v22, v56 offset:%[f3]\n"
+        "ds_read_b32 v23, v56 offset:%[f7]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "TS_FINHAVE_%=:\n"
+        "v_cmp_gt_i32_e32 vcc, 0, v20\n"
+        "v_cndmask_b32_e32 v21, v21, v14, vcc\n"
+        "v_bfe_u32 v33, v11, 28, 2\n"
+        "v_and_b32_e32 v34, 0xfffffff, v11\n"
+        "v_mul_lo_u32 v33, v33, %[np]\n"
+        "v_add_lshl_u32 v15, v33, v34, 4\n"
+        "global_store_dwordx4 v15, v[20:23], %[hit]\n"
+        "v_mbcnt_lo_u32_b32 v33, s66, 0\n"
+        "v_mbcnt_hi_u32_b32 v33, s67, v33\n"
+        "v_add_u32_e32 v33, s98, v33\n"
+        "v_add_u32_e32 v33, %[blk], v33\n"
+        "ds_write_b8 v33, v57 offset:%[o_free]\n"
+        "s_bcnt1_i32_b64 s71, s[66:67]\n"
+        "s_add_u32 s98, s98, s71\n"
+        "TS_NOFIN_%=:\n"
+        "s_mov_b64 exec, -1\n"
+        "s_branch TS_LOOP_%=\n"
+        PT_WF_ASM_SLOW
+        /* ---------------------------------------------------------------- the rays on the lists wait for the next round: their result slots say "not yet" */
+        "TS_PARK_%=:\n"
+        "v_mov_b32_e32 v35, -2\n"
+        "s_mov_b32 s71, 0\n"
+        "TS_PK1_%=:\n"
+        "s_cmp_ge_u32 s71, s96\n"
+        "s_cbranch_scc1 TS_PK1E_%=\n"
+        "v_add_u32_e32 v33, s71, v55\n"
+        "v_cmp_gt_u32_e32 vcc, s96, v33\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_add_u32_e32 v33, %[blk], v33\n"
+        "ds_read_u8 v34, v33 offset:%[o_qn]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_lshl_add_u32 v34, v34, 2, %[blk]\n"
+        "ds_read_b32 v36, v34 offset:%[f11]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_bfe_u32 v33, v36, 28, 2\n"
+        "v_and_b32_e32 v34, 0xfffffff, v36\n"
+        "v_mul_lo_u32 v33, v33, %[np]\n"
+        "v_add_lshl_u32 v33, v33, v34, 4\n"
+        "global_store_dword v33, v35, %[hit]\n"
+        "s_mov_b64 exec, -1\n"
+        "s_add_u32 s71, s71, 64\n"
+        "s_branch TS_PK1_%=\n"
+        "TS_PK1E_%=:\n"
+        "s_mov_b32 s71, 0\n"
+        "TS_PK2_%=:\n"
+        "s_cmp_ge_u32 s71, s97\n"
+        "s_cbranch_scc1 TS_PK2E_%=\n"
+        "v_add_u32_e32 v33, s71, v55\n"
+        "v_cmp_gt_u32_e32 vcc, s97, v33\n"
+        "s_mov_b64 exec, vcc\n"
+        "v_add_u32_e32 v33, %[blk], v33\n"
+        "ds_read_u8 v34, v33 offset:%[o_ql]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_lshl_add_u32 v34, v34, 2, %[blk]\n"
+        "ds_read_b32 v36, v34 offset:%[f11]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_bfe_u32 v33, v36, 28, 2\n"
+        "v_and_b32_e32 v34, 0xfffffff, v36\n"
+        "v_mul_lo_u32 v33, v33, %[np]\n"
+        "v_add_lshl_u32 v33, v33, v34, 4\n"
+        "global_store_dword v33, v35, %[hit]\n"
+        "s_mov_b64 exec, -1\n"
+        "s_add_u32 s71, s71, 64\n"
+        "s_branch TS_PK2_%=\n"
+        "TS_PK2E_%=:\n"
+        "s_mov_b64 exec, 1\n"
+        "v_mov_b32_e32 v33, %[shared]\n"
+        "v_mov_b32_e32 v34, 1\n"
+        "ds_write_b32 v33, v34 offset:%[o_parked]\n"
+        "TS_DONE_%=:\n"
+        "s_mov_b64 exec, 1\n"
+        "v_mov_b32_e32 v33, %[blk]\n"
+        "v_mov_b32_e32 v34, s96\n"
+        "v_mov_b32_e32 v35, s97\n"
+        "v_mov_b32_e32 v36, s98\n"
+        "ds_write_b32 v33, v34 offset:%[o_cnt0]\n"
+        "ds_write_b32 v33, v35 offset:%[o_cnt1]\n"
+        "ds_write_b32 v33, v36 offset:%[o_cnt2]\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        "s_mov_b64 exec, -1\n"
+        :
+        : [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill), [lstride] "s"(s_lstride), [blk] "s"(s_blk),
+          [rayq] "s"(s_rayq), [ray] "s"(s_ray), [org] "s"(s_org), [hit] "s"(s_hit), [np] "s"(s_np), [shared] "s"(s_shared), [segbase] "s"(s_segbase),
+          [depth] "n"(kWfS), [o1] "n"(kWfsRowBytes), [o2] "n"(2 * kWfsRowBytes), [o3] "n"(3 * kWfsRowBytes), [o_stk] "n"(14 * kWfsRowBytes),
+          [f0] "n"(0), [f1] "n"(kWfsRowBytes), [f2] "n"(2 * kWfsRowBytes), [f3] "n"(3 * kWfsRowBytes), [f4] "n"(4 * kWfsRowBytes), [f5] "n"(5 * kWfsRowBytes),
+          [f6] "n"(6 * kWfsRowBytes), [f7] "n"(7 * kWfsRowBytes), [f8] "n"(8 * kWfsRowBytes), [f9] "n"(9 * kWfsRowBytes), [f10] "n"(10 * kWfsRowBytes),
+          [f11] "n"(11 * kWfsRowBytes), [f12] "n"(12 * kWfsRowBytes), [f13] "n"(13 * kWfsRowBytes), [f14] "n"(14 * kWfsRowBytes), [f15] "n"(15 * kWfsRowBytes),
+          [f16] "n"(16 * kWfsRowBytes),
+          [o_qn] "n"(kWfsLists), [o_ql] "n"(kWfsLists + kWfR), [o_free] "n"(kWfsLists + 2 * kWfR),
+          [o_cnt0] "n"(kWfsCounts), [o_cnt1] "n"(kWfsCounts + 4), [o_cnt2] "n"(kWfsCounts + 8),
+          [refill_t] "n"(PT_WF_STREAM_REFILL_T), [park_t] "n"(PT_WF_STREAM_PARK_T), [mintrips] "n"(PT_WF_STREAM_MIN_TRIPS), [nchunks] "n"(kWfWgChunks),
+          [o_next] "n"(offsetof(WfShared, trace_next)), [o_parked] "n"(offsetof(WfShared, parked))
+        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
+          "s94", "s95", "s96", "s97", "s98", "s99", "s100",
+          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
+          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",
+          "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67");
+}
+#undef PT_WF_LVL
+#undef PT_WF_O1
+#undef PT_WF_O2
+#undef PT_WF_O3
+
 // ------------------------------------------------------------------------------------------- the render kernel ------
 // Persistent workgroups of four waves; a workgroup owns kWfWgChunks chunks of 64 path slots (its pool) and alternates, for as long as
 // it has paths or the batch has work items:
@@ -1833,11 +2580,14 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
 // workgroup wants (the work-item counter aside: one claim per 256 samples), and a round waits for the slowest ray among the ~1 500
 // of its own pool, not among the frame's millions.  The four workgroups of a CU are in different phases at any time: the shade
 // phase's arithmetic runs while another workgroup's trace phase waits for memory.
-template <int INTEG, bool WIDE>
+template <int INTEG, bool WIDE, bool STREAM_MODE>
 __global__ void __launch_bounds__(64 * kWfWgWaves, PT_WF_WAVES) wf_render_kernel(const DevParams P, const WfParams W)
 {
-    __shared__ uint32_t lds_stack[WIDE ? 256 + kWfWgWaves * 64 * kWfStackLevels : 1];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
-    __shared__ uint32_t lds_ids[(WIDE && PT_WF_WIDE_ASM) ? 1 : kWfWgWaves * kWfSegRays];   // the C++ walks stage a segment's ids
+    constexpr bool STREAM = WIDE && STREAM_MODE;           // (the binary tree is walked one lane per ray in both modes)
+    __shared__ uint32_t lds_stack[(WIDE && !STREAM) ? 256 + kWfWgWaves * 64 * kWfStackLevels : 1];      // (768 bytes ahead of the first stack stay addressable: see s_stack)
+    __shared__ uint32_t lds_ids[(STREAM || (WIDE && PT_WF_WIDE_ASM)) ? 1 : kWfWgWaves * kWfSegRays];   // the C++ walks stage a segment's ids
+    __shared__ WfStreamWave lds_stream[(STREAM && PT_WF_STREAM_CXX) ? kWfWgWaves : 1];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_stream_asm[(STREAM && !PT_WF_STREAM_CXX) ? kWfWgWaves * kWfsBlockBytes : 16];
     __shared__ WfShared sh;
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t chunk0 = blockIdx.x * (uint32_t)kWfWgChunks;
@@ -1845,8 +2595,22 @@ __global__ void __launch_bounds__(64 * kWfWgWaves, PT_WF_WAVES) wf_render_kernel
         sh.shade_next = sh.trace_next = sh.emitted = sh.parked = 0u;
         sh.items_left = 1u;
     }
+    if (STREAM && PT_WF_STREAM_CXX) {
+        WfStreamWave &L = lds_stream[wv];
+        for (unsigned j = lane; j < (unsigned)kWfR; j += 64u) L.freel[j] = j;
+        if (lane == 0) { L.n_qn = L.n_ql = 0u; L.n_free = (uint32_t)kWfR; }
+    }
+    if (STREAM && !PT_WF_STREAM_CXX) {          // every slot is free
+        unsigned char *blk = lds_stream_asm + wv * kWfsBlockBytes;
+        for (unsigned j = lane; j < (unsigned)kWfR; j += 64u) blk[kWfsLists + 2 * kWfR + j] = (unsigned char)j;
+        if (lane == 0) {
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(blk + kWfsCounts);
+            cnt[0] = cnt[1] = 0u;
+            cnt[2] = (uint32_t)kWfR;
+        }
+    }
     // no ray is parked for this lane (the record's third word carries the round a parked ray resumes in)
-    if (WIDE) W.save[(size_t)((blockIdx.x * (unsigned)kWfWgWaves + wv) * 64u + lane) * (uint32_t)kWfSaveDwords + 2u] = 0u;
+    if (WIDE && !STREAM) W.save[(size_t)((blockIdx.x * (unsigned)kWfWgWaves + wv) * 64u + lane) * (uint32_t)kWfSaveDwords + 2u] = 0u;
     __syncthreads();
 #if PT_WF_PROBE == 2      // probe builds: where a wave's time goes (shader-clock cycles, lane 0 of every wave) -> P.counters[0..5]
     unsigned long long pr_shade = 0, pr_trace = 0, pr_wait = 0, pr_rounds = 0, pr_chunks = 0, pr_t0 = __builtin_readcyclecounter();
@@ -1883,7 +2647,9 @@ __global__ void __launch_bounds__(64 * kWfWgWaves, PT_WF_WAVES) wf_render_kernel
         PT_WF_TICK(pr_wait)
         // ---- trace phase
         if (work) {
-            if (WIDE && PT_WF_WIDE_ASM) wf_trace_wide_asm(P, W, lds_address(lds_stack + 256 + wv * 64 * kWfStackLevels), lane, lds_address(&sh), chunk0, round);
+            if (STREAM && !PT_WF_STREAM_CXX) wf_trace_stream_asm(P, W, lds_address(lds_stream_asm + wv * kWfsBlockBytes), lds_address(&sh), chunk0);
+            else if (STREAM) wf_trace_stream(P, W, sh, chunk0, lds_stream[wv], lane);
+            else if (WIDE && PT_WF_WIDE_ASM) wf_trace_wide_asm(P, W, lds_address(lds_stack + 256 + wv * 64 * kWfStackLevels), lane, lds_address(&sh), chunk0, round);
             else wf_trace_cxx<WIDE>(P, W, sh, chunk0, lds_ids + wv * kWfSegRays, lds_stack + (WIDE ? 256 + wv * 64 * kWfStackLevels : 0), lane);
         }
         (void)resume;
@@ -1903,12 +2669,13 @@ __global__ void __launch_bounds__(64 * kWfWgWaves, PT_WF_WAVES) wf_render_kernel
 }
 
 // ---------------------------------------------------------------------------------------------------- launchers ------
-hipError_t launch_wf_render(const DevParams &P, const WfParams &W, int n_blocks, hipStream_t stream)
+hipError_t launch_wf_render(const DevParams &P, const WfParams &W, int n_blocks, bool stream_trace, hipStream_t stream)
 {
     const dim3 grid(n_blocks), block(64 * kWfWgWaves);
     const bool wide = P.traversal == GPT_TRAVERSAL_WIDE4;
-#define PT_WF_LAUNCH(I) do { if (wide) hipLaunchKernelGGL((wf_render_kernel<I, true>), grid, block, 0, stream, P, W); \
-                             else hipLaunchKernelGGL((wf_render_kernel<I, false>), grid, block, 0, stream, P, W); } while (0)
+#define PT_WF_LAUNCH(I) do { if (wide && stream_trace) hipLaunchKernelGGL((wf_render_kernel<I, true, true>), grid, block, 0, stream, P, W); \
+                             else if (wide) hipLaunchKernelGGL((wf_render_kernel<I, true, false>), grid, block, 0, stream, P, W); \
+                             else hipLaunchKernelGGL((wf_render_kernel<I, false, false>), grid, block, 0, stream, P, W); } while (0)
     if (P.integrator == GPT_IT_AO) PT_WF_LAUNCH(GPT_IT_AO);
     else if (P.integrator == GPT_IT_VPT) PT_WF_LAUNCH(GPT_IT_VPT);
     else PT_WF_LAUNCH(GPT_IT_PT);
@@ -1916,12 +2683,13 @@ hipError_t launch_wf_render(const DevParams &P, const WfParams &W, int n_blocks,
     return hipGetLastError();
 }
 
-int wf_blocks_per_cu(int integrator, bool wide)
+int wf_blocks_per_cu(int integrator, bool wide, bool stream_trace)
 {
     int n = 0;
     hipError_t e;
-#define PT_WF_OCC(I) (wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, true>, 64 * kWfWgWaves, 0) \
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, false>, 64 * kWfWgWaves, 0))
+#define PT_WF_OCC(I) ((wide && stream_trace) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, true, true>, 64 * kWfWgWaves, 0) \
+                      : wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, true, false>, 64 * kWfWgWaves, 0) \
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_render_kernel<I, false, false>, 64 * kWfWgWaves, 0))
     if (integrator == GPT_IT_AO) e = PT_WF_OCC(GPT_IT_AO);
     else if (integrator == GPT_IT_VPT) e = PT_WF_OCC(GPT_IT_VPT);
     else e = PT_WF_OCC(GPT_IT_PT);
@@ -1930,7 +2698,9 @@ int wf_blocks_per_cu(int integrator, bool wide)
     return n > 32 / kWfWgWaves ? 32 / kWfWgWaves : n;
 }
 
-int wf_lds_stack_levels() { return kWfStackLevels; }
+// stack levels a ray keeps in LDS, and the dwords of one level in a wave's slice of WfParams::spill (one per lane, or one per slot of the stream)
+int wf_lds_stack_levels(bool stream_trace) { return stream_trace ? kWfS : kWfStackLevels; }
+int wf_spill_columns(bool stream_trace) { return stream_trace ? kWfR : 64; }
 int wf_paths_per_block() { return 64 * kWfWgChunks; }
 int wf_waves_per_block() { return kWfWgWaves; }
 

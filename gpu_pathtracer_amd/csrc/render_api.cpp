@@ -93,11 +93,12 @@ struct gpt_ctx {
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
     int wide_depth = 0, n_wide = 0;
     std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
-    // the decoupled scheduler (pt_wavefront.h): "scheduler" 0 = persistent per-wave kernel, 1 = shade / trace phases over workgroup pools
+    // the decoupled scheduler (pt_wavefront.h): "scheduler" 0 = persistent per-wave kernel, 1 = shade / trace phases over workgroup pools,
+    // 2 = the same with the wide walk of the trace phase as a ray stream
     int scheduler = 0;
     pt::WfParams wf{};                    // device buffers of the phases (allocated by the first render that uses them)
     uint32_t wf_blocks = 0;               // persistent grid the buffers were sized for
-    bool wf_wide = false;
+    bool wf_wide = false, wf_stream = false;
     bool last_wavefront = false;          // the last gpt_render went through the phases
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
@@ -218,10 +219,10 @@ void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
 // float4 planes), the segmented ray-id queue, the wide walk's stack spill space and parked-ray records.
 int wf_ensure(gpt_ctx *ctx)
 {
-    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4;
-    const uint32_t n_blocks = (uint32_t)(std::max(ctx->n_cus, 1) * wf_blocks_per_cu(ctx->P.integrator, wide));
+    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4, stream = wide && ctx->scheduler == 2;
+    const uint32_t n_blocks = (uint32_t)(std::max(ctx->n_cus, 1) * wf_blocks_per_cu(ctx->P.integrator, wide, stream));
     const uint32_t n_paths = n_blocks * (uint32_t)wf_paths_per_block();
-    if (ctx->wf.s0 && ctx->wf.n_paths == n_paths && ctx->wf_blocks == n_blocks && ctx->wf_wide == wide) return GPT_OK;
+    if (ctx->wf.s0 && ctx->wf.n_paths == n_paths && ctx->wf_blocks == n_blocks && ctx->wf_wide == wide && ctx->wf_stream == stream) return GPT_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     auto drop = [&](void *q) {
         if (!q) return;
@@ -229,7 +230,7 @@ int wf_ensure(gpt_ctx *ctx)
         for (auto &a : ctx->allocs) if (a == q) a = nullptr;
     };
     drop(ctx->wf.s0);
-    if (ctx->wf.spill) drop(ctx->wf.spill - (size_t)64 * wf_lds_stack_levels());
+    if (ctx->wf.spill) drop(ctx->wf.spill - (size_t)wf_spill_columns(ctx->wf_stream) * wf_lds_stack_levels(ctx->wf_stream));
     drop(ctx->wf.save);
     ctx->wf = WfParams{};
     // one allocation: 6 state planes, 3 ray planes, 3 result planes (float4 each), the queue (3 ids per slot), the chunks' work items, the control block
@@ -252,11 +253,11 @@ int wf_ensure(gpt_ctx *ctx)
     W.n_paths = n_paths;
     // stack levels a ray of the wide walk may need beyond the LDS ones (3 * depth + 1 in all).  (The hand-scheduled walk addresses
     // level l of a lane as base + column + 256 l with the base moved back by the LDS levels: that much room is kept in front.)
-    int levels = wide ? 3 * ctx->wide_depth + 1 - wf_lds_stack_levels() : 0;
+    int levels = wide ? 3 * ctx->wide_depth + 1 - wf_lds_stack_levels(stream) : 0;
     if (levels < 1) levels = 1;
-    const size_t front = (size_t)64 * wf_lds_stack_levels();
+    const size_t front = (size_t)wf_spill_columns(stream) * wf_lds_stack_levels(stream);
     void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, (front + (size_t)n_blocks * wf_waves_per_block() * 64 * (size_t)levels) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&sp, (front + (size_t)n_blocks * wf_waves_per_block() * wf_spill_columns(stream) * (size_t)levels) * sizeof(uint32_t)));
     ctx->allocs.push_back(sp);
     W.spill = static_cast<uint32_t *>(sp) + front;
     W.spill_levels = (uint32_t)levels;
@@ -267,6 +268,7 @@ int wf_ensure(gpt_ctx *ctx)
     W.save = static_cast<uint32_t *>(sv);
     ctx->wf_blocks = n_blocks;
     ctx->wf_wide = wide;
+    ctx->wf_stream = stream;
     return GPT_OK;
 }
 
@@ -283,7 +285,7 @@ int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
     W.n_items = n_owned * W.n_chunks;
     HIP_TRY(hipMemsetAsync(W.ctrl, 0, sizeof(WfCtrl), ctx->stream));
     HIP_TRY(hipMemsetAsync(W.wave_item, 0xff, (size_t)(W.n_paths / 64u) * sizeof(uint2), ctx->stream));      // no chunk holds an item
-    HIP_TRY(launch_wf_render(P, W, (int)ctx->wf_blocks, ctx->stream));
+    HIP_TRY(launch_wf_render(P, W, (int)ctx->wf_blocks, ctx->wf_stream, ctx->stream));
     return GPT_OK;
 }
 
@@ -644,7 +646,7 @@ int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value)
     else if (n == "vpt_walk_kernel" && (value == 0 || value == 1)) ctx->force_walk = value != 0;
     else if (n == "max_batch" && value >= 1 && value <= 65536) { ctx->max_batch = (uint32_t)value; ctx->max_batch_set = true; }
     else if (n == "chunk_iters" && value >= 0 && value <= 65536) ctx->chunk_override = (uint32_t)value;
-    else if (n == "scheduler" && (value == 0 || value == 1)) ctx->scheduler = (int)value;
+    else if (n == "scheduler" && value >= 0 && value <= 2) ctx->scheduler = (int)value;
     else {
         gpt_set_error("gpt_set_option: unknown option or value out of range: %s = %lld", name, (long long)value);
         return GPT_ERR_INVALID_ARG;
@@ -669,6 +671,7 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "walk_kernel_active") *value = render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0;
     else if (n == "last_batch") *value = ctx->last_batch_cap;
     else if (n == "sample_plane_bytes") *value = (int64_t)ctx->sample_bytes;
+    else if (n == "owned_tiles") *value = ctx->P.n_tiles > ctx->P.rank ? (ctx->P.n_tiles - ctx->P.rank + ctx->P.n_ranks - 1) / ctx->P.n_ranks : 0;
     else if (n == "last_trace_us") *value = (int64_t)(ctx->last_trace_ms * 1000.0);
     else {
         gpt_set_error("gpt_get_option: unknown option %s", name);
@@ -775,7 +778,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     if (by_memory < 1) by_memory = 1;
     // the decoupled scheduler: Path, Ao and the three-ray Volpath, in the reference's order or on the 4-wide tree (work counters
     // come from the counting build of the per-wave kernel)
-    const bool use_wf = ctx->scheduler == 1 && !count && !render_uses_walk_kernel(ctx->P, ctx->force_walk);
+    const bool use_wf = ctx->scheduler >= 1 && !count && !render_uses_walk_kernel(ctx->P, ctx->force_walk);
     ctx->last_wavefront = use_wf;
     if (use_wf) {
         // a sample's plane slot and its number in the batch are 32-bit words of the path state

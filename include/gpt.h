@@ -95,8 +95,14 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
  *   "max_batch"        iterations per path-kernel launch; default 256 x the number of ranks sharing the frame (a rank's sample
  *                      planes cover its own tiles only), always bounded by 16 GiB and by the free device memory
  *   "chunk_iters"      iterations per work item, 0 (default) = cost model
- * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "last_batch", "sample_plane_bytes", "last_trace_us" (kernel
- * time of the last gpt_debug_trace). */
+ *   "scheduler"        0 (default): one persistent kernel, a wave owns 64 paths from their first ray to their last (registers and its own LDS ray
+ *                      pool); 1: the reference's Path loop cut at its Intersect calls (src/pathtracer.cu:905, 942, 960) into a shade phase over
+ *                      path slots and a trace phase over rays, alternating inside persistent workgroups with the path state in HBM, a lane per
+ *                      ray in the trace phase; 2: the same with the trace phase's 4-wide walk as a ray stream (rays in LDS, batches of rays that
+ *                      are all at a wide node or all at a leaf).  Same samples bit for bit in all three; 0 is the fastest on every measured
+ *                      configuration, 1 and 2 do not run the one-ray-at-a-time Volpath kernel nor the counting build.
+ * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "scheduler_active" (the last gpt_render went through the
+ * phases), "traversal_order", "owned_tiles", "last_batch", "sample_plane_bytes", "last_trace_us" (kernel time of the last gpt_debug_trace). */
 int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value);
 int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value);
 

@@ -82,6 +82,26 @@ def test_two_rank_bench_on_one_gpu_gives_the_one_rank_frame():
     assert two["config"]["renderer_options"]["sample_plane_bytes"] * 2 <= one["config"]["renderer_options"]["sample_plane_bytes"] + 64 * 16 * 128
 
 
+def test_eight_rank_bench_on_one_gpu_gives_the_one_rank_frame():
+    """bench.py --gpus 8 as the driver launches it on an 8-GPU node, all eight ranks on GPU 0 (the reduce travels over gloo: RCCL
+    refuses duplicate devices): the film's hash equals the 1-rank run's, every rank allocates an eighth of the sample planes, and
+    the tiles are balanced to one tile - what is left for a real 8-GPU lease to show is RCCL over xGMI itself."""
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-parity", "--no-other-configs", "--no-square"]
+    one = run_bench({}, ["--gpus", "1"] + common)
+    eight = run_bench({"GPT_BENCH_SHARE_GPU": "1"}, ["--gpus", "8"] + common,
+                      launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                                "--master-port", str(free_port())])
+    assert eight["n_gpus"] == 8 and "gloo" in eight["config"]["reduce"] and eight["config"]["all_finite"]
+    assert eight["config"]["accumulator_sha1"] == one["config"]["accumulator_sha1"]
+    ranks = eight["config"]["per_rank"]
+    assert [p["rank"] for p in ranks] == list(range(8))
+    tiles = [p["owned_tiles"] for p in ranks]
+    assert sum(tiles) == one["config"]["per_rank"][0]["owned_tiles"] == 240 * 135 and max(tiles) - min(tiles) <= 1
+    whole = one["config"]["per_rank"][0]["sample_plane_bytes"]
+    for p in ranks:          # a rank's planes hold its own tiles only: an eighth (one tile of slack)
+        assert abs(p["sample_plane_bytes"] * 8 - whole) <= 8 * 64 * 16 * 64, (p, whole)
+
+
 def test_bench_launches_its_own_ranks_when_called_plainly():
     """`python bench.py --gpus 2` with no torch.distributed.run environment around it (the shape of the driver's 1-GPU call)
     starts the two ranks itself instead of refusing: same film as one rank."""

@@ -41,8 +41,10 @@ for which in which_list:
     for mode in modes:
         base = run(ls, mode, spp, 0) if not os.environ.get("GPT_WF_ONE_BATCH") else (1.0, 0.0, "-", 0, 0)
         print(f"WF {which} {mode:9s}{' sbvh' if sbvh else ''} per-wave kernel : {base[0]:8.1f} Msamples/s ({base[1]:7.2f} ms / {spp} iterations) film {base[2]}", flush=True)
-        for n_paths in paths_list:
-            wf = run(ls, mode, spp, 1, n_paths)
-            print(f"WF {which} {mode:9s}{' sbvh' if sbvh else ''} stages {n_paths:8d}: {wf[0]:8.1f} Msamples/s ({wf[1]:7.2f} ms / {spp} iterations) film {wf[2]} "
+        for sched in (1, 2):
+            if sched == 2 and mode != "wide":
+                continue
+            wf = run(ls, mode, spp, sched, 0)
+            print(f"WF {which} {mode:9s}{' sbvh' if sbvh else ''} stages, {'a lane per ray' if sched == 1 else 'ray stream   '}: {wf[0]:8.1f} Msamples/s ({wf[1]:7.2f} ms / {spp} iterations) film {wf[2]} "
                   f"{'EQUAL' if wf[2] == base[2] else 'DIFFERENT'} paths {wf[3]} active {wf[4]} x{wf[0] / base[0]:.2f}", flush=True)
     ls.close()

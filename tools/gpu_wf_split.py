@@ -19,3 +19,11 @@ shade, trace, wait, rounds, chunks, waves = c[:6]
 tot = shade + trace + wait
 print(f"WFSPLIT {which} {mode}: {ms:.2f} ms per batch of {spp} iterations; per wave: shade {shade / tot:.3f}, trace {trace / tot:.3f}, barriers {wait / tot:.3f} of {tot / waves / 1e6:.2f} M cycles; "
       f"{rounds / waves:.1f} rounds per workgroup, {chunks / waves:.1f} chunks shaded per wave ({chunks / rounds:.2f} per round)", flush=True)
+nt, nl, lt, ll, inf = c[6:11]
+if nt + lt:
+    print(f"WFSTREAM {which} {mode}: node trips {nt} with {nl / max(nt, 1):.1f} lanes, leaf trips {lt} with {ll / max(lt, 1):.1f} lanes, {inf / (nt + lt):.1f} rays in flight per trip, "
+          f"{(nt + lt) * 64 / (ls.width * ls.height * spp):.1f} trips per 64 samples", flush=True)
+    pre, wt, proc = c[11:14]
+    if pre + wt + proc:
+        print(f"WFSTREAM {which} {mode}: cycles per trip of a wave: {pre / (nt + lt):.0f} up to the loads, {wt / (nt + lt):.0f} until they are back, {proc / (nt + lt):.0f} the step "
+              f"(trace phase {trace / (nt + lt):.0f} per trip)", flush=True)
