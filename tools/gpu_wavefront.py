@@ -41,7 +41,7 @@ for which in which_list:
     for mode in modes:
         base = run(ls, mode, spp, 0) if not os.environ.get("GPT_WF_ONE_BATCH") else (1.0, 0.0, "-", 0, 0)
         print(f"WF {which} {mode:9s}{' sbvh' if sbvh else ''} per-wave kernel : {base[0]:8.1f} Msamples/s ({base[1]:7.2f} ms / {spp} iterations) film {base[2]}", flush=True)
-        for sched in (1, 2):
+        for sched in ((1, 2) if not os.environ.get("GPT_WF_SCHEDULER") else (int(os.environ["GPT_WF_SCHEDULER"]),)):     # (counter runs: one of them)
             if sched == 2 and mode != "wide":
                 continue
             wf = run(ls, mode, spp, sched, 0)
