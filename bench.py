@@ -451,7 +451,27 @@ def main():
                           "timed": "path-kernel launches, HIP events of the library (gpt_kernel_time)", "launches": n_sq,
                           "wall_clock_value": 1088 * 1080 * 256 / wall / 1e6}
 
-        note("square frame and kernel ray counts done")
+        # "measure config 2 through the new path too and print both".  The decoupled scheduler works on scenes
+        # in global memory; the headline scene through its phases, one 64-iteration launch per leg, film hashes against the timed job's kernel.
+        phases = None
+        if single and not args.no_square:
+            phases = {}
+            for leg, order, sched in (("per-wave kernel, scene in LDS (the timed path)", "reference", 0),
+                                      ("per-wave kernel, 4-wide walk from global memory", "wide", 0),
+                                      ("phases, a lane per ray (scheduler 1), 4-wide walk", "wide", 1),
+                                      ("phases, ray stream (scheduler 2), 4-wide walk", "wide", 2)):
+                with api.Renderer(scene.desc, WIDTH, HEIGHT, EPS, device=local_rank) as rp:
+                    rp.set_traversal_order(order)
+                    rp.set_option("scheduler", sched)
+                    rp.render(cam, 1, SPP_PER_STEP, reset=True)
+                    rp.synchronize()
+                    rp.kernel_time_reset()
+                    rp.render(cam, 1, SPP_PER_STEP, reset=True)
+                    rp.synchronize()
+                    n_p, ms_p = rp.kernel_time()
+                    phases[leg] = {"value": WIDTH * HEIGHT * SPP_PER_STEP / (ms_p * 1e-3) / 1e6, "unit": "Msamples/s", "launch_ms": ms_p / max(1, n_p),
+                                   "accumulator_sha1": hashlib.sha1(rp.read_accum().tobytes()).hexdigest()[:16]}
+        note("square frame, kernel ray counts and the headline through the phases done")
         live, live_err = None, None
         if single and not args.no_counters:
             try:
@@ -524,7 +544,7 @@ def main():
                        "renderer_options": options, "options_set": dict(r.options_set),
                        "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND", "GPT_BENCH_TRY_NATIVE") if os.environ.get(k)}),
                        "reduce": (comm.kind if comm is not None else None), "per_rank": per_rank,
-                       "square_frame": square, "other_configs": others,
+                       "square_frame": square, "headline_through_phases": phases, "other_configs": others,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": roof,
         }

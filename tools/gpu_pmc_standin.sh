@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / TCC counters of one stand-in in one traversal mode (each --pmc set in its own pass, kernel-trace only).
-# usage (GPU box): bash tools/gpu_pmc_standin.sh <tag> <c3|c4|c5> <reference|wide|near> [iterations]
+# usage (GPU box): bash tools/gpu_pmc_standin.sh <tag> <c3|c4|c5> <reference|wide> [iterations]
 TAG=$1; WHICH=${2:-c5}; MODE=${3:-wide}; SPP=${4:-8}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; do

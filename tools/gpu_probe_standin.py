@@ -1,17 +1,17 @@
 """Work counters of the path kernel's counting build on a SURVEY stand-in (c3 / c4 / c5): rays, node visits and triangle tests
 per sample, and how full the wave is in the node and triangle trips of the traversal loop.
-usage (GPU box): python tools/gpu_probe_standin.py c5 [near]"""
+usage (GPU box): python tools/gpu_probe_standin.py c5 [wide]"""
 import sys, tempfile
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import scenes, oracle_lib as ol
 from gpu_pathtracer_amd import api
 which = sys.argv[1] if len(sys.argv) > 1 else "c5"
-near = {"near": True, "wide": "wide"}.get(sys.argv[2], False) if len(sys.argv) > 2 else False
+near = {"wide": "wide"}.get(sys.argv[2], False) if len(sys.argv) > 2 else False
 ls = api.LoadedScene(scenes.write_standin_scene(tempfile.mkdtemp(), which, 1920, 1080))
 W, H = 1920, 1080
 cam = ls.camera
 with api.Renderer(ls.desc, W, H, ls.epsilon) as r:
-    r.set_traversal_order(near)
+    r.set_traversal_order(near or "reference")
     r.enable_counters(True); r.render(cam, 1, 4, reset=True); r.synchronize()
     c = r.read_probe_counters()
     r.enable_counters(False)

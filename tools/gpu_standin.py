@@ -1,4 +1,4 @@
-"""Render one SURVEY stand-in at its full size (for rocprofv3 runs): python tools/gpu_standin.py c5 wide|reference|near [iterations [launches [sbvh]]]"""
+"""Render one SURVEY stand-in at its full size (for rocprofv3 runs): python tools/gpu_standin.py c5 wide|reference [iterations [launches [sbvh]]]"""
 import sys, tempfile
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import scenes

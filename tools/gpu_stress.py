@@ -6,12 +6,12 @@ import scenes, oracle_lib as ol
 from gpu_pathtracer_amd import api
 scene, meta = scenes.stress_scene(1.0, max_depth=16)
 print("stress scene:", len(scene.prims), "triangles,", len(scene.nodes), "nodes", flush=True)
-NEAR = len(sys.argv) > 1 and sys.argv[1] == "near"
-if NEAR: print("traversal order: nearer child first", flush=True)
+NEAR = len(sys.argv) > 1 and sys.argv[1] == "wide"
+if NEAR: print("traversal order: 4-wide walk", flush=True)
 for (W, H, spp) in ((1920, 1080, 16), (3840, 2160, 8)):
     cam = ol.cornell_camera(meta, W, H)
     with api.Renderer(scene.desc, W, H, 0.001) as r:
-        r.set_traversal_order(NEAR)
+        r.set_traversal_order("wide" if NEAR else "reference")
         r.render(cam, 1, 2, reset=True); r.synchronize()
         best = 1e9
         for rep in range(2):
