@@ -469,8 +469,12 @@ def main():
                     rp.render(cam, 1, SPP_PER_STEP, reset=True)
                     rp.synchronize()
                     n_p, ms_p = rp.kernel_time()
+                    film_p = rp.read_accum()
+                    if sched == 0 and order == "reference":
+                        film_ref = film_p
                     phases[leg] = {"value": WIDTH * HEIGHT * SPP_PER_STEP / (ms_p * 1e-3) / 1e6, "unit": "Msamples/s", "launch_ms": ms_p / max(1, n_p),
-                                   "accumulator_sha1": hashlib.sha1(rp.read_accum().tobytes()).hexdigest()[:16]}
+                                   "accumulator_sha1": hashlib.sha1(film_p.tobytes()).hexdigest()[:16],
+                                   "floats_differing_from_the_timed_path": int(np.count_nonzero(film_p != film_ref)), "floats": int(film_p.size)}
         note("square frame, kernel ray counts and the headline through the phases done")
         live, live_err = None, None
         if single and not args.no_counters:
