@@ -2187,7 +2187,7 @@ __device__ __forceinline__ void wf_trace_wide_asm(const DevParams &P, const WfPa
 // Registers beyond those of the trip: v55 lane, v56 address of the slot's column (block + 4 slot), v57 slot; a group of rays moving in:
 // v58 id, v59 slot, v[60:63] direction and interval end, v[64:67] origin, s[86:87] ids on their way, s[88:89] records on their way (one
 // group at a time, one stage per trip: id -> record -> 1 / direction and the slot's rows).  s96 / s97 / s98 entries of the three lists,
-// s70 s90 s91 s94 s95 as in wf_trace_wide_asm, s99 s100 s71 temporaries.
+// s70 s90 s91 s94 s95 as in wf_trace_wide_asm, s71 s92 s99 temporaries.
 constexpr int kWfsRowBytes = 4 * kWfR;
 constexpr int kWfsRows = 17 + kWfS;
 constexpr int kWfsLists = kWfsRows * kWfsRowBytes;              // byte offset of the three lists
@@ -2374,7 +2374,7 @@ __device__ __forceinline__ void wf_trace_stream_asm(const DevParams &P, const Wf
         "s_min_u32 s99, s97, 64\n"
         "s_sub_u32 s97, s97, s99\n"
         "v_cmp_gt_u32_e64 s[64:65], s99, v55\n"
-        "s_add_u32 s100, s97, %[o_ql]\n"
+        "s_add_u32 s92, s97, %[o_ql]\n"
         "s_mov_b64 s[62:63], 0\n"
         "s_mov_b64 s[60:61], s[64:65]\n"
         "s_branch TS_POPQ_%=\n"
@@ -2382,13 +2382,13 @@ __device__ __forceinline__ void wf_trace_stream_asm(const DevParams &P, const Wf
         "s_min_u32 s99, s96, 64\n"
         "s_sub_u32 s96, s96, s99\n"
         "v_cmp_gt_u32_e64 s[64:65], s99, v55\n"
-        "s_add_u32 s100, s96, %[o_qn]\n"
+        "s_add_u32 s92, s96, %[o_qn]\n"
         "s_mov_b64 s[60:61], 0\n"
         "s_mov_b64 s[62:63], s[64:65]\n"
         "TS_POPQ_%=:\n"
-        "s_add_u32 s100, s100, %[blk]\n"
+        "s_add_u32 s92, s92, %[blk]\n"
         "s_mov_b64 exec, s[64:65]\n"
-        "v_add_u32_e32 v33, s100, v55\n"
+        "v_add_u32_e32 v33, s92, v55\n"
         "ds_read_u8 v57, v33\n"
         "s_waitcnt lgkmcnt(0)\n"
         "v_lshl_add_u32 v56, v57, 2, %[blk]\n"
@@ -2559,7 +2559,7 @@ __device__ __forceinline__ void wf_trace_stream_asm(const DevParams &P, const Wf
           [o_next] "n"(offsetof(WfShared, trace_next)), [o_parked] "n"(offsetof(WfShared, parked))
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-          "s94", "s95", "s96", "s97", "s98", "s99", "s100",
+          "s94", "s95", "s96", "s97", "s98", "s99", "s92",
           "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",
