@@ -804,6 +804,37 @@ def test_wide_traversal_on_the_config5_standin(gpt, standin):
           c["prim_tests"] / c["samples"], "floats that differ from the reference-order film:", n_diff)
 
 
+def test_the_three_schedulers_give_the_same_film(gpt):
+    """gpt_set_option "scheduler": the per-wave kernel (0), the shade / trace phases with a lane per ray (1) and with the ray stream (2) on ONE
+    renderer, switched back and forth between renders (the phases' buffers are built on first use and rebuilt when the trace stage changes),
+    in both traversal orders, Path / Ao / three-ray Volpath, batches cut into several launches: every film is the oracle's bit for bit (the
+    whole suite runs through each scheduler with --gpt-opt scheduler=1 / 2; this is the switching itself)."""
+    fog = st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.3)
+    scene, meta = scenes.zoo_scene(max_depth=9, with_env=True, extra=scenes.random_soup(2500, 11, size=0.25))
+    W, H, spp = 160, 96, 5
+    cam = ol.cornell_camera(meta, W, H)
+    want = {}
+    for integ in ("pt", "ao", "vpt"):
+        if integ == "ao": scene.desc.set_integrator("ao", 0.8)
+        elif integ == "vpt":
+            scene.set_mediums([fog])
+            scene.desc.set_integrator("vpt", 9)
+            cam.medium = 0
+        for order in (0, 2):
+            want[integ, order], _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", order=order)
+        with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+            assert r.get_option("traversal_order") == 2
+            r.set_option("max_batch", 2)
+            for sched, order in ((2, 2), (0, 2), (1, 2), (2, 0), (1, 0), (2, 2), (0, 0)):
+                r.set_option("scheduler", sched)
+                r.set_traversal_order(order)
+                r.render(cam, 1, spp, reset=True)
+                assert r.get_option("scheduler_active") == (1 if sched else 0)
+                assert_bit_exact(r.read_accum(), want[integ, order], f"{integ}, scheduler {sched}, order {order}")
+            with pytest.raises(gpt.GptError):
+                r.set_option("scheduler", 3)
+
+
 def test_renderer_options_are_explicit_and_readable(gpt):
     """Nothing in the library is steered by the environment: options are set by name, refused when unknown or out of range, and
     what the renderer actually does can be read back.  None of them changes the film."""
