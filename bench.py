@@ -132,7 +132,7 @@ STANDINS = {"c3": ("config 3 stand-in: 3 x sphere.obj + cube-subdiv.obj, shaderb
             "c5": ("config 5 stand-in: Cornell walls + dragon + bunny2 + teapot + 9 spheres (248 574 triangles); 3840x2160, depth 16", 8)}
 
 
-def load_standin(which, sbvh=False):
+def load_standin(which, sbvh=False, reference_bvh=False):
     """The stand-in's scene directory is written, loaded through the product loader and removed.  The loader reports its progress
     on stdout like the reference's (parsescene.cpp): that goes to stderr here - stdout carries the one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -143,7 +143,7 @@ def load_standin(which, sbvh=False):
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        return api.LoadedScene(standins.write_standin_scene(d, which), sbvh=sbvh)      # (the loader copies everything it reads)
+        return api.LoadedScene(standins.write_standin_scene(d, which), sbvh=sbvh, reference_bvh=reference_bvh)      # (the loader copies everything it reads)
     finally:
         os.dup2(saved, 1)
         os.close(saved)
@@ -161,11 +161,11 @@ def counter_child(which="c2", mode="reference"):
             r.render(cam, SPP_PER_STEP + 1, SPP_PER_STEP, reset=False)
             r.synchronize()
         return
-    ls = load_standin(which, sbvh=mode.startswith("sbvh"))
+    ls = load_standin(which, sbvh=mode.startswith("sbvh"), reference_bvh=mode.startswith("reference"))
     spp = STANDINS[which][1]
     with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-        if mode == "reference":
-            r.set_traversal_order("reference")          # ("default" and "sbvh+default": what gpt_begin chose)
+        if mode == "reference_tree+reference_order":
+            r.set_traversal_order("reference")          # (the other legs: what gpt_begin chose)
         r.render(ls.camera, 1, spp, reset=True)
         r.render(ls.camera, spp + 1, spp, reset=False)
         r.synchronize()
@@ -221,22 +221,24 @@ def live_counters():
 
 
 def standin_leg(api, which, counters=True):
-    """One BASELINE stand-in at full size, three legs, each one launch timed with the library's HIP events:
-      "default"       what a caller gets who loads the scene and calls gpt_begin / gpt_render and nothing else: the reference builder's
-                      tree, walked in the order gpt_begin picks (the 4-wide walk for every scene that does not fit LDS)
-      "reference"     the same tree in the reference's own traversal order (opt-in: gpt_set_traversal_order)
-      "sbvh+default"  the split BVH (loader flag GPT_LOAD_SBVH) in gpt_begin's order
-    and for "default" and "sbvh+default" VALU-issue fraction, lanes and HBM-side traffic from rocprofv3 passes inside this run (SQ,
+    """One BASELINE stand-in at full size, four legs, each one launch timed with the library's HIP events:
+      "default"                         what a caller gets who calls gpt_scene_load, gpt_begin, gpt_render and nothing else: the loader's tree (the
+                                        reference builder's unless it has oversized leaves - include/gpt.h) in the order gpt_begin picks (the 4-wide
+                                        walk for every scene that does not fit LDS)
+      "reference_tree+wide"             GPT_LOAD_REFERENCE_BVH: the reference builder's tree whatever it is, gpt_begin's order
+      "reference_tree+reference_order"  ... in the reference's own traversal order (gpt_set_traversal_order)
+      "sbvh+wide"                       GPT_LOAD_SBVH: the split tree, gpt_begin's order
+    and for "default" and "reference_tree+wide" VALU-issue fraction, lanes and HBM-side traffic from rocprofv3 passes inside this run (SQ,
     FETCH_SIZE, WRITE_SIZE: each in its own pass)."""
     import numpy as np
     label, spp = STANDINS[which]
     out = {"workload": label, "iterations_per_launch": spp, "legs": {}}
     film = {}
-    for leg in ("default", "reference", "sbvh+default"):
-        ls = load_standin(which, sbvh=leg.startswith("sbvh"))
+    for leg in ("default", "reference_tree+wide", "reference_tree+reference_order", "sbvh+wide"):
+        ls = load_standin(which, sbvh=leg.startswith("sbvh"), reference_bvh=leg.startswith("reference"))
         n_samples = ls.width * ls.height * spp
         with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-            if leg == "reference":
+            if leg == "reference_tree+reference_order":
                 r.set_traversal_order("reference")
             r.render(ls.camera, 1, spp, reset=True)             # same call as the timed one: the sample planes exist afterwards
             r.synchronize()
@@ -255,12 +257,12 @@ def standin_leg(api, which, counters=True):
                                 "accumulator_sha1": hashlib.sha1(film[leg].tobytes()).hexdigest()[:16]}
         ls.close()
     # against the reference order on the reference's tree: equal films except where two hits tie within rounding (include/gpt_wide_bvh.h)
-    b = film["reference"].reshape(-1, 3).astype(np.float64)
-    for leg in ("default", "sbvh+default"):
+    b = film["reference_tree+reference_order"].reshape(-1, 3).astype(np.float64)
+    for leg in ("default", "reference_tree+wide", "sbvh+wide"):
         a = film[leg].reshape(-1, 3).astype(np.float64)
-        out["legs"][leg]["vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film[leg] != film["reference"])), "floats": int(film[leg].size),
+        out["legs"][leg]["vs_reference_order"] = {"floats_differing": int(np.count_nonzero(film[leg] != film["reference_tree+reference_order"])), "floats": int(film[leg].size),
                                                   "rel_rms": [float(x) for x in np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))], "tolerance": 1e-4}
-    for leg in (("default", "sbvh+default") if counters else ()):
+    for leg in (("default", "reference_tree+wide") if counters else ()):
         work = tempfile.mkdtemp(prefix="gpt_pmc_")
         try:
             sq, _ = rocprof_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],

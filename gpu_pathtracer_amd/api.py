@@ -169,10 +169,12 @@ def camera_init(position, lookat, up=(0, 1, 0), res=(512, 512), fov=60.0, apertu
 class LoadedScene:
     """gpt_scene_load: LoadScene + InitScene of the reference (src/parsescene.cpp:45, src/main.cpp:261-278)."""
 
-    def __init__(self, json_path, use_bvh_cache=False, sbvh=False):
+    def __init__(self, json_path, use_bvh_cache=False, sbvh=False, reference_bvh=False):
+        """sbvh: GPT_LOAD_SBVH, reference_bvh: GPT_LOAD_REFERENCE_BVH; neither: the reference builder's tree unless it has oversized leaves (gpt.h)"""
         self.lib = load()
         self.handle = C.c_void_p()
-        check(self.lib.gpt_scene_load_ex(os.fsencode(json_path), (1 if use_bvh_cache else 0) | (2 if sbvh else 0), C.byref(self.handle)))
+        check(self.lib.gpt_scene_load_ex(os.fsencode(json_path), (1 if use_bvh_cache else 0) | (2 if sbvh else 0) | (4 if reference_bvh else 0),
+                                         C.byref(self.handle)))
         self.desc = st.SceneDesc()
         check(self.lib.gpt_scene_get_desc(self.handle, C.byref(self.desc)))
         w, h, eps = C.c_int32(), C.c_int32(), C.c_float()

@@ -90,6 +90,9 @@ public:
     } integrator;
     bool use_bvh_cache = false;          // the reference always uses <scene dir>/bvh.cache; opt-in here
     bool use_sbvh = false;               // GPT_LOAD_SBVH: spatial-split tree instead of the reference's builder
+    bool reference_bvh = false;          // GPT_LOAD_REFERENCE_BVH: the reference's builder whatever tree it makes.  Neither flag: the reference's
+                                         // builder, and the split tree instead when that tree has a leaf of more than 16 primitives (the
+                                         // reference makes ONE leaf of any set whose box is thinner than 1e-4 - bvh.cpp:43 - however large)
 
     Scene();
     void Init(Camera *cam, std::string file);

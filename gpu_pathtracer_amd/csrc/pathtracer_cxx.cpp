@@ -79,6 +79,7 @@ int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out)
     // the reference always reads/writes <scene dir>/bvh.cache (src/bvh.cpp:189-218); here it is opt-in
     s->scene.use_bvh_cache = (flags & GPT_LOAD_BVH_CACHE) != 0;
     s->scene.use_sbvh = (flags & GPT_LOAD_SBVH) != 0;
+    s->scene.reference_bvh = (flags & GPT_LOAD_REFERENCE_BVH) != 0;
     try {                                            // (no exception crosses the C ABI: a file that asks for more memory than there is)
         if (!LoadScene(json_path, s->config, s->scene)) {
             delete s;

@@ -25,6 +25,7 @@
 #include "host_util.h"
 #include "imageio.h"
 #include "pathtracer.h"
+#include "../../include/gpt_wide_bvh.h"
 #include "pt_vec.h"
 
 using pt::V3;
@@ -828,7 +829,25 @@ void Scene::Init(Camera *cam, std::string file)   // scene.h:50-83
     camera = cam;
     if (use_sbvh) bvh.BuildSplit(primitives);
     else if (use_bvh_cache) bvh.LoadOrBuildBVH(primitives, file);
-    else bvh.Build(primitives);
+    else if (reference_bvh) bvh.Build(primitives);
+    else {
+        // The default: the reference's tree unless it has oversized leaves.  bvh.cpp:43 makes ONE leaf of any set of primitives whose box is
+        // thinner than 1e-4 (a tessellated floor, the flat faces of a subdivided cube): every ray that enters that box tests all of them
+        // (the config-3 stand-in: 268 triangle tests per sample against 9 on the split tree, which has no such rule).  Same primitives, same
+        // box and triangle arithmetic either way: the films agree within the 1e-4 bar (tests/test_sbvh.py).
+        std::vector<Primitive> copy = primitives;
+        bvh.Build(primitives);
+        int largest = 0;
+        for (int i = 0; i < bvh.total_nodes; ++i) {
+            const LinearBVHNode &nd = bvh.linear_root[i];
+            if (nd.is_leaf && nd.start >= 0 && nd.end - nd.start + 1 > largest) largest = nd.end - nd.start + 1;
+        }
+        if (largest > GPT_WIDE_LEAF_MAX) {
+            std::printf("Bvh: a leaf of %d primitives, split tree instead\n", largest);
+            bvh.BuildSplit(copy);
+            primitives.clear();
+        }
+    }
     std::printf("Bvh total nodes:%d\n", bvh.total_nodes);
     std::printf("Scene Bounds [%.3f, %.3f, %.3f]-[%.3f, %.3f, %.3f]\n", bvh.root_box.fmin.x, bvh.root_box.fmin.y,
                 bvh.root_box.fmin.z, bvh.root_box.fmax.x, bvh.root_box.fmax.y, bvh.root_box.fmax.z);

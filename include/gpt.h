@@ -242,9 +242,14 @@ int gpt_scene_load(const char *json_path, gpt_scene **out);
  * reference always uses it and silently reuses a stale one; here it is opt-in and carries a content hash. */
 int gpt_scene_load_cached(const char *json_path, int use_bvh_cache, gpt_scene **out);
 /* ... with flags: GPT_LOAD_BVH_CACHE as above; GPT_LOAD_SBVH builds the tree with gpt_sbvh_build (alpha 1e-5, at most 2x the
- * primitives) instead of the reference's builder: same scene, same films up to exactly-equal-distance ties, fewer node visits. */
+ * primitives) instead of the reference's builder: same scene, same films up to exactly-equal-distance ties, fewer node visits;
+ * GPT_LOAD_REFERENCE_BVH builds with the reference's builder (src/bvh.cpp:38-173) whatever tree it makes.  With neither of the two
+ * (gpt_scene_load, gpt_scene_load_cached without a cache) the tree is the reference builder's UNLESS it has a leaf of more than 16
+ * primitives - bvh.cpp:43 makes one leaf of any set whose box is thinner than 1e-4, however large - in which case it is the split
+ * tree (config-3 stand-in: 2.5 -> 3.0 Gsamples/s); every scene the reference ships keeps the reference's tree. */
 #define GPT_LOAD_BVH_CACHE 1
 #define GPT_LOAD_SBVH 2
+#define GPT_LOAD_REFERENCE_BVH 4
 int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out);
 int gpt_scene_get_desc(const gpt_scene *scene, gpt_scene_desc *desc_out);
 int gpt_scene_get_config(const gpt_scene *scene, int32_t *width, int32_t *height, float *epsilon,

@@ -160,8 +160,13 @@ def test_loader_flag_builds_the_split_tree(gpt_host):
     reference's rule that a box thinner than 1e-4 is ONE leaf (bvh.cpp:43: the floor, the cube's faces), which this builder does
     not have - a thirtieth of the triangle tests - and the oracle's film is the reference tree's."""
     path = standins.write_standin_scene(tempfile.mkdtemp(), "c3")
-    ref = gpt_host.LoadedScene(path)
+    ref = gpt_host.LoadedScene(path, reference_bvh=True)
     new = gpt_host.LoadedScene(path, sbvh=True)
+    # with neither flag the loader takes the reference's tree unless it has a leaf of more than 16 primitives: this scene's floor and cube
+    # faces are such leaves (the stand-ins of configs 4 / 5 and every scene the reference ships keep the reference's tree: test_standins.py)
+    auto = gpt_host.LoadedScene(path)
+    assert (auto.desc.n_nodes, auto.desc.n_prims) == (new.desc.n_nodes, new.desc.n_prims) != (ref.desc.n_nodes, ref.desc.n_prims)
+    assert bytes(auto.array("nodes", "n_nodes", np.dtype((np.void, 40)))) == bytes(new.array("nodes", "n_nodes", np.dtype((np.void, 40))))
     assert new.desc.n_prims >= ref.desc.n_prims and new.desc.n_materials == ref.desc.n_materials and new.desc.n_lights == ref.desc.n_lights
     W, H = 96, 54
     res = {}
