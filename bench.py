@@ -252,7 +252,6 @@ def standin_leg(api, which, counters=True):
             film[leg] = r.read_accum()
             out["legs"][leg] = {"value": n_samples / best / 1e3, "unit": "Msamples/s", "launch_ms": best,
                                 "traversal_order": {0: "reference", 2: "wide4"}[r.get_option("traversal_order")],
-                                "scheduler": "stages" if r.get_option("scheduler_active") else "per-wave",
                                 "triangles": int(ls.desc.n_prims), "bvh_nodes": int(ls.desc.n_nodes),
                                 "accumulator_sha1": hashlib.sha1(film[leg].tobytes()).hexdigest()[:16]}
         ls.close()
@@ -453,31 +452,7 @@ def main():
                           "timed": "path-kernel launches, HIP events of the library (gpt_kernel_time)", "launches": n_sq,
                           "wall_clock_value": 1088 * 1080 * 256 / wall / 1e6}
 
-        # "measure config 2 through the new path too and print both".  The decoupled scheduler works on scenes
-        # in global memory; the headline scene through its phases, one 64-iteration launch per leg, film hashes against the timed job's kernel.
-        phases = None
-        if single and not args.no_square:
-            phases = {}
-            for leg, order, sched in (("per-wave kernel, scene in LDS (the timed path)", "reference", 0),
-                                      ("per-wave kernel, 4-wide walk from global memory", "wide", 0),
-                                      ("phases, a lane per ray (scheduler 1), 4-wide walk", "wide", 1),
-                                      ("phases, ray stream (scheduler 2), 4-wide walk", "wide", 2)):
-                with api.Renderer(scene.desc, WIDTH, HEIGHT, EPS, device=local_rank) as rp:
-                    rp.set_traversal_order(order)
-                    rp.set_option("scheduler", sched)
-                    rp.render(cam, 1, SPP_PER_STEP, reset=True)
-                    rp.synchronize()
-                    rp.kernel_time_reset()
-                    rp.render(cam, 1, SPP_PER_STEP, reset=True)
-                    rp.synchronize()
-                    n_p, ms_p = rp.kernel_time()
-                    film_p = rp.read_accum()
-                    if sched == 0 and order == "reference":
-                        film_ref = film_p
-                    phases[leg] = {"value": WIDTH * HEIGHT * SPP_PER_STEP / (ms_p * 1e-3) / 1e6, "unit": "Msamples/s", "launch_ms": ms_p / max(1, n_p),
-                                   "accumulator_sha1": hashlib.sha1(film_p.tobytes()).hexdigest()[:16],
-                                   "floats_differing_from_the_timed_path": int(np.count_nonzero(film_p != film_ref)), "floats": int(film_p.size)}
-        note("square frame, kernel ray counts and the headline through the phases done")
+        note("square frame and kernel ray counts done")
         live, live_err = None, None
         if single and not args.no_counters:
             try:

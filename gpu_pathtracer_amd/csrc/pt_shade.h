@@ -1,5 +1,4 @@
-// pt_shade.h — everything a path evaluates at a surface hit, shared by the render kernels (pt_kernel.hip: the persistent
-// per-wave kernel; pt_wavefront.hip: the shade stage of the decoupled scheduler).  Each function restates the reference lines
+// pt_shade.h — everything a path evaluates at a surface hit, for the render kernels of pt_kernel.hip.  Each function restates the reference lines
 // it names; the operation order is the one oracle/pt_oracle.c follows (bit-exact contract, DESIGN.md "Float contract").
 #pragma once
 

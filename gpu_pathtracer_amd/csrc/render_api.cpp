@@ -28,7 +28,6 @@
 #include "../../include/gpt.h"
 #include "host_util.h"
 #include "pt_layout.h"
-#include "pt_wavefront.h"
 #include "../../include/gpt_traversal.h"
 #include "../../include/gpt_wide_bvh.h"
 
@@ -93,13 +92,6 @@ struct gpt_ctx {
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
     int wide_depth = 0, n_wide = 0;
     std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
-    // the decoupled scheduler (pt_wavefront.h): "scheduler" 0 = persistent per-wave kernel, 1 = shade / trace phases over workgroup pools,
-    // 2 = the same with the wide walk of the trace phase as a ray stream
-    int scheduler = 0;
-    pt::WfParams wf{};                    // device buffers of the phases (allocated by the first render that uses them)
-    uint32_t wf_blocks = 0;               // persistent grid the buffers were sized for
-    bool wf_wide = false, wf_stream = false;
-    bool last_wavefront = false;          // the last gpt_render went through the phases
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
@@ -213,82 +205,6 @@ void thread_nodes(const gpt_bvh_node *nodes, int n, std::vector<DevNode> &out)
     }
 }
 
-
-// ---- the decoupled scheduler's host side (pt_wavefront.h) ---------------------------------------------------------
-// Buffers of the persistent shade / trace kernel: one pool of path slots per workgroup of its grid (state, rays and results as
-// float4 planes), the segmented ray-id queue, the wide walk's stack spill space and parked-ray records.
-int wf_ensure(gpt_ctx *ctx)
-{
-    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4, stream = wide && ctx->scheduler == 2;
-    const uint32_t n_blocks = (uint32_t)(std::max(ctx->n_cus, 1) * wf_blocks_per_cu(ctx->P.integrator, wide, stream));
-    const uint32_t n_paths = n_blocks * (uint32_t)wf_paths_per_block();
-    if (ctx->wf.s0 && ctx->wf.n_paths == n_paths && ctx->wf_blocks == n_blocks && ctx->wf_wide == wide && ctx->wf_stream == stream) return GPT_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    auto drop = [&](void *q) {
-        if (!q) return;
-        (void)hipFree(q);
-        for (auto &a : ctx->allocs) if (a == q) a = nullptr;
-    };
-    drop(ctx->wf.s0);
-    if (ctx->wf.spill) drop(ctx->wf.spill - (size_t)wf_spill_columns(ctx->wf_stream) * wf_lds_stack_levels(ctx->wf_stream));
-    drop(ctx->wf.save);
-    ctx->wf = WfParams{};
-    // one allocation: 6 state planes, 3 ray planes, 3 result planes (float4 each), the queue (3 ids per slot), the chunks' work items, the control block
-    const size_t plane = (size_t)n_paths * sizeof(float4);
-    const size_t n_chunks = n_paths / 64;
-    const size_t bytes = 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_chunks * sizeof(uint2) + 256;
-    void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, bytes));
-    ctx->allocs.push_back(p);
-    HIP_TRY(hipMemset(p, 0, bytes));                 // every slot starts dead (flags = 0)
-    char *c = static_cast<char *>(p);
-    WfParams &W = ctx->wf;
-    W.s0 = reinterpret_cast<float4 *>(c); W.s1 = reinterpret_cast<float4 *>(c + plane); W.s2 = reinterpret_cast<float4 *>(c + 2 * plane);
-    W.s3 = reinterpret_cast<float4 *>(c + 3 * plane); W.s4 = reinterpret_cast<float4 *>(c + 4 * plane); W.org = reinterpret_cast<float4 *>(c + 5 * plane);
-    W.ray = reinterpret_cast<float4 *>(c + 6 * plane);
-    W.hit = reinterpret_cast<float4 *>(c + 9 * plane);
-    W.rayq = reinterpret_cast<uint32_t *>(c + 12 * plane);
-    W.wave_item = reinterpret_cast<uint2 *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t));
-    W.ctrl = reinterpret_cast<WfCtrl *>(c + 12 * plane + (size_t)3 * n_paths * sizeof(uint32_t) + n_chunks * sizeof(uint2));
-    W.n_paths = n_paths;
-    // stack levels a ray of the wide walk may need beyond the LDS ones (3 * depth + 1 in all).  (The hand-scheduled walk addresses
-    // level l of a lane as base + column + 256 l with the base moved back by the LDS levels: that much room is kept in front.)
-    int levels = wide ? 3 * ctx->wide_depth + 1 - wf_lds_stack_levels(stream) : 0;
-    if (levels < 1) levels = 1;
-    const size_t front = (size_t)wf_spill_columns(stream) * wf_lds_stack_levels(stream);
-    void *sp = nullptr;
-    HIP_TRY(hipMalloc(&sp, (front + (size_t)n_blocks * wf_waves_per_block() * wf_spill_columns(stream) * (size_t)levels) * sizeof(uint32_t)));
-    ctx->allocs.push_back(sp);
-    W.spill = static_cast<uint32_t *>(sp) + front;
-    W.spill_levels = (uint32_t)levels;
-    // one record per lane of the grid for a ray that is parked between two rounds
-    void *sv = nullptr;
-    HIP_TRY(hipMalloc(&sv, (size_t)n_blocks * wf_waves_per_block() * 64 * kWfSaveDwords * sizeof(uint32_t)));
-    ctx->allocs.push_back(sv);
-    W.save = static_cast<uint32_t *>(sv);
-    ctx->wf_blocks = n_blocks;
-    ctx->wf_wide = wide;
-    ctx->wf_stream = stream;
-    return GPT_OK;
-}
-
-// One batch: ONE launch of the persistent kernel; every workgroup runs its own rounds until the work items are used up and its pool is empty.
-int wf_render_batch(gpt_ctx *ctx, const DevParams &P)
-{
-    WfParams W = ctx->wf;
-    // work items = (tile, chunk of iterations): small enough that the waves which claimed the last ones do not keep the batch
-    // waiting (an item of 64 x 4 samples is ~20 rounds of one wave), large enough that claims are rare (one atomic per item)
-    const uint32_t n_owned = (uint32_t)(P.plane >> 6);
-    W.item_iters = P.iter_count < 4u ? P.iter_count : 4u;
-    W.n_chunks = (P.iter_count + W.item_iters - 1u) / W.item_iters;
-    if ((uint64_t)n_owned * W.n_chunks > 0xfffffff0ull) { gpt_set_error("gpt_render: too many work items in one batch"); return GPT_ERR_INVALID_ARG; }
-    W.n_items = n_owned * W.n_chunks;
-    HIP_TRY(hipMemsetAsync(W.ctrl, 0, sizeof(WfCtrl), ctx->stream));
-    HIP_TRY(hipMemsetAsync(W.wave_item, 0xff, (size_t)(W.n_paths / 64u) * sizeof(uint2), ctx->stream));      // no chunk holds an item
-    HIP_TRY(launch_wf_render(P, W, (int)ctx->wf_blocks, ctx->wf_stream, ctx->stream));
-    return GPT_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -312,7 +228,8 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     }
     // traversal cursors are 32-bit byte offsets into the packed node / triangle arrays (pt_layout.h)
     if ((int64_t)scene->n_nodes * (int64_t)sizeof(DevNode) > INT32_MAX || (int64_t)scene->n_prims * (int64_t)sizeof(DevTri) > INT32_MAX) {
-        gpt_set_error("gpt_begin: scene too large (%d nodes, %d primitives; limits 7456540 / 44739242)", scene->n_nodes, scene->n_prims);
+        gpt_set_error("gpt_begin: scene too large (%d nodes, %d primitives; limits %d / %d)", scene->n_nodes, scene->n_prims,
+                      (int)(INT32_MAX / (int64_t)sizeof(DevNode)), (int)(INT32_MAX / (int64_t)sizeof(DevTri)));
         return GPT_ERR_UNSUPPORTED;
     }
     for (int i = 0; i < scene->n_prims; ++i) {
@@ -600,8 +517,13 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.plane = 0;                                   // set per gpt_render call: 64 slots per owned tile
     P.counters = ctx->counters;
     if (hipDeviceSynchronize() != hipSuccess) { gpt_set_error("gpt_begin: device sync failed"); return fail(GPT_ERR_HIP); }
-    // the default traversal order (include/gpt_traversal.h): the 4-wide tree for every scene that does not fit LDS
-    if ((rc = gpt_set_traversal_order(ctx, GPT_TRAVERSAL_AUTO)) != GPT_OK) return fail(rc);
+    // the default traversal order (include/gpt_traversal.h): the 4-wide tree for every scene that does not fit LDS.  If the wide tree
+    // cannot be uploaded (allocation failure, more than 4 GB) the scene still renders in the reference's order with what is allocated.
+    if ((rc = gpt_set_traversal_order(ctx, GPT_TRAVERSAL_AUTO)) != GPT_OK) {
+        (void)hipGetLastError();                   // clear the sticky allocation error
+        ctx->wide_ok = false;
+        ctx->P.traversal = GPT_TRAVERSAL_REFERENCE;
+    }
     *out = ctx;
     return GPT_OK;
 }
@@ -646,7 +568,6 @@ int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value)
     else if (n == "vpt_walk_kernel" && (value == 0 || value == 1)) ctx->force_walk = value != 0;
     else if (n == "max_batch" && value >= 1 && value <= 65536) { ctx->max_batch = (uint32_t)value; ctx->max_batch_set = true; }
     else if (n == "chunk_iters" && value >= 0 && value <= 65536) ctx->chunk_override = (uint32_t)value;
-    else if (n == "scheduler" && value >= 0 && value <= 2) ctx->scheduler = (int)value;
     else {
         gpt_set_error("gpt_set_option: unknown option or value out of range: %s = %lld", name, (long long)value);
         return GPT_ERR_INVALID_ARG;
@@ -662,10 +583,7 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "vpt_walk_kernel") *value = ctx->force_walk ? 1 : 0;
     else if (n == "max_batch") *value = ctx->max_batch;
     else if (n == "chunk_iters") *value = ctx->chunk_override;
-    else if (n == "scheduler") *value = ctx->scheduler;
-    else if (n == "wf_paths") *value = ctx->wf.n_paths;
     else if (n == "traversal_order") *value = ctx->P.traversal;
-    else if (n == "scheduler_active") *value = ctx->last_wavefront ? 1 : 0;
     // read-only: what the renderer actually does with the current scene and settings
     else if (n == "lds_scene_active") *value = (ctx->lds_scene && render_scene_fits_lds(ctx->P)) ? 1 : 0;
     else if (n == "walk_kernel_active") *value = render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0;
@@ -776,17 +694,6 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     }
     uint32_t by_memory = (uint32_t)(budget / plane_bytes);
     if (by_memory < 1) by_memory = 1;
-    // the decoupled scheduler: Path, Ao and the three-ray Volpath, in the reference's order or on the 4-wide tree (work counters
-    // come from the counting build of the per-wave kernel)
-    const bool use_wf = ctx->scheduler >= 1 && !count && !render_uses_walk_kernel(ctx->P, ctx->force_walk);
-    ctx->last_wavefront = use_wf;
-    if (use_wf) {
-        // a sample's plane slot and its number in the batch are 32-bit words of the path state
-        const uint64_t by_index = (uint64_t)0xffffffffu / ((uint64_t)n_owned * 64);
-        if (by_index < by_memory) by_memory = by_index < 1 ? 1u : (uint32_t)by_index;
-        int rc = wf_ensure(ctx);
-        if (rc != GPT_OK) return rc;
-    }
     // unless the caller fixed it, a rank that owns 1/N of the tiles takes N times the iterations per launch: the same plane
     // memory and the same work per launch as one GPU with the whole frame, so the fixed cost of a launch stays amortised
     const uint64_t wanted = ctx->max_batch_set ? (uint64_t)ctx->max_batch : (uint64_t)ctx->max_batch * n_ranks;
@@ -863,12 +770,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
             HIP_TRY(hipEventCreate(&ev.second));
         }
         HIP_TRY(hipEventRecord(ev.first, ctx->stream));
-        if (use_wf) {
-            int rc = wf_render_batch(ctx, P);
-            if (rc != GPT_OK) return rc;
-        } else {
-            HIP_TRY(launch_render(P, count, n_blocks, ctx->lds_scene, ctx->force_walk, ctx->stream));
-        }
+        HIP_TRY(launch_render(P, count, n_blocks, ctx->lds_scene, ctx->force_walk, ctx->stream));
         HIP_TRY(hipEventRecord(ev.second, ctx->stream));
         ctx->events.push_back(ev);
         HIP_TRY(launch_output(P, ctx->stream));

@@ -34,7 +34,7 @@ extern "C" {
 
 #define GPT_OK                 0
 #define GPT_ERR_INVALID_ARG   -1
-#define GPT_ERR_UNSUPPORTED   -2   /* integrator other than "pt" / "ao", non-triangle primitive */
+#define GPT_ERR_UNSUPPORTED   -2   /* integrator other than "pt" / "ao" / "vpt", non-triangle primitive, wide tree beyond 4 GB */
 #define GPT_ERR_HIP           -3   /* a HIP runtime call failed (message has file:line) */
 #define GPT_ERR_NO_DEVICE     -4
 #define GPT_ERR_IO            -5
@@ -95,14 +95,7 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
  *   "max_batch"        iterations per path-kernel launch; default 256 x the number of ranks sharing the frame (a rank's sample
  *                      planes cover its own tiles only), always bounded by 16 GiB and by the free device memory
  *   "chunk_iters"      iterations per work item, 0 (default) = cost model
- *   "scheduler"        0 (default): one persistent kernel, a wave owns 64 paths from their first ray to their last (registers and its own LDS ray
- *                      pool); 1: the reference's Path loop cut at its Intersect calls (src/pathtracer.cu:905, 942, 960) into a shade phase over
- *                      path slots and a trace phase over rays, alternating inside persistent workgroups with the path state in HBM, a lane per
- *                      ray in the trace phase; 2: the same with the trace phase's 4-wide walk as a ray stream (rays in LDS, batches of rays that
- *                      are all at a wide node or all at a leaf).  Same samples bit for bit in all three; 0 is the fastest on every measured
- *                      configuration, 1 and 2 do not run the one-ray-at-a-time Volpath kernel nor the counting build.
- * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "scheduler_active" (the last gpt_render went through the
- * phases), "traversal_order", "owned_tiles", "last_batch", "sample_plane_bytes", "last_trace_us" (kernel time of the last gpt_debug_trace). */
+ * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "traversal_order", "owned_tiles", "last_batch", "sample_plane_bytes", "last_trace_us" (kernel time of the last gpt_debug_trace). */
 int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value);
 int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value);
 
@@ -215,7 +208,7 @@ int gpt_bvh_build(const gpt_primitive *prims_in, int32_t n, gpt_primitive *prims
 
 /* The split BVH north_star names (src/sbvh.h is an empty class in the reference; Stich et al., HPG 2009): object splits like the
  * builder above + spatial splits that DUPLICATE the primitives straddling the plane, in the same tree layout, so every
- * traversal (reference order, near-first, 4-wide) and gpt_begin take it as they take the reference's tree.
+ * traversal (reference order, 4-wide) and gpt_begin take it as they take the reference's tree.
  * alpha: a spatial split is considered when the object split's children overlap by more than alpha x the root's surface area
  * (the paper's 1e-5).  prims_out / orig_out hold prims_cap records (n .. 2n in practice; duplication stops when the capacity is
  * used), orig_out[i] = input index of prims_out[i]; nodes_out holds nodes_cap (2 * prims_cap suffices). */

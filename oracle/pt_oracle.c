@@ -369,7 +369,7 @@ static inline int tri_intersect(const gpt_triangle *t, ray_t *ray, isect_t *isec
 
 /* ---- traversal: pathtracer.cu:214-296 ------------------------------------------ */
 /* Traversal order (include/gpt_traversal.h): the reference pushes the right child, then the left one (the left one is visited first). */
-static int g_traversal = GPT_TRAVERSAL_AUTO;       /* include/gpt_traversal.h: the product's default rule */
+static int g_traversal = GPT_TRAVERSAL_REFERENCE;  /* the reference's order unless a test asks for the product's (oracle_set_traversal) */
 static inline void push_children(const gpt_bvh_node *node, int node_idx, int *stack, int *top)
 {
     stack[(*top)++] = node->second_child_offset;
@@ -1784,12 +1784,26 @@ API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *ra
 /* deepest traversal stack of the last GPT_TRAVERSAL_WIDE4 render (the GPU keeps 24 entries per ray in LDS and spills the rest) */
 API int oracle_wide_stack_max(void) { return g_wide_stack_max; }
 
-/* GPT_TRAVERSAL_AUTO (default: the product's rule), GPT_TRAVERSAL_REFERENCE or GPT_TRAVERSAL_WIDE4 for the following calls */
+/* GPT_TRAVERSAL_REFERENCE (the default: this file restates the reference), GPT_TRAVERSAL_WIDE4, or GPT_TRAVERSAL_AUTO = the product's
+ * rule (gpt_begin: the 4-wide tree for every scene that does not fit LDS) for the following calls */
 API int oracle_set_traversal(int mode)
 {
     if (mode != GPT_TRAVERSAL_AUTO && mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_WIDE4) return -1;
     g_traversal = mode;
     return 0;
+}
+
+/* 1 when GPT_TRAVERSAL_AUTO walks this scene on the 4-wide tree (what gpt_begin picks for it), 0 when in the reference's order */
+API int oracle_auto_is_wide(const gpt_scene_desc *desc)
+{
+    const int keep = g_traversal;
+    gpt_wide_node *wide = NULL;
+    int n = 0;
+    g_traversal = GPT_TRAVERSAL_AUTO;
+    scene_wide_tree(desc, &wide, &n);
+    g_traversal = keep;
+    free(wide);
+    return n > 0;
 }
 
 /* counters of the last oracle_render call: node visits, primitive tests, bounce

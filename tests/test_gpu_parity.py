@@ -468,11 +468,7 @@ def test_million_triangle_scene_all_traversal_orders(gpt):
     with gpt.Renderer(scene.desc, W, H, 0.001) as r:
         assert r.get_option("traversal_order") == 2          # (gpt_begin's choice for a scene that does not fit LDS)
         for order in (0, 2):
-            assert lib.oracle_set_traversal(order) == 0
-            try:
-                want, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", threads=threads)
-            finally:
-                lib.oracle_set_traversal(-1)
+            want, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", threads=threads, order=order)
             r.set_traversal_order(order)
             r.render(cam, 1, spp, reset=True)
             films[order] = r.read_accum()
@@ -629,11 +625,7 @@ def wide_both(gpt, scene, cam, W, H, eps, spp, what, threads=None):
     """GPU and oracle in the wide mode: bit-identical; and the wide film against the reference-order film: north_star's bar"""
     lib = ol.load("soft")
     ref_order, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft", threads=threads, order=0)
-    assert lib.oracle_set_traversal(2) == 0
-    try:
-        want, col = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft", threads=threads)
-    finally:
-        lib.oracle_set_traversal(-1)
+    want, col = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft", threads=threads, order=2)
     with gpt.Renderer(scene.desc, W, H, eps) as r:
         r.set_traversal_order("wide")
         r.render(cam, 1, spp, reset=True)
@@ -759,23 +751,15 @@ def test_wide_traversal_stack_spills_past_its_lds_entries(gpt):
     lib = ol.load("soft")
     lib.oracle_wide_stack_max.restype = C.c_int
     wide_both(gpt, scene, cam, W, H, 0.001, spp, "chain")
-    assert lib.oracle_set_traversal(2) == 0
-    try:
-        ol.render(scene, cam, W, H, 0.001, 1, 1, kind="soft")
-        deepest = lib.oracle_wide_stack_max()
-    finally:
-        lib.oracle_set_traversal(-1)
+    ol.render(scene, cam, W, H, 0.001, 1, 1, kind="soft", order=2)
+    deepest = lib.oracle_wide_stack_max()
     assert deepest > 24, deepest
     # a chain deeper than the reference's own 64-entry stack could take: the wide walk still agrees with its oracle (stack entries
     # past the ninth live in the wave's slice of the spill buffer, 3 * depth + 1 <= 256 of them)
     deep = chain_scene(71)
     far_cam = ol.make_camera((0.05, 0.1, 7.5), (0.0, 0.1, 0.0), (0, 1, 0), (W, H), 35.0)
-    assert lib.oracle_set_traversal(2) == 0
-    try:
-        want, _ = ol.render(deep, far_cam, W, H, 0.001, 1, 2, kind="soft")      # (only the wide oracle: the reference-order one has the reference's stack)
-        assert lib.oracle_wide_stack_max() > 64
-    finally:
-        lib.oracle_set_traversal(-1)
+    want, _ = ol.render(deep, far_cam, W, H, 0.001, 1, 2, kind="soft", order=2)      # (only the wide oracle: the reference-order one has the reference's stack)
+    assert lib.oracle_wide_stack_max() > 64
     with gpt.Renderer(deep.desc, W, H, 0.001) as r:
         r.set_traversal_order("wide")
         r.render(far_cam, 1, 2, reset=True)
@@ -804,11 +788,10 @@ def test_wide_traversal_on_the_config5_standin(gpt, standin):
           c["prim_tests"] / c["samples"], "floats that differ from the reference-order film:", n_diff)
 
 
-def test_the_three_schedulers_give_the_same_film(gpt):
-    """gpt_set_option "scheduler": the per-wave kernel (0), the shade / trace phases with a lane per ray (1) and with the ray stream (2) on ONE
-    renderer, switched back and forth between renders (the phases' buffers are built on first use and rebuilt when the trace stage changes),
-    in both traversal orders, Path / Ao / three-ray Volpath, batches cut into several launches: every film is the oracle's bit for bit (the
-    whole suite runs through each scheduler with --gpt-opt scheduler=1 / 2; this is the switching itself)."""
+def test_switching_the_traversal_order_between_renders(gpt):
+    """ONE renderer switched back and forth between the reference order and the 4-wide walk between renders (the wide tree is uploaded on
+    first use), Path / Ao / three-ray Volpath, batches cut into several launches: every film is the oracle's bit for bit in the order
+    that was selected, and an option the library does not have is refused."""
     fog = st.make_medium((0.0014, 0.0025, 0.0142), (0.70, 1.22, 1.90), 0.0, 0.3)
     scene, meta = scenes.zoo_scene(max_depth=9, with_env=True, extra=scenes.random_soup(2500, 11, size=0.25))
     W, H, spp = 160, 96, 5
@@ -825,14 +808,13 @@ def test_the_three_schedulers_give_the_same_film(gpt):
         with gpt.Renderer(scene.desc, W, H, 0.001) as r:
             assert r.get_option("traversal_order") == 2
             r.set_option("max_batch", 2)
-            for sched, order in ((2, 2), (0, 2), (1, 2), (2, 0), (1, 0), (2, 2), (0, 0)):
-                r.set_option("scheduler", sched)
+            for order in (2, 0, 2, 0, 0, 2):
                 r.set_traversal_order(order)
                 r.render(cam, 1, spp, reset=True)
-                assert r.get_option("scheduler_active") == (1 if sched else 0)
-                assert_bit_exact(r.read_accum(), want[integ, order], f"{integ}, scheduler {sched}, order {order}")
+                assert r.get_option("traversal_order") == order
+                assert_bit_exact(r.read_accum(), want[integ, order], f"{integ}, order {order}")
             with pytest.raises(gpt.GptError):
-                r.set_option("scheduler", 3)
+                r.set_option("scheduler", 1)        # round 4's decoupled scheduler is not in the product (tools/variants/)
 
 
 def test_renderer_options_are_explicit_and_readable(gpt):

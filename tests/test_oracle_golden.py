@@ -238,13 +238,9 @@ def test_wide_traversal_agrees_with_the_reference_order():
         auto, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")          # the product's rule: wide unless the scene fits LDS
         small = len(scene.prims) <= 40
         assert (ol.counters("soft")["node_visits"] == c_ref["node_visits"]) == small and auto.tobytes() == ref.tobytes()
-        try:
-            assert lib.oracle_set_traversal(2) == 0
-            wide, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
-            c_wide = ol.counters("soft")
-            again, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", threads=1)
-        finally:
-            lib.oracle_set_traversal(-1)
+        wide, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", order=2)
+        c_wide = ol.counters("soft")
+        again, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", threads=1, order=2)
         assert wide.tobytes() == again.tobytes()
         a, b = wide.reshape(-1, 3).astype(np.float64), ref.reshape(-1, 3).astype(np.float64)
         rms = np.sqrt(((a - b) ** 2).mean(0)) / np.sqrt((b ** 2).mean(0))

@@ -193,11 +193,7 @@ def test_kernel_on_the_split_tree(gpt):
     base, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
     with gpt.Renderer(split.desc, W, H, 0.001) as r:
         for order, name in ((0, "reference"), (2, "wide")):
-            assert lib.oracle_set_traversal(order) == 0
-            try:
-                want, _ = ol.render(split, cam, W, H, 0.001, 1, spp, kind="soft")
-            finally:
-                lib.oracle_set_traversal(-1)
+            want, _ = ol.render(split, cam, W, H, 0.001, 1, spp, kind="soft", order=order)
             r.set_traversal_order(name)
             r.render(cam, 1, spp, reset=True)
             got = r.read_accum()

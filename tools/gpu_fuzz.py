@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle soak: random triangle soups + Cornell parts, random materials, cameras, frame sizes,
 iteration batching, integrator (pt / ao / vpt with random homogeneous and density-grid media, material-less boxes and
-medium-filled meshes), traversal order, tree builder (the reference's or the split BVH), memory path and scheduler; every film must match the oracle bit for bit.
+medium-filled meshes), traversal order, tree builder (the reference's or the split BVH), and memory path; every film must match the oracle bit for bit.
 usage: python tools/gpu_fuzz.py <seconds> [seed]      (run under `timeout`; each case is small)"""
 import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -85,16 +85,9 @@ while time.time() < t_end:
         scene.sb_keep = (sb_prims, sb_nodes)
         scene.desc.prims, scene.desc.n_prims = st.ptr(sb_prims), len(sb_prims)
         scene.desc.nodes, scene.desc.n_nodes = st.ptr(sb_nodes), len(sb_nodes)
-    lib.oracle_set_traversal(order)
     if order == 2 and len(scene.nodes) == 0:
         order = near = 0
-        lib.oracle_set_traversal(0)
-    try:
-        ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft")
-    finally:
-        lib.oracle_set_traversal(-1)
-    sched = int(rng.choice([0, 0, 1, 2]))         # per-wave kernel / shade and trace phases, a lane per ray / ... ray stream (include/gpt.h "scheduler")
-    api.DEFAULT_OPTIONS["scheduler"] = sched
+    ref, _ = ol.render(scene, cam, W, H, eps, 1, spp, kind="soft", order=order)
     api.DEFAULT_OPTIONS["lds_scene"] = 0 if force_global else 1
     api.DEFAULT_OPTIONS["vpt_walk_kernel"] = 1 if force_walk else 0
     with api.Renderer(scene.desc, W, H, eps) as r:
@@ -108,7 +101,7 @@ while time.time() < t_end:
             if k < spp: r.render(cam, k + 1, spp - k, reset=False)
         got = r.read_accum()
     bad = int(np.count_nonzero(got.view(np.uint32) != ref.view(np.uint32)))
-    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} order {order} global {force_global} split {split_tree} scheduler {sched}"
+    tag = f"case {n_cases}: soup {n_soup} tris {len(scene.prims)} depth {depth} {W}x{H} spp {spp} cam {kind} env {with_env} area {with_area} ao {ao} vpt {vpt} media {len(media)} grids {len(grids)} walk {force_walk} order {order} global {force_global} split {split_tree}"
     if bad:
         n_bad += 1
         print("MISMATCH", bad, tag, flush=True)

@@ -1,5 +1,5 @@
 """How much of a stand-in's time is material divergence?  The same geometry, camera and light with EVERY material replaced by one lambertian
-(an upper bound for what sorting paths by material could return; the paths themselves differ, so it is indicative only), both schedulers.
+(an upper bound for what sorting paths by material could return; the paths themselves differ, so it is indicative only).
 python tools/gpu_matdiv.py [c3,c4,c5]"""
 import json, sys, tempfile
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -22,9 +22,8 @@ for which in (sys.argv[1] if len(sys.argv) > 1 else "c5").split(","):
                 else: m.update({"name": keep, "bsdf": "roughconduct", "alphaU": 0.025, "alphaV": 0.025, "eta": [1.0, 1.0, 1.0], "k": [1.0, 1.0, 1.0], "remap": False})
             json.dump(js, open(path, "w"))
         ls = api.LoadedScene(path)
-        for sched in (0, 1):
+        for sched in (0,):
             with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-                r.set_option("scheduler", sched)
                 r.render(ls.camera, 1, 2, reset=True); r.synchronize()
                 best = 1e9
                 for _ in range(2):

@@ -16,9 +16,7 @@ def run(stage):
             scene, meta = scenes.zoo_scene(max_depth=6, extra=scenes.random_soup(3000, 5, size=0.3))
         W, H, spp = 128, 96, 4
         cam = ol.cornell_camera(meta, W, H)
-        assert ol.load("soft").oracle_set_traversal(2) == 0
-        want, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft")
-        ol.load("soft").oracle_set_traversal(-1)
+        want, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", order=2)
         with api.Renderer(scene.desc, W, H, 0.001) as r:
             r.set_option("lds_scene", 0)
             r.set_traversal_order("wide")
