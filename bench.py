@@ -296,6 +296,43 @@ def note(what):
     print(f"[bench {time.perf_counter() - T0:7.1f} s] {what}", file=sys.stderr, flush=True)
 
 
+def volpath_leg(api):
+    import numpy as np
+    """The reference's shipped default scene (scenes/cornell_box/scene.json: "vpt", 17 bounces, a 100 x 100 x 40 density grid in a
+    material-less box, 512 x 512) rebuilt on disk from this repository's fixtures (tests/standins.py: write_smoke_scene; where
+    /root/reference exists tests/test_scene_loader.py shows it loads to the shipped scene bit for bit) and read through the product
+    loader: the one-ray-at-a-time Volpath kernel, one 64-iteration launch by HIP events."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import standins
+    d = tempfile.mkdtemp(prefix="gpt_smoke_")
+    try:
+        ls = api.LoadedScene(standins.write_smoke_scene(d))
+        spp = 64
+        with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
+            r.render(ls.camera, 1, 2, reset=True)
+            r.synchronize()
+            best = None
+            for _ in range(2):
+                r.kernel_time_reset()
+                r.render(ls.camera, 1, spp, reset=True)
+                r.synchronize()
+                n, ms = r.kernel_time()
+                best = ms if best is None else min(best, ms)
+            film = r.read_accum()
+            walk = int(r.get_option("walk_kernel_active"))
+        out = {"workload": "the reference's shipped scenes/cornell_box/scene.json rebuilt from fixtures: Cornell walls + 100x100x40 density grid "
+                           f"(sigmaT 100, albedo 0.9) in a material-less box, {ls.width}x{ls.height}, 17 bounces, ratio tracking, iterMax 2000, "
+                           f"{spp} spp in one launch",
+               "value": ls.width * ls.height * spp / best / 1e3, "unit": "Msamples/s", "launch_ms": best, "walk_kernel": walk,
+               "timed": "path-kernel launch, HIP events of the library (gpt_kernel_time)",
+               "accumulator_sha1": hashlib.sha1(film.tobytes()).hexdigest()[:16],
+               "mean_radiance": [float(x) for x in (film.reshape(-1, 3).astype(np.float64).mean(0) / spp)]}
+        ls.close()
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -505,6 +542,16 @@ def main():
                 except Exception as e:
                     others[which] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 note(f"other_configs {which} done")
+        # Volpath on the shape of the only scene the reference ships complete (scenes/cornell_box/scene.json: 512 x 512,
+        # 17 bounces, a 100 x 100 x 40 density grid with sigmaT = 100 inside a material-less box, ratio tracking, iterMax 2000) - the
+        # one-ray-at-a-time kernel (pt_render_kernel<..., PT_IT_VPT_WALK, ...>), one 64-iteration launch by HIP events
+        volpath = None
+        if single and not args.no_other_configs:
+            try:
+                volpath = volpath_leg(api)
+            except Exception as e:
+                volpath = {"error": f"{type(e).__name__}: {e}"[:300]}
+            note("volpath leg done")
         par = None
         if single and not args.no_parity:
             par = parity_check(api)
@@ -525,7 +572,7 @@ def main():
                        "renderer_options": options, "options_set": dict(r.options_set),
                        "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND", "GPT_BENCH_TRY_NATIVE") if os.environ.get(k)}),
                        "reduce": (comm.kind if comm is not None else None), "per_rank": per_rank,
-                       "square_frame": square, "headline_through_phases": phases, "other_configs": others,
+                       "square_frame": square, "other_configs": others, "volpath": volpath,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": roof,
         }

@@ -169,3 +169,37 @@ def write_standin_scene(directory, which, width=None, height=None):
     return path
 
 
+def write_smoke_scene(directory):
+    """The reference's default scene (scenes/cornell_box/scene.json: Volpath, 17 bounces, a 100 x 100 x 40 density grid in
+    a material-less box, bare Cornell walls) rebuilt on disk from what this repository holds: the wall / light meshes of
+    scenes/cornell_pt (the same geometry), the density grid fixture (tests/golden/reference_density_grid.npz, written back
+    as the text file the loader reads) and the box mesh from its corner coordinates.  Returns the json path.
+    tests/test_scene_loader.py checks, where /root/reference exists, that it loads to the same scene as the shipped file."""
+    import json
+    import shutil
+    src = os.path.join(ROOT, "scenes", "cornell_pt")
+    os.makedirs(os.path.join(directory, "geometry"), exist_ok=True)
+    for name in ("floor", "ceil", "back", "left", "right", "light"):
+        shutil.copy(os.path.join(src, "geometry", name + ".obj"), os.path.join(directory, "geometry", name + ".obj"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_density_grid.npz"))
+    with open(os.path.join(directory, "geometry", "density.d"), "w") as f:
+        f.write("".join("%d.%06d\n" % divmod(int(v), 1000000) for v in g["millionths"]))
+    lo, hi = (-0.63, 0.27, -0.2415), (0.693, 1.593, 0.2415)
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    with open(os.path.join(directory, "geometry", "density_render.obj"), "w") as f:
+        for v in ((x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)):
+            f.write("v %g %g %g\n" % v)
+        f.write("vn -1 0 0\nvn 1 0 0\nvn 0 0 1\nvn 0 0 -1\nvn 0 1 0\nvn 0 -1 0\n")
+        f.write("f 1//4 2//4 3//4 4//4\nf 5//3 6//3 7//3 8//3\nf 8//5 7//5 3//5 4//5\nf 5//6 6//6 2//6 1//6\nf 1//1 5//1 8//1 4//1\nf 6//2 7//2 3//2 2//2\n")
+    js = json.load(open(os.path.join(src, "scene.json")))
+    js.update({"screen_width": 512, "screen_height": 512, "integrator": "vpt", "maxDepth": 17, "epsilon": 0.001})
+    js["medium"] = [{"type": "homogeneous", "sigmaA": [0.0014, 0.0025, 0.0142], "sigmaS": [0.70, 1.22, 1.90], "scale": 25.0, "name": "vol"},
+                    {"type": "heterogeneous", "sigmaA": [10.0, 10.0, 10.0], "sigmaS": [90.0, 90.0, 90.0], "nx": int(g["nx"]), "ny": int(g["ny"]),
+                     "nz": int(g["nz"]), "p0": list(lo), "p1": list(hi), "density": "geometry/density.d", "iterMax": 2000, "name": "hhh"}]
+    js["scene"] = [{"mesh": "geometry/%s.obj" % n, "material": m} for n, m in
+                   (("floor", "General"), ("ceil", "General"), ("back", "General"), ("left", "Left"), ("right", "Right"))]
+    js["scene"].append({"mesh": "geometry/density_render.obj", "inside": "hhh", "outside": ""})
+    path = os.path.join(directory, "scene.json")
+    json.dump(js, open(path, "w"))
+    return path
