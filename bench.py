@@ -297,16 +297,23 @@ def note(what):
 
 
 def volpath_leg(api):
-    import numpy as np
     """The reference's shipped default scene (scenes/cornell_box/scene.json: "vpt", 17 bounces, a 100 x 100 x 40 density grid in a
     material-less box, 512 x 512) rebuilt on disk from this repository's fixtures (tests/standins.py: write_smoke_scene; where
     /root/reference exists tests/test_scene_loader.py shows it loads to the shipped scene bit for bit) and read through the product
     loader: the one-ray-at-a-time Volpath kernel, one 64-iteration launch by HIP events."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import standins
     d = tempfile.mkdtemp(prefix="gpt_smoke_")
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)                 # the loader's progress lines go to stderr: stdout carries the one JSON line
     try:
         ls = api.LoadedScene(standins.write_smoke_scene(d))
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    try:
         spp = 64
         with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
             r.render(ls.camera, 1, 2, reset=True)

@@ -1724,6 +1724,9 @@ constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBa
 #ifndef PT_WIDE_WAVES
 #define PT_WIDE_WAVES 4
 #endif
+#ifndef PT_WALK_PROBE
+#define PT_WALK_PROBE 0
+#endif
 // WIDE: scenes in global memory walked on the 4-wide tree, one lane per ray (GPT_TRAVERSAL_WIDE4, trace_pool_wide<>)
 template <bool COUNT, bool SMALL, int INTEG, bool WIDE = false>
 __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES : (WIDE ? PT_WIDE_WAVES : (SMALL ? PT_SMALL_WAVES : PT_MIN_WAVES))) pt_render_kernel(const DevParams P_in)
@@ -1784,6 +1787,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
     unsigned long long cyc_direct = 0, cyc_hit = 0, cyc_regen = 0, cyc_sub = 0;                                // ... split of cyc_shade
+#if PT_WALK_PROBE      // probe build of the one-ray Volpath kernel (tools/gpu_walk_probe.py): passes / lanes / cycles of its three activities
+    unsigned long long wp_stage_pass = 0, wp_stage_lanes = 0, wp_track_turn = 0, wp_track_lanes = 0, wp_track_steps = 0, wp_track_lane_steps = 0,
+                       wp_cyc_stage = 0, wp_cyc_track = 0;
+#endif
 #define PT_SUBPHASE(acc)                                                                     \
     if (COUNT) {                                                                             \
         const unsigned long long now_ = __builtin_readcyclecounter();                        \
@@ -1886,6 +1893,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     const int n_ready = popc(ballot(busy));
                     int n_track = popc(ballot(job_running));
                     if (n_ready > 0 && (n_ready >= kStepBatch || n_track == 0)) {
+#if PT_WALK_PROBE
+                    const unsigned long long wp_t0 = __builtin_readcyclecounter();
+                    if (COUNT && lane == 0) { wp_stage_pass++; wp_stage_lanes += (unsigned)n_ready; }
+#endif
                     if (busy) {
                         job = kJobNone;
                         for (;;) {
@@ -2246,6 +2257,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                         }
                     }
                     n_track = popc(ballot(job_running));
+#if PT_WALK_PROBE
+                    if (COUNT && lane == 0) wp_cyc_stage += __builtin_readcyclecounter() - wp_t0;
+#endif
                     }
                     {
                         const bool any_ready = __any(busy);           // (only if the stage code was put off)
@@ -2257,6 +2271,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     // of all lanes are walked together, each lane drawing from its own path's generator, for at most
                     // kTrackSteps steps per turn: a longer walk is parked and goes on next round, so that the lanes
                     // whose walks were short can fetch new work in between instead of idling until the longest ends.
+#if PT_WALK_PROBE
+                    const unsigned long long wp_t1 = __builtin_readcyclecounter();
+                    if (COUNT && lane == 0) { wp_track_turn++; wp_track_lanes += (unsigned)popc(ballot(job_running)); }
+#endif
                     if (job_running) {
                         const DevMedium M = P.mediums[job_medium];
                         if (M.type == GPT_MEDIUM_HOMOGENEOUS) {
@@ -2282,6 +2300,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             bool sampled = false, zero = false, done = false;
 #pragma unroll 1
                             for (int step = 0; step < kTrackSteps; ++step) {
+#if PT_WALK_PROBE
+                                if (COUNT) { wp_track_lane_steps++; if (first_active_lane()) wp_track_steps++; }
+#endif
                                 const float l = -gpt_logf(rng_uniform(rng));
                                 if (mode == 3) dist += l * step3;
                                 else dist += l * invMax / sigma;
@@ -2332,6 +2353,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             }
                         }
                     }
+#if PT_WALK_PROBE
+                    if (COUNT && lane == 0) wp_cyc_track += __builtin_readcyclecounter() - wp_t1;
+#endif
                 }
             }
             if (INTEG != PT_IT_VPT_WALK && alive && !waiting) {
@@ -2841,6 +2865,16 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         atomicAdd(&P.counters[3], (unsigned long long)cnt.shadow_rays);
         atomicAdd(&P.counters[4], (unsigned long long)cnt.closest_rays);
         atomicAdd(&P.counters[5], (unsigned long long)cnt.samples);
+#if PT_WALK_PROBE
+        if (INTEG == PT_IT_VPT_WALK) {
+            atomicAdd(&P.counters[6], wp_stage_pass); atomicAdd(&P.counters[7], wp_stage_lanes);
+            atomicAdd(&P.counters[8], wp_track_turn); atomicAdd(&P.counters[9], wp_track_lanes);
+            atomicAdd(&P.counters[10], wp_track_steps); atomicAdd(&P.counters[11], wp_track_lane_steps);
+            atomicAdd(&P.counters[12], wp_cyc_stage); atomicAdd(&P.counters[13], wp_cyc_track);
+            if (lane == 0) { atomicAdd(&P.counters[14], cyc_trace); atomicAdd(&P.counters[15], cyc_shade); }
+            return;
+        }
+#endif
         atomicAdd(&P.counters[6], (unsigned long long)cnt.w_node);
         atomicAdd(&P.counters[7], (unsigned long long)cnt.w_prim);
         atomicAdd(&P.counters[8], (unsigned long long)cnt.w_trip);
