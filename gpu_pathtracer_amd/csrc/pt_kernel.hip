@@ -1040,6 +1040,18 @@ __device__ __forceinline__ void trace_pool_global_asm(unsigned pool_lds, int n_r
 #ifndef PT_WIDE_SC
 #define PT_WIDE_SC ""
 #endif
+// measurement only (does the suspend records' write traffic cost time?): 1 writes every record a second time, to the
+// slice's last stack levels - twice the records' traffic, nothing else changed (profiles/r05/c1_write_traffic.log)
+#ifndef PT_WIDE_SUSP_MIRROR
+#define PT_WIDE_SUSP_MIRROR 0
+#endif
+#if PT_WIDE_SUSP_MIRROR
+#define PT_WIDE_SUSP_MIRROR_TEXT "global_store_dwordx4 v17, v[12:15], %[mirror]" PT_WIDE_SC "\n" "global_store_dwordx4 v17, v[20:23], %[mirror] offset:16" PT_WIDE_SC "\n"
+#define PT_WIDE_SUSP_MIRROR_ARG [mirror] "s"(s_mirror),
+#else
+#define PT_WIDE_SUSP_MIRROR_TEXT
+#define PT_WIDE_SUSP_MIRROR_ARG
+#endif
 // a lane's suspend record lives in the wave's slice of P.wide_stack (the hand-scheduled loop reads it when a drain starts and
 // writes it when the drain ends, both with sc0 sc1: the same wave reads what it wrote, past its L1); "no ray" at kernel start
 __device__ __forceinline__ void wide_init_suspend_record(const DevParams &P, unsigned lane)
@@ -1058,6 +1070,9 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
     const unsigned long long s_nodes = uniform64((unsigned long long)P.wide);
     const unsigned s_trioff = __builtin_amdgcn_readfirstlane(P.wide_tris_off);
     const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
+#if PT_WIDE_SUSP_MIRROR
+    const unsigned long long s_mirror = s_spill + 4ull * (kWideWaveSliceDwords - 512);     // the slice's last, never used stack levels
+#endif
     const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16;
     const unsigned s_stack = s_pool + kWideStackOff * 16 - 768;
     const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
@@ -1667,12 +1682,13 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
         "s_waitcnt vmcnt(0)\n"                             /* (an early fetch must not land after the registers have been handed back) */
         "global_store_dwordx4 v17, v[12:15], %[spill]" PT_WIDE_SC "\n"
         "global_store_dwordx4 v17, v[20:23], %[spill] offset:16" PT_WIDE_SC "\n"
+        PT_WIDE_SUSP_MIRROR_TEXT
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_mov_b64 exec, -1\n"
         :
         : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [spill] "s"(s_spill),
           [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [allow] "s"(s_allow), [vspill] "v"(v_spill), [vsusp] "v"(v_susp),
-          [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
+          PT_WIDE_SUSP_MIRROR_ARG [tstop] "s"(s_tstop), [depth] "n"(kWideStackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
           [leafmin] "n"(PT_WIDE_LEAF_MIN), [nodemin] "n"(PT_WIDE_NODE_MIN)
         : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",

@@ -619,6 +619,45 @@ def test_config5_standin_dragon_bunny_teapot_4k(gpt, standin):
     full_size_properties(gpt, ls, ls.camera, ls.width, ls.height, ls.epsilon, 1, 1024, 411)
 
 
+def test_non_finite_samples_re_add_the_stale_colour_like_the_reference(gpt, standin):
+    """src/pathtracer.cu:1019-1020, 2521-2525: a sample that is not finite leaves kernel_color as it was, and `reset` clears the
+    accumulator but NOT kernel_color - so a pixel whose first sample after a reset is not finite re-adds the last finite sample of
+    the render BEFORE the reset.  The config-5 stand-in produces such samples (about 3 per million: rough-conductor lobes, SURVEY
+    Appendix C).  Hence the same (scene, camera, iterations) gives one film on a fresh context and another on a warmed one - both
+    are the reference's behaviour, and both must be the oracle's bit for bit when it is driven the same way.  (This is why a
+    counter pass on a fresh context and a timing pass after a warm-up print different film hashes: profiles/r04.)  One eighth of
+    the tiles of the 4K frame, in gpt_begin's default order."""
+    ls = standin("c5")
+    W, H, eps = ls.width, ls.height, ls.epsilon
+    threads = min(64, os.cpu_count() or 1)
+    n = W * H * 3
+    kw = dict(kind="soft", rank=0, n_ranks=8, threads=threads)
+    # which pixels start with a non-finite sample: a colour plane full of a sentinel shows through in the accumulator
+    probe, sentinel = np.zeros(n, np.float32), np.full(n, 1000.0, np.float32)
+    ol.render(ls, ls.camera, W, H, eps, 1, 1, reset=True, acc=probe, color=sentinel, **kw)
+    first_bad = probe.reshape(-1, 3).max(1) >= 1000.0
+    assert first_bad.any(), "the stand-in no longer produces a non-finite first sample in this crop: pick another crop"
+    # the oracle, fresh: iterations 1..2; then warmed: iterations 3..4 on top, then reset and 1..2 again with the colour plane kept
+    acc, col = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ol.render(ls, ls.camera, W, H, eps, 1, 2, reset=True, acc=acc, color=col, **kw)
+    fresh_acc, fresh_col = acc.copy(), col.copy()
+    ol.render(ls, ls.camera, W, H, eps, 3, 2, reset=False, acc=acc, color=col, **kw)
+    ol.render(ls, ls.camera, W, H, eps, 1, 2, reset=True, acc=acc, color=col, **kw)
+    warm_acc, warm_col = acc, col
+    differ = (warm_acc != fresh_acc).reshape(-1, 3).any(1)
+    assert differ.any() and not (differ & ~first_bad).any(), "only pixels whose first sample is not finite may depend on the history"
+    with gpt.Renderer(ls.desc, W, H, eps) as r:
+        r.set_tile_owner(0, 8)
+        r.render(ls.camera, 1, 2, reset=True)
+        assert_bit_exact(r.read_accum(), fresh_acc, "fresh context")
+        assert_bit_exact(r.read_color(), fresh_col, "fresh context, last finite sample")
+        r.render(ls.camera, 3, 2, reset=False)
+        r.render(ls.camera, 1, 2, reset=True)
+        assert_bit_exact(r.read_accum(), warm_acc, "warmed context after reset")
+        assert_bit_exact(r.read_color(), warm_col, "warmed context after reset, last finite sample")
+    print("pixels of the crop whose first sample is not finite:", int(first_bad.sum()), "- pixels whose film depends on the history:", int(differ.sum()))
+
+
 # ---- GPT_TRAVERSAL_WIDE4: the 4-wide tree, one lane per ray (include/gpt_wide_bvh.h) ------------------------------------
 
 def wide_both(gpt, scene, cam, W, H, eps, spp, what, threads=None):
