@@ -279,7 +279,7 @@ class Renderer:
         """"reference" / 0: the reference's order on its binary tree; "wide" / 2: the 4-wide tree walked one lane per ray
         (include/gpt_wide_bvh.h); "auto" / -1: gpt_begin's choice again - "wide" for scenes that do not fit LDS, "reference"
         otherwise.  get_option("traversal_order") reads the order in force."""
-        code = {"reference": 0, "wide": 2, "wide8": 3, "auto": -1}.get(order, order)
+        code = {"reference": 0, "wide": 2, "auto": -1}.get(order, order)
         check(self.lib.gpt_set_traversal_order(self.ctx, int(code)))
 
     def set_integrator(self, kind, value):

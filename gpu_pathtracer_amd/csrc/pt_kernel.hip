@@ -40,7 +40,6 @@
 #include "pt_device.h"
 #include "pt_shade.h"
 #include "../../include/gpt_wide_bvh.h"
-#include "../../include/gpt_wide8_bvh.h"
 #include "../../include/gpt_traversal.h"
 
 namespace pt {
@@ -563,261 +562,6 @@ __device__ __forceinline__ void trace_pool_wide(const DevParams &P, float4 *pool
         }
     }
 }
-
-// ---- GPT_TRAVERSAL_WIDE8: one lane per ray on the compressed 8-wide tree (include/gpt_wide8_bvh.h) ----------------------------
-// PROTOTYPE (built with -DPT_WIDE8=1 only: it then REPLACES the 4-wide loop in the WIDE kernels; tools/build_variant.sh wide8).
-// The walk of one ray is the header's (oracle/pt_oracle.c: intersect_wide8): a node trip loads ONE 80-byte record (five
-// dwordx4), tests its eight quantised boxes and leaves a GROUP of hit inner children - visited in ascending slot ^ octant,
-// no sorting - plus a mask of the hit leaves' triangles; a leaf trip tests a WHOLE leaf (<= 4 triangles of 36 bytes).  The
-// stack holds groups (8 bytes, at most one per level): kWide8StackDepth levels in LDS, deeper ones in the wave's slice of
-// P.wide_stack.  Rays suspend and resume across shading rounds through a 16-dword record per lane in that slice.
-#ifndef PT_WIDE8
-#define PT_WIDE8 0
-#endif
-#if PT_WIDE8
-constexpr int kWide8StackDepth = 4;                               // 4 levels x 64 lanes x 8 B = 2 KB of the 2.25 KB the 4-wide stack has
-#ifndef PT_WIDE8_LEAF_MIN
-#define PT_WIDE8_LEAF_MIN 8
-#endif
-__device__ __forceinline__ unsigned *wide8_slice(const DevParams &P)
-{
-    return P.wide_stack + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords;
-}
-__device__ __forceinline__ void wide8_init_suspend_record(const DevParams &P, unsigned lane)
-{
-    volatile unsigned *rec = wide8_slice(P) + 16u * lane;
-    rec[0] = 0xffffffffu;                                         // no ray (the C++ twin keeps the slot in word 0, the hand-scheduled loop in word 3)
-    rec[3] = 0xffffffffu;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-}
-
-template <bool COUNT>
-__device__ __forceinline__ void trace_pool_wide8(const DevParams &P, float4 *pool, int n_rays, Counters &cnt, bool may_stop)
-{
-    const unsigned lane = threadIdx.x & 63u;
-    uint2 *stk = reinterpret_cast<uint2 *>(pool + kWideStackOff) + lane;           // level l of this lane at stk[64 l]
-    unsigned *slice = wide8_slice(P);
-    volatile unsigned *rec = slice + 16u * lane;
-    volatile unsigned *spill = slice + 1024u + lane;                               // level l: spill[128 l], spill[128 l + 64]
-    const char *nodes = reinterpret_cast<const char *>(P.wide);
-    const char *tris = nodes + P.wide_tris_off;
-    const int *prim_of = reinterpret_cast<const int *>(nodes + ((P.wide_tris_off + 36u * ((unsigned)P.n_prims + 4u) + 15u) & ~15u));
-    const float tmin_ray = P.eps;
-    const int tstop = P.n_nodes >= 65536 ? PT_WIDE_STOP_T : PT_WIDE_STOP_T_SMALL;
-
-    int next = 0;                          // wave-uniform: first ray of the fetch order nobody has taken yet
-    int slot = (int)rec[0], any_hit = 0;
-    V3 o = v3(0.f), d = v3(0.f), inv = v3(0.f);
-    float tmax = 0.f;
-    unsigned cur = 0xffffffffu;            // node to test next (index), or none
-    unsigned g_base = 0u, g_bits = 0u;     // the current group: first inner child of its node; imask << 8 | hits (bit = slot ^ oct)
-    unsigned tri_base = 0u, tri_valid = 0u, tri_mask = 0u;
-    unsigned oct = 0u;
-    int sp = 0;
-    int bpos = -1;
-    float bt = 0.f, bb1 = 0.f, bb2 = 0.f;
-    if (slot >= 0) {                       // a ray that was parked when the last drain stopped
-        const float4 r0 = pool[2 * slot], r1 = pool[2 * slot + 1];
-        const int tag = __float_as_int(r1.w);
-        const float4 ro = pool[2 * kPoolSlots + (tag & 255)];
-        any_hit = tag & 256;
-        o = V3{ro.x, ro.y, ro.z}; d = V3{r0.x, r0.y, r0.z}; inv = V3{r1.x, r1.y, r1.z};
-        tmax = __uint_as_float(rec[1]); sp = (int)rec[2]; g_base = rec[3]; g_bits = rec[4]; tri_base = rec[5]; tri_valid = rec[6];
-        tri_mask = rec[7]; bpos = (int)rec[8]; bt = __uint_as_float(rec[9]); bb1 = __uint_as_float(rec[10]); bb2 = __uint_as_float(rec[11]);
-        cur = rec[12];
-        oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
-    }
-
-    for (;;) {
-        const bool has = slot >= 0;
-        const bool fin = has && cur == 0xffffffffu && tri_mask == 0u;
-        const unsigned long long m_has = ballot(has), m_fin = ballot(fin);
-        if (m_fin != 0ull) {
-            if (fin) {       // a miss reports the end of the interval, like the other loops
-                const int prim = bpos < 0 ? -1 : prim_of[bpos];
-                pool[2 * slot + 1] = make_float4(__int_as_float(prim), bpos < 0 ? tmax : bt, bb1, bb2);
-                atomicAnd(reinterpret_cast<unsigned *>(pool + kPendOff) + (slot & 63), ~(1u << (slot >> 6)));
-                slot = -1;
-            }
-        }
-        const unsigned long long m_busy = m_has & ~m_fin;
-        const int n_idle = 64 - popc(m_busy);
-        if (next < n_rays && n_idle >= PT_WIDE_FETCH_T) {
-            // ---- refill: idle lanes take the next rays of the fetch order, in lane order
-            const int nth = next + lane_rank(~m_busy);
-            if (slot < 0 && nth < n_rays) {
-                const int mine = (int)reinterpret_cast<const unsigned short *>(pool + kOrderOff)[nth];
-                const float4 r0 = pool[2 * mine];
-                const float4 r1 = pool[2 * mine + 1];
-                const int tag = __float_as_int(r1.w);
-                const float4 ro = pool[2 * kPoolSlots + (tag & 255)];
-                slot = mine;
-                any_hit = tag & 256;
-                o = V3{ro.x, ro.y, ro.z};
-                d = V3{r0.x, r0.y, r0.z};
-                inv = V3{r1.x, r1.y, r1.z};
-                tmax = r0.w;
-                oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
-                cur = 0u;                  // node 0
-                g_bits = 0u;
-                tri_mask = 0u;
-                sp = 0;
-                bpos = -1;
-                bt = bb1 = bb2 = 0.f;
-            }
-            next += n_idle;
-            continue;
-        }
-        if (m_busy == 0ull) break;
-#ifndef PT_WIDE8_NOSTOP
-        if (next >= n_rays && may_stop && popc(m_busy) <= tstop) break;      // a dry pool with few rays in flight: they are parked
-#endif
-
-        bool leaf = has && !fin && tri_mask != 0u;
-        bool inner = has && !fin && tri_mask == 0u;
-        {
-            const int n_leaf = popc(ballot(leaf)), n_inner = popc(ballot(inner));
-            if (n_leaf < PT_WIDE8_LEAF_MIN && n_inner > 0) leaf = false;                      // the leaves wait
-        }
-        if (COUNT) {
-            const bool any_inner = ballot(inner) != 0ull, any_leaf = ballot(leaf) != 0ull;
-            if (lane == 0u) {
-                cnt.w_trip++;
-                cnt.l_trip += (uint32_t)popc(m_busy);
-                if (any_inner) cnt.w_node++;
-                if (any_leaf) cnt.w_prim++;
-            }
-        }
-        bool pop = false;
-        if (inner) {
-            // ---- a node: eight quantised boxes, gpt_wide8_slab each ---------------------------------
-            const uint4 *np = reinterpret_cast<const uint4 *>(nodes + (size_t)cur * 80u);
-            const uint4 h0 = np[0], h1 = np[1], q0 = np[2], q1 = np[3], q2 = np[4];
-            if (COUNT) cnt.node_visits++;
-            // h0 = {p.x, p.y, p.z, e.x | e.y << 8 | e.z << 16 | imask << 24}, h1 = {child_base, tri_base, valid, pad}
-            // q0 = {qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7]}, q1 = {qlo.z.., qlo.z.., qhi.x.., qhi.x..}, q2 = {qhi.y.., qhi.y.., qhi.z.., qhi.z..}
-            const unsigned imask = h0.w >> 24;
-            const float sx = __uint_as_float((h0.w & 255u) << 23) * inv.x, sy = __uint_as_float(((h0.w >> 8) & 255u) << 23) * inv.y,
-                        sz = __uint_as_float(((h0.w >> 16) & 255u) << 23) * inv.z;
-            const float bx = (__uint_as_float(h0.x) - o.x) * inv.x, by = (__uint_as_float(h0.y) - o.y) * inv.y, bz = (__uint_as_float(h0.z) - o.z) * inv.z;
-            // near / far planes by the sign bit of 1 / d (whole words of four children at a time)
-            const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
-            const unsigned nxw[2] = {nx ? q1.z : q0.x, nx ? q1.w : q0.y}, fxw[2] = {nx ? q0.x : q1.z, nx ? q0.y : q1.w};
-            const unsigned nyw[2] = {ny ? q2.x : q0.z, ny ? q2.y : q0.w}, fyw[2] = {ny ? q0.z : q2.x, ny ? q0.w : q2.y};
-            const unsigned nzw[2] = {nz ? q2.z : q1.x, nz ? q2.w : q1.y}, fzw[2] = {nz ? q1.x : q2.z, nz ? q1.y : q2.w};
-            unsigned hit = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int w = k >> 2, sh = 8 * (k & 3);
-                const float tnx = __builtin_fmaf((float)((nxw[w] >> sh) & 255u), sx, bx), tfx = __builtin_fmaf((float)((fxw[w] >> sh) & 255u), sx, bx);
-                const float tny = __builtin_fmaf((float)((nyw[w] >> sh) & 255u), sy, by), tfy = __builtin_fmaf((float)((fyw[w] >> sh) & 255u), sy, by);
-                const float tnz = __builtin_fmaf((float)((nzw[w] >> sh) & 255u), sz, bz), tfz = __builtin_fmaf((float)((fzw[w] >> sh) & 255u), sz, bz);
-                const float t0 = fmax_(fmax_(fmax_(tnx, tny), tnz), 0.0f);
-                const float t1 = fmin_(fmin_(fmin_(tfx, tfy), tfz), tmax);
-                if (!(t0 > t1)) hit |= 1u << k;
-            }
-            // the old group waits on the stack while this node's children are visited
-            if ((g_bits & 255u) != 0u) {
-                if (sp < kWide8StackDepth) stk[64 * sp] = make_uint2(g_base, g_bits);
-                else { spill[128 * sp] = g_base; spill[128 * sp + 64] = g_bits; }
-                ++sp;
-            }
-            // inner hits, permuted to bit (slot ^ oct): three conditional swaps of bit groups
-            unsigned hi = hit & imask;
-            hi = (oct & 1u) ? (((hi & 0xaau) >> 1) | ((hi & 0x55u) << 1)) : hi;
-            hi = (oct & 2u) ? (((hi & 0xccu) >> 2) | ((hi & 0x33u) << 2)) : hi;
-            hi = (oct & 4u) ? (((hi & 0xf0u) >> 4) | ((hi & 0x0fu) << 4)) : hi;
-            g_base = h1.x;
-            g_bits = (imask << 8) | hi;
-            // leaf hits: every hit slot's nibble, restricted to the triangles that exist
-            unsigned sp8 = hit & ~imask;                                   // 8 bits -> one per nibble
-            sp8 = (sp8 | (sp8 << 12)) & 0x000f000fu;
-            sp8 = (sp8 | (sp8 << 6)) & 0x03030303u;
-            sp8 = (sp8 | (sp8 << 3)) & 0x11111111u;
-            tri_base = h1.y;
-            tri_valid = h1.z;
-            tri_mask = (sp8 * 15u) & h1.z;
-            pop = tri_mask == 0u;
-        }
-        if (leaf) {
-            // ---- a leaf: the lowest slot with hit triangles, all of them in order, mesh.h:45-67 each --------------
-            const unsigned s4 = (unsigned)__builtin_ctz(tri_mask) & ~3u;
-            const unsigned nib = (tri_valid >> s4) & 15u;
-            const int first = (int)tri_base + popc((unsigned long long)(tri_valid & ((1u << s4) - 1u)));
-            const int count = popc((unsigned long long)nib);
-            tri_mask &= ~(15u << s4);
-            const float *tp = reinterpret_cast<const float *>(tris + (size_t)first * 36u);
-            float rec9[4][9];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int j = 0; j < 9; ++j) rec9[k][j] = tp[9 * k + j];          // (the copy is padded by four records)
-            bool ended = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < count && !ended) {
-                    if (COUNT) cnt.prim_tests++;
-                    const V3 v1 = V3{rec9[k][0], rec9[k][1], rec9[k][2]};
-                    const V3 e1 = V3{rec9[k][3], rec9[k][4], rec9[k][5]};
-                    const V3 e2 = V3{rec9[k][6], rec9[k][7], rec9[k][8]};
-                    const V3 s1 = cross(d, e2);
-                    const float divisor = dot(s1, e1);
-                    const float invDivisor = 1.0f / divisor;           // == (float)(1.0 / divisor), see trace_pool<>
-                    const V3 s = o - v1;
-                    const float b1 = dot(s, s1) * invDivisor;
-                    const V3 s2 = cross(s, e1);
-                    const float b2 = dot(d, s2) * invDivisor;
-                    const float tt = dot(e2, s2) * invDivisor;
-                    const bool accept = !(fabs_(divisor) < 1e-8f) && !(b1 < 0.0f || b1 > 1.0f) &&
-                                        !(b2 < 0.0f || b1 + b2 > 1.0f) && !(tt < tmin_ray || tt > tmax);
-                    if (accept) {
-                        const int pos = first + k;
-                        if (bpos < 0 || tt < bt || (tt == bt && pos > bpos)) {
-                            bpos = pos;
-                            bt = tt;
-                            bb1 = b1;
-                            bb2 = b2;
-                        }
-                        if (tt < tmax) tmax = tt;                      // (a NaN distance never becomes the interval's end)
-                        ended = any_hit != 0;                          // IntersectP: the first accepted triangle ends the ray
-                    }
-                }
-            }
-            if (ended) {
-                cur = 0xffffffffu;
-                tri_mask = 0u;
-                g_bits = 0u;
-                sp = 0;
-            } else {
-                pop = tri_mask == 0u;
-            }
-        }
-        if (pop) {
-            // ---- the next node: the group's child of lowest slot ^ oct; an empty group is replaced from the stack
-            if ((g_bits & 255u) == 0u && sp > 0) {
-                --sp;
-                if (sp < kWide8StackDepth) { const uint2 e = stk[64 * sp]; g_base = e.x; g_bits = e.y; }
-                else { g_base = spill[128 * sp]; g_bits = spill[128 * sp + 64]; }
-            }
-            if ((g_bits & 255u) != 0u) {
-                const unsigned bit = (unsigned)__builtin_ctz(g_bits);
-                g_bits &= g_bits - 1u;
-                const unsigned sl = bit ^ oct;
-                cur = g_base + (unsigned)popc((unsigned long long)((g_bits >> 8) & ((1u << sl) - 1u)));
-            } else {
-                cur = 0xffffffffu;
-            }
-        }
-    }
-    // ---- the drain ends: a lane's ray (if any) is parked
-    rec[0] = (unsigned)slot;
-    if (slot >= 0) {
-        rec[1] = __float_as_uint(tmax); rec[2] = (unsigned)sp; rec[3] = g_base; rec[4] = g_bits; rec[5] = tri_base; rec[6] = tri_valid;
-        rec[7] = tri_mask; rec[8] = (unsigned)bpos; rec[9] = __float_as_uint(bt); rec[10] = __float_as_uint(bb1); rec[11] = __float_as_uint(bb2);
-        rec[12] = cur;
-    }
-}
-#endif  // PT_WIDE8
 
 // ---- the same loop, hand-scheduled for a scene staged in LDS ---------------------------------------------
 // trace_pool<> above is the specification; this is its instruction-for-instruction twin with the control
@@ -1953,43 +1697,6 @@ __device__ __forceinline__ void trace_pool_wide_asm(unsigned pool_lds, int n_ray
           "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
 }
 
-#if PT_WIDE8
-// ---- trace_pool_wide8<>, hand-scheduled: the loop text is generated (tools/gen_wide8_asm.py -> pt_wide8_loop.inc) ----------
-#ifndef PT_WIDE8_ASM
-#define PT_WIDE8_ASM 1
-#endif
-__device__ __forceinline__ void trace_pool_wide8_asm(unsigned pool_lds, int n_rays, const DevParams &P, unsigned lane, bool may_stop)
-{
-    const unsigned s_pool = __builtin_amdgcn_readfirstlane(pool_lds);
-    const int s_rays = __builtin_amdgcn_readfirstlane(n_rays);
-    const unsigned s_eps = __builtin_amdgcn_readfirstlane(__float_as_uint(P.eps));
-    const unsigned long long s_nodes = uniform64((unsigned long long)P.wide);
-    const unsigned s_trioff = __builtin_amdgcn_readfirstlane(P.wide_tris_off);
-    const unsigned s_primoff = __builtin_amdgcn_readfirstlane((P.wide_tris_off + 36u * ((unsigned)P.n_prims + 4u) + 15u) & ~15u);
-    const unsigned long long s_spill = uniform64((unsigned long long)P.wide_stack);
-    const unsigned s_order = s_pool + kOrderOff * 16, s_pend = s_pool + kPendOff * 16;
-    const unsigned s_stack = s_pool + kWideStackOff * 16;
-    const int s_allow = __builtin_amdgcn_readfirstlane(may_stop ? 1 : 0);
-    const int s_tstop = __builtin_amdgcn_readfirstlane(P.n_nodes >= 65536 ? PT_WIDE_STOP_T : PT_WIDE_STOP_T_SMALL);
-    const unsigned wave_slice = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned)kWideWaveSliceDwords;
-    const unsigned v_spill = (wave_slice + 1024u + lane) * 4u;     // level l of this lane: + 512 l (and + 256 for the group's second word)
-    const unsigned v_susp = (wave_slice + 16u * lane) * 4u;        // this lane's suspend record
-    asm volatile(
-#include "pt_wide8_loop.inc"
-        :
-        : [pool] "s"(s_pool), [rays] "s"(s_rays), [eps] "s"(s_eps), [nodes] "s"(s_nodes), [trioff] "s"(s_trioff), [primoff] "s"(s_primoff),
-          [spill] "s"(s_spill), [order] "s"(s_order), [pend] "s"(s_pend), [stack] "s"(s_stack), [allow] "s"(s_allow), [vspill] "v"(v_spill),
-          [vsusp] "v"(v_susp), [tstop] "s"(s_tstop), [depth] "n"(kWide8StackDepth), [maxbusy] "n"(64 - PT_WIDE_FETCH_T), [org] "n"(2 * kPoolSlots * 16),
-          [leafmin] "n"(PT_WIDE8_LEAF_MIN)
-        : "memory", "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
-          "s74", "s75", "s76", "s77", "s78", "s79", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",
-          "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
-          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37",
-          "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v56", "v57", "v58", "v59");
-}
-#endif
-
 
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4
@@ -2086,11 +1793,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(SMALL ? (int)lds_address(lds_scene) + 32 * P.n_nodes : 32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
-#if PT_WIDE8
-    if (WIDE) wide8_init_suspend_record(P, lane);
-#else
     if (WIDE) wide_init_suspend_record(P, lane);        // trace_pool_wide_asm: a lane's record {entry, stack size, interval end, slot} {best hit}: idle
-#endif
     bool waiting = false;                               // carry: some of this path's rays are still being traced
     // Volpath: the medium the path ray travels in (-1 = none), the one the pending direct-light rays travel in, and
     // whether an occluded light sample poisons the sample (Tr = 0 times a non-finite factor is NaN, pathtracer.cu:1092,1150)
@@ -3124,15 +2827,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 else
                     trace_pool_lds_asm(lds_address(pool), L.n_rays, mem, P.eps);
             } else if (WIDE) {
-#if PT_WIDE8
-                if (COUNT || !PT_WIDE8_ASM) trace_pool_wide8<COUNT>(P, pool, n_new, cnt, !COUNT && n_new > 0);
-                else trace_pool_wide8_asm(lds_address(pool), n_new, P, lane, n_new > 0);
-#else
                 if (COUNT || !PT_WIDE_ASM)      // the counting build runs the C++ twin (it has the counters)
                     trace_pool_wide<COUNT>(P, pool, n_new, cnt);
                 else
                     trace_pool_wide_asm(lds_address(pool), n_new, P, lane, n_new > 0);
-#endif
             } else {
                 GlobalScene mem;
                 mem.nodes = reinterpret_cast<const char *>(P.nodes);
@@ -3301,11 +2999,7 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
         pool[kSuspOff + 2 * lane] = make_float4(__int_as_float(32 * P.n_nodes), __int_as_float(0), __int_as_float(-1), __int_as_float(-1));
         pool[kSuspOff + 2 * lane + 1] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
-#if PT_WIDE8
-    if (WIDE) wide8_init_suspend_record(P, lane);
-#else
     if (WIDE) wide_init_suspend_record(P, lane);
-#endif
     Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)cnt;
     const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = (int)gridDim.x * 4;
@@ -3345,13 +3039,8 @@ __global__ void __launch_bounds__(256, WIDE ? PT_WIDE_WAVES : PT_MIN_WAVES) pt_t
             for (int round = 0;; ++round) {
                 const int fresh = round == 0 ? n_new : 0;
                 if (WIDE) {
-#if PT_WIDE8
-                    if (PT_WIDE8_ASM) trace_pool_wide8_asm(lds_address(pool), fresh, P, lane, fresh > 0);
-                    else trace_pool_wide8<false>(P, pool, fresh, cnt, fresh > 0);
-#else
                     if (PT_WIDE_ASM) trace_pool_wide_asm(lds_address(pool), fresh, P, lane, fresh > 0);
                     else trace_pool_wide<false>(P, pool, fresh, cnt);
-#endif
                 } else {
                     GlobalScene mem;
                     mem.nodes = reinterpret_cast<const char *>(P.nodes);
@@ -3445,16 +3134,13 @@ bool render_scene_fits_lds(const DevParams &P)
     return P.traversal == 0 && gpt_scene_fits_lds(P.n_nodes, P.n_prims, P.n_lights, P.n_materials);
 }
 
-// the wide order the WIDE kernels of this build walk: GPT_TRAVERSAL_WIDE4, or the 8-wide prototype's (-DPT_WIDE8=1)
-int kernel_wide_order() { return PT_WIDE8 ? GPT_TRAVERSAL_WIDE8 : GPT_TRAVERSAL_WIDE4; }
-
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream)
 {
     const bool small = lds_scene && render_scene_fits_lds(P);
     const bool ao = P.integrator == GPT_IT_AO;
 #define PT_LAUNCH(C, S, I) hipLaunchKernelGGL((pt_render_kernel<C, S, I>), dim3(n_blocks), dim3(256), 0, stream, P)
 #define PT_LAUNCH_WIDE(C, I) hipLaunchKernelGGL((pt_render_kernel<C, false, I, true>), dim3(n_blocks), dim3(256), 0, stream, P)
-    if (P.traversal == GPT_TRAVERSAL_WIDE4 || P.traversal == GPT_TRAVERSAL_WIDE8) {
+    if (P.traversal == GPT_TRAVERSAL_WIDE4) {
         if (render_uses_walk_kernel(P, force_walk)) { if (count) PT_LAUNCH_WIDE(true, PT_IT_VPT_WALK); else PT_LAUNCH_WIDE(false, PT_IT_VPT_WALK); }
         else if (P.integrator == GPT_IT_VPT) { if (count) PT_LAUNCH_WIDE(true, GPT_IT_VPT); else PT_LAUNCH_WIDE(false, GPT_IT_VPT); }
         else if (!ao) { if (count) PT_LAUNCH_WIDE(true, GPT_IT_PT); else PT_LAUNCH_WIDE(false, GPT_IT_PT); }
@@ -3490,10 +3176,9 @@ hipError_t launch_trace_rays(const DevParams &P, bool lds_scene, const float4 *r
     const bool small = lds_scene && render_scene_fits_lds(P);
     int n_blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
     // the wide walk's spill stacks are indexed by workgroup: never more workgroups than that buffer has slices
-    const bool wide = P.traversal == GPT_TRAVERSAL_WIDE4 || P.traversal == GPT_TRAVERSAL_WIDE8;
-    if (wide && n_blocks > (int)P.wide_stack_blocks) n_blocks = (int)P.wide_stack_blocks;
+    if (P.traversal == GPT_TRAVERSAL_WIDE4 && n_blocks > (int)P.wide_stack_blocks) n_blocks = (int)P.wide_stack_blocks;
     if (n_blocks < 1) n_blocks = 1;
-    if (wide) hipLaunchKernelGGL((pt_trace_rays_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
+    if (P.traversal == GPT_TRAVERSAL_WIDE4) hipLaunchKernelGGL((pt_trace_rays_kernel<false, true>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
     else if (small) hipLaunchKernelGGL((pt_trace_rays_kernel<true, false>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
     else hipLaunchKernelGGL((pt_trace_rays_kernel<false, false>), dim3(n_blocks), dim3(256), 0, stream, P, rays, n, out);
     return hipGetLastError();

@@ -30,7 +30,6 @@
 #include "pt_layout.h"
 #include "../../include/gpt_traversal.h"
 #include "../../include/gpt_wide_bvh.h"
-#include "../../include/gpt_wide8_bvh.h"
 
 namespace pt {
 hipError_t launch_render(const DevParams &P, bool count, int n_blocks, bool lds_scene, bool force_walk, hipStream_t stream);
@@ -43,7 +42,6 @@ hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out,
 hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream);
 int render_kernel_blocks_per_cu(bool count, bool walk, bool wide);
 bool render_uses_walk_kernel(const DevParams &P, bool force);
-int kernel_wide_order();
 }  // namespace pt
 
 using namespace pt;
@@ -94,13 +92,6 @@ struct gpt_ctx {
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
     int wide_depth = 0, n_wide = 0;
     std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
-    // the compressed 8-wide tree (include/gpt_wide8_bvh.h; prototype: walked by builds with -DPT_WIDE8=1 only)
-    bool wide8_ok = false;
-    int wide8_depth = 0;
-    std::vector<gpt_wide8_node> wide8_host;
-    std::vector<int32_t> wide8_order;         // position in the tree's triangle order -> primitive (BVH order)
-    const void *wide4_dev = nullptr, *wide8_dev = nullptr;
-    uint32_t wide4_tris_off = 0, wide8_tris_off = 0;
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
@@ -362,22 +353,6 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
             ctx->n_wide = n_wide;
         }
     }
-    if (scene->n_nodes > 0 && scene->n_prims < (1 << 27) && kernel_wide_order() == GPT_TRAVERSAL_WIDE8) {
-        const int32_t cap = gpt_wide8_capacity(scene->n_nodes, scene->n_prims);
-        ctx->wide8_host.resize((size_t)cap);
-        ctx->wide8_order.resize((size_t)std::max(scene->n_prims, 1));
-        int32_t depth = 0, n_tris = 0;
-        const int32_t n8 = gpt_wide8_build(scene->nodes, scene->n_nodes, scene->prims, ctx->wide8_host.data(), cap, ctx->wide8_order.data(), &n_tris, &depth);
-        if (n8 > 0 && depth <= GPT_WIDE8_STACK_MAX && n8 < (1 << 24)) {
-            ctx->wide8_host.resize((size_t)n8);
-            ctx->wide8_order.resize((size_t)n_tris);
-            ctx->wide8_ok = true;
-            ctx->wide8_depth = depth;
-        } else {
-            ctx->wide8_host.clear();
-            ctx->wide8_order.clear();
-        }
-    }
     std::vector<DevLight> lights((size_t)scene->n_lights);
     for (int i = 0; i < scene->n_lights; ++i) {
         const gpt_area &a = scene->lights[i];
@@ -625,60 +600,19 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
 
 int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
 {
-    if (!ctx || (order != GPT_TRAVERSAL_AUTO && order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_WIDE4 && order != GPT_TRAVERSAL_WIDE8)) {
+    if (!ctx || (order != GPT_TRAVERSAL_AUTO && order != GPT_TRAVERSAL_REFERENCE && order != GPT_TRAVERSAL_WIDE4)) {
         gpt_set_error("gpt_set_traversal_order: invalid argument");
         return GPT_ERR_INVALID_ARG;
     }
-    if ((order == GPT_TRAVERSAL_WIDE4 || order == GPT_TRAVERSAL_WIDE8) && order != kernel_wide_order()) {
-        gpt_set_error("gpt_set_traversal_order: this build of the kernels walks wide order %d, not %d", kernel_wide_order(), (int)order);
-        return GPT_ERR_UNSUPPORTED;
-    }
-    if (order == GPT_TRAVERSAL_AUTO) {
-        const bool have = kernel_wide_order() == GPT_TRAVERSAL_WIDE8 ? ctx->wide8_ok : ctx->wide_ok;
-        order = (have && !gpt_scene_fits_lds(ctx->P.n_nodes, ctx->P.n_prims, ctx->P.n_lights, ctx->P.n_materials)) ? kernel_wide_order()
-                                                                                                                  : GPT_TRAVERSAL_REFERENCE;
-    }
-    if (order == GPT_TRAVERSAL_WIDE8) {
-        if (!ctx->wide8_ok) {
-            gpt_set_error("gpt_set_traversal_order: the scene has no 8-wide tree (empty scene, or deeper than %d levels)", GPT_WIDE8_STACK_MAX);
-            return GPT_ERR_UNSUPPORTED;
-        }
-        if (!ctx->wide8_dev) {
-            HIP_TRY(hipSetDevice(ctx->device));
-            // ONE allocation: the nodes (80 B), the triangles in the tree's own order as 36-byte records {v1, e1, e2} (padded by four
-            // records: a leaf trip reads four), and the map from that order back to the primitive index
-            const size_t n_tri = ctx->wide8_order.size();
-            const size_t node_bytes = (ctx->wide8_host.size() * sizeof(gpt_wide8_node) + 15) & ~(size_t)15;
-            const size_t tri_bytes = 36 * ((size_t)ctx->P.n_prims + 4);
-            const size_t map_off = (node_bytes + tri_bytes + 15) & ~(size_t)15;
-            const size_t total = map_off + 4 * (n_tri + 4);
-            if (total > (size_t)UINT32_MAX || n_tri != (size_t)ctx->P.n_prims) {
-                gpt_set_error("gpt_set_traversal_order: the 8-wide tree and its triangles exceed 4 GB");
-                return GPT_ERR_UNSUPPORTED;
-            }
-            std::vector<DevTri> tri_host((size_t)ctx->P.n_prims);
-            HIP_TRY(hipMemcpy(tri_host.data(), ctx->P.tris, tri_host.size() * sizeof(DevTri), hipMemcpyDeviceToHost));
-            std::vector<char> blob(total, 0);
-            std::memcpy(blob.data(), ctx->wide8_host.data(), ctx->wide8_host.size() * sizeof(gpt_wide8_node));
-            for (size_t i = 0; i < n_tri; ++i) std::memcpy(blob.data() + node_bytes + 36 * i, &tri_host[(size_t)ctx->wide8_order[i]], 36);
-            std::memcpy(blob.data() + map_off, ctx->wide8_order.data(), 4 * n_tri);
-            void *p = nullptr;
-            HIP_TRY(hipMalloc(&p, total));
-            ctx->allocs.push_back(p);
-            HIP_TRY(hipMemcpy(p, blob.data(), total, hipMemcpyHostToDevice));
-            ctx->wide8_dev = p;
-            ctx->wide8_tris_off = (uint32_t)node_bytes;
-            std::vector<gpt_wide8_node>().swap(ctx->wide8_host);
-        }
-        ctx->P.wide = static_cast<const DevWideNode *>(ctx->wide8_dev);
-        ctx->P.wide_tris_off = ctx->wide8_tris_off;
-    }
+    if (order == GPT_TRAVERSAL_AUTO)
+        order = (ctx->wide_ok && !gpt_scene_fits_lds(ctx->P.n_nodes, ctx->P.n_prims, ctx->P.n_lights, ctx->P.n_materials)) ? GPT_TRAVERSAL_WIDE4
+                                                                                                                         : GPT_TRAVERSAL_REFERENCE;
     if (order == GPT_TRAVERSAL_WIDE4) {
         if (!ctx->wide_ok) {
             gpt_set_error("gpt_set_traversal_order: the scene has no wide tree (empty scene, or deeper than %d wide levels)", (GPT_WIDE_STACK_MAX - 1) / 3);
             return GPT_ERR_UNSUPPORTED;
         }
-        if (!ctx->wide4_dev) {
+        if (!ctx->P.wide) {
             HIP_TRY(hipSetDevice(ctx->device));
             // ONE allocation holds the wide nodes and, behind them, a copy of the triangle records: a trip of the wide loop fetches
             // for its node lanes and its leaf lanes with the same seven instructions, a 32-bit offset per lane from one base
@@ -695,14 +629,10 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
             HIP_TRY(hipMemset(static_cast<char *>(p) + wide_bytes + tri_bytes, 0, 3 * sizeof(DevTri)));
             HIP_TRY(hipMemcpy(p, ctx->wide_host.data(), wide_bytes, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(static_cast<char *>(p) + wide_bytes, ctx->P.tris, tri_bytes, hipMemcpyDeviceToDevice));
-            ctx->wide4_dev = p;
-            ctx->wide4_tris_off = (uint32_t)wide_bytes;
+            ctx->P.wide = static_cast<const DevWideNode *>(p);
+            ctx->P.wide_tris_off = (uint32_t)wide_bytes;
             std::vector<DevWideNode>().swap(ctx->wide_host);
         }
-        ctx->P.wide = static_cast<const DevWideNode *>(ctx->wide4_dev);
-        ctx->P.wide_tris_off = ctx->wide4_tris_off;
-    }
-    if (order == GPT_TRAVERSAL_WIDE4 || order == GPT_TRAVERSAL_WIDE8) {
         if (!ctx->P.wide_stack) {          // spill space of the per-ray stacks: one slice per wave that can be resident
             int bpc = 1;
             for (int w = 0; w < 2; ++w)
@@ -798,7 +728,7 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
     }
     ctx->last_batch_cap = batch_cap;
 
-    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4 || ctx->P.traversal == GPT_TRAVERSAL_WIDE8;
+    const bool wide = ctx->P.traversal == GPT_TRAVERSAL_WIDE4;
     const long resident_waves = (long)ctx->n_cus * (wide ? ctx->blocks_per_cu_wide : ctx->blocks_per_cu)[render_uses_walk_kernel(ctx->P, ctx->force_walk) ? 1 : 0][count ? 1 : 0] * 4;
     for (uint32_t done = 0; done < iter_count; done += batch_cap) {
         DevParams P = ctx->P;

@@ -16,7 +16,6 @@
 
 #define GPT_TRAVERSAL_REFERENCE  0
 #define GPT_TRAVERSAL_AUTO       (-1)     /* gpt_set_traversal_order / oracle_set_traversal: back to the rule below */
-#define GPT_TRAVERSAL_AUTO_WIDE  2        /* the wide order the rule below picks for a scene that does not fit LDS: GPT_TRAVERSAL_WIDE4 */
 
 /* The default order, the same rule in gpt_begin and in the oracle: a scene whose device records fit the 12 KB of LDS the kernels
  * set aside for it (2 float4 per node, 8 per primitive - triangle + shading record -, 6 per light, 18 floats per material) is walked

@@ -68,7 +68,6 @@
 #include "../include/gpt_softmath.h"
 #include "../include/gpt_traversal.h"
 #include "../include/gpt_wide_bvh.h"
-#include "../include/gpt_wide8_bvh.h"
 
 #ifdef ORACLE_SOFTMATH
 #define M_SIN(x)   gpt_sinf(x)
@@ -133,7 +132,6 @@ static inline int is_inf3(f3 c) { return isinf(c.x) || isinf(c.y) || isinf(c.z);
 /* ---- work counters (B_alg terms) ------------------------- */
 typedef struct {
     uint64_t node_visits, prim_tests, bounce_iters, shadow_rays, closest_rays, samples;
-    uint64_t leaf_visits;      /* wide walks: leaves entered (GPT_TRAVERSAL_WIDE8: one trip of the GPU loop each) */
 } counters_t;
 static counters_t g_cnt;
 static _Thread_local counters_t t_cnt;
@@ -287,9 +285,6 @@ typedef struct {
     float eps;
     const gpt_wide_node *wide;    /* GPT_TRAVERSAL_WIDE4: the 4-wide tree (include/gpt_wide_bvh.h); NULL otherwise */
     int n_wide;
-    const gpt_wide8_node *wide8;  /* GPT_TRAVERSAL_WIDE8: the compressed 8-wide tree (include/gpt_wide8_bvh.h) and its triangle order */
-    const int32_t *tri_order8;
-    int n_wide8;
 } scene_t;
 
 /* ---- AABB slab test: bbox.h:77-96 ------------------------------------------ */
@@ -463,7 +458,6 @@ static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any
             cur = sp > 0 ? stack[--sp] : GPT_WIDE_NONE;
         } else {
             const int first = gpt_wide_entry_first(cur), count = gpt_wide_entry_count(cur);
-            t_cnt.leaf_visits++;
             for (int k = 0; k < count; ++k) {          /* in index order, each against the current interval */
                 float tt, b1, b2;
                 t_cnt.prim_tests++;
@@ -487,94 +481,8 @@ static int intersect_wide(const scene_t *sc, ray_t *ray, isect_t *isect, int any
     return 1;
 }
 
-/* ---- GPT_TRAVERSAL_WIDE8: the walk of include/gpt_wide8_bvh.h --------------------------------------------------------
- * One ray at a time what the GPU does one lane per ray: a node trip tests eight quantised boxes (gpt_wide8_slab) and leaves a
- * group of inner children (visited in ascending slot ^ octant) and a mask of leaf triangles; a leaf trip tests one whole leaf
- * with the reference's triangle arithmetic (mesh.h:45-67).  Ties: the larger position in the tree's triangle order. */
-static int intersect_wide8(const scene_t *sc, ray_t *ray, isect_t *isect, int any_hit)
-{
-    struct { uint32_t base; uint32_t imask, hits; } stack[GPT_WIDE8_STACK_MAX + 2], g;
-    int sp = 0;
-    const f3 inv_dir = mk3(1.f / ray->d.x, 1.f / ray->d.y, 1.f / ray->d.z);
-    const float inv[3] = {inv_dir.x, inv_dir.y, inv_dir.z}, org[3] = {ray->o.x, ray->o.y, ray->o.z};
-    int neg[3];
-    uint32_t oct = 0;
-    for (int a = 0; a < 3; ++a) {
-        uint32_t u;
-        memcpy(&u, &inv[a], 4);
-        neg[a] = (int)(u >> 31);
-        oct |= (uint32_t)neg[a] << a;
-    }
-    float tmax = ray->tmax;
-    int best_pos = -1;
-    float best_t = 0.f, best_b1 = 0.f, best_b2 = 0.f;
-    if (sc->n_wide8 <= 0) return 0;
-    g.base = 0; g.imask = 1; g.hits = 1u << oct;                  /* node 0 as slot 0 of a virtual parent: its bit is at 0 ^ oct */
-    uint32_t tri_base = 0, tri_valid = 0, tri_mask = 0;
-    for (;;) {
-        if (tri_mask) {
-            /* ---- a leaf: the lowest slot with hit triangles, all of them, in order */
-            const int s = __builtin_ctz(tri_mask) >> 2;
-            const uint32_t nib = (tri_valid >> (4 * s)) & 15u;
-            const int first = (int)tri_base + __builtin_popcount(tri_valid & ((1u << (4 * s)) - 1u)), count = __builtin_popcount(nib);
-            tri_mask &= ~(15u << (4 * s));
-            t_cnt.leaf_visits++;
-            for (int k = 0; k < count; ++k) {
-                float tt, b1, b2;
-                t_cnt.prim_tests++;
-                if (!tri_test(&sc->d->prims[sc->tri_order8[first + k]].triangle, ray, tmax, &tt, &b1, &b2)) continue;
-                if (best_pos < 0 || tt < best_t || (tt == best_t && first + k > best_pos)) {
-                    best_pos = first + k; best_t = tt; best_b1 = b1; best_b2 = b2;
-                }
-                if (tt < tmax) tmax = tt;              /* (a NaN distance never becomes the interval's end) */
-                if (any_hit) goto done;
-            }
-            continue;
-        }
-        if (!g.hits) {
-            if (sp == 0) break;
-            g = stack[--sp];
-        }
-        /* ---- the group's child of lowest slot ^ oct: a node trip */
-        const int bit = __builtin_ctz(g.hits);
-        g.hits &= g.hits - 1u;
-        const int slot = bit ^ (int)oct;
-        const gpt_wide8_node *node = &sc->wide8[g.base + (uint32_t)__builtin_popcount(g.imask & ((1u << slot) - 1u))];
-        t_cnt.node_visits++;
-        float s3[3], b3[3];
-        for (int a = 0; a < 3; ++a) {
-            uint32_t u = (uint32_t)node->e[a] << 23;
-            float step;
-            memcpy(&step, &u, 4);
-            s3[a] = step * inv[a];
-            b3[a] = (node->p[a] - org[a]) * inv[a];
-        }
-        uint32_t hit = 0;
-        for (int k = 0; k < 8; ++k)
-            if (gpt_wide8_slab(node, k, s3, b3, neg, tmax)) hit |= 1u << k;
-        if (g.hits) stack[sp++] = g;
-        if (sp > g_wide_stack_max) g_wide_stack_max = sp;
-        uint32_t inner = hit & node->imask, perm = 0;
-        for (int k = 0; k < 8; ++k)
-            if ((inner >> k) & 1u) perm |= 1u << (k ^ (int)oct);
-        g.base = node->child_base; g.imask = node->imask; g.hits = perm;
-        uint32_t spread = 0;
-        for (int k = 0; k < 8; ++k)
-            if ((hit >> k) & 1u) spread |= 15u << (4 * k);
-        tri_base = node->tri_base; tri_valid = node->valid; tri_mask = spread & node->valid;
-    }
-done:
-    if (best_pos < 0) return 0;
-    const int prim = sc->tri_order8[best_pos];
-    ray->tmax = best_t;
-    t_hit_prim = prim; t_hit_b1 = best_b1; t_hit_b2 = best_b2;
-    if (isect) fill_isect(&sc->d->prims[prim].triangle, ray, best_t, best_b1, best_b2, isect);
-    return 1;
-}
-
 static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
 {
-    if (sc->wide8) { t_cnt.closest_rays++; return intersect_wide8(sc, ray, isect, 0); }
     if (sc->wide) { t_cnt.closest_rays++; return intersect_wide(sc, ray, isect, 0); }
     int stack[64];
     int top = 0;
@@ -610,7 +518,6 @@ static int intersect_closest(const scene_t *sc, ray_t *ray, isect_t *isect)
 
 static int intersect_any(const scene_t *sc, ray_t *ray)
 {
-    if (sc->wide8) { t_cnt.shadow_rays++; return intersect_wide8(sc, ray, NULL, 1); }
     if (sc->wide) { t_cnt.shadow_rays++; return intersect_wide(sc, ray, NULL, 1); }
     int stack[64];
     int top = 0;
@@ -1750,40 +1657,25 @@ static inline f3 tonemap(f3 color, int filmic)
  * rendered (multi-GPU tile ownership, same rule as gpt_set_tile_owner;
  * rank=0,n_ranks=1 renders everything).
  */
-/* the wide tree of a render / trace call, or none: GPT_TRAVERSAL_WIDE4 / GPT_TRAVERSAL_WIDE8 ask for one (-1 when the scene has none),
- * GPT_TRAVERSAL_AUTO takes gpt_begin's choice for every scene that does not fit LDS and has one (include/gpt_traversal.h) */
-typedef struct { gpt_wide_node *wide; gpt_wide8_node *wide8; int32_t *order8; } trees_t;
-static void free_trees(trees_t *t) { free(t->wide); free(t->wide8); free(t->order8); t->wide = NULL; t->wide8 = NULL; t->order8 = NULL; }
-static int scene_trees(const gpt_scene_desc *desc, scene_t *sc, trees_t *t)
+/* the 4-wide tree of a render / trace call, or none: GPT_TRAVERSAL_WIDE4 asks for it (-1 when the scene has none), GPT_TRAVERSAL_AUTO
+ * takes it for every scene that does not fit LDS and has one - gpt_begin's rule (include/gpt_traversal.h) */
+static int scene_wide_tree(const gpt_scene_desc *desc, gpt_wide_node **out, int *n_out)
 {
-    t->wide = NULL; t->wide8 = NULL; t->order8 = NULL;
-    sc->wide = NULL; sc->n_wide = 0; sc->wide8 = NULL; sc->tri_order8 = NULL; sc->n_wide8 = 0;
-    if (desc->n_nodes <= 0 || g_traversal == GPT_TRAVERSAL_REFERENCE) return 0;
-    const int is_auto = g_traversal == GPT_TRAVERSAL_AUTO;
-    if (is_auto && (desc->n_prims >= (1 << 27) || gpt_scene_fits_lds(desc->n_nodes, desc->n_prims, desc->n_lights, desc->n_materials))) return 0;
-    if (g_traversal == GPT_TRAVERSAL_WIDE8 || (is_auto && GPT_TRAVERSAL_AUTO_WIDE == GPT_TRAVERSAL_WIDE8)) {
-        const int cap = gpt_wide8_capacity(desc->n_nodes, desc->n_prims);
-        int depth = 0, n_tris = 0;
-        t->wide8 = (gpt_wide8_node *)calloc((size_t)cap, sizeof(gpt_wide8_node));
-        t->order8 = (int32_t *)calloc((size_t)(desc->n_prims > 0 ? desc->n_prims : 1), sizeof(int32_t));
-        const int n = gpt_wide8_build(desc->nodes, desc->n_nodes, desc->prims, t->wide8, cap, t->order8, &n_tris, &depth);
-        if (n > 0 && depth <= GPT_WIDE8_STACK_MAX) {
-            sc->wide8 = t->wide8; sc->tri_order8 = t->order8; sc->n_wide8 = n;
-            return 0;
-        }
-        free_trees(t);
-        if (!is_auto) return -1;
-    }
+    *out = NULL;
+    *n_out = 0;
+    const int auto_wide = g_traversal == GPT_TRAVERSAL_AUTO && desc->n_prims < (1 << 27) &&
+                          !gpt_scene_fits_lds(desc->n_nodes, desc->n_prims, desc->n_lights, desc->n_materials);
+    if (!(g_traversal == GPT_TRAVERSAL_WIDE4 || auto_wide) || desc->n_nodes <= 0) return 0;
     const int cap = gpt_wide_capacity(desc->n_nodes, desc->n_prims);
     int depth = 0;
-    t->wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
-    const int n = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, t->wide, cap, &depth);
+    gpt_wide_node *wide = (gpt_wide_node *)calloc((size_t)cap, sizeof(gpt_wide_node));
+    const int n = gpt_wide_build(desc->nodes, desc->n_nodes, desc->prims, wide, cap, &depth);
     if (n <= 0 || 3 * depth + 1 > GPT_WIDE_STACK_MAX) {
-        free_trees(t);
-        return is_auto ? 0 : -1;
+        free(wide);
+        return auto_wide ? 0 : -1;
     }
-    sc->wide = t->wide;
-    sc->n_wide = n;
+    *out = wide;
+    *n_out = n;
     return 0;
 }
 
@@ -1808,9 +1700,12 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
     int filmic = cam->filmic;
     if (n_threads < 1) n_threads = 1;
     memset(&g_cnt, 0, sizeof(g_cnt));
-    trees_t trees;
+    gpt_wide_node *wide = NULL;
+    sc.wide = NULL;
+    sc.n_wide = 0;
     g_wide_stack_max = 0;
-    if (scene_trees(desc, &sc, &trees) < 0) return -3;
+    if (scene_wide_tree(desc, &wide, &sc.n_wide) < 0) return -3;
+    sc.wide = wide;
 
 #pragma omp parallel num_threads(n_threads)
     {
@@ -1849,10 +1744,9 @@ API int oracle_render(const gpt_scene_desc *desc, const gpt_camera *cam, uint32_
             g_cnt.shadow_rays += t_cnt.shadow_rays;
             g_cnt.closest_rays += t_cnt.closest_rays;
             g_cnt.samples += t_cnt.samples;
-            g_cnt.leaf_visits += t_cnt.leaf_visits;
         }
     }
-    free_trees(&trees);
+    free(wide);
     return 0;
 }
 
@@ -1865,8 +1759,11 @@ API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *ra
     sc.d = desc;
     sc.eps = eps;
     memset(&sc.inf, 0, sizeof(sc.inf));
-    trees_t trees;
-    if (scene_trees(desc, &sc, &trees) < 0) return -3;
+    gpt_wide_node *wide = NULL;
+    sc.wide = NULL;
+    sc.n_wide = 0;
+    if (scene_wide_tree(desc, &wide, &sc.n_wide) < 0) return -3;
+    sc.wide = wide;
     if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for num_threads(n_threads) schedule(dynamic, 256)
     for (int i = 0; i < n; ++i) {
@@ -1880,7 +1777,7 @@ API int oracle_trace_rays(const gpt_scene_desc *desc, float eps, const float *ra
         tb_out[3 * (size_t)i + 1] = hit ? t_hit_b1 : 0.f;
         tb_out[3 * (size_t)i + 2] = hit ? t_hit_b2 : 0.f;
     }
-    free_trees(&trees);
+    free(wide);
     return 0;
 }
 
@@ -1891,7 +1788,7 @@ API int oracle_wide_stack_max(void) { return g_wide_stack_max; }
  * rule (gpt_begin: the 4-wide tree for every scene that does not fit LDS) for the following calls */
 API int oracle_set_traversal(int mode)
 {
-    if (mode != GPT_TRAVERSAL_AUTO && mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_WIDE4 && mode != GPT_TRAVERSAL_WIDE8) return -1;
+    if (mode != GPT_TRAVERSAL_AUTO && mode != GPT_TRAVERSAL_REFERENCE && mode != GPT_TRAVERSAL_WIDE4) return -1;
     g_traversal = mode;
     return 0;
 }
@@ -1900,14 +1797,13 @@ API int oracle_set_traversal(int mode)
 API int oracle_auto_is_wide(const gpt_scene_desc *desc)
 {
     const int keep = g_traversal;
-    scene_t sc;
-    trees_t trees;
+    gpt_wide_node *wide = NULL;
+    int n = 0;
     g_traversal = GPT_TRAVERSAL_AUTO;
-    scene_trees(desc, &sc, &trees);
+    scene_wide_tree(desc, &wide, &n);
     g_traversal = keep;
-    const int wide = sc.n_wide > 0 || sc.n_wide8 > 0;
-    free_trees(&trees);
-    return wide;
+    free(wide);
+    return n > 0;
 }
 
 /* counters of the last oracle_render call: node visits, primitive tests, bounce
@@ -1917,7 +1813,6 @@ API void oracle_get_counters(uint64_t out6[6])
     out6[0] = g_cnt.node_visits; out6[1] = g_cnt.prim_tests; out6[2] = g_cnt.bounce_iters;
     out6[3] = g_cnt.shadow_rays; out6[4] = g_cnt.closest_rays; out6[5] = g_cnt.samples;
 }
-API uint64_t oracle_leaf_visits(void) { return g_cnt.leaf_visits; }
 
 /* ---- BVH build: bvh.cpp:38-173 ------------------------------------------------------------------------------ */
 typedef struct { f3 fmin, fmax; } bbox_t;

@@ -9,7 +9,7 @@ import numpy as np
 from gpu_pathtracer_amd import scene_types as st
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-ORACLE_DIR = os.environ.get("ORACLE_DIR_OVERRIDE", os.path.join(ROOT, "oracle"))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 _libs = {}
