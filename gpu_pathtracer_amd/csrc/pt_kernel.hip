@@ -1915,145 +1915,73 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
 #endif
                     if (busy) {
                         job = kJobNone;
-                        for (;;) {
-                            if (stage == kStPath) {
-                                // ---- the path ray came back (pathtracer.cu:1049-1070)
-                                if (!hit) {
-                                    if ((bounces == 0 || specular) && P.inf.isvalid)
-                                        Li += beta * inf_le(P.inf, q.dir_p);
-                                    finish = true;
-                                    busy = false;
-                                    break;
-                                }
-                                stage = kStPathB;
-                                job_sampled = false;
-                                if (medium >= 0) {
-                                    job = kJobSample;
-                                    job_medium = medium;
-                                    job_tmax = res.t_p;
-                                    break;
-                                }
-                                continue;
-                            } else if (stage == kStPathB) {
-                                // ---- ... and its medium has been sampled (:1070-1129)
-                                if (medium >= 0) beta *= job_v;
-                                if (is_black(beta)) {
-                                    finish = true;
-                                    busy = false;
-                                    break;
-                                }
-                                Ray r;
-                                r.o = q.org;
-                                r.d = q.dir_p;
-                                const Hit isect = make_hit(P, r, res.t_p, res.prim_p, res.b1_p, res.b2_p);
-                                const V3 wo = -q.dir_p;
-                                if (job_sampled) {
-                                    // a scattering event inside the medium (:1071-1101): light sample, then its shadow walk
-                                    const DevMedium &M = P.mediums[medium];
-                                    float u = rng_uniform(rng);
-                                    float choicePdf;
-                                    int idx = lookup_light_distribution(P, u, choicePdf);
-                                    bool inf = idx == P.n_lights;
-                                    V3 samplePos = q.org + q.dir_p * job_t;
-                                    float u1x = rng_uniform(rng);
-                                    float u1y = rng_uniform(rng);
-                                    V3 radiance = v3(0.f), lightNor;
-                                    Ray shadowRay;
-                                    shadowRay.o = samplePos;
-                                    shadowRay.d = v3(0.f);
-                                    shadowRay.tmin = P.eps;
-                                    shadowRay.tmax = 0.f;
-                                    float lightPdf = 0.f;
-                                    if (idx >= 0) {
-                                        if (!inf)
-                                            area_sample_light(P.lights[idx], samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
-                                        else
-                                            inf_sample_light(P.inf, samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
-                                    }
-                                    sav_w = medium_phase(M, wo, shadowRay.d);
-                                    sav_rad = radiance;
-                                    sav_den = lightPdf * choicePdf;
-                                    sav_has = !is_black(radiance);
-                                    ctx_scatter = true;
-                                    ctx_o = samplePos;
-                                    walk_tr = v3(1.f, 1.f, 1.f);       // Tr() is walked whatever the radiance is (:1092)
-                                    walk_medium = medium;
-                                    walk_left = shadowRay.tmax;
-                                    q.org = shadowRay.o;
-                                    q.dir_p = shadowRay.d;
-                                    q.tmax_s = shadowRay.tmax;
-                                    q.has_p = true;
-                                    stage = kStShadow;
-                                    busy = false;
-                                    break;
-                                }
-                                if ((bounces == 0 || specular) && isect.lightIdx != -1) {
-                                    stage = kStEmit;                                   // :1103-1115
-                                    job_v = v3(1.f, 1.f, 1.f);
-                                    if (medium >= 0) {
-                                        job = kJobTr;
-                                        job_medium = medium;
-                                        job_tmax = res.t_p;
-                                        break;
-                                    }
-                                    continue;
-                                }
-                                if (isect.matIdx == -1) {
-                                    // a surface without a material only separates two media (:1117-1124): not a bounce
-                                    medium = dot(q.dir_p, isect.nor) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
-                                    q.org = isect.pos;
-                                    q.tmax_s = __builtin_inff();
-                                    q.has_p = true;
-                                    stage = kStPath;
-                                    busy = false;
-                                    break;
-                                }
-                                ctx_scatter = false;
-                                ctx_o = q.org;
-                                ctx_d = q.dir_p;
-                                ctx_t = res.t_p;
-                                ctx_prim = res.prim_p;
-                                ctx_b1 = res.b1_p;
-                                ctx_b2 = res.b2_p;
-                                const gpt_material material = P.materials[isect.matIdx];
-                                if (is_delta(PT_MATERIAL_TYPE(material))) {
-                                    stage = kStContinue;
-                                    continue;
-                                }
-                                // direct light (:1128-1151): the light sample; its shadow ray is walked before anything else is drawn
-                                Ld_acc = v3(0.f, 0.f, 0.f);
+                        // One forward sweep over the stages, each body at most once per pass: a lane only ever moves FORWARD in this order without
+                        // tracing a ray or walking a medium in between (path ray -> medium sampled -> emitter | shadow segment -> its medium ->
+                        // Tr() complete -> BSDF-sampled light ray -> ... came back -> its medium -> continuation), so the if-else chain in a loop
+                        // that this replaces ran the heavy bodies up to four times per pass for lanes that reached them in different iterations.
+                        bool go = true;              // still sweeping (false: the lane has a ray, a job or a finished sample)
+                        if (go && stage == kStPath) do {
+                            // ---- the path ray came back (pathtracer.cu:1049-1070)
+                            if (!hit) {
+                                if ((bounces == 0 || specular) && P.inf.isvalid)
+                                    Li += beta * inf_le(P.inf, q.dir_p);
+                                finish = true;
+                                busy = false;
+                                { go = false; break; }
+                            }
+                            stage = kStPathB;
+                            job_sampled = false;
+                            if (medium >= 0) {
+                                job = kJobSample;
+                                job_medium = medium;
+                                job_tmax = res.t_p;
+                                { go = false; break; }
+                            }
+                            break;
+                        } while (0);
+                        if (go && stage == kStPathB) do {
+                            // ---- ... and its medium has been sampled (:1070-1129)
+                            if (medium >= 0) beta *= job_v;
+                            if (is_black(beta)) {
+                                finish = true;
+                                busy = false;
+                                { go = false; break; }
+                            }
+                            Ray r;
+                            r.o = q.org;
+                            r.d = q.dir_p;
+                            const Hit isect = make_hit(P, r, res.t_p, res.prim_p, res.b1_p, res.b2_p);
+                            const V3 wo = -q.dir_p;
+                            if (job_sampled) {
+                                // a scattering event inside the medium (:1071-1101): light sample, then its shadow walk
+                                const DevMedium &M = P.mediums[medium];
                                 float u = rng_uniform(rng);
                                 float choicePdf;
                                 int idx = lookup_light_distribution(P, u, choicePdf);
                                 bool inf = idx == P.n_lights;
+                                V3 samplePos = q.org + q.dir_p * job_t;
                                 float u1x = rng_uniform(rng);
                                 float u1y = rng_uniform(rng);
                                 V3 radiance = v3(0.f), lightNor;
                                 Ray shadowRay;
-                                shadowRay.o = isect.pos;
+                                shadowRay.o = samplePos;
                                 shadowRay.d = v3(0.f);
                                 shadowRay.tmin = P.eps;
                                 shadowRay.tmax = 0.f;
                                 float lightPdf = 0.f;
                                 if (idx >= 0) {
                                     if (!inf)
-                                        area_sample_light(P.lights[idx], isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                        area_sample_light(P.lights[idx], samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
                                     else
-                                        inf_sample_light(P.inf, isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                        inf_sample_light(P.inf, samplePos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
                                 }
-                                if (is_black(radiance)) {
-                                    stage = kStMisStart;
-                                    continue;
-                                }
-                                V3 fr;
-                                float samplePdf;
-                                eval_bsdf(P, material, wo, shadowRay.d, isect.nor, isect.uv, isect.dpdu, fr, samplePdf);
-                                sav_w = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
-                                sav_fr = fr;
+                                sav_w = medium_phase(M, wo, shadowRay.d);
                                 sav_rad = radiance;
-                                sav_abs = fabs_(dot(isect.nor, shadowRay.d));
                                 sav_den = lightPdf * choicePdf;
-                                walk_tr = v3(1.f, 1.f, 1.f);
+                                sav_has = !is_black(radiance);
+                                ctx_scatter = true;
+                                ctx_o = samplePos;
+                                walk_tr = v3(1.f, 1.f, 1.f);       // Tr() is walked whatever the radiance is (:1092)
                                 walk_medium = medium;
                                 walk_left = shadowRay.tmax;
                                 q.org = shadowRay.o;
@@ -2062,208 +1990,292 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 q.has_p = true;
                                 stage = kStShadow;
                                 busy = false;
+                                { go = false; break; }
+                            }
+                            if ((bounces == 0 || specular) && isect.lightIdx != -1) {
+                                stage = kStEmit;                                   // :1103-1115
+                                job_v = v3(1.f, 1.f, 1.f);
+                                if (medium >= 0) {
+                                    job = kJobTr;
+                                    job_medium = medium;
+                                    job_tmax = res.t_p;
+                                    { go = false; break; }
+                                }
                                 break;
-                            } else if (stage == kStEmit) {
-                                // ---- a directly seen emitter, attenuated by the path's medium (:1103-1115)
+                            }
+                            if (isect.matIdx == -1) {
+                                // a surface without a material only separates two media (:1117-1124): not a bounce
+                                medium = dot(q.dir_p, isect.nor) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
+                                q.org = isect.pos;
+                                q.tmax_s = __builtin_inff();
+                                q.has_p = true;
+                                stage = kStPath;
+                                busy = false;
+                                { go = false; break; }
+                            }
+                            ctx_scatter = false;
+                            ctx_o = q.org;
+                            ctx_d = q.dir_p;
+                            ctx_t = res.t_p;
+                            ctx_prim = res.prim_p;
+                            ctx_b1 = res.b1_p;
+                            ctx_b2 = res.b2_p;
+                            const gpt_material material = P.materials[isect.matIdx];
+                            if (is_delta(PT_MATERIAL_TYPE(material))) {
+                                stage = kStContinue;
+                                break;
+                            }
+                            // direct light (:1128-1151): the light sample; its shadow ray is walked before anything else is drawn
+                            Ld_acc = v3(0.f, 0.f, 0.f);
+                            float u = rng_uniform(rng);
+                            float choicePdf;
+                            int idx = lookup_light_distribution(P, u, choicePdf);
+                            bool inf = idx == P.n_lights;
+                            float u1x = rng_uniform(rng);
+                            float u1y = rng_uniform(rng);
+                            V3 radiance = v3(0.f), lightNor;
+                            Ray shadowRay;
+                            shadowRay.o = isect.pos;
+                            shadowRay.d = v3(0.f);
+                            shadowRay.tmin = P.eps;
+                            shadowRay.tmax = 0.f;
+                            float lightPdf = 0.f;
+                            if (idx >= 0) {
+                                if (!inf)
+                                    area_sample_light(P.lights[idx], isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                                else
+                                    inf_sample_light(P.inf, isect.pos, v2(u1x, u1y), radiance, shadowRay, lightNor, lightPdf, P.eps);
+                            }
+                            if (is_black(radiance)) {
+                                stage = kStMisStart;
+                                break;
+                            }
+                            V3 fr;
+                            float samplePdf;
+                            eval_bsdf(P, material, wo, shadowRay.d, isect.nor, isect.uv, isect.dpdu, fr, samplePdf);
+                            sav_w = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                            sav_fr = fr;
+                            sav_rad = radiance;
+                            sav_abs = fabs_(dot(isect.nor, shadowRay.d));
+                            sav_den = lightPdf * choicePdf;
+                            walk_tr = v3(1.f, 1.f, 1.f);
+                            walk_medium = medium;
+                            walk_left = shadowRay.tmax;
+                            q.org = shadowRay.o;
+                            q.dir_p = shadowRay.d;
+                            q.tmax_s = shadowRay.tmax;
+                            q.has_p = true;
+                            stage = kStShadow;
+                            busy = false;
+                            { go = false; break; }
+                        } while (0);
+                        if (go && stage == kStEmit) do {
+                            // ---- a directly seen emitter, attenuated by the path's medium (:1103-1115)
+                            V3 n;
+                            int lightIdx;
+                            make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                            Li += job_v * beta * area_le(P.lights[lightIdx], n, -q.dir_p);
+                            finish = true;
+                            busy = false;
+                            { go = false; break; }
+                        } while (0);
+                        if (go && stage == kStShadow) do {
+                            // ---- one segment of Tr() (:298-322) came back
+                            if (hit) {
+                                const int hit_mat = __float_as_int(reinterpret_cast<const float *>(reinterpret_cast<const float4 *>(P.shade) + 5 * res.prim_p + 4)[2]);
+                                if (hit_mat != -1) {
+                                    walk_tr = v3(0.f, 0.f, 0.f);
+                                    stage = kStShadowDone;
+                                    break;
+                                }
+                            }
+                            stage = kStShadowB;
+                            if (walk_medium >= 0) {
+                                job = kJobTr;
+                                job_medium = walk_medium;
+                                job_tmax = hit ? res.t_p : q.tmax_s;
+                                { go = false; break; }
+                            }
+                            break;
+                        } while (0);
+                        if (go && stage == kStShadowB) do {
+                            // ---- ... and the medium of the segment has been walked
+                            if (walk_medium >= 0) walk_tr = walk_tr * job_v;
+                            if (hit) {
                                 V3 n;
                                 int lightIdx;
                                 make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
-                                Li += job_v * beta * area_le(P.lights[lightIdx], n, -q.dir_p);
-                                finish = true;
+                                walk_medium = dot(q.dir_p, n) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
+                                walk_left -= res.t_p;
+                                q.org = q.org + q.dir_p * res.t_p;
+                                q.tmax_s = walk_left;
+                                q.has_p = true;
+                                stage = kStShadow;
                                 busy = false;
-                                break;
-                            } else if (stage == kStShadow) {
-                                // ---- one segment of Tr() (:298-322) came back
-                                if (hit) {
-                                    const int hit_mat = __float_as_int(reinterpret_cast<const float *>(reinterpret_cast<const float4 *>(P.shade) + 5 * res.prim_p + 4)[2]);
-                                    if (hit_mat != -1) {
-                                        walk_tr = v3(0.f, 0.f, 0.f);
-                                        stage = kStShadowDone;
-                                        continue;
+                                { go = false; break; }
+                            }
+                            stage = kStShadowDone;
+                            break;
+                        } while (0);
+                        if (go && stage == kStShadowDone) do {
+                            // ---- Tr() is complete
+                            if (ctx_scatter) {
+                                if (sav_has) Li += walk_tr * beta * sav_w * sav_rad / sav_den;             // :1096-1097
+                                float pux = rng_uniform(rng);
+                                float puy = rng_uniform(rng);
+                                const V3 dir = medium_sample_phase(P.mediums[medium], pux, puy);
+                                specular = false;
+                                finish = true;
+                                if (bounces + 1 < P.max_depth) {
+                                    bool kill = false;
+                                    if (bounces > 3) {
+                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                        if (rng_uniform(rng) < illumate)
+                                            kill = true;
+                                        else
+                                            beta /= (1 - illumate);
+                                    }
+                                    if (!kill) {
+                                        q.org = ctx_o;
+                                        q.dir_p = dir;
+                                        q.tmax_s = __builtin_inff();
+                                        q.has_p = true;
+                                        finish = false;
+                                        bounces++;
+                                        stage = kStPath;
                                     }
                                 }
-                                stage = kStShadowB;
-                                if (walk_medium >= 0) {
+                                busy = false;
+                                { go = false; break; }
+                            }
+                            Ld_acc += sav_w * walk_tr * sav_fr * sav_rad * sav_abs / sav_den;              // :1150
+                            stage = kStMisStart;
+                            break;
+                        } while (0);
+                        if (go && stage == kStMisStart) do {
+                            // ---- the BSDF-sampled light ray (:1153-1160)
+                            Ray r;
+                            r.o = ctx_o;
+                            r.d = ctx_d;
+                            const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
+                            const gpt_material material = P.materials[isect.matIdx];
+                            float usx = rng_uniform(rng);
+                            float usy = rng_uniform(rng);
+                            float usz = rng_uniform(rng);
+                            V3 out, fr;
+                            float pdf;
+                            sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
+                            if (!(is_black(fr) || pdf == 0)) {
+                                mis_fr = fr;
+                                mis_cos = fabs_(dot(out, isect.nor));
+                                mis_pdf = pdf;
+                                q.org = isect.pos;
+                                q.dir_p = out;
+                                q.tmax_s = __builtin_inff();
+                                q.has_p = true;
+                                stage = kStMis;
+                                busy = false;
+                                { go = false; break; }
+                            }
+                            Li += beta * Ld_acc;
+                            stage = kStContinue;
+                            break;
+                        } while (0);
+                        if (go && stage == kStMis) do {
+                            // ---- ... came back (:1161-1205)
+                            bool contributes = false;
+                            if (hit) {
+                                V3 n;
+                                int lightIdx;
+                                make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
+                                V3 radiance = v3(0.f, 0.f, 0.f);
+                                if (lightIdx != -1) radiance = area_le(P.lights[lightIdx], n, -q.dir_p);
+                                if (!is_black(radiance)) {
+                                    V3 pp = q.org + res.t_p * q.dir_p;
+                                    float pdfA = 1.f / P.lights[lightIdx].area;
+                                    float choicePdf = pdf_from_light_distribution(P, lightIdx);
+                                    float lenSquare = dot(pp - q.org, pp - q.org);
+                                    float costheta = fabs_(dot(n, q.dir_p));
+                                    float lPdf = pdfA * lenSquare / (costheta);
+                                    sav_w = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
+                                    sav_rad = radiance;
+                                    job_tmax = res.t_p;
+                                    contributes = true;
+                                }
+                            } else if (P.inf.isvalid) {
+                                sav_rad = inf_le(P.inf, q.dir_p);
+                                float choicePdf = pdf_from_light_distribution(P, P.n_lights);
+                                float lightPdf = ONE_OVER_FOUR_PI;
+                                sav_w = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
+                                job_tmax = __builtin_inff();
+                                contributes = true;
+                            }
+                            if (contributes) {
+                                stage = kStMisB;
+                                job_v = v3(1.f, 1.f, 1.f);
+                                if (medium >= 0) {
                                     job = kJobTr;
-                                    job_medium = walk_medium;
-                                    job_tmax = hit ? res.t_p : q.tmax_s;
-                                    break;
+                                    job_medium = medium;
+                                    { go = false; break; }
                                 }
-                                continue;
-                            } else if (stage == kStShadowB) {
-                                // ---- ... and the medium of the segment has been walked
-                                if (walk_medium >= 0) walk_tr = walk_tr * job_v;
-                                if (hit) {
-                                    V3 n;
-                                    int lightIdx;
-                                    make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
-                                    walk_medium = dot(q.dir_p, n) > 0 ? P.prim_media[2 * res.prim_p + 1] : P.prim_media[2 * res.prim_p];
-                                    walk_left -= res.t_p;
-                                    q.org = q.org + q.dir_p * res.t_p;
-                                    q.tmax_s = walk_left;
-                                    q.has_p = true;
-                                    stage = kStShadow;
-                                    busy = false;
-                                    break;
-                                }
-                                stage = kStShadowDone;
-                                continue;
-                            } else if (stage == kStShadowDone) {
-                                // ---- Tr() is complete
-                                if (ctx_scatter) {
-                                    if (sav_has) Li += walk_tr * beta * sav_w * sav_rad / sav_den;             // :1096-1097
-                                    float pux = rng_uniform(rng);
-                                    float puy = rng_uniform(rng);
-                                    const V3 dir = medium_sample_phase(P.mediums[medium], pux, puy);
-                                    specular = false;
-                                    finish = true;
-                                    if (bounces + 1 < P.max_depth) {
-                                        bool kill = false;
-                                        if (bounces > 3) {
-                                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
-                                            if (rng_uniform(rng) < illumate)
-                                                kill = true;
-                                            else
-                                                beta /= (1 - illumate);
-                                        }
-                                        if (!kill) {
-                                            q.org = ctx_o;
-                                            q.dir_p = dir;
-                                            q.tmax_s = __builtin_inff();
-                                            q.has_p = true;
-                                            finish = false;
-                                            bounces++;
-                                            stage = kStPath;
-                                        }
-                                    }
-                                    busy = false;
-                                    break;
-                                }
-                                Ld_acc += sav_w * walk_tr * sav_fr * sav_rad * sav_abs / sav_den;              // :1150
-                                stage = kStMisStart;
-                                continue;
-                            } else if (stage == kStMisStart) {
-                                // ---- the BSDF-sampled light ray (:1153-1160)
+                                break;
+                            }
+                            Li += beta * Ld_acc;
+                            stage = kStContinue;
+                            break;
+                        } while (0);
+                        if (go && stage == kStMisB) do {
+                            Ld_acc += sav_w * job_v * mis_fr * sav_rad * mis_cos / mis_pdf;
+                            Li += beta * Ld_acc;
+                            stage = kStContinue;
+                            break;
+                        } while (0);
+                        if (go && stage == kStContinue) do {
+                            // ---- kStContinue: the continuation (:1210-1229) and the roulette (:1232-1238).  On the last bounce
+                            // nothing of it reaches Li, so it is skipped.
+                            finish = true;
+                            if (bounces + 1 < P.max_depth) {
                                 Ray r;
                                 r.o = ctx_o;
                                 r.d = ctx_d;
                                 const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
                                 const gpt_material material = P.materials[isect.matIdx];
-                                float usx = rng_uniform(rng);
-                                float usy = rng_uniform(rng);
-                                float usz = rng_uniform(rng);
+                                const V3 wo = -ctx_d;
+                                float ux = rng_uniform(rng);
+                                float uy = rng_uniform(rng);
+                                float uz = rng_uniform(rng);
                                 V3 out, fr;
                                 float pdf;
-                                sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
-                                if (!(is_black(fr) || pdf == 0)) {
-                                    mis_fr = fr;
-                                    mis_cos = fabs_(dot(out, isect.nor));
-                                    mis_pdf = pdf;
-                                    q.org = isect.pos;
-                                    q.dir_p = out;
-                                    q.tmax_s = __builtin_inff();
-                                    q.has_p = true;
-                                    stage = kStMis;
-                                    busy = false;
-                                    break;
-                                }
-                                Li += beta * Ld_acc;
-                                stage = kStContinue;
-                                continue;
-                            } else if (stage == kStMis) {
-                                // ---- ... came back (:1161-1205)
-                                bool contributes = false;
-                                if (hit) {
-                                    V3 n;
-                                    int lightIdx;
-                                    make_light_hit(P, res.prim_p, res.b1_p, res.b2_p, n, lightIdx);
-                                    V3 radiance = v3(0.f, 0.f, 0.f);
-                                    if (lightIdx != -1) radiance = area_le(P.lights[lightIdx], n, -q.dir_p);
-                                    if (!is_black(radiance)) {
-                                        V3 pp = q.org + res.t_p * q.dir_p;
-                                        float pdfA = 1.f / P.lights[lightIdx].area;
-                                        float choicePdf = pdf_from_light_distribution(P, lightIdx);
-                                        float lenSquare = dot(pp - q.org, pp - q.org);
-                                        float costheta = fabs_(dot(n, q.dir_p));
-                                        float lPdf = pdfA * lenSquare / (costheta);
-                                        sav_w = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
-                                        sav_rad = radiance;
-                                        job_tmax = res.t_p;
-                                        contributes = true;
+                                sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
+                                if (!is_black(fr)) {
+                                    beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
+                                    specular = is_delta(PT_MATERIAL_TYPE(material));
+                                    const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
+                                    int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
+                                    m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
+                                    medium = m2;
+                                    bool kill = false;
+                                    if (bounces > 3) {
+                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                        if (rng_uniform(rng) < illumate)
+                                            kill = true;
+                                        else
+                                            beta /= (1 - illumate);
                                     }
-                                } else if (P.inf.isvalid) {
-                                    sav_rad = inf_le(P.inf, q.dir_p);
-                                    float choicePdf = pdf_from_light_distribution(P, P.n_lights);
-                                    float lightPdf = ONE_OVER_FOUR_PI;
-                                    sav_w = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
-                                    job_tmax = __builtin_inff();
-                                    contributes = true;
-                                }
-                                if (contributes) {
-                                    stage = kStMisB;
-                                    job_v = v3(1.f, 1.f, 1.f);
-                                    if (medium >= 0) {
-                                        job = kJobTr;
-                                        job_medium = medium;
-                                        break;
-                                    }
-                                    continue;
-                                }
-                                Li += beta * Ld_acc;
-                                stage = kStContinue;
-                                continue;
-                            } else if (stage == kStMisB) {
-                                Ld_acc += sav_w * job_v * mis_fr * sav_rad * mis_cos / mis_pdf;
-                                Li += beta * Ld_acc;
-                                stage = kStContinue;
-                                continue;
-                            } else {
-                                // ---- kStContinue: the continuation (:1210-1229) and the roulette (:1232-1238).  On the last bounce
-                                // nothing of it reaches Li, so it is skipped.
-                                finish = true;
-                                if (bounces + 1 < P.max_depth) {
-                                    Ray r;
-                                    r.o = ctx_o;
-                                    r.d = ctx_d;
-                                    const Hit isect = make_hit(P, r, ctx_t, ctx_prim, ctx_b1, ctx_b2);
-                                    const gpt_material material = P.materials[isect.matIdx];
-                                    const V3 wo = -ctx_d;
-                                    float ux = rng_uniform(rng);
-                                    float uy = rng_uniform(rng);
-                                    float uz = rng_uniform(rng);
-                                    V3 out, fr;
-                                    float pdf;
-                                    sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
-                                    if (!is_black(fr)) {
-                                        beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
-                                        specular = is_delta(PT_MATERIAL_TYPE(material));
-                                        const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
-                                        int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
-                                        m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
-                                        medium = m2;
-                                        bool kill = false;
-                                        if (bounces > 3) {
-                                            float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
-                                            if (rng_uniform(rng) < illumate)
-                                                kill = true;
-                                            else
-                                                beta /= (1 - illumate);
-                                        }
-                                        if (!kill) {
-                                            q.org = isect.pos;
-                                            q.dir_p = out;
-                                            q.tmax_s = __builtin_inff();
-                                            q.has_p = true;
-                                            finish = false;
-                                            bounces++;
-                                            stage = kStPath;
-                                        }
+                                    if (!kill) {
+                                        q.org = isect.pos;
+                                        q.dir_p = out;
+                                        q.tmax_s = __builtin_inff();
+                                        q.has_p = true;
+                                        finish = false;
+                                        bounces++;
+                                        stage = kStPath;
                                     }
                                 }
-                                busy = false;
-                                break;
                             }
-                        }
+                            busy = false;
+                            { go = false; break; }
+                        } while (0);
                         if (busy) {          // left the stage code with a job posted: a fresh walk
                             job_running = true;
                             trk_tr = 1.f;
