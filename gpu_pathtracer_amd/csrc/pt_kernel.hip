@@ -1720,9 +1720,11 @@ constexpr int kSmallSceneFloat4 = PT_SMALL_FLOAT4;      // 12 KB: with the ray p
 // Volpath with density grids or material-less surfaces: an internal fourth value of INTEG (not an integrator type of the
 // ABI; launch_render picks it when DevParams.vpt_walk is set) and the stages of its per-path state machine
 #define PT_IT_VPT_WALK 8
-// 3 waves per SIMD (168 VGPRs) instead of 4: the state machine's registers no longer spill (+16 %, kernel_variants.log)
+// 4 waves per SIMD.  (Rounds 1 - 4 ran it at 3, 168 VGPRs: at 4 the if-else chain of stage bodies spilled 270 B per lane.  As one forward
+// sweep the stage code needs 156 - 166 registers without scratch, and the fourth wave is worth more than the 124 - 168 B of scratch it
+// costs: 212 -> 232 Msamples/s on the shipped scene's shape, profiles/r05/d1_volpath.log.)
 #ifndef PT_WALK_WAVES
-#define PT_WALK_WAVES 3
+#define PT_WALK_WAVES 4
 #endif
 constexpr int kStPath = 0, kStShadow = 1, kStMisStart = 2, kStMis = 3, kStContinue = 4, kStPathB = 5, kStEmit = 6, kStShadowB = 7,
               kStShadowDone = 8, kStMisB = 9;
@@ -1731,12 +1733,17 @@ constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 #define PT_TRACK_STEPS 16
 #endif
 #ifndef PT_STEP_BATCH
-#define PT_STEP_BATCH 16
+#define PT_STEP_BATCH 8
 #endif
 #ifndef PT_TRACE_BATCH
 #define PT_TRACE_BATCH 32
 #endif
-constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH;
+// a tracking turn is the most expensive of the three activities (16 steps of ~550 instructions): with fewer than PT_TRACK_MIN walks under way the
+// wave rather runs the stage code or drains what it has, which brings lanes back to the walks
+#ifndef PT_TRACK_MIN
+#define PT_TRACK_MIN 16
+#endif
+constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH, kTrackMin = PT_TRACK_MIN;
 #ifndef PT_WIDE_WAVES
 #define PT_WIDE_WAVES 4
 #endif
@@ -1908,7 +1915,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     // (or nothing is being tracked); otherwise the wave tracks.
                     const int n_ready = popc(ballot(busy));
                     int n_track = popc(ballot(job_running));
-                    if (n_ready > 0 && (n_ready >= kStepBatch || n_track == 0)) {
+                    if (n_ready > 0 && (n_ready >= kStepBatch || n_track < kTrackMin)) {
 #if PT_WALK_PROBE
                     const unsigned long long wp_t0 = __builtin_readcyclecounter();
                     if (COUNT && lane == 0) { wp_stage_pass++; wp_stage_lanes += (unsigned)n_ready; }
@@ -2292,7 +2299,8 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     {
                         const bool any_ready = __any(busy);           // (only if the stage code was put off)
                         if (!any_ready && n_track == 0) break;
-                        if (!any_ready && popc(ballot(alive && (q.has_p || finish))) >= kTraceBatch) break;
+                        const int n_rays = popc(ballot(alive && (q.has_p || finish)));
+                        if (!any_ready && (n_rays >= kTraceBatch || (n_rays > 0 && n_track < kTrackMin))) break;
                     }
                     // ---- the tracking jobs: Sample() / Tr() of the medium `job_medium` along the lane's ray over
                     // [0, job_tmax) (medium.h:14-50,64-157).  Homogeneous media answer in closed form; the density grids

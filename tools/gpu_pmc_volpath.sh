@@ -1,12 +1,12 @@
-export TMPDIR=/tmp; mkdir -p gpurun_out/r05h
+export TMPDIR=/tmp; mkdir -p gpurun_out/${1:-vp}
 for pmc in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pmc | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/r05h/vp_$tag -o p -- python tools/gpu_volpath.py > gpurun_out/r05h/vp_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/${1:-vp}/vp_$tag -o p -- python tools/gpu_volpath.py > gpurun_out/${1:-vp}/vp_$tag.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/r05h/vp_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("gpurun_out/${1:-vp}/vp_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "pt_render_kernel" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -18,5 +18,5 @@ for k, a in acc.items():
     if "TCC_HIT_sum" in b: print(f"   L2 hit {b['TCC_HIT_sum']/(b['TCC_HIT_sum']+b['TCC_MISS_sum']):.3f}")
     if "FETCH_SIZE" in b: print(f"   fetch {b['FETCH_SIZE']*1024/1e9:.2f} GB raw, write {b.get('WRITE_SIZE',0)*1024/1e9:.2f} GB")
 PY
-grep "Msamples" gpurun_out/r05h/vp_FETCH_SIZE.log
-find gpurun_out/r05h -name "*.csv" -delete
+grep "Msamples" gpurun_out/${1:-vp}/vp_FETCH_SIZE.log
+find gpurun_out/${1:-vp} -name "*.csv" -delete

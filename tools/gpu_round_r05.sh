@@ -23,5 +23,6 @@ for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel
 if [ -z "$QUICK" ]; then
 for w in c3 c5; do for m in reference wide; do bash tools/gpu_pmc_standin.sh $TAG $w $m $( [ $w = c5 ] && echo 8 || echo 32 ) > /dev/null 2>&1; cat $OUT/${w}_${m}_pmc_summary.txt; done; done > $OUT/standin_pmc.txt; cat $OUT/standin_pmc.txt
 fi
+[ -z "$QUICK" ] && { bash tools/gpu_pmc_volpath.sh $TAG > $OUT/volpath_pmc.txt 2>&1; cat $OUT/volpath_pmc.txt | tail -12; }
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
