@@ -96,6 +96,7 @@ int gpt_scene_load_ex(const char *json_path, int flags, gpt_scene **out)
         // Scene::Init is void like the reference's; a builder that refused the primitives (a non-finite vertex after a singular
         // transform ...) leaves them where they were and the tree empty: an error here, not a scene that renders the background
         if (!s->scene.primitives.empty() && s->scene.bvh.prims.empty()) {
+            gpt_set_error("gpt_scene_load: the BVH builder refused the primitives of %s (a non-finite vertex?)", json_path);
             delete s;
             return GPT_ERR_INVALID_ARG;
         }
