@@ -3,10 +3,11 @@ for pmc in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCL
   tag=$(echo $pmc | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d gpurun_out/${1:-vp}/vp_$tag -o p -- python tools/gpu_volpath.py > gpurun_out/${1:-vp}/vp_$tag.log 2>&1
 done
-python - <<'PY'
-import csv, glob, collections
+D=gpurun_out/${1:-vp} python - <<'PY'
+import csv, glob, collections, os
+D = os.environ["D"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/${1:-vp}/vp_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(D + "/vp_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "pt_render_kernel" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -19,4 +20,4 @@ for k, a in acc.items():
     if "FETCH_SIZE" in b: print(f"   fetch {b['FETCH_SIZE']*1024/1e9:.2f} GB raw, write {b.get('WRITE_SIZE',0)*1024/1e9:.2f} GB")
 PY
 grep "Msamples" gpurun_out/${1:-vp}/vp_FETCH_SIZE.log
-find gpurun_out/${1:-vp} -name "*.csv" -delete
+find gpurun_out/${1:-vp}/vp_* -name "*.csv" -delete
