@@ -13,7 +13,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "$F" > $OUT/sm
 for opt in "" "lds_scene=0"; do
   n=pytest_gpu${opt:+_}${opt/=/}
   timeout 1700 python -m pytest tests -m gpu -q ${opt:+--gpt-opt $opt} 2>&1 | grep -av "$F" > $OUT/$n.full.log
-  (echo "# python -m pytest tests -m gpu -q ${opt:+--gpt-opt $opt}   (head $(git rev-parse --short HEAD 2>/dev/null), libgpt.so sha1 $(sha1sum gpu_pathtracer_amd/libgpt.so | cut -c1-16))"; grep -a 'passed\|failed\|error' $OUT/$n.full.log | tail -5; tail -12 $OUT/$n.full.log) > $OUT/$n.log
+  (echo "# python -m pytest tests -m gpu -q ${opt:+--gpt-opt $opt}   (libgpt.so sha1 $(sha1sum gpu_pathtracer_amd/libgpt.so | cut -c1-16))"; grep -a 'passed\|failed\|error' $OUT/$n.full.log | tail -5; tail -12 $OUT/$n.full.log) > $OUT/$n.log
   echo "$n: $(grep -a 'passed\|failed' $OUT/$n.full.log | tail -1)"
   [ -n "$QUICK" ] && break
 done
