@@ -22,9 +22,11 @@ What the JSON line carries besides the contract's fields (rank 0, N = 1):
   cpu_baseline  the oracle (CPU restatement) on one host core, bounded sample; host CPU model and core count.
   parity        GPU film against the pinned (glibc) oracle at 256x256 / 1024 spp / depth 8: per-channel relative RMS.
   config.other_configs   BASELINE.json configs 3 - 5 on their SURVEY.md 8(d) stand-ins (tests/standins.py, built from
-                tests/golden/meshes.npz through the product loader), one full-size launch per traversal order (reference / nearer child first / 4-wide): Msamples/s from the
-                library's HIP events, and for the faster order the VALU-issue fraction, active lanes and HBM-side GB/s of one extra
-                rocprofv3 pass set.  Parity-test cases, not the headline: they are here so that their numbers are driver-witnessed.
+                tests/golden/meshes.npz through the product loader), one full-size launch per leg (the loader's and gpt_begin's defaults; the reference's tree in the 4-wide walk and in the
+                reference's order; the split tree): Msamples/s from the library's HIP events, and for two legs the VALU-issue fraction,
+                active lanes and HBM-side GB/s of one extra rocprofv3 pass set.  Parity-test cases, not the headline: they are here so that their numbers are driver-witnessed.
+  config.volpath         the reference's shipped Volpath scene (cornell_box/scene.json: density grid in a material-less box, 512 x 512, 17 bounces)
+                rebuilt from fixtures through the product loader: one 64-iteration launch of the one-ray-at-a-time kernel, HIP events.
 `python bench.py --gpus N` without a torch.distributed.run environment launches itself under it (one rank per GPU).
 Nothing here reads /root/reference.
 """
