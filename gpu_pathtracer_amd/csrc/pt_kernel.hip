@@ -2309,7 +2309,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                     // whose walks were short can fetch new work in between instead of idling until the longest ends.
 #if PT_WALK_PROBE
                     const unsigned long long wp_t1 = __builtin_readcyclecounter();
-                    if (COUNT && lane == 0) { wp_track_turn++; wp_track_lanes += (unsigned)popc(ballot(job_running)); }
+                    if (COUNT && lane == 0) wp_track_turn++;
 #endif
                     if (job_running) {
                         const DevMedium M = P.mediums[job_medium];
@@ -2837,6 +2837,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 c0 = __builtin_readcyclecounter();
                 if (lane == 0) cyc_shade += c0 - cyc_mark;
             }
+#if PT_WALK_PROBE
+            if (COUNT && INTEG == PT_IT_VPT_WALK && lane == 0) wp_track_lanes++;      // (probe: drains)
+#endif
             if (SMALL) {
                 LdsScene mem;
                 mem.first = (int)lds_address(lds_scene);

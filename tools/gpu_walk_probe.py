@@ -20,7 +20,7 @@ with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
 n = c[5]
 print(f"WALKPROBE samples {n}: rays/sample {(c[3] + c[4]) / n:.2f}, bounce iterations {c[2] / n:.2f}")
 print(f"WALKPROBE stage passes per 64 samples {c[6] / n * 64:.1f}, ready lanes per pass {c[7] / max(1, c[6]):.1f}")
-print(f"WALKPROBE tracking turns per 64 samples {c[8] / n * 64:.1f}, lanes with a job per turn {c[9] / max(1, c[8]):.1f}; "
+print(f"WALKPROBE tracking turns per 64 samples {c[8] / n * 64:.1f}, drains per 64 samples {c[9] / n * 64:.1f} ({(c[3] + c[4]) / max(1, c[9]):.1f} rays and {c[14] / max(1, c[9]):.0f} cycles each); "
       f"wave-steps per turn {c[10] / max(1, c[8]):.1f}, lanes per wave-step {c[11] / max(1, c[10]):.1f}, lane-steps per sample {c[11] / n:.0f}")
 tot = c[14] + c[15]
 print(f"WALKPROBE wave cycles: drain {c[14] / tot:.2f}, stage code {c[12] / tot:.2f}, tracking {c[13] / tot:.2f}, rest {(c[15] - c[12] - c[13]) / tot:.2f}; "
