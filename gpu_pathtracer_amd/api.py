@@ -80,6 +80,7 @@ def load():
         "gpt_debug_trace": [vp, vp, C.c_int, vp, vp],
         "gpt_debug_math": [C.c_int, C.c_int, vp, vp, vp, C.c_int],
         "gpt_debug_rng": [C.c_int, u32, u32, vp, vp, C.c_int],
+        "gpt_debug_bsdf": [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp],
         "gpt_bvh_build": [vp, i32, vp, vp, C.POINTER(i32), vp],
         "gpt_light_distribution": [vp, i32, vp, vp, C.POINTER(i32)],
         "gpt_infinite_init": [vp, vp],
@@ -417,6 +418,22 @@ def debug_math(fn, x, y=None, device=0):
     y = np.ascontiguousarray(y if y is not None else x, dtype=np.float32)
     out = np.empty_like(x)
     check(load().gpt_debug_math(device, fn, st.ptr(x), st.ptr(y), st.ptr(out), len(x)))
+    return out
+
+
+def debug_bsdf(material, geom11, in3, mode, texture=None, device=0):
+    """SampleBSDF (mode 1, in3 = draws) / Fr (mode 0, in3 = direction) on the device; `texture`: an (H, W, 4) uint8 array or None.
+    Returns (n, 7): out.xyz, fr.xyz, pdf."""
+    geom11 = np.ascontiguousarray(geom11, dtype=np.float32)
+    in3 = np.ascontiguousarray(in3, dtype=np.float32)
+    out = np.zeros((len(geom11), 7), dtype=np.float32)
+    rec = None
+    if texture is not None:
+        texture = np.ascontiguousarray(texture, dtype=np.uint8)
+        rec = st.Texture()
+        rec.data, rec.height, rec.width = texture.ctypes.data, texture.shape[0], texture.shape[1]
+    check(load().gpt_debug_bsdf(device, st.ptr(material), C.byref(rec) if rec is not None else None, st.ptr(geom11), st.ptr(in3),
+                                len(geom11), mode, st.ptr(out)))
     return out
 
 

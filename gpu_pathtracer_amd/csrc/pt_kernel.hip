@@ -2028,7 +2028,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             ctx_b1 = res.b1_p;
                             ctx_b2 = res.b2_p;
                             const gpt_material material = P.materials[isect.matIdx];
-                            if (is_delta(PT_MATERIAL_TYPE(material))) {
+                            if (kind_is_delta(material.type)) {
                                 stage = kStContinue;
                                 break;
                             }
@@ -2057,11 +2057,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 stage = kStMisStart;
                                 break;
                             }
-                            V3 fr;
-                            float samplePdf;
-                            eval_bsdf(P, material, wo, shadowRay.d, isect.nor, isect.uv, isect.dpdu, fr, samplePdf);
-                            sav_w = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
-                            sav_fr = fr;
+                            const Surface S = surface_prepare(P, material, wo, isect.nor, isect.dpdu, isect.uv);
+                            const Scatter lit = surface_respond(S, material, shadowRay.d);
+                            sav_w = mis_weight(lightPdf * choicePdf, lit.pdf);
+                            sav_fr = lit.f;
                             sav_rad = radiance;
                             sav_abs = fabs_(dot(isect.nor, shadowRay.d));
                             sav_den = lightPdf * choicePdf;
@@ -2136,7 +2135,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 if (bounces + 1 < P.max_depth) {
                                     bool kill = false;
                                     if (bounces > 3) {
-                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                        float illumate = clamp(1.f - rr_luminance(beta), 0.f, 1.f);
                                         if (rng_uniform(rng) < illumate)
                                             kill = true;
                                         else
@@ -2169,15 +2168,14 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             float usx = rng_uniform(rng);
                             float usy = rng_uniform(rng);
                             float usz = rng_uniform(rng);
-                            V3 out, fr;
-                            float pdf;
-                            sample_bsdf(P, material, -ctx_d, isect.nor, isect.uv, isect.dpdu, v3(usx, usy, usz), out, fr, pdf);
-                            if (!(is_black(fr) || pdf == 0)) {
-                                mis_fr = fr;
-                                mis_cos = fabs_(dot(out, isect.nor));
-                                mis_pdf = pdf;
+                            const Surface S = surface_prepare(P, material, -ctx_d, isect.nor, isect.dpdu, isect.uv);
+                            const Scatter probe = surface_scatter(S, material, usx, usy, usz);
+                            if (!(is_black(probe.f) || probe.pdf == 0)) {
+                                mis_fr = probe.f;
+                                mis_cos = fabs_(dot(probe.wi, isect.nor));
+                                mis_pdf = probe.pdf;
                                 q.org = isect.pos;
-                                q.dir_p = out;
+                                q.dir_p = probe.wi;
                                 q.tmax_s = __builtin_inff();
                                 q.has_p = true;
                                 stage = kStMis;
@@ -2204,7 +2202,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                     float lenSquare = dot(pp - q.org, pp - q.org);
                                     float costheta = fabs_(dot(n, q.dir_p));
                                     float lPdf = pdfA * lenSquare / (costheta);
-                                    sav_w = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
+                                    sav_w = mis_weight(mis_pdf, lPdf * choicePdf);
                                     sav_rad = radiance;
                                     job_tmax = res.t_p;
                                     contributes = true;
@@ -2213,7 +2211,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 sav_rad = inf_le(P.inf, q.dir_p);
                                 float choicePdf = pdf_from_light_distribution(P, P.n_lights);
                                 float lightPdf = ONE_OVER_FOUR_PI;
-                                sav_w = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
+                                sav_w = mis_weight(mis_pdf, lightPdf * choicePdf);
                                 job_tmax = __builtin_inff();
                                 contributes = true;
                             }
@@ -2251,19 +2249,19 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 float ux = rng_uniform(rng);
                                 float uy = rng_uniform(rng);
                                 float uz = rng_uniform(rng);
-                                V3 out, fr;
-                                float pdf;
-                                sample_bsdf(P, material, wo, isect.nor, isect.uv, isect.dpdu, v3(ux, uy, uz), out, fr, pdf);
-                                if (!is_black(fr)) {
-                                    beta *= fr * fabs_(dot(isect.nor, out)) / pdf;
-                                    specular = is_delta(PT_MATERIAL_TYPE(material));
+                                const Surface S = surface_prepare(P, material, wo, isect.nor, isect.dpdu, isect.uv);
+                                const Scatter next = surface_scatter(S, material, ux, uy, uz);
+                                const V3 out = next.wi;
+                                if (!is_black(next.f)) {
+                                    beta *= next.f * fabs_(dot(isect.nor, out)) / next.pdf;
+                                    specular = kind_is_delta(material.type);
                                     const int m_in = P.prim_media[2 * ctx_prim], m_out = P.prim_media[2 * ctx_prim + 1];
                                     int m2 = dot(out, isect.nor) > 0 ? m_out : m_in;
                                     m2 = dot(wo, isect.nor) * dot(out, isect.nor) > 0 ? medium : m2;
                                     medium = m2;
                                     bool kill = false;
                                     if (bounces > 3) {
-                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                        float illumate = clamp(1.f - rr_luminance(beta), 0.f, 1.f);
                                         if (rng_uniform(rng) < illumate)
                                             kill = true;
                                         else
@@ -2419,7 +2417,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 float lenSquare = dot(p - q.org, p - q.org);
                                 float costheta = fabs_(dot(n, q.dir_m));
                                 float lPdf = pdfA * lenSquare / (costheta);
-                                float weight = power_heuristic(1, mis_pdf, 1, lPdf * choicePdf);
+                                float weight = mis_weight(mis_pdf, lPdf * choicePdf);
                                 if (INTEG == GPT_IT_VPT) Ld += weight * tr_m * mis_fr * radiance * mis_cos / mis_pdf;
                                 else Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
                             }
@@ -2428,7 +2426,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             V3 radiance = inf_le(P.inf, q.dir_m);
                             float choicePdf = pdf_from_light_distribution(P, P.n_lights);
                             float lightPdf = ONE_OVER_FOUR_PI;                             // infinite.h:38-41
-                            float weight = power_heuristic(1, mis_pdf, 1, lightPdf * choicePdf);
+                            float weight = mis_weight(mis_pdf, lightPdf * choicePdf);
                             if (INTEG == GPT_IT_VPT) Ld += weight * tr_m * mis_fr * radiance * mis_cos / mis_pdf;
                             else Ld += weight * mis_fr * radiance * mis_cos / mis_pdf;
                         }
@@ -2517,7 +2515,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             if (bounces + 1 < P.max_depth) {
                                 bool kill = false;
                                 if (bounces > 3) {
-                                    float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                    float illumate = clamp(1.f - rr_luminance(beta), 0.f, 1.f);
                                     if (rng_uniform(rng) < illumate)
                                         kill = true;
                                     else
@@ -2543,10 +2541,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             float u1 = rng_uniform(rng);
                             float u2 = rng_uniform(rng);
                             float pdf;
-                            V3 dir = cosine_hemisphere(u1, u2, pdf);
-                            V3 uu = dpdu, ww;
-                            ww = cross(uu, n);
-                            dir = to_world(dir, uu, n, ww);
+                            V3 dir = frame_to_world(cosine_lobe(u1, u2, pdf), dpdu, n, cross(dpdu, n));
                             float cosine = dot(dir, n);
                             float v = cosine * ONE_OVER_PI / pdf;
                             cand = v3(v, v, v);                 // L += v if the occlusion ray escapes
@@ -2577,7 +2572,10 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                             q.org = pos;
                             // direct light with multiple importance sampling: everything that
                             // does not depend on visibility is evaluated now
-                            if (!is_delta(PT_MATERIAL_TYPE(material))) {
+                            Surface S;
+                            if (kind_is_delta(material.type)) {
+                                S = surface_prepare(P, material, wo, nor, dpdu, uv);
+                            } else {
                                 poison_occluded = false;
                                 float u = rng_uniform(rng);
                                 float choicePdf;
@@ -2599,11 +2597,13 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                     else
                                         inf_sample_light(P.inf, pos, u1, radiance, shadowRay, lightNor, lightPdf, P.eps);
                                 }
+                                // what the bounce's three questions to the surface share (pt_bsdf.h), formed once the light's
+                                // code is through with the registers
+                                S = surface_prepare(P, material, wo, nor, dpdu, uv);
                                 if (!is_black(radiance)) {
-                                    V3 fr;
-                                    float samplePdf;
-                                    eval_bsdf(P, material, wo, shadowRay.d, nor, uv, dpdu, fr, samplePdf);
-                                    float weight = power_heuristic(1, lightPdf * choicePdf, 1, samplePdf);
+                                    const Scatter lit = surface_respond(S, material, shadowRay.d);
+                                    const V3 fr = lit.f;
+                                    float weight = mis_weight(lightPdf * choicePdf, lit.pdf);
                                     if (INTEG == GPT_IT_VPT) {
                                         // Ld += weight * tr * fr * radiance * |cos| / pdf with tr = Tr(shadowRay): the medium's
                                         // transmittance if the light is visible, 0 if not (pathtracer.cu:1146-1151)
@@ -2626,9 +2626,9 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 float usx = rng_uniform(rng);
                                 float usy = rng_uniform(rng);
                                 float usz = rng_uniform(rng);
-                                V3 out, fr;
-                                float pdf;
-                                sample_bsdf(P, material, wo, nor, uv, dpdu, v3(usx, usy, usz), out, fr, pdf);
+                                const Scatter probe = surface_scatter(S, material, usx, usy, usz);
+                                const V3 out = probe.wi, fr = probe.f;
+                                const float pdf = probe.pdf;
                                 if (!(is_black(fr) || pdf == 0)) {
                                     // The BSDF-sampled light ray contributes only if its CLOSEST hit is an emitter
                                     // triangle (pathtracer.cu:964-976) or, with an environment light, if it escapes
@@ -2668,12 +2668,11 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                 float ux = rng_uniform(rng);
                                 float uy = rng_uniform(rng);
                                 float uz = rng_uniform(rng);
-                                V3 out, fr;
-                                float pdf;
-                                sample_bsdf(P, material, wo, nor, uv, dpdu, v3(ux, uy, uz), out, fr, pdf);
-                                if (!is_black(fr)) {
-                                    beta *= fr * fabs_(dot(nor, out)) / pdf;
-                                    specular = is_delta(PT_MATERIAL_TYPE(material));
+                                const Scatter next = surface_scatter(S, material, ux, uy, uz);
+                                const V3 out = next.wi;
+                                if (!is_black(next.f)) {
+                                    beta *= next.f * fabs_(dot(nor, out)) / next.pdf;
+                                    specular = kind_is_delta(material.type);
                                     if (INTEG == GPT_IT_VPT) {
                                         // the medium on the side the new ray leaves on; a reflection stays where it was
                                         // (pathtracer.cu:1223-1227)
@@ -2684,7 +2683,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                                     }
                                     bool kill = false;
                                     if (bounces > 3) {
-                                        float illumate = clamp(1.f - luminance(beta), 0.f, 1.f);
+                                        float illumate = clamp(1.f - rr_luminance(beta), 0.f, 1.f);
                                         if (rng_uniform(rng) < illumate)
                                             kill = true;
                                         else
@@ -3104,9 +3103,30 @@ __global__ void pt_debug_math_kernel(int fn, const float *x, const float *y, flo
     case 6: r = x[i] / y[i]; break;
     case 7: r = sqrt_rn(x[i]); break;
     case 8: r = rsqrt_rn(x[i]); break;
+    case 9: r = gpt_expf(x[i]); break;
+    case 10: r = gpt_logf(x[i]); break;
     default: break;
     }
     out[i] = r;
+}
+// the surface operators on their own (gpt_debug_bsdf): one case per lane through the routines the render kernels shade with
+__global__ void pt_debug_bsdf_kernel(const gpt_material *material, const DevTexture *texture, const float *geom11, const float *in3, int n, int mode,
+                                     float *out7)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DevParams P;
+    __builtin_memset(&P, 0, sizeof(P));
+    P.textures = texture;
+    const gpt_material m = *material;
+    const float *g = geom11 + 11 * (size_t)i;
+    const Surface S = surface_prepare(P, m, v3(g[0], g[1], g[2]), v3(g[3], g[4], g[5]), v3(g[6], g[7], g[8]), v2(g[9], g[10]));
+    const float a = in3[3 * (size_t)i], b = in3[3 * (size_t)i + 1], c = in3[3 * (size_t)i + 2];
+    const Scatter r = mode == 0 ? surface_respond(S, m, v3(a, b, c)) : surface_scatter(S, m, a, b, c);
+    float *o = out7 + 7 * (size_t)i;
+    o[0] = r.wi.x; o[1] = r.wi.y; o[2] = r.wi.z;
+    o[3] = r.f.x; o[4] = r.f.y; o[5] = r.f.z;
+    o[6] = r.pdf;
 }
 __global__ void pt_debug_rng_kernel(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n)
 {
@@ -3225,6 +3245,13 @@ hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream)
 {
     hipLaunchKernelGGL(pt_debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, x, y, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_bsdf(const gpt_material *material, const DevTexture *texture, const float *geom11, const float *in3, int n, int mode,
+                             float *out7, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pt_debug_bsdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, material, texture, geom11, in3, n, mode, out7);
     return hipGetLastError();
 }
 

@@ -1,8 +1,10 @@
-// pt_shade.h — everything a path evaluates at a surface hit, for the render kernels of pt_kernel.hip.  Each function restates the reference lines
-// it names; the operation order is the one oracle/pt_oracle.c follows (bit-exact contract, DESIGN.md "Float contract").
+// pt_shade.h — what a path evaluates around a surface hit besides the surface's own scattering (pt_bsdf.h): the hit record, the camera,
+// the lights, the film's tone curve, participating media.  Each function names the reference lines whose values it reproduces; the
+// operation order is the one oracle/pt_oracle.c follows (bit-exact contract, DESIGN.md "Float contract").
 #pragma once
 
 #include "pt_device.h"
+#include "pt_bsdf.h"
 
 namespace pt {
 
@@ -25,27 +27,13 @@ __device__ __forceinline__ Hit make_hit(const DevParams &P, const Ray &ray, floa
 }
 
 // ------------------------------------------------------------- samplers ------
-__device__ __forceinline__ V3 to_world(V3 dir, V3 u, V3 v, V3 w) { return dir.x * u + dir.y * v + dir.z * w; }
-
-__device__ __forceinline__ V3 cosine_hemisphere(float u1, float u2, float &pdf)   // wrap.h:51-62
+// a direction uniform over the sphere, y-up (wrap.h:26-36); its density is the constant 1 / 4 pi
+__device__ __forceinline__ V3 sphere_direction(float u1, float u2)
 {
-    float sintheta = sqrt_rn(u1);
-    float costheta = sqrt_rn(1.f - u1);
-    float phi = TWOPI * u2;
-    float cosphi = gpt_cosf(phi);
-    float sinphi = gpt_sinf(phi);
-    pdf = costheta * ONE_OVER_PI;
-    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-}
-__device__ __forceinline__ V3 uniform_sphere(float u1, float u2, float &pdf)      // wrap.h:26-36
-{
-    float costheta = 1.f - 2.f * u1;
-    float sintheta = sqrt_rn(1.f - costheta * costheta);
-    float phi = TWOPI * u2;
-    float cosphi = gpt_cosf(phi);
-    float sinphi = gpt_sinf(phi);
-    pdf = ONE_OVER_FOUR_PI;
-    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+    float sin_p, cos_p;
+    sincos_soft(TWOPI * u2, sin_p, cos_p);
+    const float cos_t = 1.f - 2.f * u1;
+    return polar_y_up(sqrt_rn(1.f - cos_t * cos_t), cos_t, sin_p, cos_p);
 }
 
 // --------------------------------------------------------------- camera ------
@@ -71,9 +59,9 @@ __device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y
     float yy = y * c.pixel2screen.y - c.height;
     V3 dir;
     if (c.apertureRadius > 0.00001f) {
-        float rr = sqrt_rn(du1);                  // UniformDisk
-        float phi = TWOPI * du2;
-        V2 xy = v2(rr * gpt_cosf(phi), rr * gpt_sinf(phi));
+        float rr = sqrt_rn(du1), sin_p, cos_p;    // UniformDisk
+        sincos_soft(TWOPI * du2, sin_p, cos_p);
+        V2 xy = v2(rr * cos_p, rr * sin_p);
         V2 aperture_xy = xy * c.apertureRadius;
         float focal_x = c.ratio * xx;
         float focal_y = c.ratio * yy;
@@ -89,434 +77,6 @@ __device__ __forceinline__ Ray primary_ray(const gpt_camera &c, float x, float y
     ray.o = orig;
     ray.d = dir;
     return ray;
-}
-
-// ------------------------------------------------------------- textures ------
-__device__ __forceinline__ V4 texel_int(const DevTexture &t, int w, int h, int x, int y)   // pathtracer.cu:324-339
-{
-    float inv = 1.f / 255.f;
-    float rx = x - (x / w) * w;
-    float ry = y - (y / h) * h;
-    x = (rx < 0) ? rx + w : rx;
-    y = (ry < 0) ? ry + h : ry;
-    if (x < 0) x = 0;
-    if (x > w - 1) x = w - 1;
-    if (y < 0) y = 0;
-    if (y > h - 1) y = h - 1;
-    gpt_uchar4 c = t.data[y * w + x];
-    return v4(c.x * inv, c.y * inv, c.z * inv, c.w * inv);
-}
-__device__ __forceinline__ V3 get_texel(const DevParams &P, const gpt_material &m, V2 uv)   // pathtracer.cu:341-359
-{
-    if (m.textureIdx == -1)
-        return V3{m.diffuse.x, m.diffuse.y, m.diffuse.z};
-#ifdef PT_ANALYSIS_LAMBERT
-    return V3{0.f, 0.f, 0.f};
-#endif
-    const DevTexture t = P.textures[m.textureIdx];
-    int w = t.width, h = t.height;
-    float xx = w * uv.x;
-    float yy = h * uv.y;
-    int x = (int)__builtin_floorf(xx);
-    int y = (int)__builtin_floorf(yy);
-    float dx = fabs_(xx - x);
-    float dy = fabs_(yy - y);
-    V4 c00 = texel_int(t, w, h, x, y);
-    V4 c10 = texel_int(t, w, h, x + 1, y);
-    V4 c01 = texel_int(t, w, h, x, y + 1);
-    V4 c11 = texel_int(t, w, h, x + 1, y + 1);
-    V4 r = (1 - dy) * ((1 - dx) * c00 + dx * c10) + dy * ((1 - dx) * c01 + dx * c11);
-    return V3{r.x, r.y, r.z};
-}
-
-// --------------------------------------------------------- BSDF helpers ------
-__device__ __forceinline__ float dielectric_fresnel(float cosi, float cost, float etai, float etat)   // :51-56
-{
-    float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
-    float Rperp = (etai * cosi - etat * cost) / (etai * cosi + etat * cost);
-    return (Rparl * Rparl + Rperp * Rperp) * 0.5f;
-}
-__device__ __forceinline__ V3 conduct_fresnel(float cosi, V3 eta, V3 k)                              // :58-66
-{
-    V3 tmp = (eta * eta + k * k) * cosi * cosi;
-    V3 Rparl2 = (tmp - eta * cosi * 2.f + 1.f) / (tmp + eta * cosi * 2.f + 1.f);
-    V3 tmp_f = (eta * eta + k * k);
-    V3 Rperp2 = (tmp_f - eta * cosi * 2.f + cosi * cosi) / (tmp_f + eta * cosi * 2.f + cosi * cosi);
-    return (Rparl2 + Rperp2) * 0.5f;
-}
-__device__ __forceinline__ float ggx_d(V3 wh, V3 normal, V3 dpdu, float alphaU, float alphaV)        // :68-84
-{
-    float costheta = dot(wh, normal);
-    if (costheta <= 0.f) return 0.f;
-    costheta = clamp(costheta, 0.f, 1.f);
-    float costheta2 = costheta * costheta;
-    float sintheta2 = 1.f - costheta2;
-    float costheta4 = costheta2 * costheta2;
-    float tantheta2 = sintheta2 / costheta2;
-    V3 uu = dpdu;
-    V3 dir = normalize(wh - costheta * normal);
-    float cosphi = dot(dir, uu);
-    float cosphi2 = cosphi * cosphi;
-    float sinphi2 = 1.f - cosphi2;
-    float sqrD = 1.f + tantheta2 * (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
-    return 1.f / (PI * alphaU * alphaV * costheta4 * sqrD * sqrD);
-}
-__device__ __forceinline__ float smith_g(V3 w, V3 normal, V3 wh, V3 dpdu, float alphaU, float alphaV)  // :86-101
-{
-    float wdn = dot(w, normal);
-    if (wdn * dot(w, wh) < 0.f) return 0.f;
-    float sintheta = sqrt_rn(clamp(1.f - wdn * wdn, 0.f, 1.f));
-    float tantheta = sintheta / wdn;
-    if (gpt_isinff(tantheta)) return 0.f;
-    V3 uu = dpdu;
-    V3 dir = normalize(w - wdn * normal);
-    float cosphi = dot(dir, uu);
-    float cosphi2 = cosphi * cosphi;
-    float sinphi2 = 1.f - cosphi2;
-    float alpha2 = cosphi2 * (alphaU * alphaU) + sinphi2 * (alphaV * alphaV);
-    float sqrD = alpha2 * tantheta * tantheta;
-    return 2.f / (1.f + sqrt_rn(1 + sqrD));
-}
-__device__ __forceinline__ float ggx_g(V3 wo, V3 wi, V3 normal, V3 wh, V3 dpdu, float aU, float aV)    // :103-105
-{
-    return smith_g(wo, normal, wh, dpdu, aU, aV) * smith_g(wi, normal, wh, dpdu, aU, aV);
-}
-__device__ __forceinline__ V3 sample_ggx(float alphaU, float alphaV, float u1, float u2)              // :107-138
-{
-    if (alphaU == alphaV) {
-        float costheta = sqrt_rn((1.f - u1) / (u1 * (alphaU * alphaV - 1.f) + 1.f));
-        float sintheta = sqrt_rn(1.f - costheta * costheta);
-        float phi = 2 * PI * u2;
-        float cosphi = gpt_cosf(phi);
-        float sinphi = gpt_sinf(phi);
-        return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-    } else {
-        float phi;
-        if (u2 <= 0.25f) phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2));
-        else if (u2 >= 0.75f) phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2)) + TWOPI;
-        else phi = gpt_atanf(alphaV / alphaU * gpt_tanf(TWOPI * u2)) + PI;
-        float sinphi = gpt_sinf(phi), cosphi = gpt_cosf(phi);
-        float sinphi2 = sinphi * sinphi;
-        float cosphi2 = 1.0f - sinphi2;
-        float inverseA = 1.0f / (cosphi2 / (alphaU * alphaU) + sinphi2 / (alphaV * alphaV));
-        float theta = gpt_atanf(sqrt_rn(inverseA * u1 / (1.0f - u1)));
-        float sintheta = gpt_sinf(theta), costheta = gpt_cosf(theta);
-        return v3(sintheta * cosphi, costheta, sintheta * sinphi);
-    }
-}
-__device__ __forceinline__ V3 reflect(V3 in, V3 nor) { return 2.f * dot(in, nor) * nor - in; }       // :140-142
-__device__ __forceinline__ V3 refract(V3 in, V3 nor, float etai, float etat)                          // :144-158
-{
-    float cosi = dot(in, nor);
-    bool enter = cosi > 0;
-    if (!enter) {
-        float t = etai;
-        etai = etat;
-        etat = t;
-    }
-    float eta = etai / etat;
-    float sini2 = 1.f - cosi * cosi;
-    float sint2 = sini2 * eta * eta;
-    float cost = sqrt_rn(1.f - sint2);
-    return normalize((nor * cosi - in) * eta + (enter ? -cost : cost) * nor);
-}
-__device__ __forceinline__ V3 schlick_fresnel(V3 specular, float costheta)                            // :160-164
-{
-    V3 rs = specular;
-    float c = 1.f - costheta;
-    return rs + c * c * c * c * c * (v3(1.f, 1.f, 1.f) - rs);
-}
-__device__ __forceinline__ float power_heuristic(int nf, float fPdf, int ng, float gPdf)              // :166-169
-{
-    float f = nf * fPdf, g = ng * gPdf;
-    return (f * f) / (f * f + g * g);
-}
-__device__ __forceinline__ float luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)); }
-__device__ __forceinline__ bool same_hemisphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }
-// PT_ANALYSIS_LAMBERT (never shipped): compile only the lambertian / area-light path, to read its ISA
-#ifdef PT_ANALYSIS_LAMBERT
-#define PT_MATERIAL_TYPE(m) GPT_MT_LAMBERTIAN
-#else
-#define PT_MATERIAL_TYPE(m) (m).type
-#endif
-__device__ __forceinline__ bool is_delta(int type) { return type == GPT_MT_MIRROR || type == GPT_MT_DIELECTRIC; }
-__device__ __forceinline__ float max_(float a, float b) { return a > b ? a : b; }                     // common.h:98-101
-
-// ------------------------------------------------- SampleBSDF, :491-695 ------
-__device__ __forceinline__ void sample_bsdf(const DevParams &P, const gpt_material &material, V3 in, V3 nor, V2 uv,
-                                            V3 dpdu, V3 u, V3 &out, V3 &fr, float &pdf)
-{
-    const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
-    switch (PT_MATERIAL_TYPE(material)) {
-    case GPT_MT_LAMBERTIAN: {
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        out = cosine_hemisphere(u.x, u.y, pdf);
-        V3 uu = dpdu, ww;
-        ww = cross(uu, n);
-        out = to_world(out, uu, n, ww);
-        fr = get_texel(P, material, uv) * ONE_OVER_PI;
-        break;
-    }
-    case GPT_MT_MIRROR:
-        out = reflect(in, nor);
-        fr = m_spec / fabs_(dot(out, nor));
-        pdf = 1.f;
-        break;
-    case GPT_MT_DIELECTRIC: {
-        V3 wi = -in;
-        V3 normal = nor;
-        float ei = material.outsideIOR, et = material.insideIOR;
-        float cosi = dot(wi, normal);
-        bool enter = cosi < 0;
-        if (!enter) {
-            float t = ei;
-            ei = et;
-            et = t;
-        }
-        float eta = ei / et, cost;
-        float sint2 = eta * eta * (1.f - cosi * cosi);
-        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-        V3 rdir = reflect(-wi, normal);
-        V3 tdir = refract(in, nor, material.outsideIOR, material.insideIOR);
-        if (sint2 > 1.f) {   // total reflection
-            out = rdir;
-            fr = m_spec / fabs_(dot(out, normal));
-            pdf = 1.f;
-            return;
-        }
-        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
-        if (u.x > fresnel) {   // refract
-            out = tdir;
-            fr = m_spec / fabs_(dot(out, normal)) * (1.f - fresnel);
-            fr *= eta * eta;   // TransportMode::Radiance
-            pdf = 1.f - fresnel;
-        } else {               // reflect
-            out = rdir;
-            fr = m_spec / fabs_(dot(out, normal)) * fresnel;
-            pdf = fresnel;
-        }
-        break;
-    }
-    case GPT_MT_ROUGHCONDUCTOR: {
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        V3 wh = sample_ggx(material.alphaU, material.alphaV, u.x, u.y);
-        V3 uu = dpdu, ww;
-        ww = cross(uu, n);
-        wh = to_world(wh, uu, n, ww);
-        out = reflect(in, wh);
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0, 0, 0);
-            pdf = 0.f;
-            return;
-        }
-        float cosi = dot(out, wh);
-        V3 F = conduct_fresnel(fabs_(cosi), V3{material.eta.x, material.eta.y, material.eta.z},
-                               V3{material.k.x, material.k.y, material.k.z});
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-        fr = m_spec * F * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-        pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(in, wh)));
-        break;
-    }
-    case GPT_MT_SUBSTRATE: {
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        if (u.x < 0.5f) {
-            float ux = u.x * 2.f;
-            out = cosine_hemisphere(ux, u.y, pdf);
-            V3 uu = dpdu, ww;
-            ww = cross(uu, n);
-            out = to_world(out, uu, n, ww);
-        } else {
-            float ux = (u.x - 0.5f) * 2.f;
-            V3 wh = sample_ggx(material.alphaU, material.alphaV, ux, u.y);
-            V3 uu = dpdu, ww;
-            ww = cross(uu, n);
-            wh = to_world(wh, uu, n, ww);
-            out = reflect(in, wh);
-        }
-        if (!same_hemisphere(in, out, n)) {
-            fr = v3(0.f, 0.f, 0.f);
-            pdf = 0.f;
-            return;
-        }
-        float c0 = fabs_(dot(in, n));
-        float c1 = fabs_(dot(out, n));
-        V3 Rd = get_texel(P, material, uv);
-        V3 Rs = m_spec;
-        float cons0 = 1 - 0.5f * c0;
-        float cons1 = 1 - 0.5f * c1;
-        V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) *
-                     (1 - cons0 * cons0 * cons0 * cons0 * cons0) *
-                     (1 - cons1 * cons1 * cons1 * cons1 * cons1);
-        V3 wh = normalize(in + out);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        V3 specular = D / (4.f * fabs_(dot(out, wh)) * max_(c0, c1)) * schlick_fresnel(Rs, dot(out, wh));
-        fr = diffuse + specular;
-        pdf = 0.5f * (fabs_(dot(out, n)) * ONE_OVER_PI + D * fabs_(dot(wh, n)) / (4.f * dot(in, wh)));
-        break;
-    }
-    case GPT_MT_ROUGHDIELECTRIC: {
-        V3 wi = -in;
-        V3 n = nor;
-        V3 wh = sample_ggx(material.alphaU, material.alphaV, u.x, u.y);
-        V3 uu = dpdu, ww;
-        ww = cross(uu, n);
-        wh = to_world(wh, uu, n, ww);
-        float ei = material.outsideIOR, et = material.insideIOR;
-        float cosi = dot(wi, n);
-        bool enter = cosi < 0;
-        if (!enter) {
-            float t = ei;
-            ei = et;
-            et = t;
-        }
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        float eta = ei / et, cost;
-        cosi = dot(wi, wh);
-        float sint2 = eta * eta * (1.f - cosi * cosi);
-        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-        V3 rdir = reflect(-wi, wh);
-        V3 tdir = normalize((wi - wh * cosi) * eta + (enter ? -cost : cost) * wh);
-        if (sint2 > 1.f) {   // total reflection
-            out = rdir;
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            fr = m_spec * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-            pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in)));
-            return;
-        }
-        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
-        if (u.z > fresnel) {   // refract
-            out = tdir;
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            float c = et * dot(out, wh) + ei * dot(in, wh);
-            fr = m_spec * ei * ei * D * G * (1.f - fresnel) * fabs_(dot(in, wh)) * fabs_(dot(out, wh)) /
-                 (fabs_(dot(out, n)) * fabs_(dot(in, n)) * c * c);
-            fr *= (1.f / (eta * eta));
-            pdf = (1.f - fresnel) * D * fabs_(dot(wh, n)) * et * et * fabs_(dot(out, wh)) / (c * c);
-        } else {               // reflect
-            out = rdir;
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            fr = m_spec * fresnel * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-            pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in))) * fresnel;
-        }
-        break;
-    }
-    default:
-        out = v3(0, 0, 0);
-        fr = v3(0, 0, 0);
-        pdf = 0.f;
-        break;
-    }
-}
-
-// ----------------------------------------------------------- Fr, :698-826 ----
-__device__ __forceinline__ void eval_bsdf(const DevParams &P, const gpt_material &material, V3 in, V3 out, V3 nor,
-                                          V2 uv, V3 dpdu, V3 &fr, float &pdf)
-{
-    const V3 m_spec = V3{material.specular.x, material.specular.y, material.specular.z};
-    switch (PT_MATERIAL_TYPE(material)) {
-    case GPT_MT_LAMBERTIAN:
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0.f, 0.f, 0.f);
-            pdf = 0.f;
-            return;
-        }
-        fr = get_texel(P, material, uv) * ONE_OVER_PI;
-        pdf = fabs_(dot(out, nor)) * ONE_OVER_PI;
-        break;
-    case GPT_MT_MIRROR:
-    case GPT_MT_DIELECTRIC:
-        fr = v3(0.f, 0.f, 0.f);
-        pdf = 0.f;
-        break;
-    case GPT_MT_ROUGHCONDUCTOR: {
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0, 0, 0);
-            pdf = 0;
-            return;
-        }
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        V3 wh = normalize(in + out);
-        float cosi = dot(out, wh);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-        V3 F = conduct_fresnel(fabs_(cosi), V3{material.eta.x, material.eta.y, material.eta.z},
-                               V3{material.k.x, material.k.y, material.k.z});
-        fr = m_spec * F * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-        pdf = D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(in, wh)));
-        break;
-    }
-    case GPT_MT_SUBSTRATE: {
-        if (!same_hemisphere(in, out, nor)) {
-            fr = v3(0, 0, 0);
-            pdf = 0;
-            return;
-        }
-        V3 n = nor;
-        if (dot(nor, in) < 0)
-            n = -n;
-        float c0 = fabs_(dot(in, n));
-        float c1 = fabs_(dot(out, n));
-        V3 Rd = get_texel(P, material, uv);
-        V3 Rs = m_spec;
-        float cons0 = 1 - 0.5f * c0;
-        float cons1 = 1 - 0.5f * c1;
-        V3 wh = normalize(in + out);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) *
-                     (1 - cons0 * cons0 * cons0 * cons0 * cons0) *
-                     (1 - cons1 * cons1 * cons1 * cons1 * cons1);
-        V3 specular = D / (4.f * fabs_(dot(out, wh)) * max_(c0, c1)) * schlick_fresnel(Rs, dot(out, wh));
-        fr = diffuse + specular;
-        pdf = 0.5f * (fabs_(dot(out, n)) * ONE_OVER_PI + D * fabs_(dot(wh, n)) / (4.f * dot(in, wh)));
-        break;
-    }
-    case GPT_MT_ROUGHDIELECTRIC: {
-        V3 wi = -in;
-        V3 n = nor;
-        bool refl = dot(in, n) * dot(out, n) > 0;
-        float ei = material.outsideIOR, et = material.insideIOR;
-        float cosi = dot(wi, n);
-        bool enter = cosi < 0;
-        if (!enter) {
-            float t = ei;
-            ei = et;
-            et = t;
-        }
-        V3 wh = normalize(-(ei * in + et * out));
-        float eta = ei / et, cost;
-        cosi = dot(wi, wh);
-        float sint2 = eta * eta * (1.f - cosi * cosi);
-        cost = sqrt_rn(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-        float fresnel = dielectric_fresnel(fabs_(cost), fabs_(cosi), et, ei);
-        float D = ggx_d(wh, n, dpdu, material.alphaU, material.alphaV);
-        if (!refl) {   // refract
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            float c = et * dot(out, wh) + ei * dot(in, wh);
-            fr = m_spec * ei * ei * D * G * (1.f - fresnel) * fabs_(dot(in, wh)) * fabs_(dot(out, wh)) /
-                 (fabs_(dot(out, n)) * fabs_(dot(in, n)) * c * c);
-            fr *= (1.f / (eta * eta));
-            pdf = (1.f - fresnel) * D * fabs_(dot(wh, n)) * et * et * fabs_(dot(out, wh)) / (c * c);
-        } else {
-            float G = ggx_g(in, out, n, wh, dpdu, material.alphaU, material.alphaV);
-            fr = m_spec * fresnel * D * G / (4.f * fabs_(dot(in, n)) * fabs_(dot(out, n)));
-            pdf = fresnel * D * fabs_(dot(wh, n)) / (4.f * fabs_(dot(wh, in)));
-        }
-        break;
-    }
-    default:
-        fr = v3(0, 0, 0);
-        pdf = 0.f;
-        break;
-    }
 }
 
 // --------------------------------------------------------------- lights ------
@@ -591,14 +151,13 @@ __device__ __forceinline__ V3 inf_le(const DevInfinite &I, V3 dir)
 __device__ __forceinline__ void inf_sample_light(const DevInfinite &I, V3 pos, V2 uniform, V3 &rad, Ray &ray, V3 &nor,
                                                  float &pdf, float eps)   // infinite.h:17-36
 {
-    float pdfW;
-    V3 dir = uniform_sphere(uniform.x, uniform.y, pdfW);
+    V3 dir = sphere_direction(uniform.x, uniform.y);
     nor = -dir;
     ray.o = pos;
     ray.d = dir;
     ray.tmin = eps;
     ray.tmax = 2.f * I.radius - eps;
-    pdf = pdfW;
+    pdf = ONE_OVER_FOUR_PI;
     rad = inf_le(I, dir);
 }
 
@@ -691,8 +250,7 @@ __device__ __forceinline__ float medium_phase(const DevMedium &m, V3 in, V3 out)
 __device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, float uy)                      // medium.h:196-220
 {
     float g = m.g;
-    float unused;
-    if (g == 0) return uniform_sphere(ux, uy, unused);
+    if (g == 0) return sphere_direction(ux, uy);
     float costheta;
     if (fabs_(g) < 1e-3f)
         costheta = 1.f - 2.f * ux;
@@ -701,9 +259,9 @@ __device__ __forceinline__ V3 medium_sample_phase(const DevMedium &m, float ux, 
         costheta = (1.f + g * g - sqrtTerm * sqrtTerm) / (2.f * g);
     }
     float sintheta = sqrt_rn(1.f - costheta * costheta);
-    float phi = TWOPI * uy;
-    float sinphi = gpt_sinf(phi), cosphi = gpt_cosf(phi);
-    return v3(sintheta * cosphi, costheta, sintheta * sinphi);
+    float sin_p, cos_p;
+    sincos_soft(TWOPI * uy, sin_p, cos_p);
+    return polar_y_up(sintheta, costheta, sin_p, cos_p);
 }
 
 // Heterogeneous media (src/medium.h:53-182), as oracle/pt_oracle.c restates them (het_d, het_density; het_tr and

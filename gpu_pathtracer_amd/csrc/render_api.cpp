@@ -40,6 +40,8 @@ hipError_t launch_tonemap(const float *acc, float *out, uint32_t stride, uint32_
                           hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *x, const float *y, float *out, int n, hipStream_t stream);
 hipError_t launch_debug_rng(uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n, hipStream_t stream);
+hipError_t launch_debug_bsdf(const gpt_material *material, const DevTexture *texture, const float *geom11, const float *in3, int n, int mode,
+                             float *out7, hipStream_t stream);
 int render_kernel_blocks_per_cu(bool count, bool walk, bool wide);
 bool render_uses_walk_kernel(const DevParams &P, bool force);
 }  // namespace pt
@@ -1119,6 +1121,48 @@ int gpt_debug_math(int device, int fn, const float *x, const float *y, float *ou
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return GPT_OK;
+}
+
+int gpt_debug_bsdf(int device, const gpt_material *material, const gpt_texture *texture, const float *geom11, const float *in3, int n,
+                   int mode, float *out7)
+{
+    if (!material || !geom11 || !in3 || !out7 || n <= 0 || (mode != 0 && mode != 1)) { gpt_set_error("gpt_debug_bsdf: invalid argument"); return GPT_ERR_INVALID_ARG; }
+    if (material->textureIdx != -1 && (material->textureIdx != 0 || !texture || !texture->data || texture->width <= 0 || texture->height <= 0)) {
+        gpt_set_error("gpt_debug_bsdf: the material's textureIdx must be -1, or 0 with a texture given");
+        return GPT_ERR_INVALID_ARG;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { gpt_set_error("gpt_debug_bsdf: no HIP device"); return GPT_ERR_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device));
+    gpt_material *dm = nullptr;
+    DevTexture *dt = nullptr;
+    gpt_uchar4 *dtexels = nullptr;
+    float *dg = nullptr, *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **)&dm, sizeof(gpt_material)));
+    HIP_TRY(hipMemcpy(dm, material, sizeof(gpt_material), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&dt, sizeof(DevTexture)));
+    DevTexture ht;
+    ht.data = nullptr;
+    ht.width = ht.height = 0;
+    if (material->textureIdx == 0) {
+        const size_t texels = (size_t)texture->width * (size_t)texture->height;
+        HIP_TRY(hipMalloc((void **)&dtexels, texels * sizeof(gpt_uchar4)));
+        HIP_TRY(hipMemcpy(dtexels, texture->data, texels * sizeof(gpt_uchar4), hipMemcpyHostToDevice));
+        ht.data = dtexels;
+        ht.width = texture->width;
+        ht.height = texture->height;
+    }
+    HIP_TRY(hipMemcpy(dt, &ht, sizeof(DevTexture), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&dg, (size_t)n * 11 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&din, (size_t)n * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 7 * sizeof(float)));
+    HIP_TRY(hipMemcpy(dg, geom11, (size_t)n * 11 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(din, in3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(launch_debug_bsdf(dm, dt, dg, din, n, mode, dout, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out7, dout, (size_t)n * 7 * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dm); (void)hipFree(dt); (void)hipFree(dtexels); (void)hipFree(dg); (void)hipFree(din); (void)hipFree(dout);
     return GPT_OK;
 }
 

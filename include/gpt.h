@@ -186,8 +186,16 @@ int gpt_read_probe_counters(gpt_ctx *ctx, uint64_t out16[16]);
 
 /* Device-side evaluation of the elementary float operations the kernel relies
  * on, for parity tests against the CPU oracle: fn 0 sin, 1 cos, 2 tan, 3 atan,
- * 4 acos, 5 pow(x,y), 6 x/y, 7 sqrt, 8 1/sqrt.  Host pointers. */
+ * 4 acos, 5 pow(x,y), 6 x/y, 7 sqrt, 8 1/sqrt, 9 exp, 10 log (the last two: src/medium.h:15,41-43,73,
+ * src/common.h:81-86, src/wrap.h:158-160).  Host pointers. */
 int gpt_debug_math(int device, int fn, const float *x, const float *y, float *out, int n);
+/* SampleBSDF / Fr (src/pathtracer.cu:491-695, 698-826, with GetTexel :324-359) on the device, through the routines the render kernels
+ * shade with (csrc/pt_bsdf.h: surface_prepare, then surface_respond or surface_scatter).  Case i: geom11[11 i ..] = in.xyz (the unit
+ * vector back along the arriving ray), normal.xyz, dpdu.xyz, uv.xy; in3[3 i ..] = mode 0: the direction `out` Fr is asked about,
+ * mode 1: the three draws `u` of SampleBSDF.  out7[7 i ..] = out.xyz, fr.xyz, pdf.  material->textureIdx is -1, or 0 and then
+ * `texture` is that texture.  Host pointers. */
+int gpt_debug_bsdf(int device, const gpt_material *material, const gpt_texture *texture, const float *geom11, const float *in3, int n,
+                   int mode, float *out7);
 /* The traversal operators alone (Intersect / IntersectP, src/pathtracer.cu:214-296; BBox::Intersect, src/bbox.h:77-96;
  * Triangle::Intersect, src/mesh.h:45-67) on the device, through the render kernel's own ray pools and traversal loops, in the
  * context's current traversal order and memory path.  Ray i = rays8[8 i ..] = {origin.xyz, direction.xyz, tmax, any_hit != 0},

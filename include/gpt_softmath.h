@@ -81,7 +81,10 @@ GPT_HD GPT_INL double gpt_rem_pio2(double x, int *quadrant)
     const double shifter = 6755399441055744.0;           /* 1.5 * 2^52 */
     double t = x * two_over_pi + shifter;                /* round-to-nearest-even integer */
     double k = t - shifter;
-    *quadrant = (int)(int64_t)k;
+    /* k mod 2^32 sits in the low word of t (two's complement, |k| < 2^51): read it from there rather than convert k, so that
+     * arguments far outside the supported range (and inf / NaN) still give the SAME bits on host and device - a float -> integer
+     * conversion that overflows is undefined in C and saturates on gfx950.  Only bits 0 and 1 are ever looked at. */
+    *quadrant = (int)(uint32_t)gpt_d2u(t);
     return (x - k * pio2_hi) - k * pio2_lo;
 }
 

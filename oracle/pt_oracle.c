@@ -2103,6 +2103,38 @@ API void oracle_bsdf_eval_batch(const gpt_material *m, const float wo[3], const 
         pdf_out[i] = pdf;
     }
 }
+/* ... with a geometry per case and an optional texture: the checker of the device entry gpt_debug_bsdf (include/gpt.h) and of the
+ * host build of pt_bsdf.h (tests/cxx/bsdf_host.cpp).  geom11 = wo.xyz, normal.xyz, dpdu.xyz, uv.xy per case; mode 0: Fr towards
+ * wi = in3 (out7 = wi, fr, pdf), mode 1: SampleBSDF with the draws in3 (out7 = out, fr, pdf; what the reference leaves unset reads 0).
+ * `tex` (or NULL) is texture 0 of the scene the material's textureIdx refers to. */
+API void oracle_bsdf_batch(const gpt_material *m, const gpt_texture *tex, const float *geom11, const float *in3, int n, int mode, float *out7)
+{
+    gpt_scene_desc d;
+    scene_t sc;
+    memset(&d, 0, sizeof(d));
+    memset(&sc, 0, sizeof(sc));
+    d.textures = tex;
+    d.n_textures = tex ? 1 : 0;
+    sc.d = &d;
+    for (int i = 0; i < n; ++i) {
+        const float *g = geom11 + 11 * i;
+        const f3 wo = mk3(g[0], g[1], g[2]), nor = mk3(g[3], g[4], g[5]), dpdu = mk3(g[6], g[7], g[8]);
+        const f2 uv = mk2(g[9], g[10]);
+        const f3 a = mk3(in3[3 * i], in3[3 * i + 1], in3[3 * i + 2]);
+        f3 out = mk3(0, 0, 0), fr = mk3(0, 0, 0);
+        float pdf = 0.f;
+        if (mode == 0) {
+            out = a;
+            eval_bsdf(&sc, m, wo, a, nor, uv, dpdu, &fr, &pdf);
+        } else {
+            sample_bsdf(&sc, m, wo, nor, uv, dpdu, a, &out, &fr, &pdf);
+        }
+        float *o = out7 + 7 * i;
+        o[0] = out.x; o[1] = out.y; o[2] = out.z;
+        o[3] = fr.x; o[4] = fr.y; o[5] = fr.z;
+        o[6] = pdf;
+    }
+}
 /* Infinite::SampleLight and Infinite::Le (infinite.h:17-59) for n uniforms / n directions */
 API void oracle_infinite_sample_batch(const gpt_infinite *inf, const float pos[3], const float *u2, int n, float eps,
                                       float *dir_out, float *rad_out, float *pdf_out, float *tmax_out)
