@@ -160,7 +160,6 @@ struct Surface {
     // normal, the frame's third axis and wo's cosine are formed where a question needs them: what stays in registers from one
     // question to the next is what was expensive to get.
     bool turn;
-    float a_uu, a_vv;  // alphaU^2, alphaV^2 (GGX_D, SmithG)
     V3 base;           // lambertian: albedo / pi;  substrate: (28 / 23 pi) Rd (1 - Rs) (1 - (1 - |wo.n| / 2)^5)
     float mask_wo;     // rough conductor / dielectric: Smith masking of wo, before its micro-facet side test
 
@@ -184,7 +183,8 @@ PT_FN float mask_shape(V3 w, float w_n, V3 n, V3 tu, float a_uu, float a_vv)
 }
 PT_FN float mask_side(float shape, float w_n, float w_wh) { return w_n * w_wh < 0.f ? 0.f : shape; }
 
-// `uv` is only read by the kinds that have a colour (lambertian, substrate)
+// `uv` is only read by the kinds that have a colour (lambertian, substrate).  Measured on the MI355X (profiles/r06/a2_variants.log):
+// with base and mask_wo formed here the config-3 stand-in runs 9 % faster than with each question forming its own.
 PT_FN Surface surface_prepare(const DevParams &P, const gpt_material &m, V3 wo, V3 nor, V3 dpdu, V2 uv)
 {
     Surface S;
@@ -194,8 +194,6 @@ PT_FN Surface surface_prepare(const DevParams &P, const gpt_material &m, V3 wo, 
     S.tu = dpdu;
     S.wo_ng = dot(nor, wo);
     S.turn = S.wo_ng < 0 && S.kind != GPT_MT_ROUGHDIELECTRIC;
-    S.a_uu = m.alphaU * m.alphaU;
-    S.a_vv = m.alphaV * m.alphaV;
     S.base = v3(0.f);
     S.mask_wo = 0.f;
     if (S.kind == GPT_MT_LAMBERTIAN) {
@@ -205,7 +203,7 @@ PT_FN Surface surface_prepare(const DevParams &P, const gpt_material &m, V3 wo, 
         const float k0 = 1 - 0.5f * fabs_(S.wo_nm());
         S.base = kSubstrateDiffuse * surface_colour(P, m, uv) * (v3(1.f, 1.f, 1.f) - rs) * (1 - pow5(k0));   // :623-624
     } else if (S.kind == GPT_MT_ROUGHCONDUCTOR || S.kind == GPT_MT_ROUGHDIELECTRIC) {
-        S.mask_wo = mask_shape(wo, S.wo_nm(), S.nm(), dpdu, S.a_uu, S.a_vv);
+        S.mask_wo = mask_shape(wo, S.wo_nm(), S.nm(), dpdu, m.alphaU * m.alphaU, m.alphaV * m.alphaV);
     }
     return S;
 }
@@ -219,7 +217,7 @@ PT_FN float ndf(const Surface &S, const gpt_material &m, V3 nm, V3 wh, float wh_
     const V3 flat = normalize(wh - c * nm);
     const float cos_p = dot(flat, S.tu);
     const float cos_p2 = cos_p * cos_p;
-    const float stretch = 1.f + tan2 * (cos_p2 / S.a_uu + (1.f - cos_p2) / S.a_vv);
+    const float stretch = 1.f + tan2 * (cos_p2 / (m.alphaU * m.alphaU) + (1.f - cos_p2) / (m.alphaV * m.alphaV));
     const float d = 1.f / (PI * m.alphaU * m.alphaV * (c2 * c2) * stretch * stretch);
     return wh_nm <= 0.f ? 0.f : d;
 }
@@ -285,8 +283,7 @@ PT_FN Crossing crossing_of(const Boundary &b, float wo_axis)
 
 // The closing code of every rough answer: wi is known, wh is the micro-normal that links it to wo.  One normal distribution,
 // one masking term of wi (wo's comes from the Surface), then the formula of the lobe.
-PT_FN void weigh_rough(const Surface &S, const gpt_material &m, V3 wh, int close, const Boundary &b, float reflectance,
-                                            Scatter &r)
+PT_FN void weigh_rough(const Surface &S, const gpt_material &m, V3 wh, int close, float reflectance, Scatter &r)
 {
     const V3 spec = V3{m.specular.x, m.specular.y, m.specular.z};
     const V3 nm = S.nm();
@@ -307,9 +304,10 @@ PT_FN void weigh_rough(const Surface &S, const gpt_material &m, V3 wh, int close
         r.pdf = 0.5f * (c1 * ONE_OVER_PI + D * fabs_(wh_nm) / (4.f * wo_wh));
         return;
     }
-    const float G = mask_side(S.mask_wo, wo_nm, wo_wh) * mask_side(mask_shape(r.wi, wi_nm, nm, S.tu, S.a_uu, S.a_vv), wi_nm, wi_wh);
+    const float G = mask_side(S.mask_wo, wo_nm, wo_wh) * mask_side(mask_shape(r.wi, wi_nm, nm, S.tu, m.alphaU * m.alphaU, m.alphaV * m.alphaV), wi_nm, wi_wh);
     if (close == kCloseRefract) {
         // pathtracer.cu:680-688, 806-813 (radiance transport)
+        const Boundary b = boundary_of(S, m);
         const float n_i = b.n_here, n_t = b.n_there;
         const float c = n_t * wi_wh + n_i * wo_wh;
         const float ratio = n_i / n_t;
@@ -359,7 +357,7 @@ PT_FN Scatter surface_respond(const Surface &S, const gpt_material &m, V3 wi)
                 reflectance = crossing_of(b, dot(S.wo, wh)).reflectance;
                 close = same_side ? kCloseReflectAsked : kCloseRefract;
             }
-            weigh_rough(S, m, wh, close, b, reflectance, r);
+            weigh_rough(S, m, wh, close, reflectance, r);
         }
     }
     return r;
@@ -438,7 +436,7 @@ PT_FN Scatter surface_scatter(const Surface &S, const gpt_material &m, float u1,
         // a proposal that lands on the other side of the surface is void (:563-567, 599-603); the boundary has both sides
         if (boundary || S.wo_ng * dot(r.wi, S.ng) > 0) {
             if (layered) wh = normalize(S.wo + r.wi);                                        // :625
-            weigh_rough(S, m, wh, close, b, reflectance, r);
+            weigh_rough(S, m, wh, close, reflectance, r);
         }
     }
     return r;

@@ -10,3 +10,9 @@ for v in "$@"; do
   echo "== $v" | tee -a $OUT/ab.log
   python tools/gpu_configs.py 2>&1 | grep "SURVEY stand-in" | sed 's/SURVEY stand-in: //' | cut -c1-150 | tee -a $OUT/ab.log
 done
+# Volpath: the shipped scene's shape on the one-ray kernel, the fog box on both kernels
+for v in "$@"; do
+  export GPT_LIB_PATH=$PWD/var/libgpt_$v.so
+  echo "== volpath $v" | tee -a $OUT/ab.log
+  python tools/gpu_volpath.py 2>&1 | grep "Msamples" | cut -c1-110 | tee -a $OUT/ab.log
+done
