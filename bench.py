@@ -98,6 +98,31 @@ def cpu_baseline():
                       f"oracle/liboracle_soft.so single thread, {dt:.1f} s"}
 
 
+def cpu_crop_baseline(ls, n_crop, crop_rank, budget_s=8.0):
+    """The CPU leg beside a stand-in / the Volpath scene ("a reduced-spp run of each GPU config's scene"): the oracle
+    on ONE host thread, the leg's own scene, camera and frame, in the reference's traversal order on the loader's tree, restricted to the
+    8x8 tiles t with t % n_crop == crop_rank (spread over the whole frame: the tile-ownership rule of the multi-GPU split) and to as
+    many iterations as fit the time budget.  The oracle is the thing timed here and nowhere else."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    W, H = ls.width, ls.height
+    tiles = ((W + 7) // 8) * ((H + 7) // 8)
+    owned = (tiles - crop_rank + n_crop - 1) // n_crop
+    kw = dict(kind="soft", rank=crop_rank, n_ranks=n_crop, threads=1, order=0)
+    ol.render(ls, ls.camera, W, H, ls.epsilon, 1, 1, **kw)          # (the first call also pays the oracle's one-time scene set-up)
+    t = time.perf_counter()
+    ol.render(ls, ls.camera, W, H, ls.epsilon, 1, 1, **kw)
+    one = time.perf_counter() - t
+    spp = max(1, min(1024, int(budget_s / max(one, 1e-4))))
+    t = time.perf_counter()
+    ol.render(ls, ls.camera, W, H, ls.epsilon, 2, spp, **kw)
+    dt = time.perf_counter() - t
+    model, cores = host_cpu()
+    return {"value": owned * 64 * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port", "host_cpu": model, "host_cores_total": cores,
+            "sample": f"same scene / camera / {W}x{H} frame, the {owned} tiles t % {n_crop} == {crop_rank} ({owned * 64} pixels), iterations 2-{spp + 1} "
+                      f"({owned * 64 * spp} samples), reference traversal order, oracle/liboracle_soft.so single thread, {dt:.1f} s"}
+
+
 def parity_check(api):
     """north_star's tolerance at its own sample count: GPU film vs the pinned (glibc) oracle, Cornell 256x256, depth 8.
     1024 spp when the host has the cores for it (67 M oracle samples), 128 spp otherwise.  The oracle is the checker."""
@@ -163,6 +188,13 @@ def counter_child(which="c2", mode="reference"):
             r.render(cam, SPP_PER_STEP + 1, SPP_PER_STEP, reset=False)
             r.synchronize()
         return
+    if which == "volpath":
+        ls = load_shipped_volpath(api)
+        with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
+            r.render(ls.camera, 1, VOLPATH_SPP, reset=True)
+            r.render(ls.camera, VOLPATH_SPP + 1, VOLPATH_SPP, reset=False)
+            r.synchronize()
+        return
     ls = load_standin(which, sbvh=mode.startswith("sbvh"), reference_bvh=mode.startswith("reference"))
     spp = STANDINS[which][1]
     with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
@@ -222,7 +254,7 @@ def live_counters():
     return sq
 
 
-def standin_leg(api, which, counters=True):
+def standin_leg(api, which, counters=True, cpu=True):
     """One BASELINE stand-in at full size, four legs, each one launch timed with the library's HIP events:
       "default"                         what a caller gets who calls gpt_scene_load, gpt_begin, gpt_render and nothing else: the loader's tree (the
                                         reference builder's unless it has oversized leaves - include/gpt.h) in the order gpt_begin picks (the 4-wide
@@ -252,10 +284,17 @@ def standin_leg(api, which, counters=True):
                 n, ms = r.kernel_time()
                 best = ms / max(1, n) if best is None else min(best, ms / max(1, n))
             film[leg] = r.read_accum()
+            if cpu and leg == "default":
+                try:
+                    cpu_leg = cpu_crop_baseline(ls, 256, 37)
+                except Exception as e:
+                    cpu_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["legs"][leg] = {"value": n_samples / best / 1e3, "unit": "Msamples/s", "launch_ms": best,
                                 "traversal_order": {0: "reference", 2: "wide4"}[r.get_option("traversal_order")],
                                 "triangles": int(ls.desc.n_prims), "bvh_nodes": int(ls.desc.n_nodes),
                                 "accumulator_sha1": hashlib.sha1(film[leg].tobytes()).hexdigest()[:16]}
+            if cpu and leg == "default":
+                out["legs"][leg]["cpu_baseline"] = cpu_leg
         ls.close()
     # against the reference order on the reference's tree: equal films except where two hits tie within rounding (include/gpt_wide_bvh.h)
     b = film["reference_tree+reference_order"].reshape(-1, 3).astype(np.float64)
@@ -290,6 +329,41 @@ def standin_leg(api, which, counters=True):
     return out
 
 
+def shard_projection(api, scene, cam, steps, out_ptr, device, one_rank):
+    """What the 8-GPU job will cost, as far as ONE GPU can tell (no 8-GPU node has run this path yet): the eight ranks'
+    shards (tiles t % 8 == k) of the SAME job, one after another on this GPU, each timed like the real job minus the reduce - path
+    kernel by the library's events, wall clock around render + Output (root shard only) + synchronise.  The projection adds an
+    ASSUMED reduce time; everything else in it is measured here."""
+    rows = []
+    for k in range(8):
+        with api.Renderer(scene.desc, WIDTH, HEIGHT, EPS, device=device) as rs:
+            rs.set_tile_owner(k, 8)
+            rs.render(cam, 1, steps * SPP_PER_STEP, reset=True)          # the same call first: the sample planes exist afterwards
+            rs.synchronize()
+            rs.kernel_time_reset()
+            t = time.perf_counter()
+            rs.render(cam, 1, steps * SPP_PER_STEP, reset=True)
+            if k == 0:
+                rs.tonemap(steps * SPP_PER_STEP, bool(cam.filmic), out_ptr)
+            rs.synchronize()
+            wall = time.perf_counter() - t
+            n, ms = rs.kernel_time()
+            rows.append({"rank": k, "owned_tiles": rs.get_option("owned_tiles"), "launches": n, "kernel_ms": ms,
+                         "output_kernel_ms": rs.get_option("output_kernel_us") / 1e3, "wall_ms": wall * 1e3})
+    kernels = [x["kernel_ms"] for x in rows]
+    slowest = max(x["wall_ms"] for x in rows)
+    reduce_assumed_ms = 1.0        # 24.9 MB float3 frame, ring reduce to one root over xGMI at >= 25 GB/s effective + launch latency
+    sync_assumed_ms = 0.3          # the closing barrier + the MAX all-reduce of the timings (two small collectives)
+    t8 = slowest + reduce_assumed_ms + sync_assumed_ms
+    return {"what": "the job's eight shards (tiles t % 8 == k) run one after another on this one GPU; measured: kernel and wall per shard; "
+                    "assumed: reduce and closing collectives",
+            "per_shard": rows, "kernel_ms_sum_over_one_rank_kernel_ms": sum(kernels) / one_rank["kernel_ms"],
+            "kernel_ms_max_over_mean": max(kernels) / (sum(kernels) / 8.0),
+            "wall_minus_kernel_ms_max": max(x["wall_ms"] - x["kernel_ms"] for x in rows),
+            "reduce_assumed_ms": reduce_assumed_ms, "closing_collectives_assumed_ms": sync_assumed_ms,
+            "projected_8gpu_ms": t8, "projected_8gpu_speedup": one_rank["wall_s"] * 1e3 / t8}
+
+
 T0 = time.perf_counter()
 
 
@@ -298,12 +372,8 @@ def note(what):
     print(f"[bench {time.perf_counter() - T0:7.1f} s] {what}", file=sys.stderr, flush=True)
 
 
-def volpath_leg(api):
-    """The reference's shipped default scene (scenes/cornell_box/scene.json: "vpt", 17 bounces, a 100 x 100 x 40 density grid in a
-    material-less box, 512 x 512) rebuilt on disk from this repository's fixtures (tests/standins.py: write_smoke_scene; where
-    /root/reference exists tests/test_scene_loader.py shows it loads to the shipped scene bit for bit) and read through the product
-    loader: the one-ray-at-a-time Volpath kernel, one 64-iteration launch by HIP events."""
-    import numpy as np
+def load_shipped_volpath(api):
+    """scenes/cornell_box/scene.json of the reference rebuilt from fixtures (tests/standins.py: write_smoke_scene), through the product loader"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import standins
     d = tempfile.mkdtemp(prefix="gpt_smoke_")
@@ -311,35 +381,75 @@ def volpath_leg(api):
     saved = os.dup(1)
     os.dup2(2, 1)                 # the loader's progress lines go to stderr: stdout carries the one JSON line
     try:
-        ls = api.LoadedScene(standins.write_smoke_scene(d))
+        return api.LoadedScene(standins.write_smoke_scene(d))
     finally:
         os.dup2(saved, 1)
         os.close(saved)
-    try:
-        spp = 64
-        with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
-            r.render(ls.camera, 1, 2, reset=True)
-            r.synchronize()
-            best = None
-            for _ in range(2):
-                r.kernel_time_reset()
-                r.render(ls.camera, 1, spp, reset=True)
-                r.synchronize()
-                n, ms = r.kernel_time()
-                best = ms if best is None else min(best, ms)
-            film = r.read_accum()
-            walk = int(r.get_option("walk_kernel_active"))
-        out = {"workload": "the reference's shipped scenes/cornell_box/scene.json rebuilt from fixtures: Cornell walls + 100x100x40 density grid "
-                           f"(sigmaT 100, albedo 0.9) in a material-less box, {ls.width}x{ls.height}, 17 bounces, ratio tracking, iterMax 2000, "
-                           f"{spp} spp in one launch",
-               "value": ls.width * ls.height * spp / best / 1e3, "unit": "Msamples/s", "launch_ms": best, "walk_kernel": walk,
-               "timed": "path-kernel launch, HIP events of the library (gpt_kernel_time)",
-               "accumulator_sha1": hashlib.sha1(film.tobytes()).hexdigest()[:16],
-               "mean_radiance": [float(x) for x in (film.reshape(-1, 3).astype(np.float64).mean(0) / spp)]}
-        ls.close()
-        return out
-    finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+VOLPATH_SPP = 64
+
+
+def volpath_leg(api, counters=True, cpu=True):
+    """The reference's shipped default scene (scenes/cornell_box/scene.json: "vpt", 17 bounces, a 100 x 100 x 40 density grid in a
+    material-less box, 512 x 512) rebuilt on disk from this repository's fixtures (tests/standins.py: write_smoke_scene; where
+    /root/reference exists tests/test_scene_loader.py shows it loads to the shipped scene bit for bit) and read through the product
+    loader: the one-ray-at-a-time Volpath kernel, one 64-iteration launch by HIP events."""
+    import numpy as np
+    ls = load_shipped_volpath(api)
+    spp = VOLPATH_SPP
+    with api.Renderer(ls.desc, ls.width, ls.height, ls.epsilon) as r:
+        r.render(ls.camera, 1, 2, reset=True)
+        r.synchronize()
+        best = None
+        for _ in range(2):
+            r.kernel_time_reset()
+            r.render(ls.camera, 1, spp, reset=True)
+            r.synchronize()
+            n, ms = r.kernel_time()
+            best = ms if best is None else min(best, ms)
+        film = r.read_accum()
+        walk = int(r.get_option("walk_kernel_active"))
+    out = {"workload": "the reference's shipped scenes/cornell_box/scene.json rebuilt from fixtures: Cornell walls + 100x100x40 density grid "
+                       f"(sigmaT 100, albedo 0.9) in a material-less box, {ls.width}x{ls.height}, 17 bounces, ratio tracking, iterMax 2000, "
+                       f"{spp} spp in one launch",
+           "value": ls.width * ls.height * spp / best / 1e3, "unit": "Msamples/s", "launch_ms": best, "walk_kernel": walk,
+           "timed": "path-kernel launch, HIP events of the library (gpt_kernel_time)",
+           "accumulator_sha1": hashlib.sha1(film.tobytes()).hexdigest()[:16],
+           "mean_radiance": [float(x) for x in (film.reshape(-1, 3).astype(np.float64).mean(0) / spp)]}
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_crop_baseline(ls, 64, 21)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if counters:
+        # the counters of the c3 - c5 legs for this kernel (pt_render_kernel<false, true, PT_IT_VPT_WALK>): launches of the same size
+        # of the same libgpt.so under rocprofv3 --pmc inside this run, each counter set in its own pass
+        work = tempfile.mkdtemp(prefix="gpt_pmc_")
+        try:
+            sq, _ = rocprof_pass(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
+                                 work, "sq", ("volpath", "default"))
+            fetch, _ = rocprof_pass(["FETCH_SIZE"], work, "fetch", ("volpath", "default"))
+            write, _ = rocprof_pass(["WRITE_SIZE"], work, "write", ("volpath", "default"))
+            n_samples = ls.width * ls.height * spp
+            peak_issue = N_SIMD * CLOCK_HZ / VALU_CYCLES
+            traffic = (2.0 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0
+            lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+            frac = sq["SQ_INSTS_VALU"] / (best * 1e-3) / peak_issue
+            out["roofline"] = {"bound": "valu_issue at low lane occupancy (DESIGN.md section 7)", "valu_issue_frac": frac, "active_lanes_of_64": lanes,
+                               "useful_frac": frac * lanes / 64.0, "valu_insts_per_sample_lane": sq["SQ_INSTS_VALU"] / n_samples * 64,
+                               "wait_any_over_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                               "hbm_GBps": traffic / (best * 1e-3) / 1e9, "hbm_frac_of_peak": traffic / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "fetch_KiB_raw_per_launch": fetch["FETCH_SIZE"], "write_KiB_per_launch": write["WRITE_SIZE"],
+                               "compulsory_bytes_per_launch": 16.0 * n_samples,
+                               "counters": "rocprofv3 --pmc on launches of the same size of this libgpt.so, inside this run"}
+        except Exception as e:
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    ls.close()
+    return out
 
 
 def main():
@@ -419,12 +529,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    host_reduce_s = [0.0]          # the gloo stand-in synchronises inside reduce(): timed on the host; the RCCL reduce by the library's events
+
     def job(steps):
         # K steps of SPP_PER_STEP iterations each, handed to the renderer in one call: it cuts them into launches of
         # up to 256 iterations (a launch has a fixed cost; the reference's one-iteration-per-Render is the other extreme)
         r.render(cam, 1, steps * SPP_PER_STEP, reset=True)
         if comm is not None:
+            th = time.perf_counter()
             comm.reduce(root=0)                                 # the one collective: float3 framebuffer over xGMI
+            host_reduce_s[0] = time.perf_counter() - th
         if rank == 0:
             if comm is not None:
                 comm.tonemap_reduced(steps * SPP_PER_STEP, bool(cam.filmic), out.data_ptr())
@@ -449,8 +563,18 @@ def main():
     dt_max = float(t.item())
 
     samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
+    # Where this rank's wall time went: the path kernel and the accumulation kernel behind every launch (HIP events), the reduce (the
+    # library's events around ncclReduce; for the gloo stand-in, which synchronises, the host clock around it - that one includes
+    # waiting for the kernel), Output on the root, and the rest (launch gaps, the two barriers, waiting for slower ranks).
+    reduce_ms = None
+    if comm is not None:
+        reduce_ms = r.get_option("last_reduce_us") / 1e3 if comm.native else host_reduce_s[0] * 1e3
+    tonemap_ms = r.get_option("last_tonemap_us") / 1e3 if rank == 0 else None
+    output_ms = r.get_option("output_kernel_us") / 1e3        # pt_output_kernel: sample planes -> accumulator, once per launch (shards with the tiles)
     mine = {"rank": rank, "owned_tiles": r.get_option("owned_tiles"), "sample_plane_bytes": r.get_option("sample_plane_bytes"),
-            "launches": launches, "kernel_ms": kernel_ms, "wall_s": dt}
+            "launches": launches, "kernel_ms": kernel_ms, "output_kernel_ms": output_ms, "wall_s": dt, "reduce_ms": reduce_ms, "tonemap_ms": tonemap_ms,
+            "reduce_timed_by": None if comm is None else ("HIP events around ncclReduce" if comm.native else "host clock around the synchronising gloo reduce (includes waiting for this rank's kernel)"),
+            "rest_ms": dt * 1e3 - kernel_ms - output_ms - (reduce_ms if (comm is not None and comm.native) else 0.0) - (tonemap_ms or 0.0)}
     per_rank = [mine]
     if dist is not None:
         per_rank = [None] * world
@@ -499,6 +623,13 @@ def main():
                           "wall_clock_value": 1088 * 1080 * 256 / wall / 1e6}
 
         note("square frame and kernel ray counts done")
+        projection = None
+        if single and not args.no_square:
+            try:
+                projection = shard_projection(api, scene, cam, args.steps, out.data_ptr(), local_rank, mine)
+            except Exception as e:
+                projection = {"error": f"{type(e).__name__}: {e}"[:300]}
+            note("8-shard projection done")
         live, live_err = None, None
         if single and not args.no_counters:
             try:
@@ -547,7 +678,7 @@ def main():
             others = {}
             for which in ("c3", "c4", "c5"):
                 try:
-                    others[which] = standin_leg(api, which, counters=not args.no_counters)
+                    others[which] = standin_leg(api, which, counters=not args.no_counters, cpu=not args.no_cpu_baseline)
                 except Exception as e:
                     others[which] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 note(f"other_configs {which} done")
@@ -557,7 +688,7 @@ def main():
         volpath = None
         if single and not args.no_other_configs:
             try:
-                volpath = volpath_leg(api)
+                volpath = volpath_leg(api, counters=not args.no_counters, cpu=not args.no_cpu_baseline)
             except Exception as e:
                 volpath = {"error": f"{type(e).__name__}: {e}"[:300]}
             note("volpath leg done")
@@ -581,7 +712,7 @@ def main():
                        "renderer_options": options, "options_set": dict(r.options_set),
                        "env_overrides": dict(api.ENV_OVERRIDES, **{k: os.environ[k] for k in ("GPT_BENCH_SHARE_GPU", "GPT_BENCH_BACKEND", "GPT_BENCH_TRY_NATIVE") if os.environ.get(k)}),
                        "reduce": (comm.kind if comm is not None else None), "per_rank": per_rank,
-                       "square_frame": square, "other_configs": others, "volpath": volpath,
+                       "square_frame": square, "eight_gpu_projection": projection, "other_configs": others, "volpath": volpath,
                        "mean_radiance": [float(x) for x in img.astype(np.float64).mean(0)]},
             "roofline": roof,
         }

@@ -81,6 +81,7 @@ def load():
         "gpt_debug_math": [C.c_int, C.c_int, vp, vp, vp, C.c_int],
         "gpt_debug_rng": [C.c_int, u32, u32, vp, vp, C.c_int],
         "gpt_debug_bsdf": [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp],
+        "gpt_debug_fail_next_wide_alloc": [C.c_int],
         "gpt_bvh_build": [vp, i32, vp, vp, C.POINTER(i32), vp],
         "gpt_light_distribution": [vp, i32, vp, vp, C.POINTER(i32)],
         "gpt_infinite_init": [vp, vp],
@@ -435,6 +436,15 @@ def debug_bsdf(material, geom11, in3, mode, texture=None, device=0):
     check(load().gpt_debug_bsdf(device, st.ptr(material), C.byref(rec) if rec is not None else None, st.ptr(geom11), st.ptr(in3),
                                 len(geom11), mode, st.ptr(out)))
     return out
+
+
+def last_error():
+    """the message of the last failed call on this thread (gpt_last_error); also kept by gpt_begin's low-memory fall-back"""
+    return load().gpt_last_error().decode()
+
+
+def debug_fail_next_wide_alloc(enable=True):
+    check(load().gpt_debug_fail_next_wide_alloc(1 if enable else 0))
 
 
 def debug_rng(pixel, iteration, n, device=0):

@@ -1744,6 +1744,9 @@ constexpr int kJobNone = 0, kJobSample = 1, kJobTr = 2;
 #define PT_TRACK_MIN 16
 #endif
 constexpr int kTrackSteps = PT_TRACK_STEPS, kStepBatch = PT_STEP_BATCH, kTraceBatch = PT_TRACE_BATCH, kTrackMin = PT_TRACK_MIN;
+// with no walk under way (n_track == 0 < kTrackMin) a single ready lane gets its stage pass and a single ray its drain: that is what
+// guarantees progress when fewer than kStepBatch lanes are left.  0 switches both rules off and the wave spins (measured: a hung launch)
+static_assert(PT_TRACK_MIN >= 1, "PT_TRACK_MIN = 0 removes the progress guarantee of the one-ray Volpath kernel's scheduler");
 #ifndef PT_WIDE_WAVES
 #define PT_WIDE_WAVES 4
 #endif
@@ -1811,7 +1814,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
     unsigned long long cyc_trace = 0, cyc_shade = 0, cyc_mark = COUNT ? __builtin_readcyclecounter() : 0ull;   // counting build
     unsigned long long cyc_direct = 0, cyc_hit = 0, cyc_regen = 0, cyc_sub = 0;                                // ... split of cyc_shade
 #if PT_WALK_PROBE      // probe build of the one-ray Volpath kernel (tools/gpu_walk_probe.py): passes / lanes / cycles of its three activities
-    unsigned long long wp_stage_pass = 0, wp_stage_lanes = 0, wp_track_turn = 0, wp_track_lanes = 0, wp_track_steps = 0, wp_track_lane_steps = 0,
+    unsigned long long wp_stage_pass = 0, wp_stage_lanes = 0, wp_track_turn = 0, wp_drains = 0, wp_track_steps = 0, wp_track_lane_steps = 0,
                        wp_cyc_stage = 0, wp_cyc_track = 0;
 #endif
 #define PT_SUBPHASE(acc)                                                                     \
@@ -2839,7 +2842,7 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
                 if (lane == 0) cyc_shade += c0 - cyc_mark;
             }
 #if PT_WALK_PROBE
-            if (COUNT && INTEG == PT_IT_VPT_WALK && lane == 0) wp_track_lanes++;      // (probe: drains)
+            if (COUNT && INTEG == PT_IT_VPT_WALK && lane == 0) wp_drains++;
 #endif
             if (SMALL) {
                 LdsScene mem;
@@ -2907,8 +2910,11 @@ __global__ void __launch_bounds__(256, INTEG == PT_IT_VPT_WALK ? PT_WALK_WAVES :
         atomicAdd(&P.counters[5], (unsigned long long)cnt.samples);
 #if PT_WALK_PROBE
         if (INTEG == PT_IT_VPT_WALK) {
+            // probe build only: counters[6..15] mean something else than in the counting build (tools/gpu_walk_probe.py reads them):
+            // 6 stage passes, 7 lanes in them, 8 tracking turns, 9 pool drains, 10 tracking steps, 11 lane-steps, 12 / 13 cycles in
+            // stage code / tracking, 14 / 15 cycles draining / everything else
             atomicAdd(&P.counters[6], wp_stage_pass); atomicAdd(&P.counters[7], wp_stage_lanes);
-            atomicAdd(&P.counters[8], wp_track_turn); atomicAdd(&P.counters[9], wp_track_lanes);
+            atomicAdd(&P.counters[8], wp_track_turn); atomicAdd(&P.counters[9], wp_drains);
             atomicAdd(&P.counters[10], wp_track_steps); atomicAdd(&P.counters[11], wp_track_lane_steps);
             atomicAdd(&P.counters[12], wp_cyc_stage); atomicAdd(&P.counters[13], wp_cyc_track);
             if (lane == 0) { atomicAdd(&P.counters[14], cyc_trace); atomicAdd(&P.counters[15], cyc_shade); }

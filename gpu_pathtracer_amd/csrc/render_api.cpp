@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/gpt.h"
@@ -88,16 +89,45 @@ struct gpt_ctx {
     // timing of the path kernel on its own stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> output_events;   // {end of the path kernel (owned by `events`), mark behind the accumulation kernel}
+    std::vector<hipEvent_t> free_marks;
     uint32_t timed_launches = 0;
     double timed_ms = 0.0;
+    double timed_output_ms = 0.0;        // ... and of the accumulation kernel that follows every launch ("output_kernel_us")
     // multi-GPU film reduce (gpt_comm_init / gpt_reduce_film)
     bool wide_ok = false;                 // the 4-wide tree exists (GPT_TRAVERSAL_WIDE4 can be selected)
+    bool wide_fallback = false;           // gpt_begin wanted the wide order and had no room for its tree ("wide_fallback")
     int wide_depth = 0, n_wide = 0;
     std::vector<pt::DevWideNode> wide_host;   // built with the scene, uploaded by the first gpt_set_traversal_order(GPT_TRAVERSAL_WIDE4)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     float *reduced = nullptr;             // root: the whole frame after gpt_reduce_film (W*H*3); acc stays this rank's tiles
+    // HIP events around the last gpt_reduce_film and the last gpt_tonemap[_from] on the stream ("last_reduce_us", "last_tonemap_us"):
+    // where a multi-GPU job's time outside the path kernel goes (bench.py: config.per_rank)
+    hipEvent_t ev_reduce[2] = {nullptr, nullptr}, ev_tonemap[2] = {nullptr, nullptr};
 };
+
+namespace {
+std::atomic<bool> g_fail_next_wide_alloc{false};   // gpt_debug_fail_next_wide_alloc: tests of gpt_begin's low-memory path
+int span_begin(gpt_ctx *ctx, hipEvent_t ev[2])
+{
+    if (!ev[0]) {
+        HIP_TRY(hipEventCreate(&ev[0]));
+        HIP_TRY(hipEventCreate(&ev[1]));
+    }
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    return GPT_OK;
+}
+int64_t span_us(hipEvent_t ev[2])       // -1: nothing recorded
+{
+    float ms = 0.f;
+    if (!ev[0] || hipEventSynchronize(ev[1]) != hipSuccess || hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return (int64_t)(ms * 1000.0);
+}
+}  // namespace
 
 namespace {
 
@@ -125,6 +155,15 @@ int fold_events(gpt_ctx *ctx)
         ctx->free_events.push_back(ev);
     }
     ctx->events.clear();
+    // the accumulation kernel of launch i runs between the end of path kernel i and the mark recorded behind it
+    for (auto &ev : ctx->output_events) {
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        ctx->timed_output_ms += ms;
+        ctx->free_marks.push_back(ev.second);
+    }
+    ctx->output_events.clear();
     return GPT_OK;
 }
 
@@ -519,11 +558,15 @@ int gpt_begin(const gpt_scene_desc *scene, uint32_t width, uint32_t height, floa
     P.plane = 0;                                   // set per gpt_render call: 64 slots per owned tile
     P.counters = ctx->counters;
     if (hipDeviceSynchronize() != hipSuccess) { gpt_set_error("gpt_begin: device sync failed"); return fail(GPT_ERR_HIP); }
-    // the default traversal order (include/gpt_traversal.h): the 4-wide tree for every scene that does not fit LDS.  If the wide tree
-    // cannot be uploaded (allocation failure, more than 4 GB) the scene still renders in the reference's order with what is allocated.
+    // the default traversal order (include/gpt_traversal.h): the 4-wide tree for every scene that does not fit LDS.  If there is no ROOM
+    // for the wide tree (device memory exhausted, more than 4 GB: GPT_ERR_UNSUPPORTED) the scene still renders, in the reference's order,
+    // with what is allocated; the option "wide_fallback" reads 1 and gpt_last_error() keeps the reason.  Any other failure - a device
+    // fault, a failed copy - is an error of gpt_begin: going on would hide it behind a slower render.
     if ((rc = gpt_set_traversal_order(ctx, GPT_TRAVERSAL_AUTO)) != GPT_OK) {
-        (void)hipGetLastError();                   // clear the sticky allocation error
+        if (rc != GPT_ERR_UNSUPPORTED) return fail(rc);
         ctx->wide_ok = false;
+        ctx->wide_fallback = true;
+        std::vector<DevWideNode>().swap(ctx->wide_host);
         ctx->P.traversal = GPT_TRAVERSAL_REFERENCE;
     }
     *out = ctx;
@@ -592,7 +635,15 @@ int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value)
     else if (n == "last_batch") *value = ctx->last_batch_cap;
     else if (n == "sample_plane_bytes") *value = (int64_t)ctx->sample_bytes;
     else if (n == "owned_tiles") *value = ctx->P.n_tiles > ctx->P.rank ? (ctx->P.n_tiles - ctx->P.rank + ctx->P.n_ranks - 1) / ctx->P.n_ranks : 0;
+    else if (n == "wide_fallback") *value = ctx->wide_fallback ? 1 : 0;
     else if (n == "last_trace_us") *value = (int64_t)(ctx->last_trace_ms * 1000.0);
+    else if (n == "output_kernel_us") {       // since the last gpt_kernel_time_reset; synchronises like gpt_kernel_time
+        const int rc = fold_events(ctx);
+        if (rc != GPT_OK) return rc;
+        *value = (int64_t)(ctx->timed_output_ms * 1000.0);
+    }
+    else if (n == "last_reduce_us") *value = span_us(ctx->ev_reduce);        // synchronises on the end of that reduce
+    else if (n == "last_tonemap_us") *value = span_us(ctx->ev_tonemap);
     else {
         gpt_set_error("gpt_get_option: unknown option %s", name);
         return GPT_ERR_INVALID_ARG;
@@ -626,11 +677,21 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
                 return GPT_ERR_UNSUPPORTED;
             }
             void *p = nullptr;
-            HIP_TRY(hipMalloc(&p, wide_bytes + tri_bytes + 3 * sizeof(DevTri)));
+            const hipError_t ea = g_fail_next_wide_alloc.exchange(false) ? hipErrorOutOfMemory : hipMalloc(&p, wide_bytes + tri_bytes + 3 * sizeof(DevTri));
+            if (ea == hipErrorOutOfMemory) {
+                (void)hipGetLastError();           // not sticky: the caller may go on in the reference's order
+                gpt_set_error("gpt_set_traversal_order: no device memory for the wide tree (%zu bytes)", wide_bytes + tri_bytes + 3 * sizeof(DevTri));
+                return GPT_ERR_UNSUPPORTED;
+            }
+            HIP_TRY(ea);
+            if (hipMemset(static_cast<char *>(p) + wide_bytes + tri_bytes, 0, 3 * sizeof(DevTri)) != hipSuccess ||
+                hipMemcpy(p, ctx->wide_host.data(), wide_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(static_cast<char *>(p) + wide_bytes, ctx->P.tris, tri_bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+                gpt_set_error("gpt_set_traversal_order: uploading the wide tree: %s", hipGetErrorString(hipGetLastError()));
+                (void)hipFree(p);                  // nothing half-uploaded stays behind
+                return GPT_ERR_HIP;
+            }
             ctx->allocs.push_back(p);
-            HIP_TRY(hipMemset(static_cast<char *>(p) + wide_bytes + tri_bytes, 0, 3 * sizeof(DevTri)));
-            HIP_TRY(hipMemcpy(p, ctx->wide_host.data(), wide_bytes, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(static_cast<char *>(p) + wide_bytes, ctx->P.tris, tri_bytes, hipMemcpyDeviceToDevice));
             ctx->P.wide = static_cast<const DevWideNode *>(p);
             ctx->P.wide_tris_off = (uint32_t)wide_bytes;
             std::vector<DevWideNode>().swap(ctx->wide_host);
@@ -643,7 +704,13 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order)
             void *p = nullptr;
             const size_t n = blocks * 4 * (size_t)kWideWaveSliceDwords;
             HIP_TRY(hipSetDevice(ctx->device));
-            HIP_TRY(hipMalloc(&p, n * sizeof(uint32_t)));
+            const hipError_t ea = hipMalloc(&p, n * sizeof(uint32_t));
+            if (ea == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                gpt_set_error("gpt_set_traversal_order: no device memory for the wide walk's stack slices (%zu bytes)", n * sizeof(uint32_t));
+                return GPT_ERR_UNSUPPORTED;
+            }
+            HIP_TRY(ea);
             ctx->allocs.push_back(p);
             ctx->P.wide_stack = static_cast<uint32_t *>(p);
             ctx->P.wide_stack_blocks = (uint32_t)blocks;
@@ -776,6 +843,15 @@ int gpt_render(gpt_ctx *ctx, const gpt_camera *camera, uint32_t iter_first, uint
         HIP_TRY(hipEventRecord(ev.second, ctx->stream));
         ctx->events.push_back(ev);
         HIP_TRY(launch_output(P, ctx->stream));
+        hipEvent_t mark = nullptr;
+        if (!ctx->free_marks.empty()) {
+            mark = ctx->free_marks.back();
+            ctx->free_marks.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&mark));
+        }
+        HIP_TRY(hipEventRecord(mark, ctx->stream));
+        ctx->output_events.push_back({ev.second, mark});
         if (ctx->events.size() > 2048) {
             int rc = fold_events(ctx);
             if (rc != GPT_OK) return rc;
@@ -796,7 +872,10 @@ int gpt_tonemap_from(gpt_ctx *ctx, const float *acc_dev, uint32_t iter, int film
         return GPT_ERR_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));
+    int rc = span_begin(ctx, ctx->ev_tonemap);
+    if (rc != GPT_OK) return rc;
     HIP_TRY(launch_tonemap(acc_dev, out_dev, ctx->P.stride, ctx->P.rows, iter, filmic, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_tonemap[1], ctx->stream));
     return GPT_OK;
 }
 
@@ -907,9 +986,12 @@ int gpt_reduce_film(gpt_ctx *ctx, int root)
         if (rc != GPT_OK) return rc;
     }
     const size_t count = (size_t)ctx->width * ctx->height * 3;
+    const int rc_span = span_begin(ctx, ctx->ev_reduce);
+    if (rc_span != GPT_OK) return rc_span;
     const ncclResult_t e = L->Reduce(ctx->acc, ctx->comm_rank == root ? ctx->reduced : nullptr, count, ncclFloat32, ncclSum, root, ctx->comm,
                                      ctx->stream);
     if (e != ncclSuccess) { gpt_set_error("ncclReduce: %s", L->GetErrorString(e)); return GPT_ERR_HIP; }
+    HIP_TRY(hipEventRecord(ctx->ev_reduce[1], ctx->stream));
     return GPT_OK;
 }
 
@@ -999,6 +1081,9 @@ int gpt_end(gpt_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &ev : ctx->output_events) (void)hipEventDestroy(ev.second);
+    for (hipEvent_t e : ctx->free_marks) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_reduce[0], ctx->ev_reduce[1], ctx->ev_tonemap[0], ctx->ev_tonemap[1]}) if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->allocs) if (p) (void)hipFree(p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1021,6 +1106,7 @@ int gpt_kernel_time_reset(gpt_ctx *ctx)
     int rc = fold_events(ctx);
     ctx->timed_launches = 0;
     ctx->timed_ms = 0.0;
+    ctx->timed_output_ms = 0.0;
     return rc;
 }
 
@@ -1121,6 +1207,12 @@ int gpt_debug_math(int device, int fn, const float *x, const float *y, float *ou
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return GPT_OK;
+}
+
+int gpt_debug_fail_next_wide_alloc(int enable)
+{
+    g_fail_next_wide_alloc.store(enable != 0);
     return GPT_OK;
 }
 

@@ -201,6 +201,9 @@ int gpt_debug_bsdf(int device, const gpt_material *material, const gpt_texture *
  * context's current traversal order and memory path.  Ray i = rays8[8 i ..] = {origin.xyz, direction.xyz, tmax, any_hit != 0},
  * tmin = the context's epsilon.  prim_out[i] = hit primitive (BVH order) or -1, tb_out[3 i ..] = {t, b1, b2}.  Host pointers. */
 int gpt_debug_trace(gpt_ctx *ctx, const float *rays8, int n, int32_t *prim_out, float *tb_out);
+/* Test hook: the NEXT allocation of a wide tree (gpt_begin / gpt_set_traversal_order) reports "out of device memory" without asking
+ * the device - exercises gpt_begin's fall-back to the reference's traversal order (option "wide_fallback" then reads 1). */
+int gpt_debug_fail_next_wide_alloc(int enable);
 /* first n uniform draws of the (pixel, iter) stream, evaluated on the device */
 int gpt_debug_rng(int device, uint32_t pixel, uint32_t iter, uint32_t *seed_out, float *u_out, int n);
 /* the scene-file reader on its own (tests: against the rapidjson the reference vendors): -1 when the reader refuses the

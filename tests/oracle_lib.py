@@ -177,7 +177,11 @@ def render(scene, cam, width, height, eps, iter_first, iter_count, reset=True, a
     out = np.zeros(n, dtype=np.float32) if want_out else None
     threads = threads or min(8, os.cpu_count() or 1)
     check = None
-    if order == -1 and CROSSCHECK_DEFAULT_ORDER and lib.oracle_auto_is_wide(C.byref(scene.desc)):
+    # only where the comparison means something: a render that starts from a cleared film with the oracle's own (zero) last-sample
+    # plane - with reset = False the history dilutes the relative RMS, and a caller-supplied colour plane (the stale-colour test's
+    # sentinels) would enter the sums wherever a sample is not finite
+    fresh = bool(reset) and not color.any()
+    if order == -1 and CROSSCHECK_DEFAULT_ORDER and fresh and lib.oracle_auto_is_wide(C.byref(scene.desc)):
         check = (acc.copy(), color.copy())
     try:
         if check is not None:            # first, so that oracle_get_counters afterwards describes the render that was asked for

@@ -977,6 +977,30 @@ def test_switching_the_traversal_order_between_renders(gpt):
                 r.set_option("scheduler", 1)        # round 4's decoupled scheduler is not in the product (tools/variants/)
 
 
+def test_begin_falls_back_to_the_reference_order_only_when_the_wide_tree_has_no_room(gpt):
+    """gpt_begin wants the 4-wide walk for a scene beyond LDS.  When the allocation of its tree reports "out of device memory" (forced
+    here by the library's test hook) the context still comes up, in the reference's order: "wide_fallback" reads 1, gpt_last_error keeps
+    the reason, selecting the wide order later is refused, and the film is the oracle's in the REFERENCE order bit for bit.  The next
+    context (hook consumed) gets the wide walk again."""
+    scene, meta = scenes.zoo_scene(max_depth=6, with_env=True, extra=scenes.random_soup(2500, 13, size=0.25))
+    W, H, spp = 128, 96, 4
+    cam = ol.cornell_camera(meta, W, H)
+    want_ref, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", order=0)
+    want_wide, _ = ol.render(scene, cam, W, H, 0.001, 1, spp, kind="soft", order=2)
+    gpt.debug_fail_next_wide_alloc(True)
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        assert (r.get_option("wide_fallback"), r.get_option("traversal_order")) == (1, 0)
+        assert "no device memory for the wide tree" in gpt.last_error()
+        with pytest.raises(gpt.GptError):
+            r.set_traversal_order("wide")
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), want_ref, "fall-back film, reference order")
+    with gpt.Renderer(scene.desc, W, H, 0.001) as r:
+        assert (r.get_option("wide_fallback"), r.get_option("traversal_order")) == (0, 2)
+        r.render(cam, 1, spp, reset=True)
+        assert_bit_exact(r.read_accum(), want_wide, "the next context walks the wide tree again")
+
+
 def test_renderer_options_are_explicit_and_readable(gpt):
     """Nothing in the library is steered by the environment: options are set by name, refused when unknown or out of range, and
     what the renderer actually does can be read back.  None of them changes the film."""
@@ -1302,7 +1326,10 @@ def test_volpath_two_kernels_agree(gpt, monkeypatch):
     with gpt.Renderer(scene.desc, W, H, eps) as r:
         r.render(cam, 1, spp, reset=True)
         assert_bit_exact(r.read_accum(), ref, "three-ray kernel")
-        assert r.get_option("walk_kernel_active") == 0
+        # the library's own choice for this scene is the three-ray kernel - unless the whole run forces the other one
+        # (--gpt-opt vpt_walk_kernel=1: the suite with every Volpath scene on the one-ray kernel)
+        forced = bool(gpt.DEFAULT_OPTIONS.get("vpt_walk_kernel"))
+        assert r.get_option("walk_kernel_active") == (1 if forced else 0)
         r.set_option("vpt_walk_kernel", 1)
         assert r.get_option("walk_kernel_active") == 1
         r.render(cam, 1, spp, reset=True)
