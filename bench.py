@@ -19,14 +19,20 @@ What the JSON line carries besides the contract's fields (rank 0, N = 1):
                 passes, --kernel-trace only).  roofline.hbm keeps the HBM picture: SURVEY.md 8(d)'s algorithmic bytes (of
                 the reference's algorithm and of this kernel's own ray counts), the counter-measured traffic and its
                 fraction of the 8 TB/s peak.
-  cpu_baseline  the oracle (CPU restatement) on one host core, bounded sample; host CPU model and core count.
+  cpu_baseline  the oracle (CPU restatement) on one host core, bounded sample; host CPU model and core count.  The same beside every other
+                leg of the line (config.other_configs.*.legs.default.cpu_baseline, config.volpath.cpu_baseline): one thread on a tile crop
+                of the leg's own scene and frame, <= 8 s each.
   parity        GPU film against the pinned (glibc) oracle at 256x256 / 1024 spp / depth 8: per-channel relative RMS.
   config.other_configs   BASELINE.json configs 3 - 5 on their SURVEY.md 8(d) stand-ins (tests/standins.py, built from
                 tests/golden/meshes.npz through the product loader), one full-size launch per leg (the loader's and gpt_begin's defaults; the reference's tree in the 4-wide walk and in the
                 reference's order; the split tree): Msamples/s from the library's HIP events, and for two legs the VALU-issue fraction,
                 active lanes and HBM-side GB/s of one extra rocprofv3 pass set.  Parity-test cases, not the headline: they are here so that their numbers are driver-witnessed.
   config.volpath         the reference's shipped Volpath scene (cornell_box/scene.json: density grid in a material-less box, 512 x 512, 17 bounces)
-                rebuilt from fixtures through the product loader: one 64-iteration launch of the one-ray-at-a-time kernel, HIP events.
+                rebuilt from fixtures through the product loader: one 64-iteration launch of the one-ray-at-a-time kernel, HIP events; its
+                VALU-issue fraction, lanes and HBM-side traffic from rocprofv3 passes inside this run, like the c3 - c5 legs.
+  config.per_rank        where every rank's wall time went: path kernel, accumulation kernel, reduce, Output, rest (HIP-event spans of the library).
+  config.eight_gpu_projection   (N = 1) the job's eight tile shards one after another on this GPU, each timed like the real job minus the reduce,
+                plus an ASSUMED reduce / closing-collective time: what to expect from the first real 8-GPU run.
 `python bench.py --gpus N` without a torch.distributed.run environment launches itself under it (one rank per GPU).
 Nothing here reads /root/reference.
 """

@@ -95,7 +95,12 @@ int gpt_set_traversal_order(gpt_ctx *ctx, int32_t order);
  *   "max_batch"        iterations per path-kernel launch; default 256 x the number of ranks sharing the frame (a rank's sample
  *                      planes cover its own tiles only), always bounded by 16 GiB and by the free device memory
  *   "chunk_iters"      iterations per work item, 0 (default) = cost model
- * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "traversal_order", "owned_tiles", "last_batch", "sample_plane_bytes", "last_trace_us" (kernel time of the last gpt_debug_trace). */
+ * gpt_get_option also answers (read-only) "lds_scene_active", "walk_kernel_active", "traversal_order", "owned_tiles", "last_batch",
+ * "sample_plane_bytes", "wide_fallback" (1: gpt_begin wanted the 4-wide walk and had no room for its tree; gpt_last_error() keeps why),
+ * and the time spans the library measures with HIP events on its own stream (microseconds; reading one synchronises on its end):
+ * "last_trace_us" (the last gpt_debug_trace), "last_reduce_us" (the last gpt_reduce_film: the ncclReduce alone), "last_tonemap_us" (the
+ * last gpt_tonemap / gpt_tonemap_from), "output_kernel_us" (the accumulation kernel behind every path-kernel launch, summed since the last
+ * gpt_kernel_time_reset - the companion of gpt_kernel_time, which covers the path kernel only). */
 int gpt_set_option(gpt_ctx *ctx, const char *name, int64_t value);
 int gpt_get_option(gpt_ctx *ctx, const char *name, int64_t *value);
 
