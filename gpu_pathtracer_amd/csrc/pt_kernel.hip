@@ -369,7 +369,7 @@ constexpr int kWaveWideFloat4 = kSuspOff + 16 * kWideStackDepth;  // one level o
 #define PT_WIDE_FETCH_T 12                                        // idle lanes that trigger a refill
 #endif
 #ifndef PT_WIDE_STOP_T
-#define PT_WIDE_STOP_T 24                                         // a dry pool with at most this many rays in flight ends the drain
+#define PT_WIDE_STOP_T 20                                         // a dry pool with at most this many rays in flight ends the drain (16 - 24 within 1 %: profiles/r06/d1_wide_stop_sweep.log)
 #endif
 #ifndef PT_WIDE_STOP_T_SMALL
 #define PT_WIDE_STOP_T_SMALL 12                                   // ... trees of fewer than 64k binary nodes
